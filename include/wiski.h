@@ -1,0 +1,121 @@
+/*
+ * wiski.h -- C ABI of libwiski_hip.so: the MI355X (gfx950) implementation of the
+ * WISKI streaming-update hot path of wjmaddox/online_gp.
+ *
+ * The reference has no FFI: its boundary is the Python object surface
+ * (SURVEY.md section 8b).  Each entry point below replaces the torch/gpytorch
+ * op sequence at the cited reference call site (paths relative to the
+ * reference repo; BFN = online_gp/models/batched_fixed_noise_online_gp.py,
+ * URLT = online_gp/lazy/updated_root_lazy_tensor.py,
+ * BWM = online_gp/mlls/batched_woodbury_marginal_log_likelihood.py).
+ *
+ * Conventions
+ *   - every function is `extern "C" int fn(..., void* stream)`; returns
+ *     WISKI_OK or a negative WISKI_E_* code, never throws, never allocates
+ *     memory the caller can see;
+ *   - `stream` is a hipStream_t; work is enqueued asynchronously on it
+ *     (wiski_pcg_* additionally synchronises the stream at its convergence
+ *     checks);
+ *   - pointers named d_* are DEVICE pointers borrowed for the call; all other
+ *     pointers are HOST pointers (small per-dim arrays, outputs of wiski_pcg);
+ *   - `_f32` / `_f64` suffix = scalar type of every `real` array;
+ *   - dense vectors over the inducing grid are stored column-major as
+ *     V[k][m] (k contiguous m-vectors); flat grid index has dim 0 slowest;
+ *   - W^T D^-1 W is kept in block-stencil form A_st[o][i] = A[i, i+off(o)],
+ *     o in 7^d relative offsets, i in [0, m)  (layout: o-major, m contiguous).
+ */
+#ifndef WISKI_H
+#define WISKI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WISKI_OK 0
+#define WISKI_E_BADARG (-1)   /* unsupported d / k / null pointer          */
+#define WISKI_E_LAUNCH (-2)   /* hip launch or runtime error               */
+#define WISKI_E_WORKSPACE (-3) /* workspace too small                      */
+#define WISKI_E_NOTCONV (-4)  /* wiski_pcg hit max_iter (result still written) */
+
+#define WISKI_MAX_DIM 4
+
+/* Inducing-grid geometry (host struct, passed by pointer, read at call time).
+ * g0/h follow gpytorch's GridInterpolationKernel grid (BFN:114-120):
+ * delta=(hi-lo)/(g-2), grid=linspace(lo-delta, hi+delta, g). */
+typedef struct wiski_grid {
+  int32_t d;                      /* 1..WISKI_MAX_DIM                      */
+  int32_t g[WISKI_MAX_DIM];       /* points per dim (incl. 2 extension pts) */
+  double g0[WISKI_MAX_DIM];       /* first grid point per dim               */
+  double h[WISKI_MAX_DIM];        /* grid spacing per dim                   */
+} wiski_grid;
+
+int wiski_version(void);
+
+/* a1 -- replaces covar_module(X).evaluate_kernel() (BFN:143,205,261,421):
+ * cubic (Keys a=-0.5) interpolation indices/values, T=4^d taps per point,
+ * d_idx int32 [n][T], d_val real [n][T].  Out-of-grid points set *d_err != 0
+ * (the reference raises RuntimeError there). */
+int wiski_interp_f32(const wiski_grid* grid, const float* d_x, int64_t n, int32_t* d_idx, float* d_val, int32_t* d_err, void* stream);
+int wiski_interp_f64(const wiski_grid* grid, const double* d_x, int64_t n, int32_t* d_idx, double* d_val, int32_t* d_err, void* stream);
+
+/* a14 -- replaces left_interp(idx, val, pred_mean) (BFN:206-210,235), fused:
+ * weights are recomputed from x on the fly, nothing but x and V is read.
+ * d_out[n][k] = W(x) V,  V given as [k][m].  diag != 0: requires k == n and
+ * writes d_out[p] = W(x_p) . V[p]  (per-query quadratic forms, BFN:222-228). */
+int wiski_gather_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, int32_t diag, float* d_out, int32_t* d_err, void* stream);
+int wiski_gather_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, int32_t diag, double* d_out, int32_t* d_err, void* stream);
+
+/* a14, ELL form -- same product from materialised (idx, val) rows of width T
+ * (the layout InterpolatedLazyTensor keeps; BFN:206-210). k == 1 only. */
+int wiski_gather_ell_f32(const int32_t* d_idx, const float* d_val, int64_t n, int32_t T, const float* d_v, float* d_out, void* stream);
+int wiski_gather_ell_f64(const int32_t* d_idx, const double* d_val, int64_t n, int32_t T, const double* d_v, double* d_out, void* stream);
+
+/* a2+a3+a4+URLT:58 -- replaces _initialize_caches / _update_cache_dicts /
+ * UpdatedRootLazyTensor.update's `tensor + V V^T` (BFN:31-60,155-171):
+ *   d_b[m]      += W^T (y * wb)            interpolation_cache
+ *   d_A_st      += W^T diag(wa) W          WtW (block stencil; may be NULL)
+ *   d_stats[0]  += sum y^2 wb              response_cache      (double)
+ *   d_stats[1]  += sum log(noise)          D_logdet            (double)
+ * wa/wb/noise are per-point device arrays [n] (wb = 1/noise; wa = 1/noise at
+ * initialisation, 1/max(noise,1e-7) on updates -- BFN:163). */
+int wiski_scatter_stats_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_st, double* d_stats, int32_t* d_err, void* stream);
+int wiski_scatter_stats_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_st, double* d_stats, int32_t* d_err, void* stream);
+
+/* Adds W(x)^T as k = n one-hot-interpolated columns: d_out[p][idx] += val
+ * (the sparse `wmat` of BFN:22-28 for a query batch, kept column-dense only
+ * for the k right-hand sides of a solve). d_out must be zeroed by the caller. */
+int wiski_wt_columns_f32(const wiski_grid* grid, const float* d_x, int64_t n, float* d_out, int32_t* d_err, void* stream);
+int wiski_wt_columns_f64(const wiski_grid* grid, const double* d_x, int64_t n, double* d_out, int32_t* d_err, void* stream);
+
+/* replaces WtW._matmul (URLT:47-48) on the stencil form:
+ * d_out[c] = beta * d_add[c] + A_st . d_V[c]   (d_add may be NULL). */
+int wiski_stencil_spmv_f32(const wiski_grid* grid, const float* d_A_st, const float* d_V, int32_t k, const float* d_add, float beta, float* d_out, void* stream);
+int wiski_stencil_spmv_f64(const wiski_grid* grid, const double* d_A_st, const double* d_V, int32_t k, const double* d_add, double beta, double* d_out, void* stream);
+
+/* a8/a9/a11 -- replaces Kuu @ V (BFN:334-348,363-366) with
+ * Kuu = kron_i SymToeplitz(tcol_i): d_out[c] = scale * Kuu d_V[c].
+ * d_tcol = concatenated first columns (sum_i g[i] reals).  d_tmp: scratch of
+ * k*m reals (ping-pong); d_out must not alias d_V. */
+int wiski_kron_toeplitz_mm_f32(const wiski_grid* grid, const float* d_tcol, const float* d_V, int32_t k, float scale, float* d_tmp, float* d_out, void* stream);
+int wiski_kron_toeplitz_mm_f64(const wiski_grid* grid, const double* d_tcol, const double* d_V, int32_t k, double scale, double* d_tmp, double* d_out, void* stream);
+
+/* CG branch of a12 (BFN:368-383; gpytorch linear_cg under Q.inv_matmul),
+ * moved to inducing space: solves (Kt^-1 + A) U = RHS, Kt = kscale*Kuu, for k
+ * columns by CG preconditioned with Kt (no inverse of Kt is applied):
+ *   U = M RHS,  M = (Kt^-1 + A)^-1  (SURVEY 3.5).
+ * d_U/d_Z [k][m]: solution and its pre-image (U = Kt Z). warm != 0 starts
+ * from the given (U, Z) (must satisfy U = Kt Z), else from zero.
+ * Stops when every column has ||r||/||rhs|| < tol or at max_iter.
+ * workspace: wiski_pcg_workspace_bytes(...) bytes of device scratch.
+ * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
+ * be NULL): final relative residuals. */
+int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size);
+int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WISKI_H */

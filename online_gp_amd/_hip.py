@@ -1,0 +1,103 @@
+"""ctypes binding of libwiski_hip.so (C ABI declared in include/wiski.h).
+
+The library is built in-tree by :func:`build` (``hipcc --offload-arch=gfx950``);
+there is no CPU fallback: every op raises if the extension is missing or if a
+tensor is not a contiguous ROCm tensor.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libwiski_hip.so")
+_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "dense.hip"]
+_HEADERS = ["wiski_common.h", os.path.join("..", "..", "include", "wiski.h")]
+MAX_DIM = 4
+
+_lib = None
+
+
+class WiskiError(RuntimeError):
+    pass
+
+
+_ERRS = {-1: "WISKI_E_BADARG", -2: "WISKI_E_LAUNCH", -3: "WISKI_E_WORKSPACE", -4: "WISKI_E_NOTCONV"}
+
+
+class wiski_grid(ctypes.Structure):
+    _fields_ = [
+        ("d", ctypes.c_int32),
+        ("g", ctypes.c_int32 * MAX_DIM),
+        ("g0", ctypes.c_double * MAX_DIM),
+        ("h", ctypes.c_double * MAX_DIM),
+    ]
+
+
+def sources():
+    return [os.path.join(_CSRC, s) for s in _SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into csrc/libwiski_hip.so."""
+    srcs = sources()
+    deps = srcs + [os.path.join(_CSRC, h) for h in _HEADERS]
+    if not force and os.path.exists(_SO):
+        if all(os.path.getmtime(d) <= os.path.getmtime(_SO) for d in deps if os.path.exists(d)):
+            return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _SO] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise WiskiError(
+                f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). online_gp_amd has no CPU fallback."
+            )
+        _lib = ctypes.CDLL(_SO)
+        _lib.wiski_pcg_workspace_bytes.restype = ctypes.c_int64
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise WiskiError(f"{what} failed: {_ERRS.get(rc, rc)}")
+
+
+def dptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise WiskiError("online_gp_amd ops need ROCm device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise WiskiError("online_gp_amd ops need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def suffix(dtype):
+    if dtype == torch.float32:
+        return "_f32"
+    if dtype == torch.float64:
+        return "_f64"
+    raise WiskiError(f"unsupported dtype {dtype}")
+
+
+def creal(dtype):
+    return ctypes.c_float if dtype == torch.float32 else ctypes.c_double
+
+
+def fn(name, dtype):
+    return getattr(lib(), name + suffix(dtype))

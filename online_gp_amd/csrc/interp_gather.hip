@@ -1,0 +1,246 @@
+// a1 / a14: cubic interpolation stencils and the predictive gather SpMM.
+//   reference call sites: BFN:143,205,261,421 (evaluate_kernel -> interp
+//   indices/values) and BFN:206-210,235 (left_interp).
+#include "wiski_common.h"
+
+// ---------------------------------------------------------------- interp ---
+// One thread per (point, tap): the T-wide rows of idx/val are written fully
+// coalesced (tap fastest).  The per-dim stencil is recomputed per tap -- a few
+// dozen flops against an 8..12-byte store, this kernel is write-bound.
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_interp(GridDev<real> G, const real* __restrict__ x, int64_t n,
+                                                int32_t* __restrict__ idx, real* __restrict__ val, int32_t* __restrict__ err) {
+  constexpr int T = 1 << (2 * D);
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * T) return;
+  int64_t p = e / T;
+  int a = (int)(e - p * T);
+  int flat = 0;
+  real v = (real)1;
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    real w[4];
+    int j0 = dim_stencil<real>(x[p * D + q], G.g0[q], G.h[q], G.hi[q], G.g[q], w);
+    int c = (a >> (2 * (D - 1 - q))) & 3;
+    if (j0 < 0) { ok = false; j0 = 0; w[c] = (real)0; }
+    flat += (j0 + c) * G.stride[q];
+    v *= w[c];
+  }
+  idx[e] = flat;
+  val[e] = v;
+  if (!ok && a == 0) atomicOr(err, 1);
+}
+
+// ---------------------------------------------------------- fused gather ---
+// One thread per query row; the 4^D taps are a fully unrolled loop nest, the
+// 4^D loads per column are independent (deep memory-level parallelism) and hit
+// L2 / MALL: V (k*m reals) is small and read-mostly, x is the only HBM stream.
+template <typename real, int D>
+__device__ __forceinline__ real gather_one(const GridDev<real>& G, const int j0[D], const real w[D][4], const real* __restrict__ v) {
+  constexpr int off = 0;
+  real acc = (real)0;
+  if constexpr (D == 1) {
+#pragma unroll
+    for (int c0 = 0; c0 < 4; ++c0) acc += w[0][c0] * v[j0[0] + c0];
+  } else if constexpr (D == 2) {
+#pragma unroll
+    for (int c0 = 0; c0 < 4; ++c0) {
+      const real* r0 = v + (j0[0] + c0) * G.stride[off] + j0[1];
+      real s = (real)0;
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) s += w[1][c1] * r0[c1];
+      acc += w[0][c0] * s;
+    }
+  } else if constexpr (D == 3) {
+#pragma unroll
+    for (int c0 = 0; c0 < 4; ++c0) {
+      real s0 = (real)0;
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) {
+        const real* r = v + (j0[0] + c0) * G.stride[off] + (j0[1] + c1) * G.stride[off + 1] + j0[2];
+        real s1 = (real)0;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) s1 += w[2][c2] * r[c2];
+        s0 += w[1][c1] * s1;
+      }
+      acc += w[0][c0] * s0;
+    }
+  } else {
+#pragma unroll
+    for (int c0 = 0; c0 < 4; ++c0) {
+      real s0 = (real)0;
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) {
+        real s1 = (real)0;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          const real* r = v + (j0[0] + c0) * G.stride[0] + (j0[1] + c1) * G.stride[1] + (j0[2] + c2) * G.stride[2] + j0[3];
+          real s2 = (real)0;
+#pragma unroll
+          for (int c3 = 0; c3 < 4; ++c3) s2 += w[3][c3] * r[c3];
+          s1 += w[2][c2] * s2;
+        }
+        s0 += w[1][c1] * s1;
+      }
+      acc += w[0][c0] * s0;
+    }
+  }
+  return acc;
+}
+
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_gather(GridDev<real> G, const real* __restrict__ x, int64_t n, const real* __restrict__ V,
+                                                int k, int diag, real* __restrict__ out, int32_t* __restrict__ err) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int j0[D];
+  real w[D][4];
+  real xp[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) xp[q] = x[p * D + q];
+  if (!point_stencil<real, D>(G, xp, j0, w)) atomicOr(err, 1);
+  if (diag) {
+    out[p] = gather_one<real, D>(G, j0, w, V + (int64_t)p * G.m);
+  } else {
+    for (int c = 0; c < k; ++c) out[p * k + c] = gather_one<real, D>(G, j0, w, V + (int64_t)c * G.m);
+  }
+}
+
+// ------------------------------------------------------------ ELL gather ---
+// Rows of (idx, val) are streamed from HBM with 16-byte-per-lane loads:
+// LPR = T/4 lanes cooperate on one row (4 taps each), then an xor-shuffle
+// reduction inside the LPR-lane group.  v is L2-resident.
+template <typename real, int LPR>
+__global__ __launch_bounds__(256) void k_gather_ell(const int32_t* __restrict__ idx, const real* __restrict__ val, int64_t n,
+                                                    const real* __restrict__ v, real* __restrict__ out) {
+  constexpr int RPB = 256 / LPR;  // rows per block pass
+  const int sub = threadIdx.x % LPR;
+  const int rloc = threadIdx.x / LPR;
+  for (int64_t row = (int64_t)blockIdx.x * RPB + rloc; row < n; row += (int64_t)gridDim.x * RPB) {
+    const int64_t base = (row * LPR + sub) * 4;
+    int4 id = *reinterpret_cast<const int4*>(idx + base);
+    real a0, a1, a2, a3;
+    if constexpr (sizeof(real) == 4) {
+      float4 vv = *reinterpret_cast<const float4*>(val + base);
+      a0 = vv.x; a1 = vv.y; a2 = vv.z; a3 = vv.w;
+    } else {
+      double2 v0 = *reinterpret_cast<const double2*>(val + base);
+      double2 v1 = *reinterpret_cast<const double2*>(val + base + 2);
+      a0 = v0.x; a1 = v0.y; a2 = v1.x; a3 = v1.y;
+    }
+    real acc = a0 * v[id.x] + a1 * v[id.y] + a2 * v[id.z] + a3 * v[id.w];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0) out[row] = acc;
+  }
+}
+
+// ------------------------------------------------------------- W^T columns --
+// out[p][idx] += val for the T taps of query p (one dense m-column per query).
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_wt_columns(GridDev<real> G, const real* __restrict__ x, int64_t n, real* __restrict__ out,
+                                                    int32_t* __restrict__ err) {
+  constexpr int T = 1 << (2 * D);
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * T) return;
+  int64_t p = e / T;
+  int a = (int)(e - p * T);
+  int flat = 0;
+  real v = (real)1;
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    real w[4];
+    int j0 = dim_stencil<real>(x[p * D + q], G.g0[q], G.h[q], G.hi[q], G.g[q], w);
+    int c = (a >> (2 * (D - 1 - q))) & 3;
+    if (j0 < 0) { ok = false; j0 = 0; w[c] = (real)0; }
+    flat += (j0 + c) * G.stride[q];
+    v *= w[c];
+  }
+  if (v != (real)0) atomic_add_real(out + p * (int64_t)G.m + flat, v);
+  if (!ok && a == 0) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------- host side ---
+template <typename real>
+static int interp_impl(const wiski_grid* grid, const real* d_x, int64_t n, int32_t* d_idx, real* d_val, int32_t* d_err, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (n == 0) return WISKI_OK;
+  if (!d_x || !d_idx || !d_val || !d_err) return WISKI_E_BADARG;
+  int64_t total = n * G.T;
+  dim3 grd((unsigned)((total + 255) / 256));
+#define CALL(DD) hipLaunchKernelGGL((k_interp<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_idx, d_val, d_err)
+  WISKI_DISPATCH_D(G.d, CALL)
+#undef CALL
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
+template <typename real>
+static int gather_impl(const wiski_grid* grid, const real* d_x, int64_t n, const real* d_V, int32_t k, int32_t diag, real* d_out,
+                       int32_t* d_err, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (n == 0) return WISKI_OK;
+  if (!d_x || !d_V || !d_out || !d_err || k < 1) return WISKI_E_BADARG;
+  if (diag && k != n) return WISKI_E_BADARG;
+  dim3 grd((unsigned)((n + 255) / 256));
+#define CALL(DD) hipLaunchKernelGGL((k_gather<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, k, diag, d_out, d_err)
+  WISKI_DISPATCH_D(G.d, CALL)
+#undef CALL
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
+template <typename real>
+static int gather_ell_impl(const int32_t* d_idx, const real* d_val, int64_t n, int32_t T, const real* d_v, real* d_out, void* stream) {
+  if (n == 0) return WISKI_OK;
+  if (!d_idx || !d_val || !d_v || !d_out) return WISKI_E_BADARG;
+  int lpr = T / 4;
+  int64_t rpb = 256 / (lpr > 0 ? lpr : 1);
+  int64_t blocks = (n + rpb - 1) / rpb;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // 16 blocks per CU, grid-stride the rest
+  dim3 grd((unsigned)blocks);
+  hipStream_t s = (hipStream_t)stream;
+  switch (T) {
+    case 4: hipLaunchKernelGGL((k_gather_ell<real, 1>), grd, dim3(256), 0, s, d_idx, d_val, n, d_v, d_out); break;
+    case 16: hipLaunchKernelGGL((k_gather_ell<real, 4>), grd, dim3(256), 0, s, d_idx, d_val, n, d_v, d_out); break;
+    case 64: hipLaunchKernelGGL((k_gather_ell<real, 16>), grd, dim3(256), 0, s, d_idx, d_val, n, d_v, d_out); break;
+    case 256: hipLaunchKernelGGL((k_gather_ell<real, 64>), grd, dim3(256), 0, s, d_idx, d_val, n, d_v, d_out); break;
+    default: return WISKI_E_BADARG;
+  }
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
+template <typename real>
+static int wt_columns_impl(const wiski_grid* grid, const real* d_x, int64_t n, real* d_out, int32_t* d_err, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (n == 0) return WISKI_OK;
+  if (!d_x || !d_out || !d_err) return WISKI_E_BADARG;
+  int64_t total = n * G.T;
+  dim3 grd((unsigned)((total + 255) / 256));
+#define CALL(DD) hipLaunchKernelGGL((k_wt_columns<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_out, d_err)
+  WISKI_DISPATCH_D(G.d, CALL)
+#undef CALL
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
+extern "C" {
+int wiski_version(void) { return WISKI_VERSION; }
+int wiski_interp_f32(const wiski_grid* g, const float* x, int64_t n, int32_t* idx, float* val, int32_t* err, void* s) { return interp_impl<float>(g, x, n, idx, val, err, s); }
+int wiski_interp_f64(const wiski_grid* g, const double* x, int64_t n, int32_t* idx, double* val, int32_t* err, void* s) { return interp_impl<double>(g, x, n, idx, val, err, s); }
+int wiski_gather_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t k, int32_t diag, float* out, int32_t* err, void* s) { return gather_impl<float>(g, x, n, V, k, diag, out, err, s); }
+int wiski_gather_f64(const wiski_grid* g, const double* x, int64_t n, const double* V, int32_t k, int32_t diag, double* out, int32_t* err, void* s) { return gather_impl<double>(g, x, n, V, k, diag, out, err, s); }
+int wiski_gather_ell_f32(const int32_t* idx, const float* val, int64_t n, int32_t T, const float* v, float* out, void* s) { return gather_ell_impl<float>(idx, val, n, T, v, out, s); }
+int wiski_gather_ell_f64(const int32_t* idx, const double* val, int64_t n, int32_t T, const double* v, double* out, void* s) { return gather_ell_impl<double>(idx, val, n, T, v, out, s); }
+int wiski_wt_columns_f32(const wiski_grid* g, const float* x, int64_t n, float* out, int32_t* err, void* s) { return wt_columns_impl<float>(g, x, n, out, err, s); }
+int wiski_wt_columns_f64(const wiski_grid* g, const double* x, int64_t n, double* out, int32_t* err, void* s) { return wt_columns_impl<double>(g, x, n, out, err, s); }
+}

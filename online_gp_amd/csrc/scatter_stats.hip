@@ -1,0 +1,138 @@
+// a2+a3+a4+a5: streaming accumulation of the additive sufficient statistics
+//   b  = W^T D^-1 y   (interpolation_cache, BFN:46,160)
+//   A  = W^T D^-1 W   (WtW, BFN:50-53; URLT:58 `tensor + V V^T`), block stencil
+//   c  = y^T D^-1 y   (response_cache, BFN:45), ld = logdet D (BFN:55)
+// The reference densifies W^T (m x q) and adds a dense m x m outer product per
+// update; here each streamed point touches exactly its 4^d x 4^d stencil block.
+#include "wiski_common.h"
+
+// GRP = min(T, 64) lanes cooperate on one point (lane <-> tap a); each lane
+// walks all taps b and issues fire-and-forget L2 atomics on A_st[o(a,b)][idx_a].
+// Tap values are exchanged through LDS (broadcast reads, conflict-free).
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const real* __restrict__ x, const real* __restrict__ y,
+                                                       const real* __restrict__ wa, const real* __restrict__ wb,
+                                                       const real* __restrict__ noise, int64_t n, real* __restrict__ b,
+                                                       real* __restrict__ A_st, double* __restrict__ stats, int32_t* __restrict__ err) {
+  constexpr int T = 1 << (2 * D);
+  constexpr int GRP = T < 64 ? T : 64;      // lanes per point
+  constexpr int PPB = 256 / GRP;            // points per block pass
+  constexpr int TPL = T / GRP;              // taps per lane
+  __shared__ real s_val[PPB][T];
+  __shared__ double s_red[16];
+  const int sub = threadIdx.x % GRP;
+  const int loc = threadIdx.x / GRP;
+  int R = 1;
+#pragma unroll
+  for (int q = 0; q < D; ++q) R *= 7;
+  const int center = (R - 1) / 2;
+  double c_acc = 0, ld_acc = 0;
+  bool bad = false;
+
+  for (int64_t base = (int64_t)blockIdx.x * PPB; base < n; base += (int64_t)gridDim.x * PPB) {
+    const int64_t p = base + loc;
+    const bool valid = p < n;
+    int j0[D];
+    real w[D][4];
+    real yp = 0, wap = 0, wbp = 0;
+    if (valid) {
+      real xp[D];
+#pragma unroll
+      for (int q = 0; q < D; ++q) xp[q] = x[p * D + q];
+      if (!point_stencil<real, D>(G, xp, j0, w)) bad = true;
+      yp = y[p];
+      wap = wa[p];
+      wbp = wb[p];
+      if (sub == 0) {
+        c_acc += (double)yp * (double)yp * (double)wbp;
+        ld_acc += log((double)noise[p]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        j0[q] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[q][c] = 0;
+      }
+    }
+    int idx_a[TPL], code_a[TPL];
+    real val_a[TPL];
+#pragma unroll
+    for (int t = 0; t < TPL; ++t) {
+      const int a = sub + t * GRP;
+      int flat = 0, code = 0;
+      real v = (real)1;
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const int c = (a >> (2 * (D - 1 - q))) & 3;
+        flat += (j0[q] + c) * G.stride[q];
+        code = code * 7 + c;
+        v *= w[q][c];
+      }
+      idx_a[t] = flat;
+      code_a[t] = code;
+      val_a[t] = v;
+      s_val[loc][a] = v;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < TPL; ++t) {
+        if (val_a[t] != (real)0) {
+          atomic_add_real(b + idx_a[t], val_a[t] * yp * wbp);
+          if (A_st) {
+            const real va = val_a[t] * wap;
+            real* __restrict__ Arow = A_st + idx_a[t];
+            const int obase = center - code_a[t];
+#pragma unroll 4
+            for (int bb = 0; bb < T; ++bb) {
+              int codeb = 0;
+#pragma unroll
+              for (int q = 0; q < D; ++q) codeb = codeb * 7 + ((bb >> (2 * (D - 1 - q))) & 3);
+              const real vb = s_val[loc][bb];
+              if (vb != (real)0) atomic_add_real(Arow + (int64_t)(obase + codeb) * G.m, va * vb);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double c_tot = block_reduce_sum(c_acc, s_red);
+  double ld_tot = block_reduce_sum(ld_acc, s_red);
+  if (threadIdx.x == 0 && (c_tot != 0 || ld_tot != 0)) {
+    unsafeAtomicAdd(stats + 0, c_tot);
+    unsafeAtomicAdd(stats + 1, ld_tot);
+  }
+  if (bad) atomicOr(err, 1);
+}
+
+template <typename real>
+static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
+                        int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (n == 0) return WISKI_OK;
+  if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
+  const int grp = G.T < 64 ? G.T : 64;
+  const int64_t ppb = 256 / grp;
+  int64_t blocks = (n + ppb - 1) / ppb;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  dim3 grd((unsigned)blocks);
+#define CALL(DD) \
+  hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err)
+  WISKI_DISPATCH_D(G.d, CALL)
+#undef CALL
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
+extern "C" {
+int wiski_scatter_stats_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A, double* stats, int32_t* err, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A, stats, err, s);
+}
+int wiski_scatter_stats_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A, double* stats, int32_t* err, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A, stats, err, s);
+}
+}

@@ -1,0 +1,362 @@
+// Inducing-space operators and the preconditioned-CG posterior solve.
+//   stencil SpMV  : WtW @ V                (URLT:47-48) on the block-stencil form
+//   Kron-Toeplitz : Kuu @ V                (BFN:334-348,363-366)
+//   PCG           : (Kt^-1 + A)^-1 RHS     (CG branch of BFN:368-383)
+#include "wiski_common.h"
+
+#include <vector>
+
+// ---------------------------------------------------------- stencil SpMV ---
+// out[c][i] = beta*add[c][i] + sum_o A_st[o][i] * V[c][clamp(i + off(o))]
+// HBM-bound: A_st (R*m reals) is streamed exactly once, fully coalesced along
+// i; V (k*m reals) is re-read R times but stays L2 / MALL resident.  Entries
+// whose neighbour would leave the grid were never scattered (exact zeros), so
+// clamping the flat neighbour index keeps the loads legal without a branch.
+// DOT: also accumulates dots[c] += sum_i V[c][i] * out[c][i] (CG's p.Hp).
+template <typename real, int KC, bool DOT>
+__global__ __launch_bounds__(256) void k_stencil_spmv(GridDev<real> G, const real* __restrict__ A_st, const real* __restrict__ V,
+                                                      int k, const real* __restrict__ add, real beta, real* __restrict__ out,
+                                                      double* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_off = reinterpret_cast<int*>(smem);
+  const int R = G.R, m = G.m, d = G.d;
+  for (int o = threadIdx.x; o < R; o += blockDim.x) {
+    int rem = o, f = 0;
+    for (int q = d - 1; q >= 0; --q) {
+      int c = rem % 7;
+      rem /= 7;
+      f += (c - 3) * G.stride[q];
+    }
+    s_off[o] = f;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * KC;
+  real acc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) acc[c] = (real)0;
+  if (i < m) {
+    const real* __restrict__ a_ptr = A_st + i;
+#pragma unroll 8
+    for (int o = 0; o < R; ++o) {
+      const real a = a_ptr[(int64_t)o * m];
+      int j = i + s_off[o];
+      j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        if (c0 + c < k) acc[c] += a * V[(int64_t)(c0 + c) * m + j];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    double part = 0;
+    if (i < m && c0 + c < k) {
+      const int64_t e = (int64_t)(c0 + c) * m + i;
+      real r = acc[c];
+      if (add) r += beta * add[e];
+      out[e] = r;
+      if (DOT) part = (double)V[e] * (double)r;
+    }
+    if (DOT) {
+      double* s_red = reinterpret_cast<double*>(smem);
+      __syncthreads();
+      double tot = block_reduce_sum(part, s_red);
+      if (threadIdx.x == 0 && c0 + c < k) unsafeAtomicAdd(dots + c0 + c, tot);
+    }
+  }
+}
+
+template <typename real>
+static int launch_spmv(const GridDev<real>& G, const real* A_st, const real* V, int k, const real* add, real beta, real* out, double* dots,
+                       hipStream_t s) {
+  const int kc = k >= 4 ? 4 : (k >= 2 ? 2 : 1);
+  dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)((k + kc - 1) / kc));
+  size_t sh = (size_t)G.R * sizeof(int);
+  if (sh < 16 * sizeof(double)) sh = 16 * sizeof(double);
+#define SPMV(KC)                                                                                                            \
+  do {                                                                                                                      \
+    if (dots) hipLaunchKernelGGL((k_stencil_spmv<real, KC, true>), grd, dim3(256), sh, s, G, A_st, V, k, add, beta, out, dots); \
+    else hipLaunchKernelGGL((k_stencil_spmv<real, KC, false>), grd, dim3(256), sh, s, G, A_st, V, k, add, beta, out, dots);   \
+  } while (0)
+  if (kc == 4) SPMV(4);
+  else if (kc == 2) SPMV(2);
+  else SPMV(1);
+#undef SPMV
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// -------------------------------------------------- Kronecker-Toeplitz MVM --
+// One mode product of the d-way tensor view (pre, g, post):
+//   out[pp, i, s] = scale * sum_j tcol[|i-j|] * in[pp, j, s]
+// One thread per output element; the g reads per output are coalesced along s
+// (or broadcast along i for the last mode) and L2-resident (a column is m reals).
+// DOT: dots[c] += sum_e w[c][e] * out[c][e]   (CG's r.y on the last mode).
+template <typename real, bool DOT>
+__global__ __launch_bounds__(256) void k_toeplitz_mode(const real* __restrict__ tcol, int g, int post, int m, const real* __restrict__ in,
+                                                       real scale, real* __restrict__ out, const real* __restrict__ wvec,
+                                                       double* __restrict__ dots) {
+  __shared__ real s_t[256];
+  __shared__ double s_red[16];
+  for (int j = threadIdx.x; j < g; j += blockDim.x) s_t[j] = tcol[j];
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  double part = 0;
+  if (e < m) {
+    const int i = (e / post) % g;
+    const real* __restrict__ src = in + (int64_t)c * m + (e - i * post);
+    real acc = (real)0;
+#pragma unroll 4
+    for (int j = 0; j < g; ++j) {
+      const int lag = i > j ? i - j : j - i;
+      acc += s_t[lag] * src[(int64_t)j * post];
+    }
+    acc *= scale;
+    out[(int64_t)c * m + e] = acc;
+    if (DOT) part = (double)wvec[(int64_t)c * m + e] * (double)acc;
+  }
+  if (DOT) {
+    double tot = block_reduce_sum(part, s_red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dots + c, tot);
+  }
+}
+
+// out = scale * Kuu V ; tmp is a k*m scratch; out must not alias V.
+template <typename real>
+static int launch_kron(const GridDev<real>& G, const real* tcol, const real* V, int k, real scale, real* tmp, real* out, const real* wvec,
+                       double* dots, hipStream_t s) {
+  if (G.d > 1 && !tmp) return WISKI_E_BADARG;
+  for (int q = 0; q < G.d; ++q)
+    if (G.g[q] > 256) return WISKI_E_BADARG;
+  dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)k);
+  // ping-pong so that the last mode lands in `out`
+  const real* src = V;
+  int toff = 0;
+  for (int q = 0; q < G.d; ++q) {
+    const bool last = q == G.d - 1;
+    real* dst = ((G.d - 1 - q) % 2 == 0) ? out : tmp;
+    const real sc = last ? scale : (real)1;
+    if (last && dots)
+      hipLaunchKernelGGL((k_toeplitz_mode<real, true>), grd, dim3(256), 0, s, tcol + toff, G.g[q], G.stride[q], G.m, src, sc, dst, wvec, dots);
+    else
+      hipLaunchKernelGGL((k_toeplitz_mode<real, false>), grd, dim3(256), 0, s, tcol + toff, G.g[q], G.stride[q], G.m, src, sc, dst, wvec, dots);
+    src = dst;
+    toff += G.g[q];
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// -------------------------------------------------------------------- PCG ---
+// scalar slots (double): S[0..k) = ||rhs||^2 ; then per iteration slot
+// it in [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
+struct PcgScal {
+  double* base;
+  int k;
+  __host__ __device__ double* rn0() const { return base; }
+  __host__ __device__ double* rho(int it) const { return base + (int64_t)k * (1 + 3 * it); }
+  __host__ __device__ double* php(int it) const { return base + (int64_t)k * (2 + 3 * it); }
+  __host__ __device__ double* rn(int it) const { return base + (int64_t)k * (3 + 3 * it); }
+};
+
+// r = rhs - t (t may be NULL => r = rhs); rn0 += rhs^2 ; rn(0) += r^2
+template <typename real>
+__global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, real* __restrict__ r,
+                                                  PcgScal S) {
+  __shared__ double s_red[16];
+  const int c = blockIdx.y;
+  double a = 0, bsum = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const int64_t e = (int64_t)c * m + i;
+    const real f = rhs[e];
+    const real rr = t ? f - t[e] : f;
+    r[e] = rr;
+    a += (double)f * f;
+    bsum += (double)rr * rr;
+  }
+  a = block_reduce_sum(a, s_red);
+  bsum = block_reduce_sum(bsum, s_red);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(S.rn0() + c, a);
+    unsafeAtomicAdd(S.rn(0) + c, bsum);
+  }
+}
+
+__device__ __forceinline__ bool pcg_active(const PcgScal& S, int it, int c, double tol2) {
+  // column still iterating? (rn of the previous slot against the rhs norm)
+  const double rn0 = S.rn0()[c];
+  return rn0 > 0 && S.rn(it)[c] > tol2 * rn0;
+}
+
+// p = y + beta p ; pt = r + beta pt ; beta = rho(it)/rho(it-1)
+template <typename real>
+__global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2, const real* __restrict__ y, const real* __restrict__ r,
+                                                      real* __restrict__ p, real* __restrict__ pt, PcgScal S) {
+  const int c = blockIdx.y;
+  double beta = 0;
+  if (it > 0) {
+    const double den = S.rho(it - 1)[c];
+    beta = den > 0 ? S.rho(it)[c] / den : 0;
+  }
+  const real bt = (real)beta;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const int64_t e = (int64_t)c * m + i;
+    if (it == 0) { p[e] = y[e]; pt[e] = r[e]; }
+    else { p[e] = y[e] + bt * p[e]; pt[e] = r[e] + bt * pt[e]; }
+  }
+}
+
+// alpha = rho/php ; u += alpha p ; z += alpha pt ; r -= alpha hp ; rn(it+1) += r^2
+template <typename real>
+__global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2, const real* __restrict__ p, const real* __restrict__ pt,
+                                                      const real* __restrict__ hp, real* __restrict__ u, real* __restrict__ z,
+                                                      real* __restrict__ r, PcgScal S) {
+  __shared__ double s_red[16];
+  const int c = blockIdx.y;
+  double alpha = 0;
+  const double den = S.php(it)[c];
+  if (pcg_active(S, it, c, tol2) && den > 0) alpha = S.rho(it)[c] / den;
+  const real al = (real)alpha;
+  double acc = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const int64_t e = (int64_t)c * m + i;
+    u[e] += al * p[e];
+    z[e] += al * pt[e];
+    const real rr = r[e] - al * hp[e];
+    r[e] = rr;
+    acc += (double)rr * rr;
+  }
+  acc = block_reduce_sum(acc, s_red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(S.rn(it + 1) + c, acc);
+}
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+static int64_t pcg_ws_bytes(int m, int k, int max_iter, int es) {
+  int64_t vec = align_up((int64_t)k * m * es, 256);
+  int64_t scal = align_up((int64_t)k * (1 + 3 * (int64_t)(max_iter + 2)) * 8, 256);
+  return 6 * vec + scal;
+}
+
+template <typename real>
+static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_RHS, int32_t k, real* d_U,
+                    real* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes,
+                    int32_t* h_iters, double* h_relres, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_A || !d_tcol || !d_RHS || !d_U || !d_Z || !d_work || k < 1 || max_iter < 1) return WISKI_E_BADARG;
+  if (work_bytes < pcg_ws_bytes(G.m, k, max_iter, (int)sizeof(real))) return WISKI_E_WORKSPACE;
+  if (check_every < 1) check_every = 10;
+  hipStream_t s = (hipStream_t)stream;
+  const int m = G.m;
+  const int64_t vec = align_up((int64_t)k * m * sizeof(real), 256);
+  char* w = (char*)d_work;
+  real* r = (real*)(w + 0 * vec);
+  real* y = (real*)(w + 1 * vec);
+  real* p = (real*)(w + 2 * vec);
+  real* pt = (real*)(w + 3 * vec);
+  real* hp = (real*)(w + 4 * vec);
+  real* tmp = (real*)(w + 5 * vec);
+  PcgScal S{(double*)(w + 6 * vec), k};
+  const int64_t scal_bytes = (int64_t)k * (1 + 3 * (int64_t)(max_iter + 2)) * 8;
+  if (hipMemsetAsync(S.base, 0, scal_bytes, s) != hipSuccess) return WISKI_E_LAUNCH;
+  const double tol2 = tol * tol;
+  int eb = (m + 255) / 256;
+  if (eb > 1024) eb = 1024;
+  dim3 egrid((unsigned)eb, (unsigned)k);
+
+  if (warm) {
+    // r0 = rhs - (z + A u)
+    rc = launch_spmv<real>(G, d_A, d_U, k, d_Z, (real)1, hp, nullptr, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, r, S);
+  } else {
+    if (hipMemsetAsync(d_U, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+    if (hipMemsetAsync(d_Z, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, r, S);
+  }
+
+  std::vector<double> h_rn0(k), h_rn(k);
+  auto fetch = [&](int slot) -> int {
+    if (hipMemcpyAsync(h_rn0.data(), S.rn0(), k * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return WISKI_E_LAUNCH;
+    if (hipMemcpyAsync(h_rn.data(), S.rn(slot), k * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return WISKI_E_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;
+    return WISKI_OK;
+  };
+  auto converged = [&]() {
+    for (int c = 0; c < k; ++c)
+      if (h_rn0[c] > 0 && h_rn[c] > tol2 * h_rn0[c]) return false;
+    return true;
+  };
+
+  int it = 0;
+  bool done = false;
+  if (warm) {
+    rc = fetch(0);
+    if (rc) return rc;
+    done = converged();
+  }
+  while (!done && it < max_iter) {
+    // y = Kt r, rho(it) = r.y
+    rc = launch_kron<real>(G, d_tcol, r, k, kscale, tmp, y, r, S.rho(it), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_pcg_update_p<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
+    // hp = pt + A p, php(it) = p.hp
+    rc = launch_spmv<real>(G, d_A, p, k, pt, (real)1, hp, S.php(it), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_pcg_update_x<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp, d_U, d_Z,
+                       r, S);
+    ++it;
+    if (it % check_every == 0 || it == max_iter) {
+      rc = fetch(it);
+      if (rc) return rc;
+      done = converged();
+    }
+  }
+  if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
+  if (it == 0) {
+    rc = fetch(0);
+    if (rc) return rc;
+  }
+  if (h_iters) *h_iters = it;
+  if (h_relres)
+    for (int c = 0; c < k; ++c) h_relres[c] = h_rn0[c] > 0 ? sqrt(h_rn[c] / h_rn0[c]) : 0.0;
+  return done ? WISKI_OK : WISKI_E_NOTCONV;
+}
+
+template <typename real>
+static int spmv_impl(const wiski_grid* grid, const real* d_A, const real* d_V, int32_t k, const real* d_add, real beta, real* d_out, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_A || !d_V || !d_out || k < 1) return WISKI_E_BADARG;
+  return launch_spmv<real>(G, d_A, d_V, k, d_add, beta, d_out, nullptr, (hipStream_t)stream);
+}
+
+template <typename real>
+static int kron_impl(const wiski_grid* grid, const real* d_tcol, const real* d_V, int32_t k, real scale, real* d_tmp, real* d_out, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_tcol || !d_V || !d_out || k < 1 || d_out == d_V) return WISKI_E_BADARG;
+  return launch_kron<real>(G, d_tcol, d_V, k, scale, d_tmp, d_out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" {
+int wiski_stencil_spmv_f32(const wiski_grid* g, const float* A, const float* V, int32_t k, const float* add, float beta, float* out, void* s) { return spmv_impl<float>(g, A, V, k, add, beta, out, s); }
+int wiski_stencil_spmv_f64(const wiski_grid* g, const double* A, const double* V, int32_t k, const double* add, double beta, double* out, void* s) { return spmv_impl<double>(g, A, V, k, add, beta, out, s); }
+int wiski_kron_toeplitz_mm_f32(const wiski_grid* g, const float* tcol, const float* V, int32_t k, float scale, float* tmp, float* out, void* s) { return kron_impl<float>(g, tcol, V, k, scale, tmp, out, s); }
+int wiski_kron_toeplitz_mm_f64(const wiski_grid* g, const double* tcol, const double* V, int32_t k, double scale, double* tmp, double* out, void* s) { return kron_impl<double>(g, tcol, V, k, scale, tmp, out, s); }
+int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size) {
+  if (!grid || grid->d < 1 || grid->d > WISKI_MAX_DIM || k < 1 || max_iter < 1) return WISKI_E_BADARG;
+  int64_t m = 1;
+  for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
+  return pcg_ws_bytes((int)m, k, max_iter, elem_size);
+}
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+}
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+}
+}

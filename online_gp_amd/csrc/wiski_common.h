@@ -1,0 +1,149 @@
+// Shared device helpers for libwiski_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wiski.h"
+
+#define WISKI_VERSION 1
+
+// Grid geometry as a by-value kernel argument (lives in SGPRs / kernarg).
+template <typename real>
+struct GridDev {
+  int d;
+  int g[WISKI_MAX_DIM];
+  int stride[WISKI_MAX_DIM];  // flat stride of dim q (dim 0 slowest)
+  real g0[WISKI_MAX_DIM];
+  real h[WISKI_MAX_DIM];
+  real hi[WISKI_MAX_DIM];     // last grid point
+  int m;                      // prod g
+  int T;                      // 4^d taps
+  int R;                      // 7^d stencil offsets
+};
+
+template <typename real>
+static inline int make_grid_dev(const wiski_grid* grid, GridDev<real>* out) {
+  if (!grid || grid->d < 1 || grid->d > WISKI_MAX_DIM) return WISKI_E_BADARG;
+  GridDev<real> G;
+  G.d = grid->d;
+  int64_t m = 1;
+  G.T = 1;
+  G.R = 1;
+  for (int q = 0; q < WISKI_MAX_DIM; ++q) {
+    G.g[q] = q < grid->d ? grid->g[q] : 1;
+    G.g0[q] = q < grid->d ? (real)grid->g0[q] : (real)0;
+    G.h[q] = q < grid->d ? (real)grid->h[q] : (real)1;
+    G.hi[q] = G.g0[q] + G.h[q] * (real)(G.g[q] - 1);
+    if (q < grid->d) {
+      if (grid->g[q] < 4) return WISKI_E_BADARG;
+      m *= grid->g[q];
+      G.T *= 4;
+      G.R *= 7;
+    }
+  }
+  if (m >= (int64_t)1 << 31) return WISKI_E_BADARG;
+  G.m = (int)m;
+  int s = 1;
+  for (int q = WISKI_MAX_DIM - 1; q >= 0; --q) {
+    G.stride[q] = s;
+    s *= G.g[q];
+  }
+  *out = G;
+  return WISKI_OK;
+}
+
+// Keys cubic convolution kernel (a = -0.5).
+template <typename real>
+__device__ __forceinline__ real keys_cubic(real s) {
+  real a = s < (real)0 ? -s : s;
+  real near = (((real)1.5 * a - (real)2.5) * a) * a + (real)1;
+  real far = (((real)-0.5 * a + (real)2.5) * a - (real)4) * a + (real)2;
+  return a <= (real)1 ? near : (a < (real)2 ? far : (real)0);
+}
+
+// 4-tap stencil of one coordinate: lowest tap index (or -1 if outside the
+// grid) and weights.  Boundary cells collapse to a one-hot on the nearest of
+// the first/last four grid points (gpytorch Interpolation.interpolate).
+template <typename real>
+__device__ __forceinline__ int dim_stencil(real x, real g0, real h, real hi, int g, real w[4]) {
+  real u = (x - g0) / h;
+  real fl = floor(u);
+  real t = u - fl;
+  int j0 = (int)fl - 1;
+  bool oob = !(x >= g0 && x <= hi);
+  w[0] = keys_cubic<real>(t + (real)1);
+  w[1] = keys_cubic<real>(t);
+  w[2] = keys_cubic<real>(t - (real)1);
+  w[3] = keys_cubic<real>(t - (real)2);
+  if (j0 < 0 || j0 > g - 4) {
+    int base = j0 < 0 ? 0 : g - 4;
+    int best = 0;
+    real bd = (real)3.0e38;
+    for (int c = 0; c < 4; ++c) {
+      real dd = g0 + h * (real)(base + c) - x;
+      dd = dd < (real)0 ? -dd : dd;
+      if (dd < bd) { bd = dd; best = c; }
+    }
+    for (int c = 0; c < 4; ++c) w[c] = (c == best) ? (real)1 : (real)0;
+    j0 = base;
+  }
+  return oob ? -1 : j0;
+}
+
+// Per-point stencil for all dims. Returns false (and leaves a safe stencil
+// with zero weights) when the point is outside the grid.
+template <typename real, int D>
+__device__ __forceinline__ bool point_stencil(const GridDev<real>& G, const real* __restrict__ xp, int j0[D], real w[D][4]) {
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    int j = dim_stencil<real>(xp[q], G.g0[q], G.h[q], G.hi[q], G.g[q], w[q]);
+    if (j < 0) {
+      ok = false;
+      j = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[q][c] = (real)0;
+    }
+    j0[q] = j;
+  }
+  return ok;
+}
+
+__device__ __forceinline__ void atomic_add_real(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_real(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum of a double; result valid in thread 0. `sm` needs >= 16 doubles.
+__device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
+  v = wave_reduce_sum<double>(v);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+#define WISKI_LAUNCH_CHECK()                          \
+  do {                                                \
+    if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH; \
+  } while (0)
+
+#define WISKI_DISPATCH_D(d, CALL) \
+  switch (d) {                    \
+    case 1: { CALL(1); break; }   \
+    case 2: { CALL(2); break; }   \
+    case 3: { CALL(3); break; }   \
+    case 4: { CALL(4); break; }   \
+    default: return WISKI_E_BADARG; \
+  }

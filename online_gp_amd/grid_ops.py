@@ -1,0 +1,192 @@
+"""Torch-tensor front-end of the C ABI (include/wiski.h): one function per
+entry point, device pointers borrowed from contiguous ROCm tensors, launches on
+torch's current stream.  Host-side plumbing only -- all arithmetic happens in
+the HIP kernels under csrc/.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _hip
+
+
+class GridSpec:
+    """Inducing-grid geometry.  Mirrors gpytorch's GridInterpolationKernel grid
+    (reference call site online_gp/models/batched_fixed_noise_online_gp.py:114-120):
+    ``delta=(hi-lo)/(g-2)``, ``grid=linspace(lo-delta, hi+delta, g)``."""
+
+    def __init__(self, grid_bounds, grid_size):
+        gb = [[float(lo), float(hi)] for lo, hi in (torch.as_tensor(grid_bounds, dtype=torch.float64).reshape(-1, 2).tolist())]
+        d = len(gb)
+        if not 1 <= d <= _hip.MAX_DIM:
+            raise ValueError(f"grid dimension must be 1..{_hip.MAX_DIM}, got {d}")
+        if isinstance(grid_size, int):
+            g = [grid_size] * d
+        else:
+            g = [int(v) for v in grid_size]
+        if len(g) != d:
+            raise ValueError("grid_size / grid_bounds mismatch")
+        if min(g) < 4:
+            raise ValueError("cubic interpolation needs at least 4 grid points per dim")
+        self.d = d
+        self.g = g
+        self.grid_bounds = gb
+        delta = [(hi - lo) / (gi - 2) for (lo, hi), gi in zip(gb, g)]
+        self.g0 = [lo - dl for (lo, hi), dl in zip(gb, delta)]
+        self.h = [((hi + dl) - g0) / (gi - 1) for (lo, hi), dl, g0, gi in zip(gb, delta, self.g0, g)]
+        self.m = int(math.prod(g))
+        self.T = 4 ** d
+        self.R = 7 ** d
+        c = _hip.wiski_grid()
+        c.d = d
+        for q in range(d):
+            c.g[q] = g[q]
+            c.g0[q] = self.g0[q]
+            c.h[q] = self.h[q]
+        self.c = c
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    def grid_points(self, dtype=torch.float64, device="cpu"):
+        """Per-dim 1-D grids (list of d tensors), as gpytorch's ``covar_module.grid``."""
+        return [self.g0[q] + self.h[q] * torch.arange(self.g[q], dtype=dtype, device=device) for q in range(self.d)]
+
+    def stencil_offsets(self, device="cpu"):
+        offs = torch.zeros(1, dtype=torch.int64)
+        stride = [int(math.prod(self.g[q + 1:])) for q in range(self.d)]
+        for q in range(self.d):
+            offs = (offs[:, None] + (torch.arange(7) - 3)[None, :] * stride[q]).reshape(-1)
+        return offs.to(device)
+
+
+def new_err_flag(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def _x2d(x, grid):
+    if x.dim() != 2 or x.shape[1] != grid.d:
+        raise ValueError(f"expected inputs of shape [n, {grid.d}], got {tuple(x.shape)}")
+    return x.contiguous()
+
+
+def interp(grid, x, err):
+    """(idx int32 [n,T], val [n,T]) -- a1."""
+    x = _x2d(x, grid)
+    n = x.shape[0]
+    idx = torch.empty((n, grid.T), dtype=torch.int32, device=x.device)
+    val = torch.empty((n, grid.T), dtype=x.dtype, device=x.device)
+    rc = _hip.fn("wiski_interp", x.dtype)(grid.ref, _hip.dptr(x), ctypes.c_int64(n), _hip.dptr(idx), _hip.dptr(val), _hip.dptr(err),
+                                          _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_interp")
+    return idx, val
+
+
+def gather(grid, x, V, err, diag=False):
+    """W(x) @ V for V given as [k, m]; returns [n, k] (or [n] when diag) -- a14."""
+    x = _x2d(x, grid)
+    V = V.contiguous()
+    if V.dim() == 1:
+        V = V[None]
+    k = V.shape[0]
+    n = x.shape[0]
+    assert V.shape[1] == grid.m and V.dtype == x.dtype
+    out = torch.empty((n,) if diag else (n, k), dtype=x.dtype, device=x.device)
+    rc = _hip.fn("wiski_gather", x.dtype)(grid.ref, _hip.dptr(x), ctypes.c_int64(n), _hip.dptr(V), ctypes.c_int32(k), ctypes.c_int32(int(diag)),
+                                          _hip.dptr(out), _hip.dptr(err), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_gather")
+    return out
+
+
+def gather_ell(idx, val, v):
+    n, T = idx.shape
+    out = torch.empty((n,), dtype=val.dtype, device=val.device)
+    rc = _hip.fn("wiski_gather_ell", val.dtype)(_hip.dptr(idx), _hip.dptr(val), ctypes.c_int64(n), ctypes.c_int32(T), _hip.dptr(v.contiguous()),
+                                                _hip.dptr(out), _hip.stream_ptr(val.device))
+    _hip.check(rc, "wiski_gather_ell")
+    return out
+
+
+def scatter_stats(grid, x, y, wa, wb, noise, b, A_st, stats, err):
+    """In-place accumulation of (b, A_st, stats) -- a3/a4/a5."""
+    x = _x2d(x, grid)
+    n = x.shape[0]
+    rc = _hip.fn("wiski_scatter_stats", x.dtype)(grid.ref, _hip.dptr(x), _hip.dptr(y.contiguous()), _hip.dptr(wa.contiguous()),
+                                                 _hip.dptr(wb.contiguous()), _hip.dptr(noise.contiguous()), ctypes.c_int64(n), _hip.dptr(b),
+                                                 _hip.dptr(A_st), _hip.dptr(stats), _hip.dptr(err), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_scatter_stats")
+
+
+def wt_columns(grid, x, err):
+    """Dense columns of W(x)^T: [n, m]."""
+    x = _x2d(x, grid)
+    out = torch.zeros((x.shape[0], grid.m), dtype=x.dtype, device=x.device)
+    rc = _hip.fn("wiski_wt_columns", x.dtype)(grid.ref, _hip.dptr(x), ctypes.c_int64(x.shape[0]), _hip.dptr(out), _hip.dptr(err),
+                                              _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_wt_columns")
+    return out
+
+
+def stencil_spmv(grid, A_st, V, add=None, beta=1.0):
+    V2 = V.contiguous().reshape(-1, grid.m)
+    out = torch.empty_like(V2)
+    cr = _hip.creal(V2.dtype)
+    rc = _hip.fn("wiski_stencil_spmv", V2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(V2), ctypes.c_int32(V2.shape[0]),
+                                                 _hip.dptr(add.contiguous().reshape(-1, grid.m)) if add is not None else None, cr(beta),
+                                                 _hip.dptr(out), _hip.stream_ptr(V2.device))
+    _hip.check(rc, "wiski_stencil_spmv")
+    return out.reshape(V.shape)
+
+
+def kron_toeplitz_mm(grid, tcol, V, scale=1.0):
+    V2 = V.contiguous().reshape(-1, grid.m)
+    out = torch.empty_like(V2)
+    tmp = torch.empty_like(V2) if grid.d > 1 else None
+    cr = _hip.creal(V2.dtype)
+    rc = _hip.fn("wiski_kron_toeplitz_mm", V2.dtype)(grid.ref, _hip.dptr(tcol.contiguous()), _hip.dptr(V2), ctypes.c_int32(V2.shape[0]), cr(scale),
+                                                     _hip.dptr(tmp), _hip.dptr(out), _hip.stream_ptr(V2.device))
+    _hip.check(rc, "wiski_kron_toeplitz_mm")
+    return out.reshape(V.shape)
+
+
+class PCGWorkspace:
+    """Device scratch for wiski_pcg, cached per (k, max_iter)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, grid, k, max_iter, dtype, device):
+        es = 4 if dtype == torch.float32 else 8
+        need = int(_hip.lib().wiski_pcg_workspace_bytes(grid.ref, ctypes.c_int32(k), ctypes.c_int32(max_iter), ctypes.c_int32(es)))
+        if need < 0:
+            raise _hip.WiskiError("wiski_pcg_workspace_bytes: bad arguments")
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=device)
+        return self.buf, need
+
+
+def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
+        raise_on_fail=False):
+    """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres)."""
+    RHS2 = RHS.contiguous().reshape(-1, grid.m)
+    k = RHS2.shape[0]
+    if U is None or Z is None or not warm:
+        U = torch.empty_like(RHS2)
+        Z = torch.empty_like(RHS2)
+        warm = False
+    ws = workspace if workspace is not None else PCGWorkspace()
+    buf, need = ws.get(grid, k, max_iter, RHS2.dtype, RHS2.device)
+    iters = ctypes.c_int32(0)
+    relres = (ctypes.c_double * k)()
+    cr = _hip.creal(RHS2.dtype)
+    rc = _hip.fn("wiski_pcg", RHS2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(RHS2), ctypes.c_int32(k),
+                                          _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
+                                          ctypes.c_int32(check_every), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres,
+                                          _hip.stream_ptr(RHS2.device))
+    if rc == -4 and not raise_on_fail:
+        pass
+    else:
+        _hip.check(rc, "wiski_pcg")
+    return U, Z, int(iters.value), list(relres)

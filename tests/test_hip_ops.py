@@ -1,0 +1,155 @@
+"""GPU parity of every C-ABI entry point against the CPU oracle (oracle/)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cport, spec
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(1, 20), (2, 12), (3, 9), (4, 6)]
+DTYPES = [(torch.float64, np.float64, 1e-11), (torch.float32, np.float32, 2e-4)]
+
+
+def _setup(d, g, tdt, ndt, n=200, seed=0):
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(seed)
+    gb = [[-1.1, 1.1]] * d
+    grid = grid_ops.GridSpec(gb, g)
+    X = rng.uniform(-1.1, 1.1, (n, d)).astype(ndt)  # includes boundary cells
+    y = rng.standard_normal(n).astype(ndt)
+    noise = rng.uniform(0.5, 2.0, n).astype(ndt)
+    B2 = cport.MatrixFreeWISKI(gb, g, sigma2=0.5, dtype=np.float64)
+    return grid, X, y, noise, B2, rng
+
+
+def _t(a, tdt):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", tdt)
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
+def test_interp(d, g, tdt, ndt, tol):
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
+    err = grid_ops.new_err_flag("cuda")
+    idx, val = grid_ops.interp(grid, _t(X, tdt), err)
+    ridx, rval = B2.interp(X.astype(np.float64))
+    assert int(err.item()) == 0
+    # compare as dense rows (boundary ties / fp32 cell flips move taps, not the row)
+    Wg = np.zeros((X.shape[0], grid.m)); Wr = np.zeros_like(Wg)
+    for p in range(X.shape[0]):
+        np.add.at(Wg[p], idx[p].cpu().numpy(), val[p].double().cpu().numpy())
+        np.add.at(Wr[p], ridx[p], rval[p])
+    assert np.abs(Wg - Wr).max() < max(tol, 1e-12) * 10
+    if tdt == torch.float64:
+        assert np.array_equal(idx.cpu().numpy(), ridx.astype(np.int32))
+
+
+def test_interp_out_of_bounds_flag():
+    from online_gp_amd import grid_ops
+
+    grid = grid_ops.GridSpec([[-1.0, 1.0]] * 2, 8)
+    err = grid_ops.new_err_flag("cuda")
+    x = torch.tensor([[0.0, 0.0], [5.0, 0.0]], device="cuda", dtype=torch.float64)
+    grid_ops.interp(grid, x, err)
+    assert int(err.item()) != 0
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
+def test_gather_and_ell(d, g, tdt, ndt, tol):
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
+    V = rng.standard_normal((3, grid.m)).astype(ndt)
+    err = grid_ops.new_err_flag("cuda")
+    out = grid_ops.gather(grid, _t(X, tdt), _t(V, tdt), err)
+    ref = B2.gather(X.astype(np.float64), V.astype(np.float64))
+    scale = np.abs(ref).max()
+    assert np.abs(out.double().cpu().numpy() - ref).max() < tol * scale * 10
+    idx, val = grid_ops.interp(grid, _t(X, tdt), err)
+    out1 = grid_ops.gather_ell(idx, val, _t(V[0], tdt))
+    assert np.abs(out1.double().cpu().numpy() - ref[:, 0]).max() < tol * scale * 10
+    # diag form: column p for query p
+    Vd = rng.standard_normal((X.shape[0], grid.m)).astype(ndt)
+    outd = grid_ops.gather(grid, _t(X, tdt), _t(Vd, tdt), err, diag=True)
+    refd = np.einsum("pk,pk->p", B2.gather(X.astype(np.float64), Vd.astype(np.float64)), np.eye(X.shape[0]))
+    assert np.abs(outd.double().cpu().numpy() - refd).max() < tol * np.abs(refd).max() * 10
+    assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
+def test_scatter_stats(d, g, tdt, ndt, tol):
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
+    B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
+    err = grid_ops.new_err_flag("cuda")
+    b = torch.zeros(grid.m, device="cuda", dtype=tdt)
+    A = torch.zeros((grid.R, grid.m), device="cuda", dtype=tdt)
+    stats = torch.zeros(2, device="cuda", dtype=torch.float64)
+    w = _t(1.0 / noise.astype(np.float64), tdt)
+    grid_ops.scatter_stats(grid, _t(X, tdt), _t(y, tdt), w, w, _t(noise, tdt), b, A, stats, err)
+    assert int(err.item()) == 0
+    assert np.abs(b.double().cpu().numpy() - B2.b).max() < tol * np.abs(B2.b).max() * 10
+    assert np.abs(A.double().cpu().numpy() - B2.A).max() < tol * np.abs(B2.A).max() * 10
+    assert np.allclose(stats.cpu().numpy(), B2.c_ld, rtol=max(tol, 1e-12) * 10)
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
+def test_spmv_and_kron(d, g, tdt, ndt, tol):
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
+    B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
+    for k in (1, 3, 5):
+        V = rng.standard_normal((k, grid.m)).astype(ndt)
+        add = rng.standard_normal((k, grid.m)).astype(ndt)
+        out = grid_ops.stencil_spmv(grid, _t(B2.A, tdt), _t(V, tdt), _t(add, tdt), 0.7)
+        ref = B2.stencil_mv(V.astype(np.float64)) + 0.7 * add.astype(np.float64)
+        assert np.abs(out.double().cpu().numpy() - ref).max() < tol * np.abs(ref).max() * 10
+        outk = grid_ops.kron_toeplitz_mm(grid, _t(B2.tcol, tdt), _t(V, tdt), 1.3)
+        refk = B2.kuu_mv(V.astype(np.float64), 1.3)
+        assert np.abs(outk.double().cpu().numpy() - refk).max() < tol * np.abs(refk).max() * 10
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-8), (torch.float32, np.float32, 2e-3)])
+def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol):
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
+    B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
+    RHS = np.stack([B2.b, rng.standard_normal(grid.m)])
+    Uref, _, _ = B2.solve(RHS, tol=1e-13)
+    cg_tol = 1e-10 if tdt == torch.float64 else 1e-6
+    A = _t(B2.A, tdt); tc = _t(B2.tcol, tdt)
+    U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=cg_tol, max_iter=500, check_every=5)
+    assert max(res) < cg_tol * 1.01, (it, res)
+    assert np.abs(U.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
+    # U = Kt Z
+    KZ = grid_ops.kron_toeplitz_mm(grid, tc, Z, 1.0 / B2.sigma2)
+    assert (KZ - U).abs().max().item() < 50 * tol * U.abs().max().item()
+    # warm start from the solution converges immediately
+    U2, Z2, it2, res2 = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), U=U.clone(), Z=Z.clone(), warm=True, tol=cg_tol * 10,
+                                     max_iter=500, check_every=5)
+    assert it2 <= 5
+    assert np.abs(U2.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
+
+
+def test_wt_columns():
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(3, 9, torch.float64, np.float64, n=17)
+    err = grid_ops.new_err_flag("cuda")
+    Wt = grid_ops.wt_columns(grid, _t(X, torch.float64), err)
+    idx, val = B2.interp(X)
+    ref = np.zeros((17, grid.m))
+    for p in range(17):
+        np.add.at(ref[p], idx[p], val[p])
+    assert np.abs(Wt.cpu().numpy() - ref).max() < 1e-13
