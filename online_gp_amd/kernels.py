@@ -1,0 +1,168 @@
+"""Minimal stationary-kernel modules with gpytorch's parameterisation, enough for
+the WISKI hot path to run without gpytorch (absent from this image).
+
+Only what the path reads is reproduced: raw parameters under a softplus
+(`Positive`) constraint initialised at 0 (=> 0.6931), ``lengthscale`` /
+``outputscale`` properties with setters, ``batch_shape`` for independent
+hyper-parameters per output (reference
+online_gp/models/batched_fixed_noise_online_gp.py:107-120), and the
+``GridInterpolationKernel`` attributes the reference touches (``grid``,
+``grid_bounds``, ``grid_sizes``, ``base_kernel``, ``num_dims``).
+The grid kernel itself is never formed: :meth:`GridInterpolationKernel.toeplitz_columns`
+returns the first columns of the d symmetric-Toeplitz Kronecker factors
+(ScaleKernel inside => outputscale enters once per dim, i.e. s**d overall).
+"""
+import math
+
+import torch
+from torch.nn.functional import softplus
+
+from .grid_ops import GridSpec
+
+
+def inv_softplus(x):
+    x = torch.as_tensor(x, dtype=torch.float64)
+    return x + torch.log(-torch.expm1(-x))
+
+
+class Kernel(torch.nn.Module):
+    has_lengthscale = False
+
+    def __init__(self, ard_num_dims=None, batch_shape=torch.Size([]), **kwargs):
+        super().__init__()
+        self.ard_num_dims = ard_num_dims
+        self.batch_shape = torch.Size(batch_shape) if not isinstance(batch_shape, int) else torch.Size([batch_shape])
+        if self.has_lengthscale:
+            nd = 1 if ard_num_dims is None else ard_num_dims
+            self.register_parameter("raw_lengthscale", torch.nn.Parameter(torch.zeros(self.batch_shape + torch.Size([1, nd]))))
+
+    @property
+    def lengthscale(self):
+        return softplus(self.raw_lengthscale) if self.has_lengthscale else None
+
+    @lengthscale.setter
+    def lengthscale(self, value):
+        v = torch.as_tensor(value, dtype=torch.float64).expand(self.raw_lengthscale.shape)
+        with torch.no_grad():
+            self.raw_lengthscale.copy_(inv_softplus(v).to(self.raw_lengthscale))
+
+    # k(r), r = |x - x'| / lengthscale
+    def profile(self, r):
+        raise NotImplementedError
+
+    def lag_column(self, dim, lags, batch_index=None):
+        """Covariance between two points `lags` apart along input dim `dim`
+        (what gpytorch evaluates with last_dim_is_batch=True on the grid)."""
+        ls = self.lengthscale
+        if batch_index is not None and ls.dim() > 2:
+            ls = ls[batch_index]
+        ls = ls.reshape(-1)
+        ell = ls[dim] if ls.numel() > 1 else ls[0]
+        return self.profile(lags / ell)
+
+
+class RBFKernel(Kernel):
+    has_lengthscale = True
+
+    def profile(self, r):
+        return torch.exp(-0.5 * r * r)
+
+
+class MaternKernel(Kernel):
+    has_lengthscale = True
+
+    def __init__(self, nu=2.5, **kwargs):
+        if nu not in (0.5, 1.5, 2.5):
+            raise RuntimeError("nu expected to be 0.5, 1.5, or 2.5")
+        super().__init__(**kwargs)
+        self.nu = nu
+
+    def profile(self, r):
+        if self.nu == 0.5:
+            return torch.exp(-r)
+        if self.nu == 1.5:
+            s = math.sqrt(3.0) * r
+            return (1.0 + s) * torch.exp(-s)
+        s = math.sqrt(5.0) * r
+        return (1.0 + s + s * s / 3.0) * torch.exp(-s)
+
+
+class ScaleKernel(Kernel):
+    def __init__(self, base_kernel, batch_shape=torch.Size([]), **kwargs):
+        super().__init__(batch_shape=batch_shape)
+        self.base_kernel = base_kernel
+        self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(self.batch_shape)))
+
+    @property
+    def outputscale(self):
+        return softplus(self.raw_outputscale)
+
+    @outputscale.setter
+    def outputscale(self, value):
+        v = torch.as_tensor(value, dtype=torch.float64).expand(self.raw_outputscale.shape)
+        with torch.no_grad():
+            self.raw_outputscale.copy_(inv_softplus(v).to(self.raw_outputscale))
+
+    def lag_column(self, dim, lags, batch_index=None):
+        s = self.outputscale
+        if batch_index is not None and s.dim() > 0:
+            s = s[batch_index]
+        return s * self.base_kernel.lag_column(dim, lags, batch_index)
+
+
+def _lag_column_any(kernel, dim, lags, num_dims, batch_index=None):
+    """Toeplitz column of `kernel` along `dim`.  Native kernels use their closed
+    form; foreign (e.g. gpytorch) kernels are evaluated on grid points directly."""
+    if isinstance(kernel, Kernel):
+        return kernel.lag_column(dim, lags, batch_index)
+    # duck-typed stationary kernel object: evaluate k(0, lag) with last_dim_is_batch
+    x1 = torch.zeros(1, num_dims, dtype=lags.dtype, device=lags.device)
+    x2 = torch.zeros(lags.numel(), num_dims, dtype=lags.dtype, device=lags.device)
+    x2[:, dim] = lags
+    out = kernel(x1, x2, last_dim_is_batch=True)
+    out = out.evaluate() if hasattr(out, "evaluate") else (out.to_dense() if hasattr(out, "to_dense") else out)
+    out = out[..., dim, 0, :]
+    if batch_index is not None and out.dim() > 1:
+        out = out[batch_index]
+    return out.reshape(-1)
+
+
+class GridInterpolationKernel(Kernel):
+    """Structured-kernel-interpolation wrapper: holds the inducing grid and the
+    base kernel.  ``grid_size`` counts gpytorch's two extension points per dim."""
+
+    def __init__(self, base_kernel, grid_size, num_dims=None, grid_bounds=None, **kwargs):
+        super().__init__()
+        if grid_bounds is None:
+            raise RuntimeError("grid_bounds must be given (the data are not kept)")
+        gb = torch.as_tensor(grid_bounds, dtype=torch.float64).reshape(-1, 2)
+        if num_dims is None:
+            num_dims = gb.shape[0]
+        if gb.shape[0] == 1 and num_dims > 1:
+            gb = gb.expand(num_dims, 2)
+        self.base_kernel = base_kernel
+        self.num_dims = num_dims
+        self.grid_spec = GridSpec(gb.tolist(), grid_size)
+        self.grid_bounds = tuple((float(lo), float(hi)) for lo, hi in gb.tolist())
+        self.grid_sizes = list(self.grid_spec.g)
+        self.grid_is_dynamic = False
+
+    @property
+    def grid(self):
+        p = next(self.base_kernel.parameters(), None)
+        dev = p.device if p is not None else "cpu"
+        dt = p.dtype if p is not None else torch.float32
+        return self.grid_spec.grid_points(dtype=dt, device=dev)
+
+    def toeplitz_columns(self, batch_index=None, dtype=None, device=None):
+        """Concatenated first columns [sum g] of the per-dim Kronecker factors
+        (differentiable w.r.t. the hyper-parameters)."""
+        p = next(self.base_kernel.parameters(), None)
+        device = device if device is not None else (p.device if p is not None else "cpu")
+        gs = self.grid_spec
+        cols = []
+        for q in range(gs.d):
+            lags = gs.h[q] * torch.arange(gs.g[q], dtype=torch.float64, device=device)
+            cols.append(_lag_column_any(self.base_kernel, q, lags, gs.d, batch_index).to(torch.float64))
+        out = torch.cat(cols)
+        return out if dtype is None else out.to(dtype)

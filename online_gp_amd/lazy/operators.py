@@ -1,0 +1,228 @@
+"""Matrix-free operators of the WISKI hot path with the LazyTensor matmul
+contract the reference relies on (``_size/_matmul/_transpose_nonbatch/evaluate/
+matmul/@``; online_gp/lazy/updated_root_lazy_tensor.py:44-51,135-137).
+
+All arithmetic is done by the HIP kernels behind :mod:`online_gp_amd.grid_ops`.
+Each operator covers ONE output (a [m, m] or [n, n] matrix); the model stacks
+them per output.
+"""
+import torch
+
+from .. import grid_ops
+from ..distributions import LazyCovariance
+
+
+class _Operator(LazyCovariance):
+    def _size(self):
+        return self.shape
+
+    def _transpose_nonbatch(self):
+        return self  # every operator here is symmetric
+
+    def transpose(self, *a):
+        return self
+
+    def matmul(self, rhs):
+        squeeze = rhs.dim() == 1
+        rhs2 = rhs[:, None] if squeeze else rhs
+        out = self._matmul(rhs2)
+        return out[:, 0] if squeeze else out
+
+    __matmul__ = matmul
+
+    def evaluate(self):
+        n = self.shape[-1]
+        if n > 8192:
+            raise RuntimeError(f"refusing to densify a {n} x {n} operator")
+        eye = torch.eye(n, dtype=self.dtype, device=self.device)
+        return self._matmul(eye)
+
+    def diag(self):
+        return self.evaluate().diagonal()
+
+
+class StencilWtW(_Operator):
+    """W^T D^-1 W in block-stencil form: ``stencil[o, i] = A[i, i + off(o)]`` for
+    the 7^d relative offsets.  Replaces the dense m x m tensor held by the
+    reference's UpdatedRootLazyTensor (updated_root_lazy_tensor.py:42,58)."""
+
+    def __init__(self, grid, stencil):
+        self.grid = grid
+        self.stencil = stencil
+        self.shape = torch.Size([grid.m, grid.m])
+        self.dtype = stencil.dtype
+        self.device = stencil.device
+
+    @classmethod
+    def zeros(cls, grid, dtype, device):
+        return cls(grid, torch.zeros((grid.R, grid.m), dtype=dtype, device=device))
+
+    def clone(self):
+        return StencilWtW(self.grid, self.stencil.clone())
+
+    def to(self, device):
+        return StencilWtW(self.grid, self.stencil.to(device))
+
+    def _matmul(self, rhs):  # rhs [m, k]
+        V = rhs.t().contiguous()
+        return grid_ops.stencil_spmv(self.grid, self.stencil, V).t()
+
+    def diag(self):
+        return self.stencil[(self.grid.R - 1) // 2].clone()
+
+
+class KroneckerToeplitz(_Operator):
+    """scale * kron_i SymToeplitz(tcol_i): the lazy ``Kuu`` of
+    batched_fixed_noise_online_gp.py:334-341 (divided by sigma^2 when the
+    second noise is learnable)."""
+
+    def __init__(self, grid, tcol, scale=1.0):
+        self.grid = grid
+        self.tcol = tcol
+        self.scale = float(scale)
+        self.shape = torch.Size([grid.m, grid.m])
+        self.dtype = tcol.dtype
+        self.device = tcol.device
+
+    def _matmul(self, rhs):
+        V = rhs.t().contiguous()
+        return grid_ops.kron_toeplitz_mm(self.grid, self.tcol, V, self.scale).t()
+
+    def __truediv__(self, s):
+        return KroneckerToeplitz(self.grid, self.tcol, self.scale / float(s))
+
+    def diag(self):
+        d0 = self.scale
+        off = 0
+        for g in self.grid.g:
+            d0 = d0 * float(self.tcol[off])
+            off += g
+        return torch.full((self.grid.m,), d0, dtype=self.dtype, device=self.device)
+
+
+class InducingPosterior(_Operator):
+    """M = (Kt^-1 + A)^-1 = Kt - Kt L Q^-1 L^T Kt, the un-scaled posterior
+    covariance of the inducing values (batched_fixed_noise_online_gp.py:385-404),
+    applied by preconditioned CG (wiski_pcg) instead of through a root."""
+
+    def __init__(self, grid, wtw, tcol, kscale, tol, max_iter, workspace=None, check_every=10):
+        self.grid = grid
+        self.wtw = wtw
+        self.tcol = tcol
+        self.kscale = float(kscale)
+        self.tol = tol
+        self.max_iter = max_iter
+        self.workspace = workspace
+        self.check_every = check_every
+        self.shape = torch.Size([grid.m, grid.m])
+        self.dtype = tcol.dtype
+        self.device = tcol.device
+        self.last_iters = 0
+        self.last_relres = []
+
+    def solve_columns(self, RHS, U=None, Z=None, warm=False):
+        """RHS [k, m] -> (U, Z) with U = M RHS."""
+        U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, tol=self.tol,
+                                     max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace)
+        self.last_iters, self.last_relres = it, res
+        return U, Z
+
+    def _matmul(self, rhs):
+        U, _ = self.solve_columns(rhs.t().contiguous())
+        return U.t()
+
+
+class InterpolatedKernel(_Operator):
+    """W Kuu W^T for a set of points (gpytorch InterpolatedLazyTensor as built by
+    covar_module(X); batched_fixed_noise_online_gp.py:143,178,205)."""
+
+    def __init__(self, grid, x, tcol, scale, err):
+        self.grid = grid
+        self.x = x.contiguous()
+        self.tcol = tcol
+        self.scale = float(scale)
+        self.err = err
+        n = x.shape[0]
+        self.shape = torch.Size([n, n])
+        self.dtype = x.dtype
+        self.device = x.device
+
+    def _matmul(self, rhs):  # [n, k]
+        n, k = rhs.shape
+        ones = torch.ones(n, dtype=self.dtype, device=self.device)
+        WtV = torch.zeros((k, self.grid.m), dtype=self.dtype, device=self.device)
+        stats = torch.zeros(2, dtype=torch.float64, device=self.device)
+        for c in range(k):
+            grid_ops.scatter_stats(self.grid, self.x, rhs[:, c].contiguous(), ones, ones, ones, WtV[c], None, stats, self.err)
+        KW = grid_ops.kron_toeplitz_mm(self.grid, self.tcol, WtV, self.scale)
+        return grid_ops.gather(self.grid, self.x, KW, self.err)
+
+    def diag(self):
+        Wt = grid_ops.wt_columns(self.grid, self.x, self.err)
+        KW = grid_ops.kron_toeplitz_mm(self.grid, self.tcol, Wt, self.scale)
+        return grid_ops.gather(self.grid, self.x, KW, self.err, diag=True)
+
+
+class PredictiveCovariance(LazyCovariance):
+    """sigma2 * W* M W*^T for a query batch (batched_fixed_noise_online_gp.py:222-228),
+    evaluated lazily: the k = n* solves U = M W*^T run once, on first use, in
+    column chunks; ``diag`` needs only the per-query quadratic forms."""
+
+    def __init__(self, post, x, sigma2, err, chunk=64, block=None):
+        self.post = post
+        self.x = x.contiguous()
+        self.sigma2 = float(sigma2)
+        self.err = err
+        self.chunk = chunk
+        self.block = block  # q: covariance only within consecutive blocks of q points
+        n = x.shape[0]
+        self.shape = torch.Size([n, n]) if block is None else torch.Size([n // block, block, block])
+        self.dtype = x.dtype
+        self.device = x.device
+        self._diag = None
+        self._full = None
+
+    def _solve_chunks(self, want_full):
+        n = self.x.shape[0]
+        grid = self.post.grid
+        diag = torch.empty(n, dtype=self.dtype, device=self.device)
+        full = None
+        if want_full:
+            full = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        step = self.chunk if self.block is None else max(self.block, (self.chunk // self.block) * self.block)
+        for s in range(0, n, step):
+            e = min(s + step, n)
+            xs = self.x[s:e]
+            RHS = grid_ops.wt_columns(grid, xs, self.err)
+            U, _ = self.post.solve_columns(RHS)
+            diag[s:e] = grid_ops.gather(grid, xs, U, self.err, diag=True)
+            if want_full:
+                if self.block is None:
+                    full[:, s:e] = grid_ops.gather(grid, self.x, U, self.err)
+                else:
+                    q = self.block
+                    G = grid_ops.gather(grid, xs, U, self.err)  # [e-s, e-s]
+                    nb = (e - s) // q
+                    G = G.reshape(nb, q, nb, q)
+                    idx = torch.arange(nb, device=self.device)
+                    full[s // q:e // q] = G[idx, :, idx, :]
+        self._diag = diag * self.sigma2
+        if want_full:
+            full = full * self.sigma2
+            self._full = 0.5 * (full + full.transpose(-1, -2))
+
+    def diag(self):
+        if self._diag is None:
+            self._solve_chunks(False)
+        d = self._diag
+        return d if self.block is None else d.reshape(-1, self.block)
+
+    def evaluate(self):
+        if self._full is None:
+            self._solve_chunks(True)
+        return self._full
+
+    def __getitem__(self, item):
+        from ..distributions import DenseLazyTensor
+
+        return DenseLazyTensor(self.evaluate()[item])

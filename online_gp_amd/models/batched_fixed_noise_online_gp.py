@@ -1,0 +1,452 @@
+"""FixedNoiseOnlineSKIGP -- the WISKI model core, MI355X-native.
+
+Host-side mirror of the reference's
+online_gp/models/batched_fixed_noise_online_gp.py (same constructor, methods,
+cache keys and output shapes) with the arithmetic moved to the HIP kernels of
+libwiski_hip.so:
+
+  reference (dense torch/gpytorch)                    here
+  ------------------------------------------------    ---------------------------------------------
+  W^T densified m x n            (:22-28)             never formed; taps recomputed from x in-kernel
+  W^T D^-1 W dense m x m         (:50-53, URLT:58)    block stencil [7^d, m], atomically scattered
+  root L, Q = I + L^T Kuu L, chol(Q)   (:343-383)     preconditioned CG in inducing space (wiski_pcg)
+  pred_cov dense m x m           (:385-404)           lazy operator M = (Kt^-1 + A)^-1
+  left_interp / W* pred_cov W*^T (:206-228)           fused gather kernels
+
+The posterior it returns is the exact one, mean = w*^T (Kt^-1+A)^-1 b and
+cov = sigma2 W* (Kt^-1+A)^-1 W*^T, to the CG tolerance.
+"""
+import math
+
+import torch
+
+from .. import grid_ops, settings
+from ..distributions import MultivariateNormal, ZeroLazyTensor, DenseLazyTensor, LazyCovariance
+from ..kernels import GridInterpolationKernel, RBFKernel, ScaleKernel
+from ..lazy.operators import (InducingPosterior, InterpolatedKernel, KroneckerToeplitz, PredictiveCovariance, StencilWtW)
+from ..likelihoods import FNMGLikelihood
+
+
+class BatchOperator(LazyCovariance):
+    """Stack of per-output operators: shape [out, n, n]."""
+
+    def __init__(self, ops):
+        self.ops = list(ops)
+        self.shape = torch.Size([len(self.ops)]) + self.ops[0].shape
+        self.dtype = self.ops[0].dtype
+        self.device = self.ops[0].device
+
+    def __getitem__(self, i):
+        return self.ops[i]
+
+    def __len__(self):
+        return len(self.ops)
+
+    def matmul(self, rhs):
+        if rhs.dim() == 2:
+            return torch.stack([op.matmul(rhs) for op in self.ops])
+        return torch.stack([op.matmul(rhs[i]) for i, op in enumerate(self.ops)])
+
+    __matmul__ = matmul
+
+    def evaluate(self):
+        return torch.stack([op.evaluate() for op in self.ops])
+
+    def diag(self):
+        return torch.stack([op.diag() for op in self.ops])
+
+    def clone(self):
+        return BatchOperator([op.clone() for op in self.ops])
+
+    def to(self, device):
+        return BatchOperator([op.to(device) for op in self.ops])
+
+
+def _wtw_ops(wtw):
+    return wtw.ops if isinstance(wtw, BatchOperator) else [wtw]
+
+
+def _default_tol(dtype):
+    v = settings.cg_tolerance.value()
+    if v is not None:
+        return v
+    return 1e-6 if dtype == torch.float32 else 1e-10
+
+
+class FixedNoiseOnlineSKIGP(torch.nn.Module):
+    def __init__(
+        self,
+        train_inputs=None,
+        train_targets=None,
+        train_noise_term=None,
+        covar_module=None,
+        kernel_cache=None,
+        grid_bounds=None,
+        grid_size=30,
+        likelihood=None,
+        learn_additional_noise=False,
+        num_data=None,
+    ):
+        super().__init__()
+        assert train_inputs is not None or kernel_cache is not None
+
+        if train_targets is not None:
+            if train_targets.dim() == 1:
+                train_targets = train_targets[:, None]
+            num_outputs = train_targets.shape[-1]
+            self.num_data = train_inputs.shape[-2]
+            device, dtype = train_inputs.device, train_inputs.dtype
+            num_dims = train_inputs.shape[-1]
+        else:
+            ic = kernel_cache["interpolation_cache"]
+            num_outputs = ic.shape[0]
+            self.num_data = num_data
+            device, dtype = ic.device, ic.dtype
+            num_dims = None
+        self.num_outputs = num_outputs
+        _batch_shape = torch.Size([num_outputs]) if num_outputs > 1 else torch.Size()
+
+        if covar_module is None:
+            if grid_bounds is None:
+                grid_bounds = torch.stack((train_inputs.min(dim=-2)[0] - 0.1, train_inputs.max(dim=-2)[0] + 0.1)).transpose(-1, -2)
+            covar_module = ScaleKernel(RBFKernel(batch_shape=_batch_shape, ard_num_dims=train_inputs.size(-1)), batch_shape=_batch_shape)
+        if not isinstance(covar_module, GridInterpolationKernel):
+            covar_module = GridInterpolationKernel(base_kernel=covar_module, grid_size=grid_size, num_dims=train_inputs.shape[-1],
+                                                   grid_bounds=grid_bounds)
+        self._batch_shape = _batch_shape
+        self.train_inputs = [None]
+        self.train_targets = None
+        self.covar_module = covar_module.to(device)
+        self._grid = self.covar_module.grid_spec
+        self._dtype = dtype
+        self._device = device
+        if num_dims is not None and num_dims != self._grid.d:
+            raise RuntimeError(f"inputs have {num_dims} dims but the grid has {self._grid.d}")
+
+        if likelihood is None:
+            if train_noise_term is None:
+                train_noise_term = torch.ones_like(train_targets)
+            train_noise_term = self._canon_noise(train_noise_term, train_targets)
+            self.likelihood = FNMGLikelihood(noise=train_noise_term.transpose(-1, -2), learn_additional_noise=learn_additional_noise,
+                                             batch_shape=_batch_shape).to(device)
+        else:
+            self.likelihood = likelihood
+            if train_noise_term is not None and train_targets is not None:
+                train_noise_term = self._canon_noise(train_noise_term, train_targets)
+        self.has_learnable_noise = learn_additional_noise
+
+        self._err = grid_ops.new_err_flag(device)
+        self._pcg_ws = grid_ops.PCGWorkspace()
+        self._memo = {}
+        self._mean_state = None  # warm-start state of the posterior-mean solve
+
+        if kernel_cache is None:
+            self._kernel_cache = self._fresh_cache()
+            self._absorb(self._kernel_cache, train_inputs, train_targets, train_noise_term, init=True)
+        else:
+            self._kernel_cache = kernel_cache
+
+    # ------------------------------------------------------------ helpers --
+    @staticmethod
+    def _canon_noise(noise, targets):
+        """-> [n, out] like the targets."""
+        if noise.dim() == 1:
+            noise = noise[:, None]
+        if noise.shape != targets.shape and noise.transpose(-1, -2).shape == targets.shape:
+            noise = noise.transpose(-1, -2)
+        return noise.expand_as(targets) if noise.shape != targets.shape else noise
+
+    def _fresh_cache(self):
+        out, m = self.num_outputs, self._grid.m
+        b = torch.zeros((out, m, 1), dtype=self._dtype, device=self._device)
+        stats = torch.zeros((out, 2), dtype=torch.float64, device=self._device)
+        ops = [StencilWtW.zeros(self._grid, self._dtype, self._device) for _ in range(out)]
+        return self._pack_cache(b, stats, ops)
+
+    def _pack_cache(self, b, stats, ops):
+        out = b.shape[0]
+        return {
+            "response_cache": stats[:, 0].view(out, 1, 1),   # y^T D^-1 y     (:45)   [float64 view]
+            "interpolation_cache": b,                        # W^T D^-1 y     (:46)
+            "WtW": ops[0] if out == 1 else BatchOperator(ops),  # W^T D^-1 W  (:50-53)
+            "D_logdet": stats[:, 1],                         # logdet D       (:55)   [float64 view]
+            "_stats": stats,
+        }
+
+    def _clone_cache(self, cache):
+        stats = cache["_stats"].clone()
+        return self._pack_cache(cache["interpolation_cache"].clone(), stats, [op.clone() for op in _wtw_ops(cache["WtW"])])
+
+    def _absorb(self, cache, X, Y, noise, init):
+        """_initialize_caches (:31-60) / _update_cache_dicts (:155-171) fused into
+        one scatter launch per output; mutates `cache` in place."""
+        X = X.reshape(-1, self._grid.d).to(self._device, self._dtype).contiguous()
+        Y = Y.to(self._device, self._dtype)
+        if Y.dim() == 1:
+            Y = Y[:, None]
+        noise = noise.to(self._device, self._dtype)
+        b = cache["interpolation_cache"]
+        stats = cache["_stats"]
+        ops = _wtw_ops(cache["WtW"])
+        for o in range(self.num_outputs):
+            yo = Y[:, o].contiguous()
+            no = noise[:, o].contiguous()
+            wb = 1.0 / no
+            wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
+            grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
+
+    def check_bounds(self):
+        """Raise like gpytorch's grid check if any point seen so far was outside the
+        grid (the kernels only set a device flag; this is the one host sync)."""
+        if int(self._err.item()) != 0:
+            self._err.zero_()
+            raise RuntimeError("Received data that was out of bounds for the specified grid. "
+                               f"Grid bounds were {self.covar_module.grid_bounds}.")
+
+    def _sigma2(self, o=0):
+        if not self.has_learnable_noise:
+            return 1.0
+        n = self.likelihood.second_noise_covar.noise.detach().reshape(-1)
+        return float(n[o] if n.numel() > 1 else n[0])
+
+    def _hyper_version(self):
+        ps = list(self.covar_module.parameters()) + (list(self.likelihood.second_noise_covar.parameters()) if self.has_learnable_noise else [])
+        return tuple((id(p), p._version) for p in ps)
+
+    def _hyper(self):
+        """Per-output (tcol on device in the data dtype, sigma2 float); memoised on
+        the parameters' version counters."""
+        ver = self._hyper_version()
+        h = self._memo.get("hyper")
+        if h is None or h[0] != ver:
+            vals = []
+            with torch.no_grad():
+                for o in range(self.num_outputs):
+                    bi = o if self.num_outputs > 1 else None
+                    tcol = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).to(self._dtype).contiguous()
+                    vals.append((tcol, self._sigma2(o)))
+            h = (ver, vals)
+            self._memo["hyper"] = h
+        return h[1]
+
+    def _posterior_op(self, o):
+        tcol, s2 = self._hyper()[o]
+        return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
+                                 settings.max_cg_iterations.value(), workspace=self._pcg_ws)
+
+    # --------------------------------------------------------------- caches --
+    @property
+    def Kuu(self):
+        """Lazy Kuu (/ sigma2 when the second noise is learnable), :334-341."""
+        ops = [KroneckerToeplitz(self._grid, tcol, 1.0 / s2) for tcol, s2 in self._hyper()]
+        return ops[0] if self.num_outputs == 1 else BatchOperator(ops)
+
+    @property
+    def Kuu_response(self):
+        """Kuu @ W^T D^-1 y, :363-366; [out, m, 1]."""
+        b = self._kernel_cache["interpolation_cache"]
+        outs = [grid_ops.kron_toeplitz_mm(self._grid, tcol, b[o, :, 0], 1.0 / s2) for o, (tcol, s2) in enumerate(self._hyper())]
+        return torch.stack(outs)[..., None]
+
+    @property
+    def prediction_cache(self):
+        """pred_mean = (Kt^-1 + A)^-1 W^T D^-1 y  [out, m, 1]   (:368-383), and the
+        lazy pred_cov operator(s).  The mean solve is warm-started from the
+        previous solution (U, Z) after every streaming update."""
+        pc = self._memo.get("prediction_cache")
+        if pc is not None:
+            return pc
+        self.check_bounds()
+        out, m = self.num_outputs, self._grid.m
+        b = self._kernel_cache["interpolation_cache"]
+        hyper = self._hyper()
+        ver = self._hyper_version()
+        U = torch.empty((out, m), dtype=self._dtype, device=self._device)
+        Z = torch.empty_like(U)
+        iters = []
+        posts = []
+        for o in range(out):
+            post = self._posterior_op(o)
+            warm = False
+            Uo = Zo = None
+            if self._mean_state is not None:
+                Uo, Zo = self._mean_state["U"][o:o + 1].clone(), self._mean_state["Z"][o:o + 1].clone()
+                if self._mean_state["ver"] != ver:
+                    tcol, s2 = hyper[o]
+                    Uo = grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2)   # keep U = Kt Z under the new hypers
+                warm = True
+            Uo, Zo = post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm)
+            U[o], Z[o] = Uo[0], Zo[0]
+            iters.append(post.last_iters)
+            posts.append(post)
+        self._mean_state = {"U": U, "Z": Z, "ver": ver}
+        pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters}
+        self._memo["prediction_cache"] = pc
+        return pc
+
+    def _make_predictive_covar(self, *args, **kwargs):
+        return self.prediction_cache["pred_cov"]
+
+    def _root_space_unavailable(self, name):
+        raise NotImplementedError(
+            f"{name} is a root-space quantity of the reference's dense formulation (L, Q = I + L^T Kuu L); the matrix-free "
+            "formulation has no root.  Use prediction_cache / Kuu / Kuu_response, or the dense path for small grids.")
+
+    @property
+    def current_inducing_compression_matrix(self):
+        self._root_space_unavailable("current_inducing_compression_matrix")
+
+    @property
+    def current_qmatrix(self):
+        self._root_space_unavailable("current_qmatrix")
+
+    @property
+    def root_space_projection(self):
+        self._root_space_unavailable("root_space_projection")
+
+    def _dump_caches(self):
+        self._memo.pop("prediction_cache", None)
+        self._memo.pop("hyper", None)
+
+    def zero_grad(self, *args, **kwargs):
+        self._dump_caches()
+        return super().zero_grad(*args, **kwargs)
+
+    # -------------------------------------------------------------- forward --
+    def forward(self, X, **kwargs):
+        if self.training:
+            return self._train_forward(X)
+        return self._eval_forward(X)
+
+    def __call__(self, *args, **kwargs):
+        if len(args) == 0:
+            args = (None,)
+        return super().__call__(*args, **kwargs)
+
+    def _train_forward(self, X):
+        # dummy: the real action happens in the MLL (:173-203)
+        out = self.num_outputs
+        n = X.shape[-2] if X is not None else self.num_data
+        mean_shape = (out, n) if out > 1 else (n,)
+        mean = torch.zeros(mean_shape, dtype=self._dtype, device=self._device)
+        if X is None:
+            return MultivariateNormal(mean, ZeroLazyTensor(*mean_shape, n, dtype=self._dtype, device=self._device))
+        Xf = X.reshape(-1, self._grid.d).to(self._device, self._dtype)
+        ops = [InterpolatedKernel(self._grid, Xf, tcol, 1.0, self._err) for tcol, _ in self._hyper()]
+        return MultivariateNormal(mean, ops[0] if out == 1 else BatchOperator(ops))
+
+    def _eval_forward(self, X):
+        grid, out = self._grid, self.num_outputs
+        X = X.to(self._device, self._dtype)
+        block = None
+        lead = X.shape[:-1]
+        if X.dim() > 2:
+            block = X.shape[-2]
+        Xf = X.reshape(-1, grid.d).contiguous()
+        n = Xf.shape[0]
+        pc = self.prediction_cache
+        mean = grid_ops.gather(grid, Xf, pc["pred_mean"][..., 0], self._err)      # [n, out]   left_interp, :206-210
+        if settings.skip_posterior_variances.on():
+            covs = None
+        else:
+            chunk = settings.variance_chunk.value()
+            covs = [PredictiveCovariance(_wtw_post, Xf, self._hyper()[o][1] if self.has_learnable_noise else 1.0, self._err, chunk=chunk,
+                                         block=block if X.dim() > 2 else None)
+                    for o, _wtw_post in enumerate(pc["pred_cov"].ops if out > 1 else [pc["pred_cov"]])]
+        # output shapes follow :248-252
+        if out == 1:
+            mean_o = mean[:, 0].reshape(lead)
+            if covs is None:
+                cov = ZeroLazyTensor(*lead, lead[-1], dtype=self._dtype, device=self._device)
+            else:
+                cov = covs[0]
+            return MultivariateNormal(mean_o, cov)
+        mean_o = mean.t().reshape((out,) + tuple(lead))
+        if covs is None:
+            cov = ZeroLazyTensor(out, *lead, lead[-1], dtype=self._dtype, device=self._device)
+        else:
+            cov = BatchOperator(covs)
+        return MultivariateNormal(mean_o, cov)
+
+    # -------------------------------------------------------------- updates --
+    def condition_on_observations(self, X, Y, noise=None, inplace=False):
+        """a7, :258-285.  inplace: the statistics buffers are updated where they
+        live (O(4^{2d}) atomics per point); otherwise they are cloned first and a
+        sibling model sharing covar_module / likelihood is returned."""
+        if Y.dim() == 1:
+            Y = Y[:, None]
+        if noise is None:
+            noise = torch.ones_like(Y)
+        noise = self._canon_noise(noise, Y)
+        q = X.reshape(-1, self._grid.d).shape[0]
+        if inplace:
+            self._absorb(self._kernel_cache, X, Y, noise, init=False)
+            self.num_data = self.num_data + q
+            self._dump_caches()
+            return None
+        new_cache = self._clone_cache(self._kernel_cache)
+        new_gp = type(self)(
+            covar_module=self.covar_module,
+            kernel_cache=new_cache,
+            learn_additional_noise=self.has_learnable_noise,
+            likelihood=self.likelihood,
+            num_data=self.num_data + q,
+        )
+        new_gp._absorb(new_cache, X, Y, noise, init=False)
+        if self._mean_state is not None:
+            new_gp._mean_state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._mean_state.items()}
+        if not self.training:
+            new_gp.eval()
+        return new_gp
+
+    def get_fantasy_model(self, inputs, targets, noise_term=None, **kwargs):
+        """Single-batch fantasy: condition a copy on (inputs, targets).  The
+        reference's batched version (:287-332) is broken at HEAD."""
+        if targets.dim() == 1:
+            targets = targets[:, None]
+        if noise_term is None:
+            noise_term = torch.ones_like(targets)
+        if inputs.dim() > 2 or targets.dim() > 2:
+            raise RuntimeError("Unsupported batch shapes: batched fantasies are not supported (the reference path is broken, SURVEY.md section 0)")
+        return self.condition_on_observations(inputs, targets, noise_term, inplace=False)
+
+    def set_train_data(self, train_inputs, train_targets, train_noise_term):
+        """:420-428 -- rebuild every statistic from scratch."""
+        if train_targets.dim() == 1:
+            train_targets = train_targets[:, None]
+        noise = self._canon_noise(train_noise_term, train_targets)
+        cache = self._kernel_cache
+        cache["interpolation_cache"].zero_()
+        cache["_stats"].zero_()
+        for op in _wtw_ops(cache["WtW"]):
+            op.stencil.zero_()
+        self._absorb(cache, train_inputs, train_targets, noise, init=True)
+        self.num_data = train_inputs.reshape(-1, self._grid.d).shape[0]
+        self._mean_state = None
+        self._dump_caches()
+
+    def to(self, *args, **kwargs):
+        res = super().to(*args, **kwargs)
+        device = None
+        for a in args:
+            if isinstance(a, (str, torch.device)):
+                device = torch.device(a)
+            elif torch.is_tensor(a):
+                device = a.device
+        device = kwargs.get("device", device)
+        if device is not None and self._kernel_cache is not None and torch.device(device) != self._device:
+            c = self._kernel_cache
+            stats = c["_stats"].to(device)
+            self._kernel_cache = self._pack_cache(c["interpolation_cache"].to(device), stats, [op.to(device) for op in _wtw_ops(c["WtW"])])
+            self._device = torch.device(device)
+            self._err = grid_ops.new_err_flag(device)
+            self._mean_state = None
+            self._memo = {}
+        return res
+
+    # ------------------------------------------------- distributed statistics --
+    def stats_buffers(self):
+        """Tensors that are additive over data shards (what RCCL all-reduces):
+        b, the W^T W stencils and (y^T D^-1 y, logdet D)."""
+        c = self._kernel_cache
+        return [c["interpolation_cache"], c["_stats"]] + [op.stencil for op in _wtw_ops(c["WtW"])]
