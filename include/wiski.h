@@ -115,6 +115,12 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
 int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
 int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
 
+/* Measurement hook (bench.py roofline leg): brackets every stencil-SpMV launch
+ * with HIP events on the launch stream.  wiski_prof_stop returns the summed
+ * kernel time and launch count; synchronise the stream before calling it. */
+int wiski_prof_start(int32_t max_launches);
+int wiski_prof_stop(double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,42 @@
 
 #include <vector>
 
+// ------------------------------------------------------- profiling hook ---
+// Optional HIP-event bracket around every stencil-SpMV launch, recorded on the
+// stream the kernel runs on (bench.py's roofline leg).  Off by default.
+static struct WiskiProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+} g_prof;
+
+extern "C" int wiski_prof_start(int max_launches) {
+  if (max_launches < 1) return WISKI_E_BADARG;
+  while (g_prof.ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return WISKI_E_LAUNCH;
+    g_prof.ev.push_back(e);
+  }
+  g_prof.used = 0;
+  g_prof.on = true;
+  return WISKI_OK;
+}
+
+// Stops recording; the caller must have synchronised the stream(s).
+extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
+  g_prof.on = false;
+  double tot = 0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return WISKI_E_LAUNCH;
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)(g_prof.used / 2);
+  g_prof.used = 0;
+  return WISKI_OK;
+}
+
 // ---------------------------------------------------------- stencil SpMV ---
 // out[c][i] = beta*add[c][i] + sum_o A_st[o][i] * V[c][clamp(i + off(o))]
 // HBM-bound: A_st (R*m reals) is streamed exactly once, fully coalesced along
@@ -73,6 +109,8 @@ static int launch_spmv(const GridDev<real>& G, const real* A_st, const real* V, 
   dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)((k + kc - 1) / kc));
   size_t sh = (size_t)G.R * sizeof(int);
   if (sh < 16 * sizeof(double)) sh = 16 * sizeof(double);
+  const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
 #define SPMV(KC)                                                                                                            \
   do {                                                                                                                      \
     if (dots) hipLaunchKernelGGL((k_stencil_spmv<real, KC, true>), grd, dim3(256), sh, s, G, A_st, V, k, add, beta, out, dots); \
@@ -82,6 +120,7 @@ static int launch_spmv(const GridDev<real>& G, const real* A_st, const real* V, 
   else if (kc == 2) SPMV(2);
   else SPMV(1);
 #undef SPMV
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 

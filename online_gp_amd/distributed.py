@@ -1,0 +1,77 @@
+"""Data-parallel accumulation of the WISKI sufficient statistics.
+
+Every cache of the hot path is a sum over data points (reference
+online_gp/models/batched_fixed_noise_online_gp.py:44-55,160), so the stream
+shards naturally over GPUs: each rank scatters its shard of a batch into a
+zeroed *delta* copy of (b, W^T D^-1 W stencil, [y^T D^-1 y, logdet D]), one
+all-reduce(SUM) (RCCL over xGMI; gloo in the CPU tests) makes the delta global,
+and every rank adds it into its replica of the statistics.  Roots / solves are
+then computed redundantly per rank (they do not add).
+
+The reference has no distributed code; this is the one collective of the path.
+"""
+import torch
+import torch.distributed as dist
+
+
+def allreduce_sum_(tensors, group=None):
+    """In-place SUM all-reduce of a list of tensors (no-op without a process group).
+    Tensors of one dtype are coalesced by the backend where it pays; the dominant
+    message is the stencil (7^d * m reals)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    handles = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
+    for h in handles:
+        h.wait()
+    return tensors
+
+
+class ShardedStatsUpdater:
+    """Streams rank-local shards into a model whose statistics stay replicated.
+
+    ``update(X, Y, noise)`` == ``model.condition_on_observations(X_all, Y_all,
+    noise_all, inplace=True)`` on every rank, where *_all is the concatenation of
+    all ranks' shards."""
+
+    def __init__(self, model, group=None):
+        self.model = model
+        self.group = group
+        self._delta = None
+
+    def _delta_cache(self):
+        if self._delta is None:
+            self._delta = self.model._fresh_cache()
+        else:
+            d = self._delta
+            d["interpolation_cache"].zero_()
+            d["_stats"].zero_()
+            from .models.batched_fixed_noise_online_gp import _wtw_ops
+
+            for op in _wtw_ops(d["WtW"]):
+                op.stencil.zero_()
+        return self._delta
+
+    def update(self, X, Y, noise=None):
+        from .models.batched_fixed_noise_online_gp import _wtw_ops
+
+        m = self.model
+        if Y.dim() == 1:
+            Y = Y[:, None]
+        if noise is None:
+            noise = torch.ones_like(Y)
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1:
+            m.condition_on_observations(X, Y, noise, inplace=True)
+            return
+        delta = self._delta_cache()
+        m._absorb(delta, X, Y, m._canon_noise(noise, Y), init=False)
+        count = torch.tensor([float(X.reshape(-1, m._grid.d).shape[0])], dtype=torch.float64, device=delta["_stats"].device)
+        bufs = [delta["interpolation_cache"], delta["_stats"], count] + [op.stencil for op in _wtw_ops(delta["WtW"])]
+        allreduce_sum_(bufs, self.group)
+        c = m._kernel_cache
+        c["interpolation_cache"].add_(delta["interpolation_cache"])
+        c["_stats"].add_(delta["_stats"])
+        for dst, src in zip(_wtw_ops(c["WtW"]), _wtw_ops(delta["WtW"])):
+            dst.stencil.add_(src.stencil)
+        m.num_data = m.num_data + int(count.item())
+        m._dump_caches()
