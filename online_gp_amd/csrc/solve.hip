@@ -124,6 +124,156 @@ static int launch_spmv(const GridDev<real>& G, const real* A_st, const real* V, 
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+// ------------------------------------------------- stencil SpMV, wide form ---
+// Fast path for m % 4 == 0.  Each thread owns 4 consecutive rows and streams
+// A_st with 16-byte loads; the grid is additionally split over the leading
+// stencil digit (NCH = 7 chunks for d >= 2) so that >= 13 waves per CU keep
+// ~90 KB of HBM requests in flight.  For one "mid" offset combination the 7
+// innermost offsets of 4 rows read a shared 10-wide window of v (10 loads for
+// 28 FMAs).  Each chunk writes its own partial vector (plain coalesced 16-byte
+// stores, no atomics); the consumer sums the NCH partials (k_spmv_reduce, or
+// fused into k_pcg_update_x / k_pcg_init).
+//   part[ch][c][i] = sum_{o in chunk ch} A_st[o][i] * V[c][clamp(i+off(o))]
+//   DOT: dots[c] += sum_i V[c][i] * part[ch][c][i]  (+ beta * V.add for ch == 0)
+template <typename real>
+struct Vec4 { real x, y, z, w; };
+
+template <typename real>
+__device__ __forceinline__ Vec4<real> load4(const real* __restrict__ p) {
+  Vec4<real> r;
+  if constexpr (sizeof(real) == 4) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+  } else {
+    double2 a = *reinterpret_cast<const double2*>(p);
+    double2 b = *reinterpret_cast<const double2*>(p + 2);
+    r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y;
+  }
+  return r;
+}
+
+template <typename real>
+__device__ __forceinline__ void store4(real* __restrict__ p, real a, real b, real c, real d) {
+  if constexpr (sizeof(real) == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  } else {
+    *reinterpret_cast<double2*>(p) = make_double2(a, b);
+    *reinterpret_cast<double2*>(p + 2) = make_double2(c, d);
+  }
+}
+
+static inline int spmv_nch(int d) { return d >= 2 ? 7 : 1; }
+
+template <typename real, int KC, bool DOT>
+__global__ __launch_bounds__(256) void k_stencil_spmv4(GridDev<real> G, const real* __restrict__ A_st, const real* __restrict__ V, int k,
+                                                       int nmid, real* __restrict__ part, const real* __restrict__ add, real beta,
+                                                       double* __restrict__ dots) {
+  __shared__ int s_off[352];
+  __shared__ double s_red[16];
+  const int m = G.m, d = G.d;
+  const int ch = blockIdx.y;
+  const int c0 = blockIdx.z * KC;
+  for (int mid = threadIdx.x; mid < nmid; mid += blockDim.x) {
+    int rem = mid, f = d >= 2 ? (ch - 3) * G.stride[0] : 0;
+    for (int q = d - 2; q >= 1; --q) {
+      const int c = rem % 7;
+      rem /= 7;
+      f += (c - 3) * G.stride[q];
+    }
+    s_off[mid] = f;
+  }
+  __syncthreads();
+  const int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const bool live = i4 < m;
+  real acc[KC][4];
+#pragma unroll
+  for (int c = 0; c < KC; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[c][r] = (real)0;
+  if (live) {
+    const real* __restrict__ a_base = A_st + (int64_t)ch * nmid * 7 * m + i4;
+    for (int mid = 0; mid < nmid; ++mid) {
+      const int base = i4 + s_off[mid] - 3;
+      real win[KC][10];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) {
+        int j = base + e;
+        j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) win[c][e] = (c0 + c < k) ? V[(int64_t)(c0 + c) * m + j] : (real)0;
+      }
+      const real* __restrict__ a_mid = a_base + (int64_t)mid * 7 * m;
+#pragma unroll
+      for (int c7 = 0; c7 < 7; ++c7) {
+        const Vec4<real> a = load4<real>(a_mid + (int64_t)c7 * m);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          acc[c][0] += a.x * win[c][c7 + 0];
+          acc[c][1] += a.y * win[c][c7 + 1];
+          acc[c][2] += a.z * win[c][c7 + 2];
+          acc[c][3] += a.w * win[c][c7 + 3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    double pd = 0;
+    if (live && c0 + c < k) {
+      const int64_t e = (int64_t)(c0 + c) * m + i4;
+      store4<real>(part + ((int64_t)ch * k) * m + e, acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+      if (DOT) {
+        const Vec4<real> v = load4<real>(V + e);
+        pd = (double)v.x * acc[c][0] + (double)v.y * acc[c][1] + (double)v.z * acc[c][2] + (double)v.w * acc[c][3];
+        if (ch == 0 && add) {
+          const Vec4<real> ad = load4<real>(add + e);
+          pd += (double)beta * ((double)v.x * ad.x + (double)v.y * ad.y + (double)v.z * ad.z + (double)v.w * ad.w);
+        }
+      }
+    }
+    if (DOT) {
+      const double tot = block_reduce_sum(pd, s_red);
+      if (threadIdx.x == 0 && c0 + c < k) unsafeAtomicAdd(dots + c0 + c, tot);
+    }
+  }
+}
+
+// out[c][i] = beta * add[c][i] + sum_ch part[ch][c][i]
+template <typename real>
+__global__ __launch_bounds__(256) void k_spmv_reduce(int64_t km, int nch, const real* __restrict__ part, const real* __restrict__ add, real beta,
+                                                     real* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < km; e += (int64_t)gridDim.x * blockDim.x) {
+    real r = add ? beta * add[e] : (real)0;
+    for (int ch = 0; ch < nch; ++ch) r += part[(int64_t)ch * km + e];
+    out[e] = r;
+  }
+}
+
+// partial SpMV launcher (requires m % 4 == 0); part holds spmv_nch(d)*k*m reals.
+template <typename real>
+static int launch_spmv4(const GridDev<real>& G, const real* A_st, const real* V, int k, real* part, const real* add, real beta, double* dots,
+                        hipStream_t s) {
+  const int nch = spmv_nch(G.d);
+  int nmid = 1;
+  for (int q = 1; q < G.d - 1; ++q) nmid *= 7;
+  const int kc = k >= 8 ? 8 : (k >= 4 ? 4 : (k >= 2 ? 2 : 1));
+  dim3 grd((unsigned)((G.m / 4 + 255) / 256), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
+  const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
+#define SPMV4(KC)                                                                                                              \
+  do {                                                                                                                         \
+    if (dots) hipLaunchKernelGGL((k_stencil_spmv4<real, KC, true>), grd, dim3(256), 0, s, G, A_st, V, k, nmid, part, add, beta, dots); \
+    else hipLaunchKernelGGL((k_stencil_spmv4<real, KC, false>), grd, dim3(256), 0, s, G, A_st, V, k, nmid, part, add, beta, dots);   \
+  } while (0)
+  if (kc == 8) SPMV4(8);
+  else if (kc == 4) SPMV4(4);
+  else if (kc == 2) SPMV4(2);
+  else SPMV4(1);
+#undef SPMV4
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 // -------------------------------------------------- Kronecker-Toeplitz MVM --
 // One mode product of the d-way tensor view (pre, g, post):
 //   out[pp, i, s] = scale * sum_j tcol[|i-j|] * in[pp, j, s]
@@ -185,6 +335,103 @@ static int launch_kron(const GridDev<real>& G, const real* tcol, const real* V, 
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+// ------------------------------------------- dense Kronecker mode products ---
+// out[pp, i, s] = sum_j F[i, j] * in[pp, j, s] for a general g x g factor F (held
+// in LDS).  Used for the Kronecker eigenbasis of Kuu (Kuu = (kron V_q) Lam (kron V_q)^T):
+//   MODE 0  plain
+//   MODE 1  spectral scaling epilogue of the forward transform: with
+//           lam = kscale * prod_q eval_q[i_q],  f1 = 1/(1 + shift*lam):
+//           out = f1 * acc  and  out[out2_off + .] = lam * f1 * acc
+//   MODE 2  dot epilogue: dots[c - dot_c0] += sum_e wvec[c - dot_c0][e] * acc for c >= dot_c0
+template <typename real, int MODE>
+__global__ __launch_bounds__(256) void k_dense_mode(GridDev<real> G, int q, const real* __restrict__ F, int transposed,
+                                                    const real* __restrict__ in, real* __restrict__ out, int64_t out2_off,
+                                                    const real* __restrict__ evals, real kscale, real shift,
+                                                    const real* __restrict__ wvec, int dot_c0, double* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  real* sF = reinterpret_cast<real*>(smem);
+  __shared__ double s_red[16];
+  const int g = G.g[q], post = G.stride[q], m = G.m;
+  for (int t = threadIdx.x; t < g * g; t += blockDim.x) {
+    const int i = t / g, j = t - i * g;
+    sF[t] = transposed ? F[j * g + i] : F[t];
+  }
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  double part = 0;
+  if (e < m) {
+    const int i = (e / post) % g;
+    const real* __restrict__ src = in + (int64_t)c * m + (e - i * post);
+    const real* __restrict__ frow = sF + i * g;
+    real acc = (real)0;
+#pragma unroll 4
+    for (int j = 0; j < g; ++j) acc += frow[j] * src[(int64_t)j * post];
+    if (MODE == 1) {
+      real lam = kscale;
+      int eoff = 0;
+      for (int qq = 0; qq < G.d; ++qq) {
+        lam *= evals[eoff + (e / G.stride[qq]) % G.g[qq]];
+        eoff += G.g[qq];
+      }
+      const real f1 = (real)1 / ((real)1 + shift * lam);
+      out[(int64_t)c * m + e] = f1 * acc;
+      out[out2_off + (int64_t)c * m + e] = lam * f1 * acc;
+    } else {
+      out[(int64_t)c * m + e] = acc;
+      if (MODE == 2 && c >= dot_c0) part = (double)wvec[(int64_t)(c - dot_c0) * m + e] * (double)acc;
+    }
+  }
+  if (MODE == 2 && c >= dot_c0) {
+    const double tot = block_reduce_sum(part, s_red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dots + (c - dot_c0), tot);
+  }
+}
+
+// Spectral preconditioner apply:  t = (I + a Kt)^-1 r,  y = Kt t = (Kt^-1 + a I)^-1 r
+// via Kt = V diag(lam) V^T.  ty = [t (k cols) | y (k cols)]; sa/sb: 2k-column scratch.
+// Also accumulates rho[c] += r[c] . y[c].
+template <typename real>
+static int launch_spectral_precond(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, const real* r, int k,
+                                   real* sa, real* sb, real* ty, double* rho, hipStream_t s) {
+  const int m = G.m, d = G.d;
+  const int64_t km = (int64_t)k * m;
+  int eoff[WISKI_MAX_DIM + 1];
+  eoff[0] = 0;
+  for (int q = 0; q < d; ++q) {
+    if (G.g[q] > 128) return WISKI_E_BADARG;
+    eoff[q + 1] = eoff[q] + G.g[q] * G.g[q];
+  }
+  const unsigned gx = (unsigned)((m + 255) / 256);
+  const real* cur = r;
+  // forward: w = (kron V^T) r, scaled on the last mode into two column groups
+  for (int q = 0; q < d; ++q) {
+    real* dst = (cur == sa) ? sb : sa;
+    const size_t sh = (size_t)G.g[q] * G.g[q] * sizeof(real);
+    if (q < d - 1)
+      hipLaunchKernelGGL((k_dense_mode<real, 0>), dim3(gx, (unsigned)k), dim3(256), sh, s, G, q, evec + eoff[q], 1, cur, dst, (int64_t)0, evals,
+                         kscale, shift, (const real*)nullptr, 0, (double*)nullptr);
+    else
+      hipLaunchKernelGGL((k_dense_mode<real, 1>), dim3(gx, (unsigned)k), dim3(256), sh, s, G, q, evec + eoff[q], 1, cur, dst, km, evals, kscale,
+                         shift, (const real*)nullptr, 0, (double*)nullptr);
+    cur = dst;
+  }
+  // backward on 2k columns: [t | y] = (kron V) [f1 w | f2 w]; rho += r . y on the last mode
+  for (int q = 0; q < d; ++q) {
+    const bool last = q == d - 1;
+    real* dst = last ? ty : ((cur == sa) ? sb : sa);
+    const size_t sh = (size_t)G.g[q] * G.g[q] * sizeof(real);
+    if (!last)
+      hipLaunchKernelGGL((k_dense_mode<real, 0>), dim3(gx, (unsigned)(2 * k)), dim3(256), sh, s, G, q, evec + eoff[q], 0, cur, dst, (int64_t)0,
+                         evals, kscale, shift, (const real*)nullptr, 0, (double*)nullptr);
+    else
+      hipLaunchKernelGGL((k_dense_mode<real, 2>), dim3(gx, (unsigned)(2 * k)), dim3(256), sh, s, G, q, evec + eoff[q], 0, cur, dst, (int64_t)0,
+                         evals, kscale, shift, r, k, rho);
+    cur = dst;
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 // -------------------------------------------------------------------- PCG ---
 // scalar slots (double): S[0..k) = ||rhs||^2 ; then per iteration slot
 // it in [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
@@ -197,17 +444,18 @@ struct PcgScal {
   __host__ __device__ double* rn(int it) const { return base + (int64_t)k * (3 + 3 * it); }
 };
 
-// r = rhs - t (t may be NULL => r = rhs); rn0 += rhs^2 ; rn(0) += r^2
+// r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
 template <typename real>
-__global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, real* __restrict__ r,
-                                                  PcgScal S) {
+__global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, const real* __restrict__ part,
+                                                  int nch, real* __restrict__ r, PcgScal S) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   double a = 0, bsum = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
     const int64_t e = (int64_t)c * m + i;
     const real f = rhs[e];
-    const real rr = t ? f - t[e] : f;
+    real rr = t ? f - t[e] : f;
+    for (int ch = 0; ch < nch; ++ch) rr -= part[(int64_t)ch * S.k * m + e];
     r[e] = rr;
     a += (double)f * f;
     bsum += (double)rr * rr;
@@ -226,7 +474,8 @@ __device__ __forceinline__ bool pcg_active(const PcgScal& S, int it, int c, doub
   return rn0 > 0 && S.rn(it)[c] > tol2 * rn0;
 }
 
-// p = y + beta p ; pt = r + beta pt ; beta = rho(it)/rho(it-1)
+// p = y + beta p ; pt = t + beta pt ; beta = rho(it)/rho(it-1)   (t = Kt^-1 y: r for
+// the plain Kt preconditioner, (I + a Kt)^-1 r for the spectral one)
 template <typename real>
 __global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2, const real* __restrict__ y, const real* __restrict__ r,
                                                       real* __restrict__ p, real* __restrict__ pt, PcgScal S) {
@@ -245,10 +494,11 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2
 }
 
 // alpha = rho/php ; u += alpha p ; z += alpha pt ; r -= alpha hp ; rn(it+1) += r^2
+// nch > 0: hp is not materialised, hp = pt + sum_ch part[ch]  (wide SpMV path).
 template <typename real>
 __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2, const real* __restrict__ p, const real* __restrict__ pt,
-                                                      const real* __restrict__ hp, real* __restrict__ u, real* __restrict__ z,
-                                                      real* __restrict__ r, PcgScal S) {
+                                                      const real* __restrict__ hp, const real* __restrict__ part, int nch,
+                                                      real* __restrict__ u, real* __restrict__ z, real* __restrict__ r, PcgScal S) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   double alpha = 0;
@@ -258,9 +508,17 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
   double acc = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
     const int64_t e = (int64_t)c * m + i;
+    const real pte = pt[e];
     u[e] += al * p[e];
-    z[e] += al * pt[e];
-    const real rr = r[e] - al * hp[e];
+    z[e] += al * pte;
+    real h;
+    if (nch > 0) {
+      h = pte;
+      for (int ch = 0; ch < nch; ++ch) h += part[(int64_t)ch * S.k * m + e];
+    } else {
+      h = hp[e];
+    }
+    const real rr = r[e] - al * h;
     r[e] = rr;
     acc += (double)rr * rr;
   }
@@ -273,17 +531,19 @@ static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * 
 static int64_t pcg_ws_bytes(int m, int k, int max_iter, int es) {
   int64_t vec = align_up((int64_t)k * m * es, 256);
   int64_t scal = align_up((int64_t)k * (1 + 3 * (int64_t)(max_iter + 2)) * 8, 256);
-  return 6 * vec + scal;
+  return (6 + 7 + 6) * vec + scal;
 }
 
 template <typename real>
-static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_RHS, int32_t k, real* d_U,
-                    real* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes,
-                    int32_t* h_iters, double* h_relres, void* stream) {
+static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_eval,
+                    real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
+                    int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
-  if (!d_A || !d_tcol || !d_RHS || !d_U || !d_Z || !d_work || k < 1 || max_iter < 1) return WISKI_E_BADARG;
+  if (!d_A || !d_RHS || !d_U || !d_Z || !d_work || k < 1 || max_iter < 1) return WISKI_E_BADARG;
+  const bool spectral = d_evec != nullptr && d_eval != nullptr;
+  if (!spectral && !d_tcol) return WISKI_E_BADARG;
   if (work_bytes < pcg_ws_bytes(G.m, k, max_iter, (int)sizeof(real))) return WISKI_E_WORKSPACE;
   if (check_every < 1) check_every = 10;
   hipStream_t s = (hipStream_t)stream;
@@ -296,7 +556,13 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   real* pt = (real*)(w + 3 * vec);
   real* hp = (real*)(w + 4 * vec);
   real* tmp = (real*)(w + 5 * vec);
-  PcgScal S{(double*)(w + 6 * vec), k};
+  real* part = (real*)(w + 6 * vec);
+  real* ty = (real*)(w + 13 * vec);
+  real* sa = (real*)(w + 15 * vec);
+  real* sb = (real*)(w + 17 * vec);
+  PcgScal S{(double*)(w + 19 * vec), k};
+  const bool wide = (m % 4) == 0;
+  const int nch = wide ? spmv_nch(G.d) : 0;
   const int64_t scal_bytes = (int64_t)k * (1 + 3 * (int64_t)(max_iter + 2)) * 8;
   if (hipMemsetAsync(S.base, 0, scal_bytes, s) != hipSuccess) return WISKI_E_LAUNCH;
   const double tol2 = tol * tol;
@@ -306,13 +572,19 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
 
   if (warm) {
     // r0 = rhs - (z + A u)
-    rc = launch_spmv<real>(G, d_A, d_U, k, d_Z, (real)1, hp, nullptr, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, r, S);
+    if (wide) {
+      rc = launch_spmv4<real>(G, d_A, d_U, k, part, nullptr, (real)0, nullptr, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, (const real*)part, nch, r, S);
+    } else {
+      rc = launch_spmv<real>(G, d_A, d_U, k, d_Z, (real)1, hp, nullptr, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (const real*)nullptr, 0, r, S);
+    }
   } else {
     if (hipMemsetAsync(d_U, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
     if (hipMemsetAsync(d_Z, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
-    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, r, S);
+    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (const real*)nullptr, 0, r, S);
   }
 
   std::vector<double> h_rn0(k), h_rn(k);
@@ -337,14 +609,24 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   }
   while (!done && it < max_iter) {
     // y = Kt r, rho(it) = r.y
-    rc = launch_kron<real>(G, d_tcol, r, k, kscale, tmp, y, r, S.rho(it), s);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_pcg_update_p<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
+    if (spectral) {
+      // [t | y] = spectral preconditioner applied to r, rho(it) = r.y
+      rc = launch_spectral_precond<real>(G, d_evec, d_eval, kscale, shift, r, k, sa, sb, ty, S.rho(it), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_pcg_update_p<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)(ty + (int64_t)k * m), (const real*)ty, p, pt,
+                         S);
+    } else {
+      // y = Kt r, rho(it) = r.y
+      rc = launch_kron<real>(G, d_tcol, r, k, kscale, tmp, y, r, S.rho(it), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_pcg_update_p<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
+    }
     // hp = pt + A p, php(it) = p.hp
-    rc = launch_spmv<real>(G, d_A, p, k, pt, (real)1, hp, S.php(it), s);
+    if (wide) rc = launch_spmv4<real>(G, d_A, p, k, part, pt, (real)1, S.php(it), s);
+    else rc = launch_spmv<real>(G, d_A, p, k, pt, (real)1, hp, S.php(it), s);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_pcg_update_x<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp, d_U, d_Z,
-                       r, S);
+    hipLaunchKernelGGL((k_pcg_update_x<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
+                       (const real*)part, nch, d_U, d_Z, r, S);
     ++it;
     if (it % check_every == 0 || it == max_iter) {
       rc = fetch(it);
@@ -369,7 +651,21 @@ static int spmv_impl(const wiski_grid* grid, const real* d_A, const real* d_V, i
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
   if (!d_A || !d_V || !d_out || k < 1) return WISKI_E_BADARG;
-  return launch_spmv<real>(G, d_A, d_V, k, d_add, beta, d_out, nullptr, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (G.m % 4 != 0) return launch_spmv<real>(G, d_A, d_V, k, d_add, beta, d_out, nullptr, s);
+  const int nch = spmv_nch(G.d);
+  const int64_t km = (int64_t)k * G.m;
+  real* part = nullptr;
+  if (hipMallocAsync((void**)&part, (size_t)nch * km * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;  // stream-ordered scratch
+  rc = launch_spmv4<real>(G, d_A, d_V, k, part, nullptr, (real)0, nullptr, s);
+  if (rc == WISKI_OK) {
+    int64_t blocks = (km + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((k_spmv_reduce<real>), dim3((unsigned)blocks), dim3(256), 0, s, km, nch, (const real*)part, d_add, beta, d_out);
+    if (hipGetLastError() != hipSuccess) rc = WISKI_E_LAUNCH;
+  }
+  (void)hipFreeAsync(part, s);
+  return rc;
 }
 
 template <typename real>
@@ -392,10 +688,10 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
 }
-int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<float>(g, A, tcol, kscale, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
 }
-int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<double>(g, A, tcol, kscale, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
 }
 }

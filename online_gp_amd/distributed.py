@@ -64,8 +64,11 @@ class ShardedStatsUpdater:
             m.condition_on_observations(X, Y, noise, inplace=True)
             return
         delta = self._delta_cache()
-        m._absorb(delta, X, Y, m._canon_noise(noise, Y), init=False)
-        count = torch.tensor([float(X.reshape(-1, m._grid.d).shape[0])], dtype=torch.float64, device=delta["_stats"].device)
+        noise = m._canon_noise(noise, Y)
+        m._absorb(delta, X, Y, noise, init=False)
+        dev = delta["_stats"].device
+        wsum = (1.0 / noise.to(dev, torch.float64).clamp_min(1e-7)).sum(0)            # [out]
+        count = torch.cat([torch.tensor([float(X.reshape(-1, m._grid.d).shape[0])], dtype=torch.float64, device=dev), wsum])
         bufs = [delta["interpolation_cache"], delta["_stats"], count] + [op.stencil for op in _wtw_ops(delta["WtW"])]
         allreduce_sum_(bufs, self.group)
         c = m._kernel_cache
@@ -73,5 +76,6 @@ class ShardedStatsUpdater:
         c["_stats"].add_(delta["_stats"])
         for dst, src in zip(_wtw_ops(c["WtW"]), _wtw_ops(delta["WtW"])):
             dst.stencil.add_(src.stencil)
-        m.num_data = m.num_data + int(count.item())
+        m._wsum_dev += count[1:]
+        m.num_data = m.num_data + int(count[0].item())
         m._dump_caches()

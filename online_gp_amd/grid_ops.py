@@ -167,9 +167,32 @@ class PCGWorkspace:
         return self.buf, need
 
 
+def kron_eigen(grid, tcol):
+    """Eigen-decomposition of the d small symmetric-Toeplitz Kronecker factors
+    (host side, fp64, O(d g^3) -- done once per hyper-parameter change):
+    returns (evec [sum g^2] row-major V_q, evals [sum g], clamped >= 0) on
+    tcol's device / dtype.  Feeds wiski_pcg's spectral preconditioner."""
+    import numpy as np
+
+    tc = tcol.detach().to("cpu", torch.float64).numpy()
+    vecs, vals, off = [], [], 0
+    for g in grid.g:
+        c = tc[off:off + g]
+        idx = np.abs(np.arange(g)[:, None] - np.arange(g)[None, :])
+        w, V = np.linalg.eigh(c[idx])
+        vals.append(np.clip(w, 0.0, None))
+        vecs.append(V.reshape(-1))
+        off += g
+    evec = torch.as_tensor(np.concatenate(vecs)).to(tcol.device, tcol.dtype)
+    evals = torch.as_tensor(np.concatenate(vals)).to(tcol.device, tcol.dtype)
+    return evec, evals
+
+
 def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
-        raise_on_fail=False):
-    """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres)."""
+        raise_on_fail=False, eigen=None, shift=0.0):
+    """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres).
+    eigen = (evec, evals) from :func:`kron_eigen` selects the spectral
+    preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions."""
     RHS2 = RHS.contiguous().reshape(-1, grid.m)
     k = RHS2.shape[0]
     if U is None or Z is None or not warm:
@@ -181,7 +204,9 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
     iters = ctypes.c_int32(0)
     relres = (ctypes.c_double * k)()
     cr = _hip.creal(RHS2.dtype)
-    rc = _hip.fn("wiski_pcg", RHS2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(RHS2), ctypes.c_int32(k),
+    evec, evals = eigen if eigen is not None else (None, None)
+    rc = _hip.fn("wiski_pcg", RHS2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(evec), _hip.dptr(evals),
+                                          cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
                                           _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
                                           ctypes.c_int32(check_every), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres,
                                           _hip.stream_ptr(RHS2.device))

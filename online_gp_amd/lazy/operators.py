@@ -105,7 +105,7 @@ class InducingPosterior(_Operator):
     covariance of the inducing values (batched_fixed_noise_online_gp.py:385-404),
     applied by preconditioned CG (wiski_pcg) instead of through a root."""
 
-    def __init__(self, grid, wtw, tcol, kscale, tol, max_iter, workspace=None, check_every=10):
+    def __init__(self, grid, wtw, tcol, kscale, tol, max_iter, workspace=None, check_every=10, eigen=None, shift=0.0):
         self.grid = grid
         self.wtw = wtw
         self.tcol = tcol
@@ -114,6 +114,8 @@ class InducingPosterior(_Operator):
         self.max_iter = max_iter
         self.workspace = workspace
         self.check_every = check_every
+        self.eigen = eigen
+        self.shift = float(shift)
         self.shape = torch.Size([grid.m, grid.m])
         self.dtype = tcol.dtype
         self.device = tcol.device
@@ -123,7 +125,8 @@ class InducingPosterior(_Operator):
     def solve_columns(self, RHS, U=None, Z=None, warm=False):
         """RHS [k, m] -> (U, Z) with U = M RHS."""
         U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, tol=self.tol,
-                                     max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace)
+                                     max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace, eigen=self.eigen,
+                                     shift=self.shift)
         self.last_iters, self.last_relres = it, res
         return U, Z
 

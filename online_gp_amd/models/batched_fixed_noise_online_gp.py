@@ -136,6 +136,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self.has_learnable_noise = learn_additional_noise
 
         self._err = grid_ops.new_err_flag(device)
+        self._wsum_dev = torch.zeros(num_outputs, dtype=torch.float64, device=device)   # sum_p 1/noise_p per output
         self._pcg_ws = grid_ops.PCGWorkspace()
         self._memo = {}
         self._mean_state = None  # warm-start state of the posterior-mean solve
@@ -194,6 +195,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             wb = 1.0 / no
             wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
             grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
+            if cache is self._kernel_cache or init:
+                self._wsum_dev[o] += wa.sum(dtype=torch.float64)
+
+    @property
+    def _wsum(self):
+        return self._wsum_dev.tolist()
 
     def check_bounds(self):
         """Raise like gpytorch's grid check if any point seen so far was outside the
@@ -224,28 +231,32 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 for o in range(self.num_outputs):
                     bi = o if self.num_outputs > 1 else None
                     tcol = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).to(self._dtype).contiguous()
-                    vals.append((tcol, self._sigma2(o)))
+                    eig = grid_ops.kron_eigen(self._grid, tcol) if settings.spectral_preconditioner.on() else None
+                    vals.append((tcol, self._sigma2(o), eig))
             h = (ver, vals)
             self._memo["hyper"] = h
         return h[1]
 
     def _posterior_op(self, o):
-        tcol, s2 = self._hyper()[o]
+        tcol, s2, eig = self._hyper()[o]
+        # preconditioner shift ~ mean row sum of A = (sum_p 1/noise_p) / m  (W rows sum to one)
+        shift = float(self._wsum[o]) / self._grid.m
         return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
-                                 settings.max_cg_iterations.value(), workspace=self._pcg_ws)
+                                 settings.max_cg_iterations.value(), workspace=self._pcg_ws, check_every=settings.cg_check_every.value(),
+                                 eigen=eig, shift=shift)
 
     # --------------------------------------------------------------- caches --
     @property
     def Kuu(self):
         """Lazy Kuu (/ sigma2 when the second noise is learnable), :334-341."""
-        ops = [KroneckerToeplitz(self._grid, tcol, 1.0 / s2) for tcol, s2 in self._hyper()]
+        ops = [KroneckerToeplitz(self._grid, tcol, 1.0 / s2) for tcol, s2, _ in self._hyper()]
         return ops[0] if self.num_outputs == 1 else BatchOperator(ops)
 
     @property
     def Kuu_response(self):
         """Kuu @ W^T D^-1 y, :363-366; [out, m, 1]."""
         b = self._kernel_cache["interpolation_cache"]
-        outs = [grid_ops.kron_toeplitz_mm(self._grid, tcol, b[o, :, 0], 1.0 / s2) for o, (tcol, s2) in enumerate(self._hyper())]
+        outs = [grid_ops.kron_toeplitz_mm(self._grid, tcol, b[o, :, 0], 1.0 / s2) for o, (tcol, s2, _) in enumerate(self._hyper())]
         return torch.stack(outs)[..., None]
 
     @property
@@ -272,7 +283,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             if self._mean_state is not None:
                 Uo, Zo = self._mean_state["U"][o:o + 1].clone(), self._mean_state["Z"][o:o + 1].clone()
                 if self._mean_state["ver"] != ver:
-                    tcol, s2 = hyper[o]
+                    tcol, s2, _ = hyper[o]
                     Uo = grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2)   # keep U = Kt Z under the new hypers
                 warm = True
             Uo, Zo = post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm)
@@ -332,7 +343,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if X is None:
             return MultivariateNormal(mean, ZeroLazyTensor(*mean_shape, n, dtype=self._dtype, device=self._device))
         Xf = X.reshape(-1, self._grid.d).to(self._device, self._dtype)
-        ops = [InterpolatedKernel(self._grid, Xf, tcol, 1.0, self._err) for tcol, _ in self._hyper()]
+        ops = [InterpolatedKernel(self._grid, Xf, tcol, 1.0, self._err) for tcol, _, _ in self._hyper()]
         return MultivariateNormal(mean, ops[0] if out == 1 else BatchOperator(ops))
 
     def _eval_forward(self, X):
@@ -392,6 +403,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             likelihood=self.likelihood,
             num_data=self.num_data + q,
         )
+        new_gp._wsum_dev = self._wsum_dev.clone()
         new_gp._absorb(new_cache, X, Y, noise, init=False)
         if self._mean_state is not None:
             new_gp._mean_state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._mean_state.items()}
@@ -420,6 +432,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         cache["_stats"].zero_()
         for op in _wtw_ops(cache["WtW"]):
             op.stencil.zero_()
+        self._wsum_dev.zero_()
         self._absorb(cache, train_inputs, train_targets, noise, init=True)
         self.num_data = train_inputs.reshape(-1, self._grid.d).shape[0]
         self._mean_state = None

@@ -115,3 +115,16 @@ class variance_chunk(_value_context):
     """Right-hand sides per batched PCG solve when predictive variances are requested."""
 
     _global_value = 64
+
+
+class spectral_preconditioner(_feature_flag):
+    """Precondition wiski_pcg with (Kt^-1 + a I)^-1 in the Kronecker eigenbasis of
+    Kuu (a = mean row sum of W^T D^-1 W) instead of Kt alone."""
+
+    _state = True
+
+
+class cg_check_every(_value_context):
+    """Iterations between host-side convergence checks of wiski_pcg."""
+
+    _global_value = 5

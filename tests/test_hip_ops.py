@@ -118,9 +118,10 @@ def test_spmv_and_kron(d, g, tdt, ndt, tol):
         assert np.abs(outk.double().cpu().numpy() - refk).max() < tol * np.abs(refk).max() * 10
 
 
+@pytest.mark.parametrize("spectral", [False, True])
 @pytest.mark.parametrize("d,g", CASES)
 @pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-8), (torch.float32, np.float32, 2e-3)])
-def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol):
+def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral):
     from online_gp_amd import grid_ops
 
     grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
@@ -129,7 +130,8 @@ def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol):
     Uref, _, _ = B2.solve(RHS, tol=1e-13)
     cg_tol = 1e-10 if tdt == torch.float64 else 1e-6
     A = _t(B2.A, tdt); tc = _t(B2.tcol, tdt)
-    U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=cg_tol, max_iter=500, check_every=5)
+    kw = dict(eigen=grid_ops.kron_eigen(grid, tc), shift=X.shape[0] / grid.m) if spectral else {}
+    U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=cg_tol, max_iter=500, check_every=5, **kw)
     assert max(res) < cg_tol * 1.01, (it, res)
     assert np.abs(U.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
     # U = Kt Z
@@ -137,7 +139,7 @@ def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol):
     assert (KZ - U).abs().max().item() < 50 * tol * U.abs().max().item()
     # warm start from the solution converges immediately
     U2, Z2, it2, res2 = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), U=U.clone(), Z=Z.clone(), warm=True, tol=cg_tol * 10,
-                                     max_iter=500, check_every=5)
+                                     max_iter=500, check_every=5, **kw)
     assert it2 <= 5
     assert np.abs(U2.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
 

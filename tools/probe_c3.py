@@ -43,9 +43,10 @@ for k in (1, 4, 16):
     t = timeit(lambda: grid_ops.kron_toeplitz_mm(grid, tcol, V), 20)
     print(f'kron k={k}: {t*1e6:.1f} us')
 ws = grid_ops.PCGWorkspace()
+EIG = grid_ops.kron_eigen(grid, tcol) if (len(sys.argv) < 3 or sys.argv[2] != "plain") else None
 for tol in (1e-2, 1e-4, 1e-6):
     torch.cuda.synchronize(); t = time.perf_counter()
-    U, Z, it, res = grid_ops.pcg(grid, A, tcol, 1 / s2, b[None], tol=tol, max_iter=1000, check_every=10, workspace=ws)
+    U, Z, it, res = grid_ops.pcg(grid, A, tcol, 1 / s2, b[None], tol=tol, max_iter=1000, check_every=5, workspace=ws, eigen=EIG, shift=N / grid.m)
     torch.cuda.synchronize(); t = time.perf_counter() - t
     print(f'pcg tol={tol}: iters {it} res {res[0]:.2e} time {t*1e3:.2f} ms  ({t/it*1e6:.1f} us/iter)')
 for nq in (4096, 1 << 20):
