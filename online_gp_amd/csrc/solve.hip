@@ -396,6 +396,7 @@ static int launch_spectral_precond(const GridDev<real>& G, const real* evec, con
                                    real* sa, real* sb, real* ty, double* rho, hipStream_t s) {
   const int m = G.m, d = G.d;
   const int64_t km = (int64_t)k * m;
+  if (spectral_fused_ok<real>(G)) return launch_spectral_fused<real>(G, evec, evals, kscale, shift, r, k, sa, sb, ty, rho, s);
   int eoff[WISKI_MAX_DIM + 1];
   eoff[0] = 0;
   for (int q = 0; q < d; ++q) {
@@ -476,7 +477,8 @@ __device__ __forceinline__ bool pcg_active(const PcgScal& S, int it, int c, doub
 
 // p = y + beta p ; pt = t + beta pt ; beta = rho(it)/rho(it-1)   (t = Kt^-1 y: r for
 // the plain Kt preconditioner, (I + a Kt)^-1 r for the spectral one)
-template <typename real>
+// VEC = 4: 16-byte accesses (requires m % 4 == 0).
+template <typename real, int VEC>
 __global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2, const real* __restrict__ y, const real* __restrict__ r,
                                                       real* __restrict__ p, real* __restrict__ pt, PcgScal S) {
   const int c = blockIdx.y;
@@ -486,16 +488,40 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2
     beta = den > 0 ? S.rho(it)[c] / den : 0;
   }
   const real bt = (real)beta;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    const int64_t e = (int64_t)c * m + i;
-    if (it == 0) { p[e] = y[e]; pt[e] = r[e]; }
-    else { p[e] = y[e] + bt * p[e]; pt[e] = r[e] + bt * pt[e]; }
+  const int64_t cm = (int64_t)c * m;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < m; i += gridDim.x * blockDim.x * VEC) {
+    real yv[VEC], rv[VEC], pv[VEC], ptv[VEC];
+    if constexpr (VEC == 4) {
+      const Vec4<real> a = load4<real>(y + cm + i), b = load4<real>(r + cm + i);
+      yv[0] = a.x; yv[1] = a.y; yv[2] = a.z; yv[3] = a.w;
+      rv[0] = b.x; rv[1] = b.y; rv[2] = b.z; rv[3] = b.w;
+      if (it > 0) {
+        const Vec4<real> cpp = load4<real>(p + cm + i), dpp = load4<real>(pt + cm + i);
+        pv[0] = cpp.x; pv[1] = cpp.y; pv[2] = cpp.z; pv[3] = cpp.w;
+        ptv[0] = dpp.x; ptv[1] = dpp.y; ptv[2] = dpp.z; ptv[3] = dpp.w;
+      }
+    } else {
+      yv[0] = y[cm + i]; rv[0] = r[cm + i];
+      if (it > 0) { pv[0] = p[cm + i]; ptv[0] = pt[cm + i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      pv[u] = it == 0 ? yv[u] : yv[u] + bt * pv[u];
+      ptv[u] = it == 0 ? rv[u] : rv[u] + bt * ptv[u];
+    }
+    if constexpr (VEC == 4) {
+      store4<real>(p + cm + i, pv[0], pv[1], pv[2], pv[3]);
+      store4<real>(pt + cm + i, ptv[0], ptv[1], ptv[2], ptv[3]);
+    } else {
+      p[cm + i] = pv[0]; pt[cm + i] = ptv[0];
+    }
   }
 }
 
 // alpha = rho/php ; u += alpha p ; z += alpha pt ; r -= alpha hp ; rn(it+1) += r^2
 // nch > 0: hp is not materialised, hp = pt + sum_ch part[ch]  (wide SpMV path).
-template <typename real>
+// VEC = 4: 16-byte accesses (requires m % 4 == 0); all partial loads are independent.
+template <typename real, int VEC>
 __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2, const real* __restrict__ p, const real* __restrict__ pt,
                                                       const real* __restrict__ hp, const real* __restrict__ part, int nch,
                                                       real* __restrict__ u, real* __restrict__ z, real* __restrict__ r, PcgScal S) {
@@ -506,21 +532,55 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
   if (pcg_active(S, it, c, tol2) && den > 0) alpha = S.rho(it)[c] / den;
   const real al = (real)alpha;
   double acc = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    const int64_t e = (int64_t)c * m + i;
-    const real pte = pt[e];
-    u[e] += al * p[e];
-    z[e] += al * pte;
-    real h;
-    if (nch > 0) {
-      h = pte;
-      for (int ch = 0; ch < nch; ++ch) h += part[(int64_t)ch * S.k * m + e];
+  const int64_t cm = (int64_t)c * m;
+  const int64_t km = (int64_t)S.k * m;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < m; i += gridDim.x * blockDim.x * VEC) {
+    const int64_t e = cm + i;
+    real pv[VEC], ptv[VEC], hv[VEC], uv[VEC], zv[VEC], rv[VEC];
+    if constexpr (VEC == 4) {
+      const Vec4<real> a = load4<real>(p + e), b = load4<real>(pt + e), cu = load4<real>(u + e), cz = load4<real>(z + e), cr = load4<real>(r + e);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+      ptv[0] = b.x; ptv[1] = b.y; ptv[2] = b.z; ptv[3] = b.w;
+      uv[0] = cu.x; uv[1] = cu.y; uv[2] = cu.z; uv[3] = cu.w;
+      zv[0] = cz.x; zv[1] = cz.y; zv[2] = cz.z; zv[3] = cz.w;
+      rv[0] = cr.x; rv[1] = cr.y; rv[2] = cr.z; rv[3] = cr.w;
+      if (nch > 0) {
+        Vec4<real> pp[7];
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch)
+          if (ch < nch) pp[ch] = load4<real>(part + (int64_t)ch * km + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = ptv[q];
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch)
+          if (ch < nch) { hv[0] += pp[ch].x; hv[1] += pp[ch].y; hv[2] += pp[ch].z; hv[3] += pp[ch].w; }
+      } else {
+        const Vec4<real> h4 = load4<real>(hp + e);
+        hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
+      }
     } else {
-      h = hp[e];
+      pv[0] = p[e]; ptv[0] = pt[e]; uv[0] = u[e]; zv[0] = z[e]; rv[0] = r[e];
+      if (nch > 0) {
+        hv[0] = ptv[0];
+        for (int ch = 0; ch < nch; ++ch) hv[0] += part[(int64_t)ch * km + e];
+      } else {
+        hv[0] = hp[e];
+      }
     }
-    const real rr = r[e] - al * h;
-    r[e] = rr;
-    acc += (double)rr * rr;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      uv[q] += al * pv[q];
+      zv[q] += al * ptv[q];
+      rv[q] -= al * hv[q];
+      acc += (double)rv[q] * rv[q];
+    }
+    if constexpr (VEC == 4) {
+      store4<real>(u + e, uv[0], uv[1], uv[2], uv[3]);
+      store4<real>(z + e, zv[0], zv[1], zv[2], zv[3]);
+      store4<real>(r + e, rv[0], rv[1], rv[2], rv[3]);
+    } else {
+      u[e] = uv[0]; z[e] = zv[0]; r[e] = rv[0];
+    }
   }
   acc = block_reduce_sum(acc, s_red);
   if (threadIdx.x == 0) unsafeAtomicAdd(S.rn(it + 1) + c, acc);
@@ -569,6 +629,9 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   int eb = (m + 255) / 256;
   if (eb > 1024) eb = 1024;
   dim3 egrid((unsigned)eb, (unsigned)k);
+  int vb = (m / 4 + 255) / 256;
+  if (vb < 1) vb = 1;
+  dim3 vgrid((unsigned)vb, (unsigned)k);   // one 16-byte group per thread
 
   if (warm) {
     // r0 = rhs - (z + A u)
@@ -613,20 +676,29 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       // [t | y] = spectral preconditioner applied to r, rho(it) = r.y
       rc = launch_spectral_precond<real>(G, d_evec, d_eval, kscale, shift, r, k, sa, sb, ty, S.rho(it), s);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_update_p<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)(ty + (int64_t)k * m), (const real*)ty, p, pt,
-                         S);
+      if (wide)
+        hipLaunchKernelGGL((k_pcg_update_p<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)(ty + (int64_t)k * m), (const real*)ty, p,
+                           pt, S);
+      else
+        hipLaunchKernelGGL((k_pcg_update_p<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)(ty + (int64_t)k * m), (const real*)ty, p,
+                           pt, S);
     } else {
       // y = Kt r, rho(it) = r.y
       rc = launch_kron<real>(G, d_tcol, r, k, kscale, tmp, y, r, S.rho(it), s);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_update_p<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
+      if (wide) hipLaunchKernelGGL((k_pcg_update_p<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
+      else hipLaunchKernelGGL((k_pcg_update_p<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
     }
     // hp = pt + A p, php(it) = p.hp
     if (wide) rc = launch_spmv4<real>(G, d_A, p, k, part, pt, (real)1, S.php(it), s);
     else rc = launch_spmv<real>(G, d_A, p, k, pt, (real)1, hp, S.php(it), s);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_pcg_update_x<real>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                       (const real*)part, nch, d_U, d_Z, r, S);
+    if (wide)
+      hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
+                         (const real*)part, nch, d_U, d_Z, r, S);
+    else
+      hipLaunchKernelGGL((k_pcg_update_x<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
+                         (const real*)part, nch, d_U, d_Z, r, S);
     ++it;
     if (it % check_every == 0 || it == max_iter) {
       rc = fetch(it);

@@ -1,0 +1,395 @@
+// Fused Kronecker-eigenbasis preconditioner for d = 3 grids (the 50^3 workload).
+//
+//   [t | y] = (kron V) diag(f1 | f2) (kron V)^T r,   f1 = 1/(1 + a lam), f2 = lam f1,
+//   lam = kscale * lam0[i0] lam1[i1] lam2[i2]
+//
+// i.e. t = (I + a Kt)^-1 r and y = (Kt^-1 + a I)^-1 r, the two vectors one PCG
+// iteration needs (solve.hip).  Six mode products, done in three launches:
+//   k_spec_mode0 (fwd)  : mode 0 of the forward transform, tiled over the 2500 fibres
+//   k_spec_slab         : per i0-slab (g1 x g2, LDS resident): fwd modes 1,2 ->
+//                         spectral scaling -> bwd modes 2,1; one block per
+//                         (i0, output half), the forward part recomputed per half
+//   k_spec_mode0 (bwd)  : mode 0 of the backward transform for both halves, with
+//                         the r.y dot product fused into the epilogue
+// All small GEMMs use one LDS primitive: Out[x][y] = sum_b F[b][x] * In[b][y] with
+// a 4x4 register tile per thread and 16-byte LDS reads of both operands (2 reads
+// per 16 FMAs; conflict-free: consecutive lanes read consecutive 16-B slots or
+// broadcast).
+#include "wiski_common.h"
+
+#ifdef SPEC_TIMING
+__device__ long long g_spec_dbg[16];
+#define SPEC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_spec_dbg[i] = clock64(); } while (0)
+#else
+#define SPEC_STAMP(i) do {} while (0)
+#endif
+#ifndef SPEC_ABLATE
+#define SPEC_ABLATE 0   // micro-benchmark hook (tools/ubench): 1 = skip LDS products, 2 = skip transposed LDS writes
+#endif
+
+template <typename real>
+struct V4 { real v[4]; };
+
+template <typename real>
+__device__ __forceinline__ V4<real> lds_read4(const real* p) {
+  V4<real> r;
+  if constexpr (sizeof(real) == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    double2 a = *reinterpret_cast<const double2*>(p);
+    double2 b = *reinterpret_cast<const double2*>(p + 2);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+  }
+  return r;
+}
+
+// acc[i][j] = sum_{b<gb4} F[b*ldf + 4*tx + i] * In[b*ldi + 4*ty + j]      (F stored [b][x])
+// gb4 is a multiple of 4 (rows of F / In in [g, gb4) are zero).
+// NOTE (measured, tools/ubench): these LDS products run ~5x below the FMA issue
+// bound because one wave per SIMD exposes the LDS latency of every step and
+// hipcc re-serialises source-level register rings at the loop back-edge; a
+// compile-time trip count or an asm inner loop is the known next step.
+template <typename real>
+__device__ __forceinline__ void tile_product(const real* __restrict__ sF, int ldf, const real* __restrict__ sIn, int ldi, int gb4, int tx, int ty,
+                                             real acc[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (real)0;
+  const real* pf = sF + 4 * tx;
+  const real* pi = sIn + 4 * ty;
+  if (SPEC_ABLATE & 1) { acc[0][0] = pf[0] + pi[0]; return; }
+#pragma unroll 2
+  for (int b0 = 0; b0 < gb4; b0 += 4) {
+    V4<real> f[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f[u] = lds_read4<real>(pf + (b0 + u) * ldf);
+      v[u] = lds_read4<real>(pi + (b0 + u) * ldi);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += f[u].v[i] * v[u].v[j];
+  }
+}
+
+// acc[i][j] = sum_{b<gb4} F[(4*tx + i)*ldf + b] * In[b*ldi + 4*ty + j]    (F stored [x][b];
+// gb4 = gb rounded up to 4; F columns and In rows in [gb, gb4) must be zero)
+template <typename real>
+__device__ __forceinline__ void tile_product_t(const real* __restrict__ sF, int ldf, const real* __restrict__ sIn, int ldi, int gb4, int tx, int ty,
+                                               real acc[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (real)0;
+  const real* pf = sF + 4 * tx * ldf;
+  const real* pi = sIn + 4 * ty;
+  if (SPEC_ABLATE & 1) { acc[0][0] = pf[0] + pi[0]; return; }
+#pragma unroll 2
+  for (int b0 = 0; b0 < gb4; b0 += 4) {
+    V4<real> f[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f[u] = lds_read4<real>(pf + u * ldf + b0);       // F[4tx+u][b0..b0+3]
+      v[u] = lds_read4<real>(pi + (b0 + u) * ldi);     // In[b0+u][4ty..]
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += f[i].v[bb] * v[bb].v[j];
+  }
+}
+
+// g x g row-major matrix -> LDS with row stride P (P = g rounded up to 4).  Split in
+// two so that a kernel can issue every global load before its first barrier:
+// matrix_issue() only loads into registers, matrix_commit() writes LDS (the
+// destination must have been zero-filled, and a barrier passed, beforehand).
+template <typename real, int NT>
+struct MatrixLoad {
+  static constexpr int MAXIT = (64 * 64 + NT - 1) / NT;
+  real tmp[MAXIT];
+  __device__ __forceinline__ void issue(const real* __restrict__ V, int g) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = threadIdx.x + it * NT;
+      tmp[it] = V[idx < g * g ? idx : 0];
+    }
+  }
+  __device__ __forceinline__ void commit(real* sF, int g, int P) const {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = threadIdx.x + it * NT;
+      if (idx < g * g) {
+        const int r = idx / g;
+        sF[r * P + (idx - r * g)] = tmp[it];
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------- mode 0 ---
+// dst[c][x, s] = sum_b Fm[b][x] src[c][b, s]  for an s-tile of 32 fibres, with
+// Fm = V0 (forward, transposed == 0: V0^T .) or V0^T (backward: V0 .).
+// grid = (ceil(S/32), ncols), block = 128 (tiles: (P0/4) x 8 <= 128 for g0 <= 64).
+template <typename real, bool DOT>
+__global__ __launch_bounds__(128) void k_spec_mode0(GridDev<real> G, const real* __restrict__ V0, int transposed, const real* __restrict__ src,
+                                                    real* __restrict__ dst, const real* __restrict__ rvec, int dot_c0, double* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double s_red[16];
+  constexpr int ST = 32;
+  const int g0 = G.g[0], S = G.stride[0], m = G.m;
+  const int P0 = (g0 + 3) & ~3;
+  real* sF = reinterpret_cast<real*>(smem);   // [P0][P0]
+  real* sIn = sF + P0 * P0;                   // [P0][ST]
+  const int c = blockIdx.y;
+  const int s0 = blockIdx.x * ST;
+  const real* __restrict__ sc = src + (int64_t)c * m;
+  // In tile: rows b < g0 (rows up to P0 zero), 8 x 16-byte loads per row; issue all loads first
+  constexpr int NV = (64 * (ST / 4) + 127) / 128;   // <= 4
+  V4<real> tin[NV];
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int t = threadIdx.x + it * 128;
+    const int b = t / (ST / 4), q4 = (t - b * (ST / 4)) * 4;
+    V4<real> z;
+    z.v[0] = z.v[1] = z.v[2] = z.v[3] = (real)0;
+    tin[it] = (b < g0 && s0 + q4 < S) ? lds_read4<real>(sc + (int64_t)b * S + s0 + q4) : z;   // S % 4 == 0 (precondition)
+  }
+  MatrixLoad<real, 128> ml;
+  ml.issue(V0, g0);
+  for (int e = threadIdx.x; e < P0 * P0; e += 128) sF[e] = (real)0;
+  __syncthreads();
+  ml.commit(sF, g0, P0);
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int t = threadIdx.x + it * 128;
+    const int b = t / (ST / 4), q4 = (t - b * (ST / 4)) * 4;
+    if (b < P0) {
+      real* d = sIn + b * ST + q4;
+      d[0] = tin[it].v[0]; d[1] = tin[it].v[1]; d[2] = tin[it].v[2]; d[3] = tin[it].v[3];
+    }
+  }
+  __syncthreads();
+  const int nty = ST / 4;
+  const int ntx = P0 / 4;
+  const int t = threadIdx.x;
+  double part = 0;
+  if (t < ntx * nty) {
+    const int tx = t / nty, ty = t - tx * nty;
+    real acc[4][4];
+    if (transposed) tile_product_t<real>(sF, P0, sIn, ST, P0, tx, ty, acc);
+    else tile_product<real>(sF, P0, sIn, ST, P0, tx, ty, acc);
+    const int s = s0 + 4 * ty;
+    if (s < S) {
+      real* __restrict__ dc = dst + (int64_t)c * m;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = 4 * tx + i;
+        if (x < g0) {
+          const int64_t e = (int64_t)x * S + s;
+          if constexpr (sizeof(real) == 4) {
+            *reinterpret_cast<float4*>(dc + e) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+          } else {
+            *reinterpret_cast<double2*>(dc + e) = make_double2(acc[i][0], acc[i][1]);
+            *reinterpret_cast<double2*>(dc + e + 2) = make_double2(acc[i][2], acc[i][3]);
+          }
+          if (DOT && c >= dot_c0) {
+            const V4<real> rv = lds_read4<real>(rvec + (int64_t)(c - dot_c0) * m + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part += (double)rv.v[j] * (double)acc[i][j];
+          }
+        }
+      }
+    }
+  }
+  if (DOT && c >= dot_c0) {
+    const double tot = block_reduce_sum(part, s_red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dots + (c - dot_c0), tot);
+  }
+}
+
+// -------------------------------------------------------------- slab ---
+// One block per (i0, half h, column c): src slab X[i1][i2] ->
+//   YT[i2][i1'] = sum_i1 V1[i1][i1'] X[i1][i2]
+//   ZT[i2'][i1'] = sum_i2 V2[i2][i2'] YT[i2][i1']      (full forward transform)
+//   scale by f_h(lam)                                    (h = 0: f1, h = 1: f2)
+//   T'T[i1'][i2] = sum_i2' V2[i2][i2'] ZT[i2'][i1']     (written transposed)
+//   out[i1][i2]  = sum_i1' V1[i1][i1'] T'T[i1'][i2]  -> dst[h*k + c] slab i0
+// V1, V2 stay in LDS in their natural layout; the backward products read them
+// through tile_product_t.  Every global load of the block is issued up front.
+template <typename real>
+__global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* __restrict__ V1, const real* __restrict__ V2,
+                                                   const real* __restrict__ evals, real kscale, real shift, const real* __restrict__ src,
+                                                   real* __restrict__ dst, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2], m = G.m;
+  const int P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
+  const int PM = P1 > P2 ? P1 : P2;
+  real* B0 = reinterpret_cast<real*>(smem);
+  real* B1 = B0 + PM * PM;
+  real* sV1 = B1 + PM * PM;
+  real* sV2 = sV1 + P1 * P1;
+  real* sE = sV2 + P2 * P2;   // [P1 + P2] eigenvalues of dims 1, 2 (zero padded)
+  const int i0 = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
+  const int t = threadIdx.x;
+  const real* __restrict__ xs = src + (int64_t)c * m + (int64_t)i0 * g1 * g2;
+  SPEC_STAMP(0);
+
+  // X slab: g1*g2 contiguous reals, 16-byte loads (g1*g2 % 4 == 0: precondition)
+  constexpr int NX = (64 * 64 / 4 + 255) / 256;   // <= 4
+  V4<real> tx4[NX];
+  const int nvec = g1 * g2 / 4;
+#pragma unroll
+  for (int it = 0; it < NX; ++it) {
+    const int e4 = t + it * 256;
+    V4<real> z;
+    z.v[0] = z.v[1] = z.v[2] = z.v[3] = (real)0;
+    tx4[it] = e4 < nvec ? lds_read4<real>(xs + 4 * e4) : z;
+  }
+  real ev = (real)0;
+  if (t < P1) ev = t < g1 ? evals[g0 + t] : (real)0;
+  else if (t < P1 + P2) ev = (t - P1) < g2 ? evals[g0 + g1 + (t - P1)] : (real)0;
+  const real l0 = kscale * evals[i0];
+  MatrixLoad<real, 256> m1, m2;
+  m1.issue(V1, g1);
+  m2.issue(V2, g2);
+  for (int e = t; e < 2 * PM * PM + P1 * P1 + P2 * P2; e += 256) B0[e] = (real)0;   // B0, B1, sV1, sV2 (padding must be zero)
+  __syncthreads();
+  m1.commit(sV1, g1, P1);
+  m2.commit(sV2, g2, P2);
+  if (t < P1 + P2) sE[t] = ev;
+#pragma unroll
+  for (int it = 0; it < NX; ++it) {
+    const int e4 = t + it * 256;
+    if (e4 < nvec) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = 4 * e4 + u;
+        const int b = e / g2;
+        B0[b * P2 + (e - b * g2)] = tx4[it].v[u];   // X as [b = i1][y = i2], stride P2
+      }
+    }
+  }
+  __syncthreads();
+  SPEC_STAMP(1);
+  real acc[4][4];
+  {  // step 2: Out[x = i1'][y = i2] = sum_b V1[b][x] X[b][y]  -> YT[i2][i1'] (B1, stride P1)
+    const int ntx = P1 / 4, nty = P2 / 4;
+    if (t < ntx * nty) {
+      const int tx = t / nty, ty = t - tx * nty;
+      tile_product<real>(sV1, P1, B0, P2, P1, tx, ty, acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B1[(4 * ty + j) * P1 + 4 * tx + i] = acc[i][j];
+    }
+  }
+  __syncthreads();
+  SPEC_STAMP(2);
+  {  // step 3 + scaling: Out[x = i2'][y = i1'] = sum_b V2[b][x] YT[b][y] -> ZT[i2'][i1'] (B0, stride P1)
+    const int ntx = P2 / 4, nty = P1 / 4;
+    if (t < ntx * nty) {
+      const int tx = t / nty, ty = t - tx * nty;
+      tile_product<real>(sV2, P2, B1, P1, P2, tx, ty, acc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const real l2 = l0 * sE[P1 + 4 * tx + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const real lam = l2 * sE[4 * ty + j];
+          real f1;
+          if constexpr (sizeof(real) == 4) f1 = __frcp_rn((real)1 + shift * lam);
+          else f1 = (real)1 / ((real)1 + shift * lam);
+          B0[(4 * tx + i) * P1 + 4 * ty + j] = acc[i][j] * (h == 0 ? f1 : lam * f1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  SPEC_STAMP(3);
+  {  // step 5: Out[x = i2][y = i1'] = sum_b V2[x][b] ZT[b][y]  -> T'T[i1'][i2] (B1, stride P2)
+    const int ntx = P2 / 4, nty = P1 / 4;
+    if (t < ntx * nty) {
+      const int tx = t / nty, ty = t - tx * nty;
+      tile_product_t<real>(sV2, P2, B0, P1, P2, tx, ty, acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B1[(4 * ty + j) * P2 + 4 * tx + i] = acc[i][j];
+    }
+  }
+  __syncthreads();
+  SPEC_STAMP(4);
+  {  // step 6: Out[x = i1][y = i2] = sum_b V1[x][b] T'T[b][y]  -> global
+    const int ntx = P1 / 4, nty = P2 / 4;
+    if (t < ntx * nty) {
+      const int tx = t / nty, ty = t - tx * nty;
+      tile_product_t<real>(sV1, P1, B1, P2, P1, tx, ty, acc);
+      real* __restrict__ os = dst + ((int64_t)h * k + c) * m + (int64_t)i0 * g1 * g2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = 4 * tx + i;
+        if (x < g1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int y = 4 * ty + j;
+            if (y < g2) os[x * g2 + y] = acc[i][j];
+          }
+        }
+      }
+    }
+  }
+  SPEC_STAMP(5);
+}
+
+// ------------------------------------------------------------ host side ---
+template <typename real>
+bool spectral_fused_ok(const GridDev<real>& G) {
+  if (G.d != 3) return false;
+  for (int q = 0; q < 3; ++q)
+    if (G.g[q] > 64) return false;
+  if (G.stride[0] % 4 != 0) return false;   // 16-byte slab / fibre-tile loads
+  return true;
+}
+
+// ty = [t | y] (2k columns), w0 = scratch of k*m reals; rho[c] += r[c].y[c]
+template <typename real>
+int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, const real* r, int k, real* w0,
+                          real* w1 /* 2k*m scratch */, real* ty, double* rho, hipStream_t s) {
+  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
+  const real* V0 = evec;
+  const real* V1 = evec + g0 * g0;
+  const real* V2 = V1 + g1 * g1;
+  const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
+  const int PM = P1 > P2 ? P1 : P2;
+  const int S = G.stride[0];
+  const size_t sh0 = (size_t)(P0 * P0 + P0 * 32) * sizeof(real);
+  const size_t sh1 = (size_t)(2 * PM * PM + P1 * P1 + P2 * P2 + P1 + P2) * sizeof(real);
+  const unsigned sx = (unsigned)((S + 31) / 32);
+  if (sh1 > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
+      return WISKI_E_LAUNCH;
+  }
+  // forward mode 0: w0 = V0^T r
+  hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, 0, r, w0, (const real*)nullptr, 0,
+                     (double*)nullptr);
+  // slab: forward modes 1,2 + scaling + backward modes 2,1 -> w1 = [half 0 | half 1]
+  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, evals, kscale, shift, (const real*)w0,
+                     w1, k);
+  // backward mode 0 on 2k columns, rho += r . y for the second half
+  hipLaunchKernelGGL((k_spec_mode0<real, true>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, 1, (const real*)w1, ty, r, k, rho);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+template bool spectral_fused_ok<float>(const GridDev<float>&);
+template bool spectral_fused_ok<double>(const GridDev<double>&);
+template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, float, float, const float*, int, float*, float*,
+                                          float*, double*, hipStream_t);
+template int launch_spectral_fused<double>(const GridDev<double>&, const double*, const double*, double, double, const double*, int, double*,
+                                           double*, double*, double*, hipStream_t);

@@ -147,3 +147,10 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
     case 4: { CALL(4); break; }   \
     default: return WISKI_E_BADARG; \
   }
+
+// spectral.hip: fused Kronecker-eigenbasis preconditioner (d = 3)
+template <typename real>
+bool spectral_fused_ok(const GridDev<real>& G);
+template <typename real>
+int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, const real* r, int k, real* w0,
+                          real* w1, real* ty, double* rho, hipStream_t s);

@@ -7,7 +7,7 @@ from oracle import cport, spec
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(1, 20), (2, 12), (3, 9), (4, 6)]
+CASES = [(1, 20), (2, 12), (3, 9), (3, 12), (4, 6)]  # (3, 12) takes the fused-spectral and wide-SpMV paths
 DTYPES = [(torch.float64, np.float64, 1e-11), (torch.float32, np.float32, 2e-4)]
 
 

@@ -1,7 +1,7 @@
 """Ad-hoc probe of the C3 workload (d=3, 50^3, fp32) kernel timings."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from online_gp_amd import grid_ops
 from oracle import spec
 
