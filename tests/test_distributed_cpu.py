@@ -1,0 +1,108 @@
+"""CPU, world_size 2, gloo: the data-parallel statistics path (ShardedStatsUpdater +
+all-reduce) equals single-process accumulation of the concatenated shards.
+The HIP scatter is replaced by the CPU oracle inside a stub model (test
+infrastructure only) so that the collective logic runs without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Grid:
+    d = 2
+
+
+class _StubOp:
+    def __init__(self, stencil):
+        self.stencil = stencil
+
+
+class StubModel:
+    """Host-side surface ShardedStatsUpdater touches, with the scatter done by the C oracle."""
+
+    def __init__(self, gb, g):
+        from oracle import cport
+
+        self.cp = cport
+        self.gb, self.g = gb, g
+        self._grid = _Grid()
+        self.num_outputs = 1
+        ref = cport.MatrixFreeWISKI(gb, g)
+        self.m, self.R = ref.m, ref.R
+        self._kernel_cache = self._fresh_cache()
+        self._wsum_dev = torch.zeros(1, dtype=torch.float64)
+        self.num_data = 0
+        self.dumped = 0
+
+    def _fresh_cache(self):
+        b = torch.zeros(1, self.m, 1, dtype=torch.float64)
+        stats = torch.zeros(1, 2, dtype=torch.float64)
+        return {"interpolation_cache": b, "_stats": stats, "WtW": _StubOp(torch.zeros(self.R, self.m, dtype=torch.float64))}
+
+    @staticmethod
+    def _canon_noise(noise, Y):
+        return noise
+
+    def _absorb(self, cache, X, Y, noise, init):
+        B2 = self.cp.MatrixFreeWISKI(self.gb, self.g)
+        B2.absorb(X.numpy(), Y[:, 0].numpy(), noise[:, 0].numpy(), init=init)
+        cache["interpolation_cache"][0, :, 0] += torch.from_numpy(B2.b)
+        cache["WtW"].stencil += torch.from_numpy(B2.A)
+        cache["_stats"][0] += torch.from_numpy(B2.c_ld)
+
+    def condition_on_observations(self, X, Y, noise, inplace=True):
+        self._absorb(self._kernel_cache, X, Y, noise, init=False)
+        self.num_data += X.shape[0]
+
+    def _dump_caches(self):
+        self.dumped += 1
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from online_gp_amd.distributed import ShardedStatsUpdater, allreduce_sum_
+
+    # plain all-reduce helper
+    t = [torch.full((3,), float(rank + 1), dtype=torch.float64), torch.ones(2, 2) * rank]
+    allreduce_sum_(t)
+    assert torch.allclose(t[0], torch.full((3,), 3.0, dtype=torch.float64)) and torch.allclose(t[1], torch.ones(2, 2))
+
+    gb, g = [[-1.1, 1.1]] * 2, 8
+    rng = np.random.default_rng(0)
+    X = torch.from_numpy(rng.uniform(-1, 1, (3, 40, 2)))          # 3 steps x 40 points, split over ranks
+    Y = torch.from_numpy(rng.standard_normal((3, 40, 1)))
+    N = torch.from_numpy(rng.uniform(0.5, 2.0, (3, 40, 1)))
+    model = StubModel(gb, g)
+    upd = ShardedStatsUpdater(model)
+    for s in range(3):
+        sl = slice(rank * 20, (rank + 1) * 20)
+        upd.update(X[s, sl], Y[s, sl], N[s, sl])
+    ref = StubModel(gb, g)
+    for s in range(3):
+        ref.condition_on_observations(X[s], Y[s], N[s])
+    c, r = model._kernel_cache, ref._kernel_cache
+    ok = (torch.allclose(c["interpolation_cache"], r["interpolation_cache"], atol=1e-12) and
+          torch.allclose(c["WtW"].stencil, r["WtW"].stencil, atol=1e-12) and torch.allclose(c["_stats"], r["_stats"], atol=1e-10) and
+          model.num_data == 120 and model.dumped == 3 and
+          abs(float(model._wsum_dev[0]) - float((1.0 / N).sum())) < 1e-9)
+    open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_stats_allreduce_world2(tmp_path, oracle_lib):
+    import socket
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"ok_{r}").read() == "1"

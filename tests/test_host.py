@@ -1,0 +1,122 @@
+"""CPU: host logic, the C-ABI library loads and exports every symbol include/wiski.h
+declares, and the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from online_gp_amd import _hip
+
+    if not os.path.exists(_hip._SO):
+        _hip.build()
+    return ctypes.CDLL(_hip._SO)
+
+
+def test_cabi_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "wiski.h")).read()
+    names = set(re.findall(r"^\s*(?:int|int64_t)\s+(wiski_\w+)\s*\(", hdr, flags=re.M))
+    assert len(names) >= 20, names
+    for n in sorted(names):
+        assert hasattr(built_lib, n), f"libwiski_hip.so does not export {n}"
+    assert built_lib.wiski_version() >= 1
+
+
+def test_workspace_query_runs_without_gpu(built_lib):
+    from online_gp_amd import grid_ops
+
+    g = grid_ops.GridSpec([[-1.1, 1.1]] * 3, 50)
+    built_lib.wiski_pcg_workspace_bytes.restype = ctypes.c_int64
+    need = built_lib.wiski_pcg_workspace_bytes(g.ref, 1, 100, 4)
+    assert need >= 19 * 125000 * 4
+    assert built_lib.wiski_pcg_workspace_bytes(g.ref, 0, 100, 4) < 0   # bad k -> WISKI_E_BADARG
+
+
+def test_grid_spec_matches_oracle_spec():
+    from online_gp_amd import grid_ops
+    from oracle import spec
+
+    for gb, gs in [([[-1.1, 1.1]] * 3, 50), ([[0.0, 1.0], [-2.0, 3.0]], [5, 9]), ([[-4.0, 14.0]], 20)]:
+        g = grid_ops.GridSpec(gb, gs)
+        g0, h, gg = spec.make_grid(gb, gs)
+        assert np.allclose(g.g0, g0, rtol=0, atol=1e-15) and np.allclose(g.h, h, rtol=0, atol=1e-15) and list(gg) == g.g
+        assert g.m == int(np.prod(gg)) and g.T == 4 ** g.d and g.R == 7 ** g.d
+        pts = g.grid_points()
+        delta = (gb[0][1] - gb[0][0]) / (g.g[0] - 2)               # linspace(lo - delta, hi + delta, g)
+        assert abs(float(pts[0][0]) - (gb[0][0] - delta)) < 1e-12 and abs(float(pts[0][-1]) - (gb[0][1] + delta)) < 1e-12
+    with pytest.raises(ValueError):
+        grid_ops.GridSpec([[0, 1]] * 5, 8)
+    with pytest.raises(ValueError):
+        grid_ops.GridSpec([[0, 1]], 3)
+
+
+def test_kernel_modules_match_oracle_columns():
+    from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, RBFKernel, ScaleKernel
+    from oracle import spec
+
+    for kind, mk in [("rbf", lambda: RBFKernel(ard_num_dims=2)), ("matern52", lambda: MaternKernel(nu=2.5, ard_num_dims=2)),
+                     ("matern12", lambda: MaternKernel(nu=0.5, ard_num_dims=2))]:
+        k = GridInterpolationKernel(ScaleKernel(mk()), grid_size=[7, 9], num_dims=2, grid_bounds=[[-1, 1], [0, 2]])
+        k.base_kernel.outputscale = 1.7
+        k.base_kernel.base_kernel.lengthscale = torch.tensor([0.4, 1.3])
+        g0, h, g = spec.make_grid([[-1, 1], [0, 2]], [7, 9])
+        ref = np.concatenate(spec.toeplitz_columns(kind, h, g, [0.4, 1.3], 1.7))
+        assert np.allclose(k.toeplitz_columns().detach().numpy(), ref, rtol=1e-6)
+    # default raw parameters -> softplus(0)
+    k = ScaleKernel(RBFKernel(ard_num_dims=3))
+    assert abs(float(k.outputscale) - spec.SOFTPLUS0) < 1e-6
+    assert torch.allclose(k.base_kernel.lengthscale, torch.full((1, 3), spec.SOFTPLUS0))
+    # gradients flow to the raw hyper-parameters
+    gk = GridInterpolationKernel(k, grid_size=6, num_dims=3, grid_bounds=[[-1, 1]] * 3)
+    gk.toeplitz_columns().sum().backward()
+    assert k.raw_outputscale.grad is not None and k.base_kernel.raw_lengthscale.grad.abs().sum() > 0
+
+
+def test_likelihood_noise_product():
+    from online_gp_amd.likelihoods import FNMGLikelihood
+
+    lk = FNMGLikelihood(noise=torch.full((1, 5), 2.0), learn_additional_noise=True)
+    assert torch.allclose(lk.noise, 2.0 * lk.second_noise)          # fnmg_likelihood.py:16-18
+    lk.second_noise = 0.3
+    assert abs(float(lk.second_noise) - 0.3) < 1e-6
+    lk2 = FNMGLikelihood(noise=torch.ones(1, 5), learn_additional_noise=False)
+    assert lk2.second_noise == 0 and lk2.second_noise_covar is None
+    with pytest.raises(RuntimeError):
+        lk2.second_noise = 1.0
+
+
+def test_settings_context_managers():
+    from online_gp_amd import settings
+
+    assert settings.skip_posterior_variances.off()
+    with settings.skip_posterior_variances(True):
+        assert settings.skip_posterior_variances.on()
+    assert settings.skip_posterior_variances.off()
+    assert settings.cg_tolerance.value() is None
+    with settings.cg_tolerance(1e-3):
+        assert settings.cg_tolerance.value() == 1e-3
+    assert settings.detach_interp_coeff.off() and settings.check_decomposition.off()
+
+
+def test_product_path_refuses_cpu_tensors():
+    """There is no CPU fallback: constructing the model on CPU tensors must raise."""
+    from online_gp_amd import _hip
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    with pytest.raises(_hip.WiskiError):
+        FixedNoiseOnlineSKIGP(torch.rand(5, 2), torch.rand(5, 1), None, grid_size=8)
+
+
+def test_product_code_never_imports_the_oracle():
+    import glob
+
+    for f in glob.glob(os.path.join(ROOT, "online_gp_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
