@@ -101,6 +101,20 @@ int wiski_stencil_spmv_f64(const wiski_grid* grid, const double* d_A_st, const d
 int wiski_kron_toeplitz_mm_f32(const wiski_grid* grid, const float* d_tcol, const float* d_V, int32_t k, float scale, float* d_tmp, float* d_out, void* stream);
 int wiski_kron_toeplitz_mm_f64(const wiski_grid* grid, const double* d_tcol, const double* d_V, int32_t k, double scale, double* d_tmp, double* d_out, void* stream);
 
+/* a17 backward -- gradient of bilinear forms in Kuu w.r.t. the Toeplitz columns
+ * (what autograd computes through Kuu in BWM:19-51 / BFN:334-366):
+ *   d_grad[sum g] += d/d tcol  sum_c X[c]^T (kron_q SymToeplitz(tcol_q)) Y[c]
+ * d_tmp: 2*k*m reals of scratch; d_grad is double and is accumulated into. */
+int wiski_kron_toeplitz_grad_f32(const wiski_grid* grid, const float* d_tcol, const float* d_X, const float* d_Y, int32_t k, float* d_tmp, double* d_grad, void* stream);
+int wiski_kron_toeplitz_grad_f64(const wiski_grid* grid, const double* d_tcol, const double* d_X, const double* d_Y, int32_t k, double* d_tmp, double* d_grad, void* stream);
+
+/* Spectral functions of Kt = kscale*Kuu in its Kronecker eigenbasis (d_evec/d_eval
+ * as for wiski_pcg): d_out[c] = V diag(lam^pw / (1 + shift*lam)^rw) V^T d_V[c].
+ * pw = 0.5, rw = 0 gives the symmetric root Kt^(1/2) (logdet(Q) by stochastic
+ * Lanczos quadrature, BWM:27 inv_quad_logdet).  d_tmp: k*m reals. */
+int wiski_kron_spectral_mm_f32(const wiski_grid* grid, const float* d_evec, const float* d_eval, float kscale, float shift, float pw, float rw, const float* d_V, int32_t k, float* d_tmp, float* d_out, void* stream);
+int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, const double* d_eval, double kscale, double shift, double pw, double rw, const double* d_V, int32_t k, double* d_tmp, double* d_out, void* stream);
+
 /* CG branch of a12 (BFN:368-383; gpytorch linear_cg under Q.inv_matmul),
  * moved to inducing space: solves (Kt^-1 + A) U = RHS, Kt = kscale*Kuu, for k
  * columns by preconditioned CG (no inverse of Kt is ever applied):

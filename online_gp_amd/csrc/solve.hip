@@ -433,6 +433,126 @@ static int launch_spectral_precond(const GridDev<real>& G, const real* evec, con
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+// ------------------------------------------- d/d tcol of bilinear Kron forms ---
+// For symmetric-Toeplitz Kronecker factors K = kron_q T(tcol_q):
+//   d/d tcol_q[l]  sum_c x_c^T K y_c  =  sum_c sum_{pp,s} sum_{|i-j| = l} X_c[pp,i,s] * Yq_c[pp,j,s]
+// with Yq = (kron_{r != q} T_r) Y (all modes but q applied; done by the caller with
+// a delta first column for dim q).  One thread per element of X; lag bins are
+// accumulated with LDS fp64 atomics, then one global fp64 atomic per bin per block.
+// Used by the Woodbury MLL backward (BWM:19-51 gradients; not on the streaming path).
+template <typename real>
+__global__ __launch_bounds__(256) void k_lag_correlate(int g, int post, int m, int k, const real* __restrict__ X, const real* __restrict__ Yq,
+                                                       double* __restrict__ out) {
+  __shared__ double s_bins[256];
+  for (int l = threadIdx.x; l < g; l += blockDim.x) s_bins[l] = 0.0;
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < m) {
+    const int i = (e / post) % g;
+    for (int c = 0; c < k; ++c) {
+      const double x = (double)X[(int64_t)c * m + e];
+      const real* __restrict__ src = Yq + (int64_t)c * m + (e - i * post);
+      for (int j = 0; j < g; ++j) {
+        const int lag = i > j ? i - j : j - i;
+        atomicAdd(&s_bins[lag], x * (double)src[(int64_t)j * post]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < g; l += blockDim.x)
+    if (s_bins[l] != 0.0) unsafeAtomicAdd(out + l, s_bins[l]);
+}
+
+// d_grad[sum g] (double, accumulated into) ; d_tmp: 2*k*m reals of scratch.
+template <typename real>
+static int kron_grad_impl(const wiski_grid* grid, const real* d_tcol, const real* d_X, const real* d_Y, int32_t k, real* d_tmp,
+                          double* d_grad, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_tcol || !d_X || !d_Y || !d_tmp || !d_grad || k < 1) return WISKI_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int m = G.m;
+  real* yq = d_tmp;
+  real* scratch = d_tmp + (int64_t)k * m;
+  dim3 grd((unsigned)((m + 255) / 256), (unsigned)k);
+  int toff = 0;
+  for (int q = 0; q < G.d; ++q) {
+    if (G.g[q] > 256) return WISKI_E_BADARG;
+    // Yq = product of all modes r != q applied to Y (ping-pong yq <-> scratch)
+    const real* src = d_Y;
+    int nmodes = G.d - 1, done = 0, off2 = 0;
+    for (int r = 0; r < G.d; ++r) {
+      if (r != q) {
+        // land the last applied mode in yq
+        real* dst = ((nmodes - 1 - done) % 2 == 0) ? yq : scratch;
+        hipLaunchKernelGGL((k_toeplitz_mode<real, false>), grd, dim3(256), 0, s, d_tcol + off2, G.g[r], G.stride[r], m, src, (real)1, dst,
+                           (const real*)nullptr, (double*)nullptr);
+        src = dst;
+        ++done;
+      }
+      off2 += G.g[r];
+    }
+    hipLaunchKernelGGL((k_lag_correlate<real>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, G.g[q], G.stride[q], m, k, d_X, src,
+                       d_grad + toff);
+    toff += G.g[q];
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// ------------------------------------------------ general spectral Kron apply ---
+// out = (kron V_q) diag(f(lam)) (kron V_q)^T v,  lam = kscale * prod_q eval_q[i_q],
+// f(lam) = lam^p / (1 + shift*lam)^r : p = 1/2, r = 0 is Kt^{1/2} (symmetric root
+// used by the stochastic-Lanczos logdet); p = 1, r = 1 the CG preconditioner.
+template <typename real>
+__global__ __launch_bounds__(256) void k_spectral_scale(GridDev<real> G, const real* __restrict__ evals, real kscale, real shift, real pw, real rw,
+                                                        real* __restrict__ v) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (e >= G.m) return;
+  real lam = kscale;
+  int eoff = 0;
+  for (int qq = 0; qq < G.d; ++qq) {
+    lam *= evals[eoff + (e / G.stride[qq]) % G.g[qq]];
+    eoff += G.g[qq];
+  }
+  real f = (real)1;
+  if (pw != (real)0) f = lam > (real)0 ? (real)pow((double)lam, (double)pw) : (real)0;
+  if (rw != (real)0) f *= (real)pow(1.0 + (double)shift * (double)lam, -(double)rw);
+  v[(int64_t)c * G.m + e] *= f;
+}
+
+template <typename real>
+static int spectral_mm_impl(const wiski_grid* grid, const real* d_evec, const real* d_eval, real kscale, real shift, real pw, real rw,
+                            const real* d_V, int32_t k, real* d_tmp, real* d_out, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_evec || !d_eval || !d_V || !d_tmp || !d_out || k < 1 || d_out == d_V) return WISKI_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int m = G.m, d = G.d;
+  int eoff[WISKI_MAX_DIM + 1];
+  eoff[0] = 0;
+  for (int q = 0; q < d; ++q) {
+    if (G.g[q] > 128) return WISKI_E_BADARG;
+    eoff[q + 1] = eoff[q] + G.g[q] * G.g[q];
+  }
+  dim3 grd((unsigned)((m + 255) / 256), (unsigned)k);
+  const real* cur = d_V;
+  // 2d mode products; ping-pong so that the last one lands in d_out
+  for (int step = 0; step < 2 * d; ++step) {
+    const int q = step < d ? step : step - d;
+    const int transposed = step < d ? 1 : 0;
+    real* dst = ((2 * d - 1 - step) % 2 == 0) ? d_out : d_tmp;
+    const size_t sh = (size_t)G.g[q] * G.g[q] * sizeof(real);
+    hipLaunchKernelGGL((k_dense_mode<real, 0>), grd, dim3(256), sh, s, G, q, d_evec + eoff[q], transposed, cur, dst, (int64_t)0, d_eval, kscale,
+                       shift, (const real*)nullptr, 0, (double*)nullptr);
+    cur = dst;
+    if (step == d - 1) hipLaunchKernelGGL((k_spectral_scale<real>), grd, dim3(256), 0, s, G, d_eval, kscale, shift, pw, rw, dst);
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 // -------------------------------------------------------------------- PCG ---
 // scalar slots (double): S[0..k) = ||rhs||^2 ; then per iteration slot
 // it in [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
@@ -754,6 +874,10 @@ int wiski_stencil_spmv_f32(const wiski_grid* g, const float* A, const float* V, 
 int wiski_stencil_spmv_f64(const wiski_grid* g, const double* A, const double* V, int32_t k, const double* add, double beta, double* out, void* s) { return spmv_impl<double>(g, A, V, k, add, beta, out, s); }
 int wiski_kron_toeplitz_mm_f32(const wiski_grid* g, const float* tcol, const float* V, int32_t k, float scale, float* tmp, float* out, void* s) { return kron_impl<float>(g, tcol, V, k, scale, tmp, out, s); }
 int wiski_kron_toeplitz_mm_f64(const wiski_grid* g, const double* tcol, const double* V, int32_t k, double scale, double* tmp, double* out, void* s) { return kron_impl<double>(g, tcol, V, k, scale, tmp, out, s); }
+int wiski_kron_toeplitz_grad_f32(const wiski_grid* g, const float* tcol, const float* X, const float* Y, int32_t k, float* tmp, double* grad, void* s) { return kron_grad_impl<float>(g, tcol, X, Y, k, tmp, grad, s); }
+int wiski_kron_toeplitz_grad_f64(const wiski_grid* g, const double* tcol, const double* X, const double* Y, int32_t k, double* tmp, double* grad, void* s) { return kron_grad_impl<double>(g, tcol, X, Y, k, tmp, grad, s); }
+int wiski_kron_spectral_mm_f32(const wiski_grid* g, const float* evec, const float* eval, float kscale, float shift, float pw, float rw, const float* V, int32_t k, float* tmp, float* out, void* s) { return spectral_mm_impl<float>(g, evec, eval, kscale, shift, pw, rw, V, k, tmp, out, s); }
+int wiski_kron_spectral_mm_f64(const wiski_grid* g, const double* evec, const double* eval, double kscale, double shift, double pw, double rw, const double* V, int32_t k, double* tmp, double* out, void* s) { return spectral_mm_impl<double>(g, evec, eval, kscale, shift, pw, rw, V, k, tmp, out, s); }
 int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size) {
   if (!grid || grid->d < 1 || grid->d > WISKI_MAX_DIM || k < 1 || max_iter < 1) return WISKI_E_BADARG;
   int64_t m = 1;

@@ -215,3 +215,30 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
     else:
         _hip.check(rc, "wiski_pcg")
     return U, Z, int(iters.value), list(relres)
+
+
+def kron_toeplitz_grad(grid, tcol, X, Y):
+    """d/d tcol of sum_c X[c]^T (kron SymToeplitz(tcol)) Y[c]  -> float64 [sum g]."""
+    X2 = X.contiguous().reshape(-1, grid.m)
+    Y2 = Y.contiguous().reshape(-1, grid.m)
+    k = X2.shape[0]
+    tmp = torch.empty((2 * k, grid.m), dtype=X2.dtype, device=X2.device)
+    grad = torch.zeros(sum(grid.g), dtype=torch.float64, device=X2.device)
+    rc = _hip.fn("wiski_kron_toeplitz_grad", X2.dtype)(grid.ref, _hip.dptr(tcol.contiguous()), _hip.dptr(X2), _hip.dptr(Y2), ctypes.c_int32(k),
+                                                       _hip.dptr(tmp), _hip.dptr(grad), _hip.stream_ptr(X2.device))
+    _hip.check(rc, "wiski_kron_toeplitz_grad")
+    return grad
+
+
+def kron_spectral_mm(grid, eigen, V, kscale=1.0, shift=0.0, power=0.5, rpower=0.0):
+    """V diag(lam^power / (1 + shift lam)^rpower) V^T applied to the columns of V ([k, m])."""
+    evec, evals = eigen
+    V2 = V.contiguous().reshape(-1, grid.m)
+    out = torch.empty_like(V2)
+    tmp = torch.empty_like(V2)
+    cr = _hip.creal(V2.dtype)
+    rc = _hip.fn("wiski_kron_spectral_mm", V2.dtype)(grid.ref, _hip.dptr(evec), _hip.dptr(evals), cr(kscale), cr(shift), cr(power), cr(rpower),
+                                                     _hip.dptr(V2), ctypes.c_int32(V2.shape[0]), _hip.dptr(tmp), _hip.dptr(out),
+                                                     _hip.stream_ptr(V2.device))
+    _hip.check(rc, "wiski_kron_spectral_mm")
+    return out.reshape(V.shape)

@@ -1,6 +1,130 @@
-"""BatchedWoodburyMarginalLogLikelihood (reference
-online_gp/mlls/batched_woodbury_marginal_log_likelihood.py:6-51)."""
+"""BatchedWoodburyMarginalLogLikelihood -- the WISKI marginal log-likelihood from the
+caches alone (reference online_gp/mlls/batched_woodbury_marginal_log_likelihood.py:6-51).
+
+Reference (root space, L L^T = W^T D^-1 W, Q = I + L^T Kt L, Kt = Kuu / sigma2):
+    inv_quad = (y^T D^-1 y - b^T Kt b) + (L^T Kt b)^T Q^-1 (L^T Kt b)       (BWM:27-34)
+    logdet   = logdet(Q) + logdet(D)                                         (BWM:35)
+    res      = -0.5 * (inv_quad / sigma2 + logdet + n log sigma2 + n log 2 pi) / n   (BWM:37-51)
+Matrix-free equivalents used here (same values):
+    inv_quad = y^T D^-1 y - b^T M b,  M = (Kt^-1 + A)^-1     (one wiski_pcg solve, mu = M b, z = Kt^-1 mu)
+    logdet(Q) = logdet(I + Kt A) = logdet(I + Kt^1/2 A Kt^1/2)   (stochastic Lanczos quadrature on the symmetric form)
+Gradients w.r.t. the hyper-parameters flow through torch autograd into the Toeplitz columns and sigma2:
+    d(b^T M b)   = z^T dKt z                                 (wiski_kron_toeplitz_grad on (z, z))
+    d logdet(Q)  = tr(S dKt),  S = (I + A Kt)^-1 A           (Hutchinson: s_j = Z-output of wiski_pcg for rhs A e_j)
+Like the reference, the `distro` and `targets` arguments are ignored: only `model._kernel_cache` is read.
+"""
+import math
+
 import torch
+
+from .. import grid_ops, settings
+
+
+class num_trace_samples(settings._value_context):
+    """Probe vectors for the logdet gradient / SLQ value (gpytorch default: 10)."""
+
+    _global_value = 10
+
+
+class exact_trace_max_size(settings._value_context):
+    """Grids with m <= this use the m unit vectors as probes (exact trace, deterministic)."""
+
+    _global_value = 256
+
+
+class _WoodburyTerms(torch.autograd.Function):
+    """(b^T M b, logdet(I + Kt A)) as a differentiable function of (tcol, kappa = 1/sigma2)."""
+
+    @staticmethod
+    def forward(ctx, tcol64, kappa, model, o, want_logdet):
+        grid = model._grid
+        dt, dev = model._dtype, model._device
+        tcol = tcol64.detach().to(dt).contiguous()
+        kap = float(kappa.detach())
+        A = model._kernel_cache["WtW"]
+        A = A.ops[o] if hasattr(A, "ops") else A
+        b = model._kernel_cache["interpolation_cache"][o, :, 0]
+        eig = grid_ops.kron_eigen(grid, tcol)
+        shift = float(model._wsum[o]) / grid.m
+        tol = settings.cg_tolerance.value() or (1e-7 if dt == torch.float32 else 1e-11)
+        kw = dict(tol=tol, max_iter=settings.max_cg_iterations.value(), check_every=settings.cg_check_every.value(), workspace=model._pcg_ws,
+                  eigen=eig, shift=shift)
+        U, Z, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, b[None], **kw)
+        bMb = (b.double() * U[0].double()).sum()
+        # probes for tr(S dKt)
+        m = grid.m
+        if m <= exact_trace_max_size.value():
+            E = torch.eye(m, dtype=dt, device=dev)
+        else:
+            gen = torch.Generator(device="cpu").manual_seed(0x5EED + model.num_data)
+            E = (torch.randint(0, 2, (num_trace_samples.value(), m), generator=gen).to(dt) * 2 - 1).to(dev)
+        P = E.shape[0]
+        S_cols = torch.empty_like(E)
+        chunk = settings.variance_chunk.value()
+        for s in range(0, P, chunk):
+            rhs = grid_ops.stencil_spmv(grid, A.stencil, E[s:s + chunk])
+            _, Zs, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, rhs, **kw)
+            S_cols[s:s + chunk] = Zs
+        logdet = torch.zeros((), dtype=torch.float64, device=dev)
+        if want_logdet:
+            logdet = _logdet_value(grid, A, eig, kap, E, m <= exact_trace_max_size.value())
+        # unit-vector probes sum to the exact trace; Rademacher probes average to it
+        ctx.grid, ctx.P, ctx.kap = grid, (1 if m <= exact_trace_max_size.value() else P), kap
+        ctx.save_for_backward(tcol, Z[0].clone(), U[0].clone(), S_cols, E)
+        return bMb, logdet
+
+    @staticmethod
+    def backward(ctx, g_bMb, g_logdet):
+        tcol, z, u, S_cols, E = ctx.saved_tensors
+        grid, P, kap = ctx.grid, ctx.P, ctx.kap
+        # columns [z | s_1..s_P] against [z | e_1..e_P], weighted by the incoming gradients
+        X = torch.cat([z[None] * float(g_bMb), S_cols * (float(g_logdet) / P)])
+        Y = torch.cat([z[None], E])
+        g_tcol = None
+        if ctx.needs_input_grad[0]:
+            g_tcol = kap * grid_ops.kron_toeplitz_grad(grid, tcol, X, Y)
+        g_kap = None
+        if ctx.needs_input_grad[1]:
+            KY = grid_ops.kron_toeplitz_mm(grid, tcol, Y, 1.0)
+            g_kap = (X.double() * KY.double()).sum()
+        return g_tcol, g_kap, None, None, None
+
+
+def _logdet_value(grid, A, eig, kap, E, exact, lanczos_steps=40):
+    """logdet(I + G A G), G = Kt^(1/2): exact via the dense m x m matrix for small grids
+    (E is the identity there), otherwise stochastic Lanczos quadrature with probes E."""
+    dev = E.device
+
+    def C(V):
+        GV = grid_ops.kron_spectral_mm(grid, eig, V, kscale=kap, power=0.5)
+        AGV = grid_ops.stencil_spmv(grid, A.stencil, GV)
+        return V + grid_ops.kron_spectral_mm(grid, eig, AGV, kscale=kap, power=0.5)
+
+    if exact:
+        Cm = C(E).double()
+        Cm = 0.5 * (Cm + Cm.t())
+        return torch.linalg.eigvalsh(Cm.cpu()).clamp_min(1e-300).log().sum().to(dev)
+    P, m = E.shape
+    Q_prev = torch.zeros_like(E)
+    q = E / E.norm(dim=1, keepdim=True)
+    alphas, betas = [], []
+    beta = torch.zeros(P, dtype=torch.float64, device=dev)
+    for _ in range(lanczos_steps):
+        w = C(q) - beta.to(q.dtype)[:, None] * Q_prev
+        alpha = (w.double() * q.double()).sum(1)
+        w = w - alpha.to(q.dtype)[:, None] * q
+        beta = w.double().norm(dim=1)
+        alphas.append(alpha)
+        betas.append(beta)
+        Q_prev, q = q, w / beta.clamp_min(1e-300).to(q.dtype)[:, None]
+    al = torch.stack(alphas, 1).cpu()
+    be = torch.stack(betas, 1).cpu()
+    est = 0.0
+    for j in range(P):
+        T = torch.diag(al[j]) + torch.diag(be[j, :-1], 1) + torch.diag(be[j, :-1], -1)
+        ev, evec = torch.linalg.eigh(T)
+        est += float((evec[0] ** 2 * ev.clamp_min(1e-300).log()).sum())
+    return torch.tensor(est / P * m, dtype=torch.float64, device=dev)
 
 
 class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
@@ -11,5 +135,28 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
         self.has_learnable_noise = self.likelihood.second_noise_covar is not None
         self.clear_caches_every_iteration = clear_caches_every_iteration
 
-    def forward(self, distro, targets, *args):
-        raise NotImplementedError
+    def forward(self, distro=None, targets=None, *args):
+        model = self.model
+        if self.clear_caches_every_iteration:
+            model.zero_grad()
+        model.check_bounds()
+        cache = model._kernel_cache
+        n = model.num_data
+        want_logdet = settings.skip_logdet_forward.off()
+        out = []
+        for o in range(model.num_outputs):
+            bi = o if model.num_outputs > 1 else None
+            tcol = model.covar_module.toeplitz_columns(batch_index=bi, device=model._device)          # float64, differentiable
+            if self.has_learnable_noise:
+                s2 = self.likelihood.second_noise_covar.noise.reshape(-1)
+                s2 = (s2[o] if s2.numel() > 1 else s2[0]).double()
+            else:
+                s2 = torch.ones((), dtype=torch.float64, device=model._device)
+            bMb, logdet_q = _WoodburyTerms.apply(tcol, 1.0 / s2, model, o, want_logdet)
+            c = cache["_stats"][o, 0]
+            ld = cache["_stats"][o, 1]
+            inv_quad = (c - bMb) / s2                                               # BWM:34,43
+            final = n * math.log(2 * math.pi) + n * torch.log(s2)                   # BWM:40-47 (log sigma2 = 0 when fixed)
+            out.append(-0.5 * (inv_quad + logdet_q + ld + final) / n)              # BWM:49-51
+        res = torch.stack(out)
+        return res[0] if model.num_outputs == 1 else res
