@@ -166,6 +166,14 @@ def main():
         n_l = int(launches.value)
         avg_ms = tot_ms.value / max(n_l, 1)
         achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if n_l else 0.0
+        traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), if recorded
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "k_stencil_spmv4<%s, 1, true>" % ("float" if args.dtype == "f32" else "double")
+            if args.grid == 50 and d == 3 and key in pmc["kernels"]:
+                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         res = {
             "metric": "streaming updates/sec (WISKI, 50^3 inducing grid)",
             "value": world * K * q / elapsed,
@@ -183,7 +191,7 @@ def main():
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}",
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": f"dp{world} (stats all-reduce)" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_stencil_spmv (A_st . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes},
             "extra": {"cg_iters_per_step_mean": float(np.mean(iters)), "absorb_only_updates_per_s": q / ta,
                       "variance_ms_per_64_queries": tv * 1e3, "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
