@@ -135,6 +135,24 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
 int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
 int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
 
+/* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
+ * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky
+ * solve `Q.inv_matmul` (BFN:375), a13 `pred_cov` (BFN:399-403), BWM:27 logdet.
+ * Row-major matrices with explicit leading dimensions, all DEVICE pointers.
+ *   wiski_gemm   C[M,N] = alpha op(A) op(B) + beta C   (ta/tb != 0: transposed operand), MFMA
+ *   wiski_potrf  in-place lower Cholesky (upper triangle zeroed); *d_info |= 1 on a
+ *                non-positive pivot (caller adds jitter and retries, like psd_safe_cholesky)
+ *   wiski_trsm   in-place solve  L X = B (trans = 0)  or  L^T X = B (trans = 1), B is n x nrhs
+ *   wiski_logdiag  *d_out += sum_i log A[i,i]   (double) */
+int wiski_gemm_f32(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, float alpha, const float* d_A, int32_t lda, const float* d_B, int32_t ldb, float beta, float* d_C, int32_t ldc, void* stream);
+int wiski_gemm_f64(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, double alpha, const double* d_A, int32_t lda, const double* d_B, int32_t ldb, double beta, double* d_C, int32_t ldc, void* stream);
+int wiski_potrf_f32(int32_t n, float* d_A, int32_t lda, int32_t* d_info, void* stream);
+int wiski_potrf_f64(int32_t n, double* d_A, int32_t lda, int32_t* d_info, void* stream);
+int wiski_trsm_f32(int32_t trans, int32_t n, int32_t nrhs, const float* d_L, int32_t ldl, float* d_B, int32_t ldb, void* stream);
+int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* d_L, int32_t ldl, double* d_B, int32_t ldb, void* stream);
+int wiski_logdiag_f32(int32_t n, const float* d_A, int32_t lda, double* d_out, void* stream);
+int wiski_logdiag_f64(int32_t n, const double* d_A, int32_t lda, double* d_out, void* stream);
+
 /* Measurement hook (bench.py roofline leg): brackets every stencil-SpMV launch
  * with HIP events on the launch stream.  wiski_prof_stop returns the summed
  * kernel time and launch count; synchronise the stream before calling it. */

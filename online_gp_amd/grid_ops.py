@@ -242,3 +242,64 @@ def kron_spectral_mm(grid, eigen, V, kscale=1.0, shift=0.0, power=0.5, rpower=0.
                                                      _hip.stream_ptr(V2.device))
     _hip.check(rc, "wiski_kron_spectral_mm")
     return out.reshape(V.shape)
+
+
+# ------------------------------------------------------------ dense (small-m) ops --
+def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, C=None):
+    """C = alpha op(A) op(B) + beta C on the matrix cores (row-major 2-D tensors)."""
+    A, B = A.contiguous(), B.contiguous()
+    M = A.shape[1] if ta else A.shape[0]
+    K = A.shape[0] if ta else A.shape[1]
+    N = B.shape[0] if tb else B.shape[1]
+    assert (B.shape[1] if tb else B.shape[0]) == K and A.dtype == B.dtype
+    if C is None:
+        C = torch.empty((M, N), dtype=A.dtype, device=A.device)
+        beta = 0.0
+    cr = _hip.creal(A.dtype)
+    rc = _hip.fn("wiski_gemm", A.dtype)(ctypes.c_int32(int(ta)), ctypes.c_int32(int(tb)), ctypes.c_int32(M), ctypes.c_int32(N), ctypes.c_int32(K),
+                                        cr(alpha), _hip.dptr(A), ctypes.c_int32(A.shape[1]), _hip.dptr(B), ctypes.c_int32(B.shape[1]), cr(beta),
+                                        _hip.dptr(C), ctypes.c_int32(C.shape[1]), _hip.stream_ptr(A.device))
+    _hip.check(rc, "wiski_gemm")
+    return C
+
+
+def potrf_(A, info=None):
+    """In-place lower Cholesky; returns the device info flag (non-zero: not positive definite)."""
+    assert A.dim() == 2 and A.shape[0] == A.shape[1] and A.is_contiguous()
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    rc = _hip.fn("wiski_potrf", A.dtype)(ctypes.c_int32(A.shape[0]), _hip.dptr(A), ctypes.c_int32(A.shape[1]), _hip.dptr(info),
+                                         _hip.stream_ptr(A.device))
+    _hip.check(rc, "wiski_potrf")
+    return info
+
+
+def psd_safe_cholesky(A, jitter=None, max_tries=6):
+    """Cholesky with gpytorch's jitter escalation (psd_safe_cholesky; imported by the
+    reference at updated_root_lazy_tensor.py:5): try plain, then add jitter*10^i."""
+    if jitter is None:
+        jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
+    for i in range(max_tries + 1):
+        L = A.clone()
+        if i > 0:
+            L.diagonal().add_(jitter * (10 ** (i - 1)))
+        if int(potrf_(L).item()) == 0 and bool(torch.isfinite(L.diagonal()).all()):
+            return L
+    raise RuntimeError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter * 10 ** (max_tries - 1):.1e}.")
+
+
+def trsm_(L, B, trans=False):
+    """In-place B <- L^-1 B (trans=False) or L^-T B (trans=True); B is [n, nrhs]."""
+    assert B.dim() == 2 and B.is_contiguous() and L.is_contiguous() and L.shape[0] == B.shape[0]
+    rc = _hip.fn("wiski_trsm", L.dtype)(ctypes.c_int32(int(trans)), ctypes.c_int32(L.shape[0]), ctypes.c_int32(B.shape[1]), _hip.dptr(L),
+                                        ctypes.c_int32(L.shape[1]), _hip.dptr(B), ctypes.c_int32(B.shape[1]), _hip.stream_ptr(L.device))
+    _hip.check(rc, "wiski_trsm")
+    return B
+
+
+def chol_logdet(L):
+    out = torch.zeros(1, dtype=torch.float64, device=L.device)
+    rc = _hip.fn("wiski_logdiag", L.dtype)(ctypes.c_int32(L.shape[0]), _hip.dptr(L), ctypes.c_int32(L.shape[1]), _hip.dptr(out),
+                                           _hip.stream_ptr(L.device))
+    _hip.check(rc, "wiski_logdiag")
+    return 2.0 * out[0]
