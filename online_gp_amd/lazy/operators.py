@@ -185,7 +185,23 @@ class PredictiveCovariance(LazyCovariance):
         self._diag = None
         self._full = None
 
+    def _dense_path(self, want_full):
+        """M is cached dense: rows w_p^T M by one gather, then a second gather."""
+        grid = self.post.grid
+        Mg = grid_ops.gather(grid, self.x, self.post.dense, self.err)              # [n, m]: row p = w_p^T M (M symmetric)
+        self._diag = grid_ops.gather(grid, self.x, Mg, self.err, diag=True) * self.sigma2
+        if want_full:
+            full = grid_ops.gather(grid, self.x, Mg, self.err) * self.sigma2      # [n, n]
+            if self.block is not None:
+                q = self.block
+                nb = full.shape[0] // q
+                idx = torch.arange(nb, device=self.device)
+                full = full.reshape(nb, q, nb, q)[idx, :, idx, :]
+            self._full = 0.5 * (full + full.transpose(-1, -2))
+
     def _solve_chunks(self, want_full):
+        if hasattr(self.post, "dense"):
+            return self._dense_path(want_full)
         n = self.x.shape[0]
         grid = self.post.grid
         diag = torch.empty(n, dtype=self.dtype, device=self.device)

@@ -26,12 +26,6 @@ class num_trace_samples(settings._value_context):
     _global_value = 10
 
 
-class exact_trace_max_size(settings._value_context):
-    """Grids with m <= this use the m unit vectors as probes (exact trace, deterministic)."""
-
-    _global_value = 256
-
-
 class _WoodburyTerms(torch.autograd.Function):
     """(b^T M b, logdet(I + Kt A)) as a differentiable function of (tcol, kappa = 1/sigma2)."""
 
@@ -45,19 +39,33 @@ class _WoodburyTerms(torch.autograd.Function):
         A = A.ops[o] if hasattr(A, "ops") else A
         b = model._kernel_cache["interpolation_cache"][o, :, 0]
         eig = grid_ops.kron_eigen(grid, tcol)
+        m = grid.m
+        if model._use_dense():
+            # small grid: everything from the dense factor, exact trace (S = A - A M A by Woodbury)
+            from ..lazy.dense_woodbury import DenseInducingPosterior
+
+            post = DenseInducingPosterior(grid, A, tcol, kap, eig)
+            U, _ = post.solve_columns(b[None])
+            Z = b[None] - grid_ops.stencil_spmv(grid, A.stencil, U)              # z = Kt^-1 mu = b - A mu
+            Ad = A.evaluate().contiguous()
+            AM = grid_ops.gemm(Ad, post.dense)
+            S_cols = Ad - grid_ops.gemm(AM, Ad)
+            E = torch.eye(m, dtype=dt, device=dev)
+            P = 1
+            bMb = (b.double() * U[0].double()).sum()
+            logdet = post.logdet.clone() if want_logdet else torch.zeros((), dtype=torch.float64, device=dev)
+            ctx.grid, ctx.P, ctx.kap = grid, 1, kap
+            ctx.save_for_backward(tcol, Z[0].clone(), U[0].clone(), S_cols, E)
+            return bMb, logdet
         shift = float(model._wsum[o]) / grid.m
         tol = settings.cg_tolerance.value() or (1e-7 if dt == torch.float32 else 1e-11)
         kw = dict(tol=tol, max_iter=settings.max_cg_iterations.value(), check_every=settings.cg_check_every.value(), workspace=model._pcg_ws,
                   eigen=eig, shift=shift)
         U, Z, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, b[None], **kw)
         bMb = (b.double() * U[0].double()).sum()
-        # probes for tr(S dKt)
-        m = grid.m
-        if m <= exact_trace_max_size.value():
-            E = torch.eye(m, dtype=dt, device=dev)
-        else:
-            gen = torch.Generator(device="cpu").manual_seed(0x5EED + model.num_data)
-            E = (torch.randint(0, 2, (num_trace_samples.value(), m), generator=gen).to(dt) * 2 - 1).to(dev)
+        # probes for tr(S dKt): Rademacher (Hutchinson)
+        gen = torch.Generator(device="cpu").manual_seed(0x5EED + model.num_data)
+        E = (torch.randint(0, 2, (num_trace_samples.value(), m), generator=gen).to(dt) * 2 - 1).to(dev)
         P = E.shape[0]
         S_cols = torch.empty_like(E)
         chunk = settings.variance_chunk.value()
@@ -67,9 +75,8 @@ class _WoodburyTerms(torch.autograd.Function):
             S_cols[s:s + chunk] = Zs
         logdet = torch.zeros((), dtype=torch.float64, device=dev)
         if want_logdet:
-            logdet = _logdet_value(grid, A, eig, kap, E, m <= exact_trace_max_size.value())
-        # unit-vector probes sum to the exact trace; Rademacher probes average to it
-        ctx.grid, ctx.P, ctx.kap = grid, (1 if m <= exact_trace_max_size.value() else P), kap
+            logdet = _logdet_value(grid, A, eig, kap, E, False)
+        ctx.grid, ctx.P, ctx.kap = grid, P, kap   # Rademacher probes average to the trace
         ctx.save_for_backward(tcol, Z[0].clone(), U[0].clone(), S_cols, E)
         return bMb, logdet
 
@@ -101,9 +108,9 @@ def _logdet_value(grid, A, eig, kap, E, exact, lanczos_steps=40):
         return V + grid_ops.kron_spectral_mm(grid, eig, AGV, kscale=kap, power=0.5)
 
     if exact:
-        Cm = C(E).double()
-        Cm = 0.5 * (Cm + Cm.t())
-        return torch.linalg.eigvalsh(Cm.cpu()).clamp_min(1e-300).log().sum().to(dev)
+        Cm = C(E)
+        Cm = (0.5 * (Cm + Cm.t())).contiguous()
+        return grid_ops.chol_logdet(grid_ops.psd_safe_cholesky(Cm)).to(dev)
     P, m = E.shape
     Q_prev = torch.zeros_like(E)
     q = E / E.norm(dim=1, keepdim=True)

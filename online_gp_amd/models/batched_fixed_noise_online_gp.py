@@ -24,6 +24,7 @@ from .. import grid_ops, settings
 from ..distributions import MultivariateNormal, ZeroLazyTensor, DenseLazyTensor, LazyCovariance
 from ..kernels import GridInterpolationKernel, RBFKernel, ScaleKernel
 from ..lazy.operators import (InducingPosterior, InterpolatedKernel, KroneckerToeplitz, PredictiveCovariance, StencilWtW)
+from ..lazy.dense_woodbury import DenseInducingPosterior
 from ..likelihoods import FNMGLikelihood
 
 
@@ -237,8 +238,15 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._memo["hyper"] = h
         return h[1]
 
+    def _use_dense(self):
+        return settings.dense_small_grids.on() and self._grid.m <= settings.max_cholesky_size.value()
+
     def _posterior_op(self, o):
         tcol, s2, eig = self._hyper()[o]
+        if self._use_dense():
+            if eig is None:
+                eig = grid_ops.kron_eigen(self._grid, tcol)
+            return DenseInducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, eig)
         # preconditioner shift ~ mean row sum of A = (sum_p 1/noise_p) / m  (W rows sum to one)
         shift = float(self._wsum[o]) / self._grid.m
         return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
@@ -278,6 +286,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         posts = []
         for o in range(out):
             post = self._posterior_op(o)
+            if isinstance(post, DenseInducingPosterior):
+                Uo, _ = post.solve_columns(b[o, :, 0][None])
+                U[o] = Uo[0]
+                Z[o].zero_()
+                iters.append(0)
+                posts.append(post)
+                continue
             warm = False
             Uo = Zo = None
             if self._mean_state is not None:
@@ -290,7 +305,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             U[o], Z[o] = Uo[0], Zo[0]
             iters.append(post.last_iters)
             posts.append(post)
-        self._mean_state = {"U": U, "Z": Z, "ver": ver}
+        self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "ver": ver}
         pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters}
         self._memo["prediction_cache"] = pc
         return pc
@@ -303,21 +318,44 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             f"{name} is a root-space quantity of the reference's dense formulation (L, Q = I + L^T Kuu L); the matrix-free "
             "formulation has no root.  Use prediction_cache / Kuu / Kuu_response, or the dense path for small grids.")
 
+    def _root_space(self):
+        """Reference root-space objects (BFN:343-366) for small grids: L = chol(A + jitter),
+        Kt L, Q = I + L^T Kt L, L^T Kt b -- dense, on the MFMA GEMM / Cholesky kernels."""
+        if not self._use_dense():
+            self._root_space_unavailable("root-space quantities")
+        rs = self._memo.get("root_space")
+        if rs is None:
+            Ls, KLs, Qs, projs = [], [], [], []
+            b = self._kernel_cache["interpolation_cache"]
+            for o, (tcol, s2, _) in enumerate(self._hyper()):
+                A = _wtw_ops(self._kernel_cache["WtW"])[o].evaluate().contiguous()
+                L = grid_ops.psd_safe_cholesky(A, jitter=settings.cholesky_jitter.value())
+                KL = grid_ops.kron_toeplitz_mm(self._grid, tcol, L.t().contiguous(), 1.0 / s2).t().contiguous()     # Kt L
+                Q = grid_ops.gemm(L, KL, ta=True)
+                Q.diagonal().add_(1.0)                                                                                # add_jitter(1.0), :355
+                Kb = grid_ops.kron_toeplitz_mm(self._grid, tcol, b[o, :, 0], 1.0 / s2)
+                Ls.append(L); KLs.append(KL); Qs.append(Q); projs.append(grid_ops.gemm(L, Kb[:, None].contiguous(), ta=True))
+            st = (lambda xs: xs[0]) if self.num_outputs == 1 else torch.stack
+            rs = {"L": st(Ls), "KL": st(KLs), "Q": st(Qs), "proj": st(projs)}
+            self._memo["root_space"] = rs
+        return rs
+
     @property
     def current_inducing_compression_matrix(self):
-        self._root_space_unavailable("current_inducing_compression_matrix")
+        return self._root_space()["KL"]
 
     @property
     def current_qmatrix(self):
-        self._root_space_unavailable("current_qmatrix")
+        return self._root_space()["Q"]
 
     @property
     def root_space_projection(self):
-        self._root_space_unavailable("root_space_projection")
+        return self._root_space()["proj"]
 
     def _dump_caches(self):
         self._memo.pop("prediction_cache", None)
         self._memo.pop("hyper", None)
+        self._memo.pop("root_space", None)
 
     def zero_grad(self, *args, **kwargs):
         self._dump_caches()

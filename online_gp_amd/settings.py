@@ -128,3 +128,10 @@ class cg_check_every(_value_context):
     """Iterations between host-side convergence checks of wiski_pcg."""
 
     _global_value = 5
+
+
+class dense_small_grids(_feature_flag):
+    """Grids with m <= max_cholesky_size use the dense MFMA Cholesky factor (the
+    reference's own regime) instead of PCG; the posterior matrix M is then cached."""
+
+    _state = True

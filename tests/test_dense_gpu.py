@@ -58,3 +58,61 @@ def test_not_pd_sets_info_and_psd_safe_adds_jitter():
     assert int(grid_ops.potrf_(A.clone()).item()) != 0
     L = grid_ops.psd_safe_cholesky(A)
     assert ((L @ L.t()) - A).abs().max().item() < 1e-3
+
+
+def test_updated_root_lazy_tensor_contract():
+    """UpdatedRootLazyTensor (URLT:9-159): functional update, roots, matmul, evaluate."""
+    from online_gp_amd.lazy import UpdatedRootLazyTensor
+
+    torch.manual_seed(0)
+    m, q = 40, 3
+    W = torch.randn(m, 60, device=DEV, dtype=torch.float64)
+    A = W @ W.t()
+    lt = UpdatedRootLazyTensor(A, initial_is_root=False)
+    assert lt.shape == (m, m) and torch.equal(lt.evaluate(), A)
+    v = torch.randn(m, 2, device=DEV, dtype=torch.float64)
+    assert torch.allclose(lt @ v, A @ v, atol=1e-10) and torch.allclose(lt._matmul(v), A @ v, atol=1e-10)
+    L = lt.root_decomposition().root.evaluate()
+    R = lt.root_inv_decomposition().root.evaluate()
+    assert torch.allclose(L @ L.t(), A, atol=1e-8) and torch.allclose(R @ R.t(), torch.linalg.inv(A), atol=1e-8)
+    V = torch.randn(m, q, device=DEV, dtype=torch.float64)
+    lt2 = lt.update(V)
+    assert lt2 is not lt and torch.equal(lt.evaluate(), A)                 # functional: the old object is untouched
+    A2 = A + V @ V.t()
+    assert torch.allclose(lt2.evaluate(), A2, atol=1e-10)
+    L2, R2 = lt2.root, lt2.inv_root
+    assert torch.allclose(L2 @ L2.t(), A2, atol=1e-8)                      # L~ L~^T = A + V V^T   (URLT:70-100)
+    assert torch.allclose(R2.t() @ L2, torch.eye(m, device=DEV, dtype=torch.float64), atol=1e-8)   # R~ = L~^-T  (URLT:111-117)
+    lt3 = lt2.update(V[:, 0])                                               # 1-D vector form (URLT:54-55)
+    assert torch.allclose(lt3.evaluate(), A2 + V[:, :1] @ V[:, :1].t(), atol=1e-10)
+    root_init = UpdatedRootLazyTensor(W.t().contiguous(), initial_is_root=True)      # tensor = root^T root (URLT:29-30)
+    assert torch.allclose(root_init.evaluate(), A, atol=1e-9)
+    assert lt.expand(2, m, m).shape == (2, m, m)
+
+
+@pytest.mark.parametrize("dtype,rt", [(torch.float64, 1e-8), (torch.float32, 2e-3)])
+def test_dense_path_matches_pcg_path_and_exposes_root_space(dtype, rt):
+    """m = 1000 (the BO grid): dense MFMA factor == matrix-free PCG posterior; Q, K L, L^T K b shapes."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (400, 3)); y = np.sin(2 * X[:, 0]) + X[:, 1] * X[:, 2] + 0.1 * rng.standard_normal(400)
+    Xt, yt = torch.as_tensor(X, device=DEV, dtype=dtype), torch.as_tensor(y, device=DEV, dtype=dtype)[:, None]
+    Xs = Xt[:32]
+    outs = []
+    for dense in (True, False):
+        with settings.dense_small_grids(dense), settings.cg_tolerance(1e-11 if dtype == torch.float64 else 1e-6):
+            m = FixedNoiseOnlineSKIGP(Xt[:300], yt[:300], None, grid_bounds=torch.tensor([[-1.1, 1.1]] * 3), grid_size=10, learn_additional_noise=True)
+            m.eval()
+            m.condition_on_observations(Xt[300:], yt[300:], inplace=True)
+            d = m(Xs)
+            outs.append((d.mean.double(), d.variance.double(), d.covariance_matrix.double()))
+            if dense:
+                assert m.prediction_cache["cg_iters"] == [0]
+                assert m.current_qmatrix.shape == (1000, 1000) and m.current_inducing_compression_matrix.shape == (1000, 1000)
+                assert m.root_space_projection.shape == (1000, 1)
+                Q = m.current_qmatrix
+                assert torch.allclose(Q, Q.t(), atol=1e-3 if dtype == torch.float32 else 1e-9)
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= rt * b.abs().max().item()

@@ -77,7 +77,9 @@ def test_mll_learnable_noise_gradient_matches_finite_difference():
 
 
 def test_mll_stochastic_trace_and_slq_on_a_larger_grid():
-    """m = 1000 > exact_trace_max_size: Hutchinson gradient + stochastic-Lanczos logdet (loose tolerances)."""
+    """Matrix-free branch (dense path disabled): Hutchinson gradient + stochastic-Lanczos logdet (loose
+    tolerances), and the dense branch on the same model (exact) for comparison."""
+    from online_gp_amd import settings
     from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood
     from online_gp_amd.mlls.batched_woodbury_marginal_log_likelihood import num_trace_samples
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
@@ -88,14 +90,22 @@ def test_mll_stochastic_trace_and_slq_on_a_larger_grid():
     m = FixedNoiseOnlineSKIGP(Xt, yt, None, grid_bounds=torch.tensor([[-1.1, 1.1]] * 3), grid_size=10, learn_additional_noise=True)
     mll = BatchedWoodburyMarginalLogLikelihood(m.likelihood, m)
     m.train()
-    with num_trace_samples(64):
+    with num_trace_samples(64), settings.dense_small_grids(False):
         v = mll(m(Xt), yt)
         v.backward()
+    g_stoch = m.covar_module.base_kernel.base_kernel.raw_lengthscale.grad.clone()
+    m.zero_grad()
+    for p_ in m.parameters():
+        p_.grad = None
+    v_dense = mll(m(Xt), yt)
+    v_dense.backward()
+    g_dense = m.covar_module.base_kernel.base_kernel.raw_lengthscale.grad.clone()
     s2 = float(m.likelihood.second_noise.detach())
     O = dataspace.DataSpaceGP([[-1.1, 1.1]] * 3, 10, sigma2=s2).fit(X, y, np.ones(300))
     assert abs(float(v.detach()) - O.mll()) < 0.05 * abs(O.mll())
-    g = m.covar_module.base_kernel.base_kernel.raw_lengthscale.grad
-    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    assert abs(float(v_dense.detach()) - O.mll()) < 1e-6 * abs(O.mll())
+    assert torch.isfinite(g_stoch).all() and g_stoch.abs().sum() > 0
+    assert (g_stoch - g_dense).abs().max() < 0.3 * g_dense.abs().max()          # 64 Rademacher probes
 
 
 def test_update_with_hyperparameter_step_and_fit():
