@@ -53,7 +53,7 @@ def cpu_baseline(args, tol):
 
     cport.build()
     ndt = np.float32 if args.dtype == "f32" else np.float64
-    n_init, q, steps = 8192, 2048, 2
+    n_init, q, steps = 8192, 2048, 5
     Xt, yt = synth_stream(n_init + q * (steps + 1), args.dim, 0, "cpu", torch.float64)
     X, y = Xt.numpy(), yt.numpy()[:, 0]
     B2 = cport.MatrixFreeWISKI([[-1.1, 1.1]] * args.dim, args.grid, sigma2=spec.SOFTPLUS0 + 1e-4, dtype=ndt)
@@ -147,6 +147,17 @@ def main():
         torch.cuda.synchronize(); ta = time.perf_counter()
         model.condition_on_observations(xb, yb, inplace=True)
         torch.cuda.synchronize(); ta = time.perf_counter() - ta
+        # small-batch latencies (the reference driver streams with batch_size 1, config/regression.yaml:22)
+        small = {}
+        for qs in (1, 64):
+            torch.cuda.synchronize(); tq = time.perf_counter()
+            for i in range(10):
+                xq, yq = Xs[i * qs:(i + 1) * qs], ys[i * qs:(i + 1) * qs]
+                model(xq).mean
+                model.condition_on_observations(xq, yq, inplace=True)
+                model.prediction_cache
+            torch.cuda.synchronize()
+            small[qs] = (time.perf_counter() - tq) / 10 * 1e3
     with settings.cg_tolerance(tol), torch.no_grad():
         xv = Xs[:64]
         torch.cuda.synchronize(); tv = time.perf_counter()
@@ -194,7 +205,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes},
             "extra": {"cg_iters_per_step_mean": float(np.mean(iters)), "absorb_only_updates_per_s": q / ta,
-                      "variance_ms_per_64_queries": tv * 1e3, "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
+                      "variance_ms_per_64_queries": tv * 1e3, "step_ms_q1": small[1], "step_ms_q64": small[64], "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, tol)
