@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--n-init", type=int, default=21743, help="5%% of 434874 (init_ratio of the reference config)")
     ap.add_argument("--tol", type=float, default=None, help="CG relative-residual tolerance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +127,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.check_every:
+        settings.cg_check_every._set_value(args.check_every)
     with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), torch.no_grad():
         model.prediction_cache                     # cold solve on the init data (not timed)
         for t in range(Wm):

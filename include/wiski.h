@@ -83,6 +83,16 @@ int wiski_gather_ell_f64(const int32_t* d_idx, const double* d_val, int64_t n, i
 int wiski_scatter_stats_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_st, double* d_stats, int32_t* d_err, void* stream);
 int wiski_scatter_stats_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_st, double* d_stats, int32_t* d_err, void* stream);
 
+/* Same statistics with W^T diag(wa) W accumulated into a symmetric HALF stencil
+ * d_A_half[(7^d+1)/2][m] (offsets o >= centre only; half the atomics).  Used as a
+ * per-batch delta: wiski_stencil_expand_add folds the delta and its mirror image
+ * into the full stencil A_st and zeroes the delta (streaming, no atomics).  The
+ * half delta is also what the data-parallel path all-reduces. */
+int wiski_scatter_stats_sym_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, double* d_stats, int32_t* d_err, void* stream);
+int wiski_scatter_stats_sym_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_stats, int32_t* d_err, void* stream);
+int wiski_stencil_expand_add_f32(const wiski_grid* grid, float* d_A_half, float* d_A_st, void* stream);
+int wiski_stencil_expand_add_f64(const wiski_grid* grid, double* d_A_half, double* d_A_st, void* stream);
+
 /* Adds W(x)^T as k = n one-hot-interpolated columns: d_out[p][idx] += val
  * (the sparse `wmat` of BFN:22-28 for a query batch, kept column-dense only
  * for the k right-hand sides of a solve). d_out must be zeroed by the caller. */

@@ -9,7 +9,10 @@
 // GRP = min(T, 64) lanes cooperate on one point (lane <-> tap a); each lane
 // walks all taps b and issues fire-and-forget L2 atomics on A_st[o(a,b)][idx_a].
 // Tap values are exchanged through LDS (broadcast reads, conflict-free).
-template <typename real, int D>
+// HALF: A_st is a symmetric half-stencil delta [ (7^d+1)/2 ][m] holding only the offsets
+// o >= centre (pairs with code(b) >= code(a)); T(T+1)/2 atomics per point instead of T^2.
+// k_stencil_expand_add folds it (and its mirror image) into the full stencil.
+template <typename real, int D, bool HALF>
 __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const real* __restrict__ x, const real* __restrict__ y,
                                                        const real* __restrict__ wa, const real* __restrict__ wb,
                                                        const real* __restrict__ noise, int64_t n, real* __restrict__ b,
@@ -90,7 +93,11 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
 #pragma unroll
               for (int q = 0; q < D; ++q) codeb = codeb * 7 + ((bb >> (2 * (D - 1 - q))) & 3);
               const real vb = s_val[loc][bb];
-              if (vb != (real)0) atomic_add_real(Arow + (int64_t)(obase + codeb) * G.m, va * vb);
+              if (HALF) {
+                if (codeb >= code_a[t] && vb != (real)0) atomic_add_real(Arow + (int64_t)(codeb - code_a[t]) * G.m, va * vb);
+              } else {
+                if (vb != (real)0) atomic_add_real(Arow + (int64_t)(obase + codeb) * G.m, va * vb);
+              }
             }
           }
         }
@@ -107,9 +114,52 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
   if (bad) atomicOr(err, 1);
 }
 
+// full[c + oh][i] += half[oh][i];  full[c - oh][i + off(oh)] += half[oh][i] (oh > 0);  half[oh][i] = 0.
+// Pure streaming: every full entry is touched by exactly one (oh, i), so no atomics.
+template <typename real>
+__global__ __launch_bounds__(256) void k_stencil_expand_add(GridDev<real> G, real* __restrict__ half, real* __restrict__ full) {
+  const int m = G.m, d = G.d;
+  const int c = (G.R - 1) / 2;
+  const int oh = blockIdx.y;
+  // flat offset of stencil index o = c + oh
+  int rem = c + oh, off = 0;
+  for (int q = d - 1; q >= 0; --q) {
+    off += (rem % 7 - 3) * G.stride[q];
+    rem /= 7;
+  }
+  real* __restrict__ h = half + (int64_t)oh * m;
+  real* __restrict__ fd = full + (int64_t)(c + oh) * m;
+  real* __restrict__ fm = full + (int64_t)(c - oh) * m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const real v = h[i];
+    if (v != (real)0) {
+      fd[i] += v;
+      if (oh > 0) {
+        const int j = i + off;
+        if (j >= 0 && j < m) fm[j] += v;
+      }
+      h[i] = (real)0;
+    }
+  }
+}
+
+template <typename real>
+static int expand_impl(const wiski_grid* grid, real* d_half, real* d_full, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_half || !d_full) return WISKI_E_BADARG;
+  int bx = (G.m + 255) / 256;
+  if (bx > 64) bx = 64;
+  dim3 grd((unsigned)bx, (unsigned)((G.R + 1) / 2));
+  hipLaunchKernelGGL((k_stencil_expand_add<real>), grd, dim3(256), 0, (hipStream_t)stream, G, d_half, d_full);
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
 template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
-                        int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream) {
+                        int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -120,8 +170,11 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   int64_t blocks = (n + ppb - 1) / ppb;
   if (blocks > 256 * 8) blocks = 256 * 8;
   dim3 grd((unsigned)blocks);
-#define CALL(DD) \
-  hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err)
+#define CALL(DD)                                                                                                                              \
+  do {                                                                                                                                        \
+    if (half) hipLaunchKernelGGL((k_scatter_stats<real, DD, true>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err); \
+    else hipLaunchKernelGGL((k_scatter_stats<real, DD, false>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err);   \
+  } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
 #undef CALL
   WISKI_LAUNCH_CHECK();
@@ -135,4 +188,12 @@ int wiski_scatter_stats_f32(const wiski_grid* g, const float* x, const float* y,
 int wiski_scatter_stats_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A, double* stats, int32_t* err, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A, stats, err, s);
 }
+int wiski_scatter_stats_sym_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, double* stats, int32_t* err, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true);
+}
+int wiski_scatter_stats_sym_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* stats, int32_t* err, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true);
+}
+int wiski_stencil_expand_add_f32(const wiski_grid* g, float* half, float* full, void* s) { return expand_impl<float>(g, half, full, s); }
+int wiski_stencil_expand_add_f64(const wiski_grid* g, double* half, double* full, void* s) { return expand_impl<double>(g, half, full, s); }
 }

@@ -556,15 +556,6 @@ static int spectral_mm_impl(const wiski_grid* grid, const real* d_evec, const re
 // -------------------------------------------------------------------- PCG ---
 // scalar slots (double): S[0..k) = ||rhs||^2 ; then per iteration slot
 // it in [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
-struct PcgScal {
-  double* base;
-  int k;
-  __host__ __device__ double* rn0() const { return base; }
-  __host__ __device__ double* rho(int it) const { return base + (int64_t)k * (1 + 3 * it); }
-  __host__ __device__ double* php(int it) const { return base + (int64_t)k * (2 + 3 * it); }
-  __host__ __device__ double* rn(int it) const { return base + (int64_t)k * (3 + 3 * it); }
-};
-
 // r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
 template <typename real>
 __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, const real* __restrict__ part,
@@ -589,11 +580,6 @@ __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict_
   }
 }
 
-__device__ __forceinline__ bool pcg_active(const PcgScal& S, int it, int c, double tol2) {
-  // column still iterating? (rn of the previous slot against the rhs norm)
-  const double rn0 = S.rn0()[c];
-  return rn0 > 0 && S.rn(it)[c] > tol2 * rn0;
-}
 
 // p = y + beta p ; pt = t + beta pt ; beta = rho(it)/rho(it-1)   (t = Kt^-1 y: r for
 // the plain Kt preconditioner, (I + a Kt)^-1 r for the spectral one)
@@ -790,7 +776,33 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (rc) return rc;
     done = converged();
   }
+  const bool fused_cg = spectral && wide && spectral_fused_ok<real>(G);
+  bool pending = false;   // fused path: update_x of iteration it-1 not applied yet
+  auto flush_update = [&]() {
+    if (pending) {
+      hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it - 1, tol2, (const real*)p, (const real*)pt, (const real*)hp,
+                         (const real*)part, nch, d_U, d_Z, r, S);
+      pending = false;
+    }
+  };
   while (!done && it < max_iter) {
+    if (fused_cg) {
+      // 4 launches per iteration: [update_x(it-1) + mode-0 fwd] -> slab (+rho) -> [mode-0 bwd + update_p] -> SpMV (+p.Hp)
+      rc = launch_spectral_fused_cg<real>(G, d_evec, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, (const real*)part, nch,
+                                          d_U, d_Z, S, s);
+      if (rc) return rc;
+      rc = launch_spmv4<real>(G, d_A, p, k, part, pt, (real)1, S.php(it), s);
+      if (rc) return rc;
+      pending = true;
+      ++it;
+      if (it % check_every == 0 || it == max_iter) {
+        flush_update();
+        rc = fetch(it);
+        if (rc) return rc;
+        done = converged();
+      }
+      continue;
+    }
     // y = Kt r, rho(it) = r.y
     if (spectral) {
       // [t | y] = spectral preconditioner applied to r, rho(it) = r.y
@@ -826,6 +838,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       done = converged();
     }
   }
+  flush_update();
   if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
   if (it == 0) {
     rc = fetch(0);

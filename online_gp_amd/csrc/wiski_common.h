@@ -148,9 +148,32 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
     default: return WISKI_E_BADARG; \
   }
 
+// PCG scalar slots (double): [0..k) = ||rhs||^2 ; then per iteration slot it in
+// [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
+struct PcgScal {
+  double* base;
+  int k;
+  __host__ __device__ double* rn0() const { return base; }
+  __host__ __device__ double* rho(int it) const { return base + (int64_t)k * (1 + 3 * it); }
+  __host__ __device__ double* php(int it) const { return base + (int64_t)k * (2 + 3 * it); }
+  __host__ __device__ double* rn(int it) const { return base + (int64_t)k * (3 + 3 * it); }
+};
+
+__device__ __forceinline__ bool pcg_active(const PcgScal& S, int it, int c, double tol2) {
+  // column still iterating? (rn of the previous slot against the rhs norm)
+  const double rn0 = S.rn0()[c];
+  return rn0 > 0 && S.rn(it)[c] > tol2 * rn0;
+}
+
 // spectral.hip: fused Kronecker-eigenbasis preconditioner (d = 3)
 template <typename real>
 bool spectral_fused_ok(const GridDev<real>& G);
 template <typename real>
 int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, const real* r, int k, real* w0,
                           real* w1, real* ty, double* rho, hipStream_t s);
+
+// Fused CG-iteration front end (d = 3): [apply update_x(it-1)] + mode-0 fwd -> slab (+rho) -> mode-0 bwd (+update_p)
+template <typename real>
+int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, real* r, int k, real* w0,
+                             real* w1, int it, int apply, double tol2, real* p, real* pt, const real* part, int nch, real* u, real* z,
+                             PcgScal S, hipStream_t s);

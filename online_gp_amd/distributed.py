@@ -39,19 +39,20 @@ class ShardedStatsUpdater:
         self._delta = None
 
     def _delta_cache(self):
+        """Zeroed delta copies of (b, stats); the W^T W delta lives in the model's symmetric
+        half-stencil buffers (half the all-reduce bytes), which the fold pass re-zeroes."""
+        m = self.model
         if self._delta is None:
-            self._delta = self.model._fresh_cache()
+            b = torch.zeros_like(m._kernel_cache["interpolation_cache"])
+            stats = torch.zeros_like(m._kernel_cache["_stats"])
+            self._delta = {"interpolation_cache": b, "_stats": stats, "WtW": m._kernel_cache["WtW"]}
         else:
-            d = self._delta
-            d["interpolation_cache"].zero_()
-            d["_stats"].zero_()
-            from .models.batched_fixed_noise_online_gp import _wtw_ops
-
-            for op in _wtw_ops(d["WtW"]):
-                op.stencil.zero_()
+            self._delta["interpolation_cache"].zero_()
+            self._delta["_stats"].zero_()
         return self._delta
 
     def update(self, X, Y, noise=None):
+        from . import grid_ops
         from .models.batched_fixed_noise_online_gp import _wtw_ops
 
         m = self.model
@@ -65,17 +66,17 @@ class ShardedStatsUpdater:
             return
         delta = self._delta_cache()
         noise = m._canon_noise(noise, Y)
-        m._absorb(delta, X, Y, noise, init=False)
+        halves = m._half_buffers()
+        m._absorb(delta, X, Y, noise, init=False, half_delta=halves)
         dev = delta["_stats"].device
         wsum = (1.0 / noise.to(dev, torch.float64).clamp_min(1e-7)).sum(0)            # [out]
         count = torch.cat([torch.tensor([float(X.reshape(-1, m._grid.d).shape[0])], dtype=torch.float64, device=dev), wsum])
-        bufs = [delta["interpolation_cache"], delta["_stats"], count] + [op.stencil for op in _wtw_ops(delta["WtW"])]
-        allreduce_sum_(bufs, self.group)
+        allreduce_sum_([delta["interpolation_cache"], delta["_stats"], count] + list(halves), self.group)
         c = m._kernel_cache
         c["interpolation_cache"].add_(delta["interpolation_cache"])
         c["_stats"].add_(delta["_stats"])
-        for dst, src in zip(_wtw_ops(c["WtW"]), _wtw_ops(delta["WtW"])):
-            dst.stencil.add_(src.stencil)
+        for dst, half in zip(_wtw_ops(c["WtW"]), halves):
+            grid_ops.stencil_expand_add(m._grid, half, dst.stencil)
         m._wsum_dev += count[1:]
         m.num_data = m.num_data + int(count[0].item())
         m._dump_caches()

@@ -119,6 +119,21 @@ def scatter_stats(grid, x, y, wa, wb, noise, b, A_st, stats, err):
     _hip.check(rc, "wiski_scatter_stats")
 
 
+def scatter_stats_sym(grid, x, y, wa, wb, noise, b, A_half, stats, err):
+    """As scatter_stats, but W^T diag(wa) W goes into a symmetric half-stencil delta [(R+1)/2, m]."""
+    x = _x2d(x, grid)
+    rc = _hip.fn("wiski_scatter_stats_sym", x.dtype)(grid.ref, _hip.dptr(x), _hip.dptr(y.contiguous()), _hip.dptr(wa.contiguous()),
+                                                     _hip.dptr(wb.contiguous()), _hip.dptr(noise.contiguous()), ctypes.c_int64(x.shape[0]),
+                                                     _hip.dptr(b), _hip.dptr(A_half), _hip.dptr(stats), _hip.dptr(err), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_scatter_stats_sym")
+
+
+def stencil_expand_add(grid, A_half, A_st):
+    """A_st += expand(A_half) (delta and its mirror image); A_half is zeroed."""
+    rc = _hip.fn("wiski_stencil_expand_add", A_st.dtype)(grid.ref, _hip.dptr(A_half), _hip.dptr(A_st), _hip.stream_ptr(A_st.device))
+    _hip.check(rc, "wiski_stencil_expand_add")
+
+
 def wt_columns(grid, x, err):
     """Dense columns of W(x)^T: [n, m]."""
     x = _x2d(x, grid)

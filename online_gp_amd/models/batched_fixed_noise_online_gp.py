@@ -179,9 +179,21 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         stats = cache["_stats"].clone()
         return self._pack_cache(cache["interpolation_cache"].clone(), stats, [op.clone() for op in _wtw_ops(cache["WtW"])])
 
-    def _absorb(self, cache, X, Y, noise, init):
+    def _half_buffers(self):
+        """Per-output symmetric half-stencil delta buffers [(R+1)/2, m] (zero between uses)."""
+        if getattr(self, "_half_delta", None) is None:
+            H = (self._grid.R + 1) // 2
+            self._half_delta = [torch.zeros((H, self._grid.m), dtype=self._dtype, device=self._device) for _ in range(self.num_outputs)]
+        return self._half_delta
+
+    def _absorb(self, cache, X, Y, noise, init, half_delta=None):
         """_initialize_caches (:31-60) / _update_cache_dicts (:155-171) fused into
-        one scatter launch per output; mutates `cache` in place."""
+        one scatter launch per output; mutates `cache` in place.
+
+        Batches of >= settings.sym_scatter_min_batch points go through a symmetric
+        half-stencil delta (half the atomics) that is then folded into the full
+        stencil by a streaming pass.  With `half_delta` given (data-parallel path) the
+        W^T W increments are left in those buffers for the caller to all-reduce and fold."""
         X = X.reshape(-1, self._grid.d).to(self._device, self._dtype).contiguous()
         Y = Y.to(self._device, self._dtype)
         if Y.dim() == 1:
@@ -190,12 +202,19 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         b = cache["interpolation_cache"]
         stats = cache["_stats"]
         ops = _wtw_ops(cache["WtW"])
+        use_half = half_delta is not None or X.shape[0] >= settings.sym_scatter_min_batch.value()
+        bufs = half_delta if half_delta is not None else (self._half_buffers() if use_half else None)
         for o in range(self.num_outputs):
             yo = Y[:, o].contiguous()
             no = noise[:, o].contiguous()
             wb = 1.0 / no
             wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
-            grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
+            if use_half:
+                grid_ops.scatter_stats_sym(self._grid, X, yo, wa, wb, no, b[o, :, 0], bufs[o], stats[o], self._err)
+                if half_delta is None:
+                    grid_ops.stencil_expand_add(self._grid, bufs[o], ops[o].stencil)
+            else:
+                grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
             if cache is self._kernel_cache or init:
                 self._wsum_dev[o] += wa.sum(dtype=torch.float64)
 
@@ -354,8 +373,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
 
     def _dump_caches(self):
         self._memo.pop("prediction_cache", None)
-        self._memo.pop("hyper", None)
         self._memo.pop("root_space", None)
+        # "hyper" (Toeplitz columns + Kronecker eigenbasis) is keyed on the parameters' version
+        # counters and survives streaming updates: only a hyper-parameter change invalidates it
 
     def zero_grad(self, *args, **kwargs):
         self._dump_caches()

@@ -135,3 +135,10 @@ class dense_small_grids(_feature_flag):
     reference's own regime) instead of PCG; the posterior matrix M is then cached."""
 
     _state = True
+
+
+class sym_scatter_min_batch(_value_context):
+    """Batches with at least this many points accumulate W^T D^-1 W through the symmetric
+    half-stencil delta (T(T+1)/2 atomics per point + one streaming expand pass)."""
+
+    _global_value = 1024

@@ -49,11 +49,19 @@ class StubModel:
     def _canon_noise(noise, Y):
         return noise
 
-    def _absorb(self, cache, X, Y, noise, init):
+    def _half_buffers(self):
+        if not hasattr(self, "_half"):
+            self._half = [torch.zeros((self.R + 1) // 2, self.m, dtype=torch.float64)]
+        return self._half
+
+    def _absorb(self, cache, X, Y, noise, init, half_delta=None):
         B2 = self.cp.MatrixFreeWISKI(self.gb, self.g)
         B2.absorb(X.numpy(), Y[:, 0].numpy(), noise[:, 0].numpy(), init=init)
         cache["interpolation_cache"][0, :, 0] += torch.from_numpy(B2.b)
-        cache["WtW"].stencil += torch.from_numpy(B2.A)
+        if half_delta is not None:
+            half_delta[0] += torch.from_numpy(B2.A[(self.R - 1) // 2:])      # offsets o >= centre
+        else:
+            cache["WtW"].stencil += torch.from_numpy(B2.A)
         cache["_stats"][0] += torch.from_numpy(B2.c_ld)
 
     def condition_on_observations(self, X, Y, noise, inplace=True):
@@ -64,12 +72,34 @@ class StubModel:
         self.dumped += 1
 
 
+def _cpu_expand_add(grid, half, full):
+    """CPU stand-in for wiski_stencil_expand_add (test infrastructure)."""
+    R, m = full.shape
+    c = (R - 1) // 2
+    g = [8, 8]
+    stride = [8, 1]
+    for oh in range(half.shape[0]):
+        o, off = c + oh, 0
+        rem = o
+        for q in (1, 0):
+            off += (rem % 7 - 3) * stride[q]
+            rem //= 7
+        full[c + oh] += half[oh]
+        if oh > 0:
+            idx = torch.nonzero(half[oh]).reshape(-1)
+            full[c - oh, idx + off] += half[oh, idx]
+    half.zero_()
+
+
 def _worker(rank, world, port, tmpdir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from online_gp_amd import grid_ops
     from online_gp_amd.distributed import ShardedStatsUpdater, allreduce_sum_
+
+    grid_ops.stencil_expand_add = _cpu_expand_add        # the HIP fold pass needs a GPU; emulate it
 
     # plain all-reduce helper
     t = [torch.full((3,), float(rank + 1), dtype=torch.float64), torch.ones(2, 2) * rank]

@@ -155,3 +155,28 @@ def test_wt_columns():
     for p in range(17):
         np.add.at(ref[p], idx[p], val[p])
     assert np.abs(Wt.cpu().numpy() - ref).max() < 1e-13
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
+def test_symmetric_half_scatter_and_expand(d, g, tdt, ndt, tol):
+    """half-stencil delta + streaming fold == direct full-stencil scatter == oracle."""
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
+    B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
+    err = grid_ops.new_err_flag("cuda")
+    b = torch.zeros(grid.m, device="cuda", dtype=tdt)
+    H = (grid.R + 1) // 2
+    half = torch.zeros((H, grid.m), device="cuda", dtype=tdt)
+    full = torch.zeros((grid.R, grid.m), device="cuda", dtype=tdt)
+    stats = torch.zeros(2, device="cuda", dtype=torch.float64)
+    w = _t(1.0 / noise.astype(np.float64), tdt)
+    grid_ops.scatter_stats_sym(grid, _t(X, tdt), _t(y, tdt), w, w, _t(noise, tdt), b, half, stats, err)
+    c = (grid.R - 1) // 2
+    assert np.abs(half.double().cpu().numpy() - B2.A[c:]).max() < tol * np.abs(B2.A).max() * 10
+    grid_ops.stencil_expand_add(grid, half, full)
+    assert float(half.abs().max()) == 0.0
+    assert np.abs(full.double().cpu().numpy() - B2.A).max() < tol * np.abs(B2.A).max() * 10
+    assert np.abs(b.double().cpu().numpy() - B2.b).max() < tol * np.abs(B2.b).max() * 10
+    assert int(err.item()) == 0
