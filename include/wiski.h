@@ -67,6 +67,12 @@ int wiski_interp_f64(const wiski_grid* grid, const double* d_x, int64_t n, int32
 int wiski_gather_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, int32_t diag, float* d_out, int32_t* d_err, void* stream);
 int wiski_gather_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, int32_t diag, double* d_out, int32_t* d_err, void* stream);
 
+/* a14 with the dense operand stored ROW-major, d_Vr[m][ncols] (left_interp's own layout,
+ * BFN:206-210): d_out[n][ncols] = W(x) Vr.  Every tap reads a contiguous row segment;
+ * used for W* M with the cached dense posterior M of small grids (BFN:222-225). */
+int wiski_gather_rows_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_Vr, int32_t ncols, float* d_out, int32_t* d_err, void* stream);
+int wiski_gather_rows_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_Vr, int32_t ncols, double* d_out, int32_t* d_err, void* stream);
+
 /* a14, ELL form -- same product from materialised (idx, val) rows of width T
  * (the layout InterpolatedLazyTensor keeps; BFN:206-210). k == 1 only. */
 int wiski_gather_ell_f32(const int32_t* d_idx, const float* d_val, int64_t n, int32_t T, const float* d_v, float* d_out, void* stream);

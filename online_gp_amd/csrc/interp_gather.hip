@@ -162,6 +162,61 @@ __global__ __launch_bounds__(256) void k_wt_columns(GridDev<real> G, const real*
   if (!ok && a == 0) atomicOr(err, 1);
 }
 
+// ------------------------------------------------------- row-major gather ---
+// out[p][c] = sum_a val_a(x_p) * Vr[idx_a(x_p)][c]  for Vr stored row-major [m][ncols]
+// (the layout of left_interp's dense operand, BFN:206-210).  One block per query:
+// the 4^D taps are computed once into LDS, then lanes run over columns so that every
+// tap reads a contiguous row segment of Vr (coalesced; Vr is L2 / MALL resident).
+// Used with Vr = M (dense posterior of small grids): W* M in n* x 4^D row reads.
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_gather_rows(GridDev<real> G, const real* __restrict__ x, int64_t n, const real* __restrict__ Vr,
+                                                     int ncols, real* __restrict__ out, int32_t* __restrict__ err) {
+  constexpr int T = 1 << (2 * D);
+  __shared__ int s_idx[T];
+  __shared__ real s_val[T];
+  const int64_t p = blockIdx.x;
+  for (int a = threadIdx.x; a < T; a += blockDim.x) {
+    int flat = 0;
+    real v = (real)1;
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      real w[4];
+      int j0 = dim_stencil<real>(x[p * D + q], G.g0[q], G.h[q], G.hi[q], G.g[q], w);
+      const int c = (a >> (2 * (D - 1 - q))) & 3;
+      if (j0 < 0) { ok = false; j0 = 0; w[c] = (real)0; }
+      flat += (j0 + c) * G.stride[q];
+      v *= w[c];
+    }
+    s_idx[a] = flat;
+    s_val[a] = v;
+    if (!ok && a == 0) atomicOr(err, 1);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+    real acc = (real)0;
+#pragma unroll 8
+    for (int a = 0; a < T; ++a) acc += s_val[a] * Vr[(int64_t)s_idx[a] * ncols + c];
+    out[p * ncols + c] = acc;
+  }
+}
+
+template <typename real>
+static int gather_rows_impl(const wiski_grid* grid, const real* d_x, int64_t n, const real* d_Vr, int32_t ncols, real* d_out, int32_t* d_err,
+                            void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (n == 0) return WISKI_OK;
+  if (!d_x || !d_Vr || !d_out || !d_err || ncols < 1) return WISKI_E_BADARG;
+  dim3 grd((unsigned)n);
+#define CALL(DD) hipLaunchKernelGGL((k_gather_rows<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_Vr, ncols, d_out, d_err)
+  WISKI_DISPATCH_D(G.d, CALL)
+#undef CALL
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
 // ------------------------------------------------------------- host side ---
 template <typename real>
 static int interp_impl(const wiski_grid* grid, const real* d_x, int64_t n, int32_t* d_idx, real* d_val, int32_t* d_err, void* stream) {
@@ -239,6 +294,8 @@ int wiski_interp_f32(const wiski_grid* g, const float* x, int64_t n, int32_t* id
 int wiski_interp_f64(const wiski_grid* g, const double* x, int64_t n, int32_t* idx, double* val, int32_t* err, void* s) { return interp_impl<double>(g, x, n, idx, val, err, s); }
 int wiski_gather_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t k, int32_t diag, float* out, int32_t* err, void* s) { return gather_impl<float>(g, x, n, V, k, diag, out, err, s); }
 int wiski_gather_f64(const wiski_grid* g, const double* x, int64_t n, const double* V, int32_t k, int32_t diag, double* out, int32_t* err, void* s) { return gather_impl<double>(g, x, n, V, k, diag, out, err, s); }
+int wiski_gather_rows_f32(const wiski_grid* g, const float* x, int64_t n, const float* Vr, int32_t ncols, float* out, int32_t* err, void* s) { return gather_rows_impl<float>(g, x, n, Vr, ncols, out, err, s); }
+int wiski_gather_rows_f64(const wiski_grid* g, const double* x, int64_t n, const double* Vr, int32_t ncols, double* out, int32_t* err, void* s) { return gather_rows_impl<double>(g, x, n, Vr, ncols, out, err, s); }
 int wiski_gather_ell_f32(const int32_t* idx, const float* val, int64_t n, int32_t T, const float* v, float* out, void* s) { return gather_ell_impl<float>(idx, val, n, T, v, out, s); }
 int wiski_gather_ell_f64(const int32_t* idx, const double* val, int64_t n, int32_t T, const double* v, double* out, void* s) { return gather_ell_impl<double>(idx, val, n, T, v, out, s); }
 int wiski_wt_columns_f32(const wiski_grid* g, const float* x, int64_t n, float* out, int32_t* err, void* s) { return wt_columns_impl<float>(g, x, n, out, err, s); }

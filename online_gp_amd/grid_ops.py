@@ -100,6 +100,18 @@ def gather(grid, x, V, err, diag=False):
     return out
 
 
+def gather_rows(grid, x, Vr, err):
+    """W(x) @ Vr for a row-major dense operand Vr [m, ncols]; returns [n, ncols]."""
+    x = _x2d(x, grid)
+    Vr = Vr.contiguous()
+    assert Vr.shape[0] == grid.m and Vr.dtype == x.dtype
+    out = torch.empty((x.shape[0], Vr.shape[1]), dtype=x.dtype, device=x.device)
+    rc = _hip.fn("wiski_gather_rows", x.dtype)(grid.ref, _hip.dptr(x), ctypes.c_int64(x.shape[0]), _hip.dptr(Vr), ctypes.c_int32(Vr.shape[1]),
+                                               _hip.dptr(out), _hip.dptr(err), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_gather_rows")
+    return out
+
+
 def gather_ell(idx, val, v):
     n, T = idx.shape
     out = torch.empty((n,), dtype=val.dtype, device=val.device)

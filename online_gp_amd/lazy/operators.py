@@ -186,17 +186,25 @@ class PredictiveCovariance(LazyCovariance):
         self._full = None
 
     def _dense_path(self, want_full):
-        """M is cached dense: rows w_p^T M by one gather, then a second gather."""
+        """M is cached dense: rows w_p^T M by one row-gather, then quadratic forms by diag-gathers."""
         grid = self.post.grid
-        Mg = grid_ops.gather(grid, self.x, self.post.dense, self.err)              # [n, m]: row p = w_p^T M (M symmetric)
-        self._diag = grid_ops.gather(grid, self.x, Mg, self.err, diag=True) * self.sigma2
+        if getattr(self, "_Mg", None) is None:
+            self._Mg = grid_ops.gather_rows(grid, self.x, self.post.dense, self.err)    # [n, m]: row p = w_p^T M (coalesced row reads)
+        Mg = self._Mg
+        if self._diag is None:
+            self._diag = grid_ops.gather(grid, self.x, Mg, self.err, diag=True) * self.sigma2
         if want_full:
-            full = grid_ops.gather(grid, self.x, Mg, self.err) * self.sigma2      # [n, n]
-            if self.block is not None:
+            n = self.x.shape[0]
+            if self.block is None:
+                full = grid_ops.gather(grid, self.x, Mg, self.err) * self.sigma2                      # [n, n]
+            else:
+                # only the q x q blocks: pair (row b*q+i, query b*q+j) -> one diag-gather of n*q pairs
                 q = self.block
-                nb = full.shape[0] // q
-                idx = torch.arange(nb, device=self.device)
-                full = full.reshape(nb, q, nb, q)[idx, :, idx, :]
+                base = (torch.arange(n, device=self.device) // q) * q
+                rows = torch.arange(n, device=self.device).repeat_interleave(q)
+                cols = (base[:, None] + torch.arange(q, device=self.device)[None, :]).reshape(-1)
+                full = grid_ops.gather(grid, self.x[cols].contiguous(), Mg[rows].contiguous(), self.err, diag=True)
+                full = full.reshape(n // q, q, q) * self.sigma2
             self._full = 0.5 * (full + full.transpose(-1, -2))
 
     def _solve_chunks(self, want_full):

@@ -180,3 +180,17 @@ def test_symmetric_half_scatter_and_expand(d, g, tdt, ndt, tol):
     assert np.abs(full.double().cpu().numpy() - B2.A).max() < tol * np.abs(B2.A).max() * 10
     assert np.abs(b.double().cpu().numpy() - B2.b).max() < tol * np.abs(B2.b).max() * 10
     assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
+def test_gather_rows_row_major_operand(d, g, tdt, ndt, tol):
+    from online_gp_amd import grid_ops
+
+    grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt, n=37)
+    Vr = rng.standard_normal((grid.m, 11)).astype(ndt)          # asymmetric, row-major [m, ncols]
+    err = grid_ops.new_err_flag("cuda")
+    out = grid_ops.gather_rows(grid, _t(X, tdt), _t(Vr, tdt), err)
+    ref = B2.gather(X.astype(np.float64), Vr.T.astype(np.float64))
+    assert out.shape == (37, 11) and int(err.item()) == 0
+    assert np.abs(out.double().cpu().numpy() - ref).max() < tol * np.abs(ref).max() * 10
