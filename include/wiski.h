@@ -67,6 +67,12 @@ int wiski_interp_f64(const wiski_grid* grid, const double* d_x, int64_t n, int32
 int wiski_gather_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, int32_t diag, float* d_out, int32_t* d_err, void* stream);
 int wiski_gather_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, int32_t diag, double* d_out, int32_t* d_err, void* stream);
 
+/* Input gradient of the interpolation row (learned stems; streaming_partial_mll.py:20-36
+ * differentiates through W):  d_out[n][d] = d/dx ( W(x_p) . V_c ), c = 0 (diag == 0, one
+ * column d_V[m]) or c = p (diag != 0, d_V[n][m]). */
+int wiski_gather_grad_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t diag, float* d_out, void* stream);
+int wiski_gather_grad_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t diag, double* d_out, void* stream);
+
 /* a14 with the dense operand stored ROW-major, d_Vr[m][ncols] (left_interp's own layout,
  * BFN:206-210): d_out[n][ncols] = W(x) Vr.  Every tap reads a contiguous row segment;
  * used for W* M with the cached dense posterior M of small grids (BFN:222-225). */

@@ -162,6 +162,60 @@ __global__ __launch_bounds__(256) void k_wt_columns(GridDev<real> G, const real*
   if (!ok && a == 0) atomicOr(err, 1);
 }
 
+// ------------------------------------------------ gradient w.r.t. the inputs ---
+// out[p][q] = d/dx_q ( W(x_p) . V_c ),  c = 0 (k == 1) or c = p (diag): the derivative of the
+// cubic interpolation row, needed when a learned stem feeds the GP (sm_partial_mll,
+// reference online_gp/mlls/streaming_partial_mll.py:20-36 differentiates through W).
+// One thread per (query, dim): product of the other dims' weights and this dim's
+// weight derivative k'(s)/h.  Boundary (one-hot) cells have zero derivative.
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_gather_grad(GridDev<real> G, const real* __restrict__ x, int64_t n, const real* __restrict__ V, int diag,
+                                                     real* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * D) return;
+  const int64_t p = e / D;
+  const int qd = (int)(e - p * D);
+  int j0[D];
+  real w[D][4];
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    const real xv = x[p * D + q];
+    int j = dim_stencil<real>(xv, G.g0[q], G.h[q], G.hi[q], G.g[q], w[q]);
+    if (j < 0) {
+      j = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[q][c] = (real)0;
+    }
+    if (q == qd) {
+      const real u = (xv - G.g0[q]) / G.h[q];
+      const real fl = floor(u);
+      const real t = u - fl;
+      const int jj = (int)fl - 1;
+      const bool interior = !(jj < 0 || jj > G.g[q] - 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[q][c] = interior ? keys_cubic_deriv<real>(t + (real)1 - (real)c) / G.h[q] : (real)0;
+    }
+    j0[q] = j;
+  }
+  const real* __restrict__ v = V + (diag ? p : 0) * (int64_t)G.m;
+  out[e] = gather_one<real, D>(G, j0, w, v);
+}
+
+template <typename real>
+static int gather_grad_impl(const wiski_grid* grid, const real* d_x, int64_t n, const real* d_V, int32_t diag, real* d_out, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (n == 0) return WISKI_OK;
+  if (!d_x || !d_V || !d_out) return WISKI_E_BADARG;
+  dim3 grd((unsigned)((n * G.d + 255) / 256));
+#define CALL(DD) hipLaunchKernelGGL((k_gather_grad<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, diag, d_out)
+  WISKI_DISPATCH_D(G.d, CALL)
+#undef CALL
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
 // ------------------------------------------------------- row-major gather ---
 // out[p][c] = sum_a val_a(x_p) * Vr[idx_a(x_p)][c]  for Vr stored row-major [m][ncols]
 // (the layout of left_interp's dense operand, BFN:206-210).  One block per query:
@@ -294,6 +348,8 @@ int wiski_interp_f32(const wiski_grid* g, const float* x, int64_t n, int32_t* id
 int wiski_interp_f64(const wiski_grid* g, const double* x, int64_t n, int32_t* idx, double* val, int32_t* err, void* s) { return interp_impl<double>(g, x, n, idx, val, err, s); }
 int wiski_gather_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t k, int32_t diag, float* out, int32_t* err, void* s) { return gather_impl<float>(g, x, n, V, k, diag, out, err, s); }
 int wiski_gather_f64(const wiski_grid* g, const double* x, int64_t n, const double* V, int32_t k, int32_t diag, double* out, int32_t* err, void* s) { return gather_impl<double>(g, x, n, V, k, diag, out, err, s); }
+int wiski_gather_grad_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t diag, float* out, void* s) { return gather_grad_impl<float>(g, x, n, V, diag, out, s); }
+int wiski_gather_grad_f64(const wiski_grid* g, const double* x, int64_t n, const double* V, int32_t diag, double* out, void* s) { return gather_grad_impl<double>(g, x, n, V, diag, out, s); }
 int wiski_gather_rows_f32(const wiski_grid* g, const float* x, int64_t n, const float* Vr, int32_t ncols, float* out, int32_t* err, void* s) { return gather_rows_impl<float>(g, x, n, Vr, ncols, out, err, s); }
 int wiski_gather_rows_f64(const wiski_grid* g, const double* x, int64_t n, const double* Vr, int32_t ncols, double* out, int32_t* err, void* s) { return gather_rows_impl<double>(g, x, n, Vr, ncols, out, err, s); }
 int wiski_gather_ell_f32(const int32_t* idx, const float* val, int64_t n, int32_t T, const float* v, float* out, void* s) { return gather_ell_impl<float>(idx, val, n, T, v, out, s); }

@@ -61,6 +61,16 @@ __device__ __forceinline__ real keys_cubic(real s) {
   return a <= (real)1 ? near : (a < (real)2 ? far : (real)0);
 }
 
+// d/ds of the Keys kernel.
+template <typename real>
+__device__ __forceinline__ real keys_cubic_deriv(real s) {
+  const real a = s < (real)0 ? -s : s;
+  const real sg = s < (real)0 ? (real)-1 : (real)1;
+  const real near = ((real)4.5 * a - (real)5) * a;
+  const real far = ((real)-1.5 * a + (real)5) * a - (real)4;
+  return a <= (real)1 ? sg * near : (a < (real)2 ? sg * far : (real)0);
+}
+
 // 4-tap stencil of one coordinate: lowest tap index (or -1 if outside the
 // grid) and weights.  Boundary cells collapse to a one-hot on the nearest of
 // the first/last four grid points (gpytorch Interpolation.interpolate).

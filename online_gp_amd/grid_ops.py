@@ -100,6 +100,36 @@ def gather(grid, x, V, err, diag=False):
     return out
 
 
+def gather_grad(grid, x, V, diag=False):
+    """d/dx of W(x_p) . V_c  (c = 0, or c = p when diag): [n, d]."""
+    x = _x2d(x, grid)
+    V = V.contiguous()
+    out = torch.empty((x.shape[0], grid.d), dtype=x.dtype, device=x.device)
+    rc = _hip.fn("wiski_gather_grad", x.dtype)(grid.ref, _hip.dptr(x), ctypes.c_int64(x.shape[0]), _hip.dptr(V), ctypes.c_int32(int(diag)),
+                                               _hip.dptr(out), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_gather_grad")
+    return out
+
+
+class InterpDot(torch.autograd.Function):
+    """f(x)_p = W(x_p) . V_c (c = 0 or c = p), differentiable w.r.t. the inputs x only."""
+
+    @staticmethod
+    def forward(ctx, grid, x, V, diag, err):
+        xd = x.detach().contiguous()
+        Vd = V.detach().contiguous().reshape(-1, grid.m)
+        ctx.grid, ctx.diag = grid, diag
+        ctx.save_for_backward(xd, Vd)
+        out = gather(grid, xd, Vd, err, diag=diag)
+        return out if diag else out[:, 0]
+
+    @staticmethod
+    def backward(ctx, g):
+        xd, Vd = ctx.saved_tensors
+        gx = gather_grad(ctx.grid, xd, Vd, diag=ctx.diag) * g[:, None]
+        return None, gx, None, None, None
+
+
 def gather_rows(grid, x, Vr, err):
     """W(x) @ Vr for a row-major dense operand Vr [m, ncols]; returns [n, ncols]."""
     x = _x2d(x, grid)

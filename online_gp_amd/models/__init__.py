@@ -1,6 +1,6 @@
 from .batched_fixed_noise_online_gp import FixedNoiseOnlineSKIGP
 from .online_ski_regression import OnlineSKIRegression
 from .online_ski_botorch_model import OnlineSKIBotorchModel
-from .stems import Identity
+from .stems import Identity, LinearStem
 
-__all__ = ["FixedNoiseOnlineSKIGP", "OnlineSKIRegression", "OnlineSKIBotorchModel", "Identity"]
+__all__ = ["FixedNoiseOnlineSKIGP", "OnlineSKIRegression", "OnlineSKIBotorchModel", "Identity", "LinearStem"]

@@ -5,7 +5,7 @@ import torch
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
 from .. import settings
-from ..mlls import BatchedWoodburyMarginalLogLikelihood
+from ..mlls import BatchedWoodburyMarginalLogLikelihood, sm_partial_mll
 from .batched_fixed_noise_online_gp import FixedNoiseOnlineSKIGP
 
 
@@ -111,6 +111,9 @@ class OnlineSKIRegression(torch.nn.Module):
             self.gp.condition_on_observations(features, targets, noise_term, inplace=True)
             if any(True for _ in self.stem.modules()):
                 self._raw_inputs = [torch.cat([*self._raw_inputs, inputs])]
+                self.stem.train()
+                if update_stem:
+                    self._get_features(inputs)
         self.eval()
         return stem_loss, gp_loss
 
@@ -129,10 +132,24 @@ class OnlineSKIRegression(torch.nn.Module):
         return loss.item()
 
     def _update_stem(self, inputs, targets):
+        self.stem_optimizer.zero_grad()
+        num_seen = self.gp.num_data
+        self.stem.eval()  # deterministic features: BatchNorm in eval mode (OSR:152)
         new_features = self.stem(inputs)
         if new_features.requires_grad is False:               # Identity stem, OSR:154-155
             return 0
-        raise NotImplementedError("learned stems need d W / d x (sm_partial_mll); out of the round-1 scope (SURVEY 8f-2)")
+        loss = -sm_partial_mll(self.gp, new_features, targets.transpose(-1, -2), num_seen).sum()
+        loss.backward()
+        self.stem_optimizer.step()
+        return loss.item()
+
+    def _get_features(self, inputs):
+        # refresh the BatchNorm statistics with the new points plus a replay sample (OSR:164-174)
+        inputs = inputs.view(-1, self.stem.input_dim)
+        num_seen = self._raw_inputs[0].size(0)
+        batch_idxs = torch.randint(0, num_seen, (1024,), device=self._raw_inputs[0].device)
+        input_batch = torch.cat([inputs, self._raw_inputs[0][batch_idxs]])
+        return self.stem(input_batch)[:inputs.size(0)]
 
     def _refresh_features(self, inputs, targets):
         features = self.stem(inputs)

@@ -128,3 +128,73 @@ def test_update_with_hyperparameter_step_and_fit():
     assert (r.gp.covar_module.base_kernel.base_kernel.raw_lengthscale.detach() - before).abs().max() > 0
     rmse, nll = r.evaluate(Xt[:100], yt[:100])
     assert rmse < 0.5 and np.isfinite(nll)
+
+
+def test_gather_grad_matches_finite_differences():
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(0)
+    for d, g in [(1, 12), (2, 9), (3, 8)]:
+        grid = grid_ops.GridSpec([[-1.1, 1.1]] * d, g)
+        X = rng.uniform(-0.95, 0.95, (20, d))
+        V = rng.standard_normal((20, grid.m))
+        err = grid_ops.new_err_flag(DEV)
+        Xt, Vt = torch.as_tensor(X, device=DEV), torch.as_tensor(V, device=DEV)
+        for diag in (False, True):
+            Vuse = Vt if diag else Vt[:1]
+            got = grid_ops.gather_grad(grid, Xt, Vuse, diag=diag).cpu().numpy()
+            fd = np.zeros((20, d))
+            for q in range(d):
+                for sgn in (+1, -1):
+                    Xp = X.copy(); Xp[:, q] += sgn * 1e-6
+                    out = grid_ops.gather(grid, torch.as_tensor(Xp, device=DEV), Vuse, err, diag=diag)
+                    out = out if diag else out[:, 0]
+                    fd[:, q] += sgn * out.cpu().numpy() / 2e-6
+            assert np.abs(got - fd).max() < 1e-5 * max(np.abs(fd).max(), 1.0)
+
+
+def test_sm_partial_mll_value_matches_dense_restatement_and_is_differentiable():
+    """Value vs the op-for-op restatement of streaming_partial_mll.py (oracle/dense_reference.py);
+    gradient w.r.t. the new input vs finite differences of the same restatement."""
+    from oracle import dense_reference
+    from online_gp_amd.mlls import sm_partial_mll
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(2)
+    X = rng.uniform(-0.9, 0.9, (60, 2)); y = np.sin(2 * X[:, 0]) + 0.5 * X[:, 1] + 0.1 * rng.standard_normal(60)
+    Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+    m = FixedNoiseOnlineSKIGP(Xt, yt, None, grid_bounds=torch.tensor([[-1.1, 1.1]] * 2), grid_size=9, learn_additional_noise=True)
+    m.eval()
+    s2 = float(m.likelihood.second_noise.detach())
+    B1 = dense_reference.DenseWISKI([[-1.1, 1.1]] * 2, 9, sigma2=s2, chol_jitter=1e-10)
+    B1.set_train_data(X, y, np.ones(60))
+    xn = np.array([[0.31, -0.42]]); yn = 0.7
+    xt = torch.tensor(xn, device=DEV, requires_grad=True)
+    val = sm_partial_mll(m, xt, torch.tensor([[yn]], device=DEV), 60)
+    ref = B1.sm_partial_mll(xn, yn)
+    assert abs(float(val.detach()) - ref) < 1e-6 * abs(ref)
+    val.sum().backward()
+    fd = np.zeros(2)
+    for q in range(2):
+        for sgn in (+1, -1):
+            xp = xn.copy(); xp[0, q] += sgn * 1e-5
+            fd[q] += sgn * B1.sm_partial_mll(xp, yn) / 2e-5
+    assert np.abs(xt.grad.cpu().numpy()[0] - fd).max() < 1e-4 * max(np.abs(fd).max(), 1e-3)
+
+
+def test_learned_stem_streaming_update_runs():
+    from online_gp_amd.models import LinearStem, OnlineSKIRegression
+
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (400, 5)); y = np.sin(X[:, :1] + X[:, 1:2]) + 0.1 * rng.standard_normal((400, 1))
+    Xt, yt = torch.as_tensor(X, device=DEV, dtype=torch.float32), torch.as_tensor(y, device=DEV, dtype=torch.float32)
+    stem = LinearStem(5, 2).to(DEV)
+    r = OnlineSKIRegression(stem, Xt[:200], yt[:200], 1e-2, 16, 1.0)
+    w0 = stem[0].weight.detach().clone()
+    for s in range(200, 260, 20):
+        stem_loss, gp_loss = r.update(Xt[s:s + 20], yt[s:s + 20])
+        assert np.isfinite(stem_loss) and np.isfinite(gp_loss) and stem_loss != 0
+    assert (stem[0].weight.detach() - w0).abs().max() > 0
+    rmse, nll = r.evaluate(Xt[300:], yt[300:])
+    assert np.isfinite(rmse) and np.isfinite(nll)
