@@ -143,10 +143,12 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  *   U = M RHS,  M = (Kt^-1 + A)^-1  (SURVEY 3.5).
  * Preconditioner:
  *   d_evec == NULL : P = Kt                      (needs d_tcol)
- *   d_evec != NULL : P = (Kt^-1 + shift I)^-1    applied in the Kronecker
- *     eigenbasis Kuu = (kron V_q) diag(kron lam_q) (kron V_q)^T; d_evec =
- *     concatenated row-major g_q x g_q matrices V_q, d_eval = concatenated
- *     eigenvalues lam_q (>= 0); shift ~ mean row sum of A (d_tcol unused).
+ *   d_evec != NULL : P = (Kt^-1 + shift * kron_q diag(t_q))^-1, a separable model of A
+ *     (t_q = per-dim data-density profile; t_q = 1 gives shift * I), applied through the
+ *     per-dim generalized eigenproblems  K_q = X_q D_q X_q^T,  X_q^T diag(t_q) X_q = I:
+ *     d_evec = concatenated row-major g_q x g_q matrices X_q, d_evec2 = Z_q = diag(t_q) X_q
+ *     (NULL when t_q = 1: Z_q = X_q orthogonal), d_eval = concatenated D_q (>= 0);
+ *     shift = density scale (d_tcol unused).
  * d_U/d_Z [k][m]: solution and its pre-image (U = Kt Z). warm != 0 starts
  * from the given (U, Z) (must satisfy U = Kt Z), else from zero.
  * Stops when every column has ||r||/||rhs|| < tol or at max_iter.
@@ -154,8 +156,8 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
  * be NULL): final relative residuals. */
 int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size);
-int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
-int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

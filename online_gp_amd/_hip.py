@@ -58,6 +58,11 @@ def build(force=False, verbose=False):
 def lib():
     global _lib
     if _lib is None:
+        alt = os.environ.get("WISKI_HIP_SO")          # A/B testing of kernel variants (tools/ubench)
+        if alt:
+            _lib = ctypes.CDLL(alt)
+            _lib.wiski_pcg_workspace_bytes.restype = ctypes.c_int64
+            return _lib
         if not os.path.exists(_SO):
             raise WiskiError(
                 f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

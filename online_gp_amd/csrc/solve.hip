@@ -152,6 +152,24 @@ __device__ __forceinline__ Vec4<real> load4(const real* __restrict__ p) {
   return r;
 }
 
+// Same, with the non-temporal cache policy: A_st is read exactly once per launch, so
+// it should not displace v / the partial vectors from L2.
+template <typename real>
+__device__ __forceinline__ Vec4<real> load4_nt(const real* __restrict__ p) {
+  Vec4<real> r;
+  if constexpr (sizeof(real) == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+  } else {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + 2));
+    r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y;
+  }
+  return r;
+}
+
 template <typename real>
 __device__ __forceinline__ void store4(real* __restrict__ p, real a, real b, real c, real d) {
   if constexpr (sizeof(real) == 4) {
@@ -205,7 +223,11 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4(GridDev<real> G, const re
       const real* __restrict__ a_mid = a_base + (int64_t)mid * 7 * m;
 #pragma unroll
       for (int c7 = 0; c7 < 7; ++c7) {
+#ifdef WISKI_SPMV_NT
+        const Vec4<real> a = load4_nt<real>(a_mid + (int64_t)c7 * m);
+#else
         const Vec4<real> a = load4<real>(a_mid + (int64_t)c7 * m);
+#endif
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
           acc[c][0] += a.x * win[c][c7 + 0];
@@ -344,7 +366,8 @@ static int launch_kron(const GridDev<real>& G, const real* tcol, const real* V, 
 //           out = f1 * acc  and  out[out2_off + .] = lam * f1 * acc
 //   MODE 2  dot epilogue: dots[c - dot_c0] += sum_e wvec[c - dot_c0][e] * acc for c >= dot_c0
 template <typename real, int MODE>
-__global__ __launch_bounds__(256) void k_dense_mode(GridDev<real> G, int q, const real* __restrict__ F, int transposed,
+__global__ __launch_bounds__(256) void k_dense_mode(GridDev<real> G, int q, const real* __restrict__ Fmain, const real* __restrict__ Falt, int split,
+                                                    int transposed,
                                                     const real* __restrict__ in, real* __restrict__ out, int64_t out2_off,
                                                     const real* __restrict__ evals, real kscale, real shift,
                                                     const real* __restrict__ wvec, int dot_c0, double* __restrict__ dots) {
@@ -352,6 +375,7 @@ __global__ __launch_bounds__(256) void k_dense_mode(GridDev<real> G, int q, cons
   real* sF = reinterpret_cast<real*>(smem);
   __shared__ double s_red[16];
   const int g = G.g[q], post = G.stride[q], m = G.m;
+  const real* __restrict__ F = (Falt != nullptr && (int)blockIdx.y < split) ? Falt : Fmain;   // columns [0, split) may use another factor
   for (int t = threadIdx.x; t < g * g; t += blockDim.x) {
     const int i = t / g, j = t - i * g;
     sF[t] = transposed ? F[j * g + i] : F[t];
@@ -392,11 +416,12 @@ __global__ __launch_bounds__(256) void k_dense_mode(GridDev<real> G, int q, cons
 // via Kt = V diag(lam) V^T.  ty = [t (k cols) | y (k cols)]; sa/sb: 2k-column scratch.
 // Also accumulates rho[c] += r[c] . y[c].
 template <typename real>
-static int launch_spectral_precond(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, const real* r, int k,
+static int launch_spectral_precond(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift,
+                                   const real* r, int k,
                                    real* sa, real* sb, real* ty, double* rho, hipStream_t s) {
   const int m = G.m, d = G.d;
   const int64_t km = (int64_t)k * m;
-  if (spectral_fused_ok<real>(G)) return launch_spectral_fused<real>(G, evec, evals, kscale, shift, r, k, sa, sb, ty, rho, s);
+  if (spectral_fused_ok<real>(G)) return launch_spectral_fused<real>(G, evec, evec2, evals, kscale, shift, r, k, sa, sb, ty, rho, s);
   int eoff[WISKI_MAX_DIM + 1];
   eoff[0] = 0;
   for (int q = 0; q < d; ++q) {
@@ -410,10 +435,10 @@ static int launch_spectral_precond(const GridDev<real>& G, const real* evec, con
     real* dst = (cur == sa) ? sb : sa;
     const size_t sh = (size_t)G.g[q] * G.g[q] * sizeof(real);
     if (q < d - 1)
-      hipLaunchKernelGGL((k_dense_mode<real, 0>), dim3(gx, (unsigned)k), dim3(256), sh, s, G, q, evec + eoff[q], 1, cur, dst, (int64_t)0, evals,
+      hipLaunchKernelGGL((k_dense_mode<real, 0>), dim3(gx, (unsigned)k), dim3(256), sh, s, G, q, evec + eoff[q], (const real*)nullptr, 0, 1, cur, dst, (int64_t)0, evals,
                          kscale, shift, (const real*)nullptr, 0, (double*)nullptr);
     else
-      hipLaunchKernelGGL((k_dense_mode<real, 1>), dim3(gx, (unsigned)k), dim3(256), sh, s, G, q, evec + eoff[q], 1, cur, dst, km, evals, kscale,
+      hipLaunchKernelGGL((k_dense_mode<real, 1>), dim3(gx, (unsigned)k), dim3(256), sh, s, G, q, evec + eoff[q], (const real*)nullptr, 0, 1, cur, dst, km, evals, kscale,
                          shift, (const real*)nullptr, 0, (double*)nullptr);
     cur = dst;
   }
@@ -423,10 +448,10 @@ static int launch_spectral_precond(const GridDev<real>& G, const real* evec, con
     real* dst = last ? ty : ((cur == sa) ? sb : sa);
     const size_t sh = (size_t)G.g[q] * G.g[q] * sizeof(real);
     if (!last)
-      hipLaunchKernelGGL((k_dense_mode<real, 0>), dim3(gx, (unsigned)(2 * k)), dim3(256), sh, s, G, q, evec + eoff[q], 0, cur, dst, (int64_t)0,
+      hipLaunchKernelGGL((k_dense_mode<real, 0>), dim3(gx, (unsigned)(2 * k)), dim3(256), sh, s, G, q, evec + eoff[q], evec2 ? evec2 + eoff[q] : (const real*)nullptr, k, 0, cur, dst, (int64_t)0,
                          evals, kscale, shift, (const real*)nullptr, 0, (double*)nullptr);
     else
-      hipLaunchKernelGGL((k_dense_mode<real, 2>), dim3(gx, (unsigned)(2 * k)), dim3(256), sh, s, G, q, evec + eoff[q], 0, cur, dst, (int64_t)0,
+      hipLaunchKernelGGL((k_dense_mode<real, 2>), dim3(gx, (unsigned)(2 * k)), dim3(256), sh, s, G, q, evec + eoff[q], evec2 ? evec2 + eoff[q] : (const real*)nullptr, k, 0, cur, dst, (int64_t)0,
                          evals, kscale, shift, r, k, rho);
     cur = dst;
   }
@@ -545,7 +570,7 @@ static int spectral_mm_impl(const wiski_grid* grid, const real* d_evec, const re
     const int transposed = step < d ? 1 : 0;
     real* dst = ((2 * d - 1 - step) % 2 == 0) ? d_out : d_tmp;
     const size_t sh = (size_t)G.g[q] * G.g[q] * sizeof(real);
-    hipLaunchKernelGGL((k_dense_mode<real, 0>), grd, dim3(256), sh, s, G, q, d_evec + eoff[q], transposed, cur, dst, (int64_t)0, d_eval, kscale,
+    hipLaunchKernelGGL((k_dense_mode<real, 0>), grd, dim3(256), sh, s, G, q, d_evec + eoff[q], (const real*)nullptr, 0, transposed, cur, dst, (int64_t)0, d_eval, kscale,
                        shift, (const real*)nullptr, 0, (double*)nullptr);
     cur = dst;
     if (step == d - 1) hipLaunchKernelGGL((k_spectral_scale<real>), grd, dim3(256), 0, s, G, d_eval, kscale, shift, pw, rw, dst);
@@ -701,7 +726,7 @@ static int64_t pcg_ws_bytes(int m, int k, int max_iter, int es) {
 }
 
 template <typename real>
-static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_eval,
+static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_evec2, const real* d_eval,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream) {
   GridDev<real> G;
@@ -788,7 +813,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   while (!done && it < max_iter) {
     if (fused_cg) {
       // 4 launches per iteration: [update_x(it-1) + mode-0 fwd] -> slab (+rho) -> [mode-0 bwd + update_p] -> SpMV (+p.Hp)
-      rc = launch_spectral_fused_cg<real>(G, d_evec, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, (const real*)part, nch,
+      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, (const real*)part, nch,
                                           d_U, d_Z, S, s);
       if (rc) return rc;
       rc = launch_spmv4<real>(G, d_A, p, k, part, pt, (real)1, S.php(it), s);
@@ -806,7 +831,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     // y = Kt r, rho(it) = r.y
     if (spectral) {
       // [t | y] = spectral preconditioner applied to r, rho(it) = r.y
-      rc = launch_spectral_precond<real>(G, d_evec, d_eval, kscale, shift, r, k, sa, sb, ty, S.rho(it), s);
+      rc = launch_spectral_precond<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, ty, S.rho(it), s);
       if (rc) return rc;
       if (wide)
         hipLaunchKernelGGL((k_pcg_update_p<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)(ty + (int64_t)k * m), (const real*)ty, p,
@@ -897,10 +922,10 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
 }
-int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<float>(g, A, tcol, kscale, evec, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
 }
-int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<double>(g, A, tcol, kscale, evec, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
 }
 }

@@ -138,8 +138,9 @@ struct MatrixLoad {
 // Fm = V0 (forward, transposed == 0: V0^T .) or V0^T (backward: V0 .).
 // grid = (ceil(S/32), ncols), block = 128 (tiles: (P0/4) x 8 <= 128 for g0 <= 64).
 template <typename real, bool DOT>
-__global__ __launch_bounds__(128) void k_spec_mode0(GridDev<real> G, const real* __restrict__ V0, int transposed, const real* __restrict__ src,
-                                                    real* __restrict__ dst, const real* __restrict__ rvec, int dot_c0, double* __restrict__ dots) {
+__global__ __launch_bounds__(128) void k_spec_mode0(GridDev<real> G, const real* __restrict__ Va, const real* __restrict__ Vb, int split,
+                                                    int transposed, const real* __restrict__ src, real* __restrict__ dst,
+                                                    const real* __restrict__ rvec, int dot_c0, double* __restrict__ dots) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
   constexpr int ST = 32;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(128) void k_spec_mode0(GridDev<real> G, const real*
   real* sIn = sF + P0 * P0;                   // [P0][ST]
   const int c = blockIdx.y;
   const int s0 = blockIdx.x * ST;
+  const real* __restrict__ V0 = c < split ? Va : Vb;   // generalized eigenbasis: t-half and y-half use different factors
   const real* __restrict__ sc = src + (int64_t)c * m;
   // In tile: rows b < g0 (rows up to P0 zero), 8 x 16-byte loads per row; issue all loads first
   constexpr int NV = (64 * (ST / 4) + 127) / 128;   // <= 4
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(128) void k_spec_mode0(GridDev<real> G, const real*
 // through tile_product_t.  Every global load of the block is issued up front.
 template <typename real>
 __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* __restrict__ V1, const real* __restrict__ V2,
-                                                   const real* __restrict__ evals, real kscale, real shift, const real* __restrict__ src,
+                                                   const real* __restrict__ Z1, const real* __restrict__ Z2, const real* __restrict__ evals, real kscale, real shift, const real* __restrict__ src,
                                                    real* __restrict__ dst, int k, double* __restrict__ rho) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
@@ -236,7 +238,9 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
   real* B1 = B0 + PM * PM;
   real* sV1 = B1 + PM * PM;
   real* sV2 = sV1 + P1 * P1;
-  real* sE = sV2 + P2 * P2;   // [P1 + P2] eigenvalues of dims 1, 2 (zero padded)
+  real* sZ1 = sV2 + P2 * P2;   // backward factors of the t-half (h == 0) when they differ from V (generalized eigenbasis)
+  real* sZ2 = sZ1 + P1 * P1;
+  real* sE = sZ2 + P2 * P2;   // [P1 + P2] eigenvalues of dims 1, 2 (zero padded)
   const int i0 = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
   const int t = threadIdx.x;
   const real* __restrict__ xs = src + (int64_t)c * m + (int64_t)i0 * g1 * g2;
@@ -257,13 +261,24 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
   if (t < P1) ev = t < g1 ? evals[g0 + t] : (real)0;
   else if (t < P1 + P2) ev = (t - P1) < g2 ? evals[g0 + g1 + (t - P1)] : (real)0;
   const real l0 = kscale * evals[i0];
-  MatrixLoad<real, 256> m1, m2;
+  const bool alt = (h == 0) && (Z1 != V1 || Z2 != V2);   // block-uniform
+  MatrixLoad<real, 256> m1, m2, m3, m4;
   m1.issue(V1, g1);
   m2.issue(V2, g2);
-  for (int e = t; e < 2 * PM * PM + P1 * P1 + P2 * P2; e += 256) B0[e] = (real)0;   // B0, B1, sV1, sV2 (padding must be zero)
+  if (alt) {
+    m3.issue(Z1, g1);
+    m4.issue(Z2, g2);
+  }
+  for (int e = t; e < 2 * PM * PM + 2 * (P1 * P1 + P2 * P2); e += 256) B0[e] = (real)0;   // B0, B1, sV1, sV2, sZ1, sZ2 (padding must be zero)
   __syncthreads();
   m1.commit(sV1, g1, P1);
   m2.commit(sV2, g2, P2);
+  if (alt) {
+    m3.commit(sZ1, g1, P1);
+    m4.commit(sZ2, g2, P2);
+  }
+  const real* bV1 = alt ? sZ1 : sV1;   // factors of the backward products
+  const real* bV2 = alt ? sZ2 : sV2;
   if (t < P1 + P2) sE[t] = ev;
 #pragma unroll
   for (int it = 0; it < NX; ++it) {
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
     const int ntx = P2 / 4, nty = P1 / 4;
     if (t < ntx * nty) {
       const int tx = t / nty, ty = t - tx * nty;
-      tile_product_t<real>(sV2, P2, B0, P1, P2, tx, ty, acc);
+      tile_product_t<real>(bV2, P2, B0, P1, P2, tx, ty, acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
     const int ntx = P1 / 4, nty = P2 / 4;
     if (t < ntx * nty) {
       const int tx = t / nty, ty = t - tx * nty;
-      tile_product_t<real>(sV1, P1, B1, P2, P1, tx, ty, acc);
+      tile_product_t<real>(bV1, P1, B1, P2, P1, tx, ty, acc);
       real* __restrict__ os = dst + ((int64_t)h * k + c) * m + (int64_t)i0 * g1 * g2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -471,8 +486,9 @@ __global__ __launch_bounds__(128) void k_spec_mode0_fwd_upd(GridDev<real> G, con
 //   columns [0,k):  t = V0 (.)  ->  pt = t + beta pt      columns [k,2k):  y = V0 (.)  ->  p = y + beta p
 //   beta = rho(it)/rho(it-1) (0 at it == 0); t and y themselves are never written.   -- k_pcg_update_p
 template <typename real>
-__global__ __launch_bounds__(128) void k_spec_mode0_bwd_updp(GridDev<real> G, const real* __restrict__ V0, const real* __restrict__ src, int k,
-                                                            int it, real* __restrict__ p, real* __restrict__ pt, PcgScal S) {
+__global__ __launch_bounds__(128) void k_spec_mode0_bwd_updp(GridDev<real> G, const real* __restrict__ X0, const real* __restrict__ Z0,
+                                                            const real* __restrict__ src, int k, int it, real* __restrict__ p,
+                                                            real* __restrict__ pt, PcgScal S) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ST = 32;
   const int g0 = G.g[0], Sf = G.stride[0], m = G.m;
@@ -482,6 +498,7 @@ __global__ __launch_bounds__(128) void k_spec_mode0_bwd_updp(GridDev<real> G, co
   const int cc = blockIdx.y;
   const int half = cc / k, c = cc - half * k;
   const int s0 = blockIdx.x * ST;
+  const real* __restrict__ V0 = half == 0 ? Z0 : X0;
   const real* __restrict__ sc = src + (int64_t)cc * m;
   double beta = 0;
   if (it > 0) {
@@ -558,67 +575,80 @@ bool spectral_fused_ok(const GridDev<real>& G) {
 
 // ty = [t | y] (2k columns), w0 = scratch of k*m reals; rho[c] += r[c].y[c]
 template <typename real>
-int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, const real* r, int k, real* w0,
-                          real* w1 /* 2k*m scratch */, real* ty, double* rho, hipStream_t s) {
+int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, const real* r,
+                          int k, real* w0, real* w1 /* 2k*m scratch */, real* ty, double* rho, hipStream_t s) {
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
+  if (!evec2) evec2 = evec;
   const real* V0 = evec;
   const real* V1 = evec + g0 * g0;
   const real* V2 = V1 + g1 * g1;
+  const real* Z0 = evec2;
+  const real* Z1 = evec2 + g0 * g0;
+  const real* Z2 = Z1 + g1 * g1;
   const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
   const int PM = P1 > P2 ? P1 : P2;
   const int S = G.stride[0];
   const size_t sh0 = (size_t)(P0 * P0 + P0 * 32) * sizeof(real);
-  const size_t sh1 = (size_t)(2 * PM * PM + P1 * P1 + P2 * P2 + P1 + P2) * sizeof(real);
+  const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
   const unsigned sx = (unsigned)((S + 31) / 32);
-  if (sh1 > 48 * 1024) {
+  static size_t slab_lds_set = 0;   // per instantiation; raise the dynamic-LDS limit once
+  if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
     if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
       return WISKI_E_LAUNCH;
+    slab_lds_set = sh1;
   }
   // forward mode 0: w0 = V0^T r
-  hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, 0, r, w0, (const real*)nullptr, 0,
+  hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, V0, 0, 0, r, w0, (const real*)nullptr, 0,
                      (double*)nullptr);
   // slab: forward modes 1,2 + scaling + backward modes 2,1 -> w1 = [half 0 | half 1]
-  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, evals, kscale, shift, (const real*)w0,
-                     w1, k, (double*)nullptr);
+  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift,
+                     (const real*)w0, w1, k, (double*)nullptr);
   // backward mode 0 on 2k columns, rho += r . y for the second half
-  hipLaunchKernelGGL((k_spec_mode0<real, true>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, 1, (const real*)w1, ty, r, k, rho);
+  hipLaunchKernelGGL((k_spec_mode0<real, true>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, Z0, V0, k, 1, (const real*)w1, ty, r, k, rho);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
 // One CG iteration's preconditioner + vector updates in three launches (see kernels above).
 template <typename real>
-int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evals, real kscale, real shift, real* r, int k, real* w0,
-                             real* w1, int it, int apply, double tol2, real* p, real* pt, const real* part, int nch, real* u, real* z,
-                             PcgScal S, hipStream_t s) {
+int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
+                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, const real* part, int nch, real* u,
+                             real* z, PcgScal S, hipStream_t s) {
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
+  if (!evec2) evec2 = evec;
   const real* V0 = evec;
   const real* V1 = evec + g0 * g0;
   const real* V2 = V1 + g1 * g1;
+  const real* Z0 = evec2;
+  const real* Z1 = evec2 + g0 * g0;
+  const real* Z2 = Z1 + g1 * g1;
   const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
   const int PM = P1 > P2 ? P1 : P2;
   const int Sf = G.stride[0];
   const size_t sh0 = (size_t)(P0 * P0 + P0 * 32) * sizeof(real);
-  const size_t sh1 = (size_t)(2 * PM * PM + P1 * P1 + P2 * P2 + P1 + P2) * sizeof(real);
+  const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
   const unsigned sx = (unsigned)((Sf + 31) / 32);
-  if (sh1 > 48 * 1024) {
+  static size_t slab_lds_set = 0;   // per instantiation; raise the dynamic-LDS limit once
+  if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
     if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
       return WISKI_E_LAUNCH;
+    slab_lds_set = sh1;
   }
   hipLaunchKernelGGL((k_spec_mode0_fwd_upd<real>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, r, w0, it, apply, tol2, (const real*)p,
                      (const real*)pt, part, nch, u, z, S);
-  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, evals, kscale, shift, (const real*)w0,
-                     w1, k, S.rho(it));
-  hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, (const real*)w1, k, it, p, pt, S);
+  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift,
+                     (const real*)w0, w1, k, S.rho(it));
+  hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, Z0, (const real*)w1, k, it, p, pt, S);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
-template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, float, float, float*, int, float*, float*, int, int,
-                                             double, float*, float*, const float*, int, float*, float*, PcgScal, hipStream_t);
-template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, double, double, double*, int, double*, double*,
-                                              int, int, double, double*, double*, const double*, int, double*, double*, PcgScal, hipStream_t);
+template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, float*, int, float*,
+                                             float*, int, int, double, float*, float*, const float*, int, float*, float*, PcgScal, hipStream_t);
+template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, double*, int,
+                                              double*, double*, int, int, double, double*, double*, const double*, int, double*, double*, PcgScal,
+                                              hipStream_t);
 template bool spectral_fused_ok<double>(const GridDev<double>&);
-template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, float, float, const float*, int, float*, float*,
-                                          float*, double*, hipStream_t);
-template int launch_spectral_fused<double>(const GridDev<double>&, const double*, const double*, double, double, const double*, int, double*,
-                                           double*, double*, double*, hipStream_t);
+template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int, float*,
+                                          float*, float*, double*, hipStream_t);
+template int launch_spectral_fused<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, const double*, int,
+                                           double*, double*, double*, double*, hipStream_t);

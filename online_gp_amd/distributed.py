@@ -46,9 +46,13 @@ class ShardedStatsUpdater:
             b = torch.zeros_like(m._kernel_cache["interpolation_cache"])
             stats = torch.zeros_like(m._kernel_cache["_stats"])
             self._delta = {"interpolation_cache": b, "_stats": stats, "WtW": m._kernel_cache["WtW"]}
+            if "_cnt" in m._kernel_cache:
+                self._delta["_cnt"] = torch.zeros_like(m._kernel_cache["_cnt"])
         else:
             self._delta["interpolation_cache"].zero_()
             self._delta["_stats"].zero_()
+            if "_cnt" in self._delta:
+                self._delta["_cnt"].zero_()
         return self._delta
 
     def update(self, X, Y, noise=None):
@@ -71,10 +75,13 @@ class ShardedStatsUpdater:
         dev = delta["_stats"].device
         wsum = (1.0 / noise.to(dev, torch.float64).clamp_min(1e-7)).sum(0)            # [out]
         count = torch.cat([torch.tensor([float(X.reshape(-1, m._grid.d).shape[0])], dtype=torch.float64, device=dev), wsum])
-        allreduce_sum_([delta["interpolation_cache"], delta["_stats"], count] + list(halves), self.group)
+        small = [delta["interpolation_cache"], delta["_stats"], count] + ([delta["_cnt"]] if "_cnt" in delta else [])
+        allreduce_sum_(small + list(halves), self.group)
         c = m._kernel_cache
         c["interpolation_cache"].add_(delta["interpolation_cache"])
         c["_stats"].add_(delta["_stats"])
+        if "_cnt" in delta and "_cnt" in c:
+            c["_cnt"].add_(delta["_cnt"])
         for dst, half in zip(_wtw_ops(c["WtW"]), halves):
             grid_ops.stencil_expand_add(m._grid, half, dst.stencil)
         m._wsum_dev += count[1:]

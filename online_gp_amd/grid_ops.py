@@ -224,25 +224,37 @@ class PCGWorkspace:
         return self.buf, need
 
 
-def kron_eigen(grid, tcol):
-    """Eigen-decomposition of the d small symmetric-Toeplitz Kronecker factors
-    (host side, fp64, O(d g^3) -- done once per hyper-parameter change):
-    returns (evec [sum g^2] row-major V_q, evals [sum g], clamped >= 0) on
-    tcol's device / dtype.  Feeds wiski_pcg's spectral preconditioner."""
+def kron_eigen(grid, tcol, profiles=None):
+    """Per-dim (generalized) eigen-decomposition of the d small symmetric-Toeplitz Kronecker
+    factors (host side, fp64, O(d g^3) -- done when the hyper-parameters or the data-density
+    profile change, not per streaming update).
+
+    profiles=None:  K_q = V_q diag(lam_q) V_q^T                         -> (evec, evals)
+    profiles=[t_q]: K_q = X_q D_q X_q^T with X_q^T diag(t_q) X_q = I     -> (evec = X, evals = D, evec2 = Z = diag(t) X)
+    Eigenvalues are clamped >= 0.  Feeds wiski_pcg's preconditioner (K^-1 + a kron diag(t_q))^-1."""
     import numpy as np
 
     tc = tcol.detach().to("cpu", torch.float64).numpy()
-    vecs, vals, off = [], [], 0
-    for g in grid.g:
+    X, Z, vals, off = [], [], [], 0
+    for q, g in enumerate(grid.g):
         c = tc[off:off + g]
         idx = np.abs(np.arange(g)[:, None] - np.arange(g)[None, :])
-        w, V = np.linalg.eigh(c[idx])
+        K = c[idx]
+        if profiles is None:
+            w, V = np.linalg.eigh(K)
+            X.append(V.reshape(-1))
+        else:
+            t = np.asarray(profiles[q], dtype=np.float64)
+            rt = np.sqrt(t)
+            w, U = np.linalg.eigh(rt[:, None] * K * rt[None, :])
+            X.append((U / rt[:, None]).reshape(-1))
+            Z.append((U * rt[:, None]).reshape(-1))
         vals.append(np.clip(w, 0.0, None))
-        vecs.append(V.reshape(-1))
         off += g
-    evec = torch.as_tensor(np.concatenate(vecs)).to(tcol.device, tcol.dtype)
-    evals = torch.as_tensor(np.concatenate(vals)).to(tcol.device, tcol.dtype)
-    return evec, evals
+    mk = lambda parts: torch.as_tensor(np.concatenate(parts)).to(tcol.device, tcol.dtype)
+    if profiles is None:
+        return mk(X), mk(vals)
+    return mk(X), mk(vals), mk(Z)
 
 
 def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
@@ -261,8 +273,9 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
     iters = ctypes.c_int32(0)
     relres = (ctypes.c_double * k)()
     cr = _hip.creal(RHS2.dtype)
-    evec, evals = eigen if eigen is not None else (None, None)
-    rc = _hip.fn("wiski_pcg", RHS2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(evec), _hip.dptr(evals),
+    evec, evals, evec2 = (tuple(eigen) + (None,))[:3] if eigen is not None else (None, None, None)
+    rc = _hip.fn("wiski_pcg", RHS2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(evec), _hip.dptr(evec2),
+                                          _hip.dptr(evals),
                                           cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
                                           _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
                                           ctypes.c_int32(check_every), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres,
@@ -289,7 +302,8 @@ def kron_toeplitz_grad(grid, tcol, X, Y):
 
 def kron_spectral_mm(grid, eigen, V, kscale=1.0, shift=0.0, power=0.5, rpower=0.0):
     """V diag(lam^power / (1 + shift lam)^rpower) V^T applied to the columns of V ([k, m])."""
-    evec, evals = eigen
+    evec, evals = eigen[0], eigen[1]
+    assert len(eigen) == 2, "kron_spectral_mm needs the orthogonal eigenbasis (kron_eigen without profiles)"
     V2 = V.contiguous().reshape(-1, grid.m)
     out = torch.empty_like(V2)
     tmp = torch.empty_like(V2)

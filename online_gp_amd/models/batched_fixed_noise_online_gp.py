@@ -163,11 +163,15 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         b = torch.zeros((out, m, 1), dtype=self._dtype, device=self._device)
         stats = torch.zeros((out, 2), dtype=torch.float64, device=self._device)
         ops = [StencilWtW.zeros(self._grid, self._dtype, self._device) for _ in range(out)]
-        return self._pack_cache(b, stats, ops)
+        cnt = torch.zeros((out, m), dtype=self._dtype, device=self._device)
+        return self._pack_cache(b, stats, ops, cnt)
 
-    def _pack_cache(self, b, stats, ops):
+    def _pack_cache(self, b, stats, ops, cnt=None):
         out = b.shape[0]
+        if cnt is None:
+            cnt = torch.zeros((out, b.shape[1]), dtype=b.dtype, device=b.device)
         return {
+            "_cnt": cnt,                                     # W^T D^-1 1 = row sums of W^T D^-1 W (preconditioner density model)
             "response_cache": stats[:, 0].view(out, 1, 1),   # y^T D^-1 y     (:45)   [float64 view]
             "interpolation_cache": b,                        # W^T D^-1 y     (:46)
             "WtW": ops[0] if out == 1 else BatchOperator(ops),  # W^T D^-1 W  (:50-53)
@@ -177,7 +181,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
 
     def _clone_cache(self, cache):
         stats = cache["_stats"].clone()
-        return self._pack_cache(cache["interpolation_cache"].clone(), stats, [op.clone() for op in _wtw_ops(cache["WtW"])])
+        cnt = cache["_cnt"].clone() if "_cnt" in cache else None
+        return self._pack_cache(cache["interpolation_cache"].clone(), stats, [op.clone() for op in _wtw_ops(cache["WtW"])], cnt)
 
     def _half_buffers(self):
         """Per-output symmetric half-stencil delta buffers [(R+1)/2, m] (zero between uses)."""
@@ -215,6 +220,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                     grid_ops.stencil_expand_add(self._grid, bufs[o], ops[o].stencil)
             else:
                 grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
+            if "_cnt" in cache:   # row sums of the increment: W^T wa (y = 1, weight wa), 4^d atomics per point
+                if getattr(self, "_scratch_stats", None) is None:
+                    self._scratch_stats = torch.zeros(2, dtype=torch.float64, device=self._device)
+                    self._ones_cache = None
+                if self._ones_cache is None or self._ones_cache.shape[0] < X.shape[0]:
+                    self._ones_cache = torch.ones(X.shape[0], dtype=self._dtype, device=self._device)
+                grid_ops.scatter_stats(self._grid, X, self._ones_cache[:X.shape[0]], wa, wa, self._ones_cache[:X.shape[0]], cache["_cnt"][o], None,
+                                       self._scratch_stats, self._err)
             if cache is self._kernel_cache or init:
                 self._wsum_dev[o] += wa.sum(dtype=torch.float64)
 
@@ -251,8 +264,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 for o in range(self.num_outputs):
                     bi = o if self.num_outputs > 1 else None
                     tcol = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).to(self._dtype).contiguous()
-                    eig = grid_ops.kron_eigen(self._grid, tcol) if settings.spectral_preconditioner.on() else None
-                    vals.append((tcol, self._sigma2(o), eig))
+                    vals.append((tcol, self._sigma2(o), None))
             h = (ver, vals)
             self._memo["hyper"] = h
         return h[1]
@@ -260,14 +272,41 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
     def _use_dense(self):
         return settings.dense_small_grids.on() and self._grid.m <= settings.max_cholesky_size.value()
 
+    def _precond(self, o, tcol):
+        """(eigen tuple, shift) of wiski_pcg's preconditioner (Kt^-1 + a kron_q diag(t_q))^-1.
+        t_q = per-dim marginal of the row sums of W^T D^-1 W (the data-density profile: the
+        grid nodes outside the data box carry no data), a = total mass / prod_q sum(t_q).
+        The d small generalized eigenproblems are re-solved only when the hyper-parameters
+        change or the data volume has grown by 30 %; `a` follows the stream exactly."""
+        if settings.spectral_preconditioner.off():
+            return None, 0.0
+        ver = self._hyper_version()
+        st = self._memo.setdefault("precond", {}).get(o)
+        wsum = float(self._wsum[o])
+        if st is None or st["ver"] != ver or wsum > 1.3 * st["wsum"] or wsum < 0.5 * st["wsum"]:
+            profiles, norm = None, float(self._grid.m)
+            cnt = self._kernel_cache.get("_cnt") if settings.density_profile_preconditioner.on() else None
+            if cnt is not None and wsum > 0:
+                c3 = cnt[o].reshape(self._grid.g).double()
+                margs = [c3.sum(dim=[r for r in range(self._grid.d) if r != q]) if self._grid.d > 1 else c3 for q in range(self._grid.d)]
+                margs = torch.stack([torch.nn.functional.pad(mg, (0, max(self._grid.g) - mg.numel())) for mg in margs]).cpu().numpy()
+                if margs.max() > 0:
+                    profiles, norm = [], 1.0
+                    for q, gq in enumerate(self._grid.g):
+                        t = margs[q, :gq] / margs[q, :gq].max()
+                        t = t.clip(1e-2, None)
+                        profiles.append(t)
+                        norm *= float(t.sum())
+            eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles)
+            st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm}
+            self._memo["precond"][o] = st
+        return st["eig"], wsum / st["norm"]
+
     def _posterior_op(self, o):
-        tcol, s2, eig = self._hyper()[o]
+        tcol, s2, _ = self._hyper()[o]
         if self._use_dense():
-            if eig is None:
-                eig = grid_ops.kron_eigen(self._grid, tcol)
-            return DenseInducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, eig)
-        # preconditioner shift ~ mean row sum of A = (sum_p 1/noise_p) / m  (W rows sum to one)
-        shift = float(self._wsum[o]) / self._grid.m
+            return DenseInducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, grid_ops.kron_eigen(self._grid, tcol))
+        eig, shift = self._precond(o, tcol)
         return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
                                  settings.max_cg_iterations.value(), workspace=self._pcg_ws, check_every=settings.cg_check_every.value(),
                                  eigen=eig, shift=shift)
@@ -488,9 +527,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         cache = self._kernel_cache
         cache["interpolation_cache"].zero_()
         cache["_stats"].zero_()
+        if "_cnt" in cache:
+            cache["_cnt"].zero_()
         for op in _wtw_ops(cache["WtW"]):
             op.stencil.zero_()
         self._wsum_dev.zero_()
+        self._memo.pop("precond", None)
         self._absorb(cache, train_inputs, train_targets, noise, init=True)
         self.num_data = train_inputs.reshape(-1, self._grid.d).shape[0]
         self._mean_state = None
@@ -508,7 +550,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if device is not None and self._kernel_cache is not None and torch.device(device) != self._device:
             c = self._kernel_cache
             stats = c["_stats"].to(device)
-            self._kernel_cache = self._pack_cache(c["interpolation_cache"].to(device), stats, [op.to(device) for op in _wtw_ops(c["WtW"])])
+            self._kernel_cache = self._pack_cache(c["interpolation_cache"].to(device), stats, [op.to(device) for op in _wtw_ops(c["WtW"])],
+                                                  c["_cnt"].to(device) if "_cnt" in c else None)
             self._device = torch.device(device)
             self._err = grid_ops.new_err_flag(device)
             self._mean_state = None
@@ -520,4 +563,4 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """Tensors that are additive over data shards (what RCCL all-reduces):
         b, the W^T W stencils and (y^T D^-1 y, logdet D)."""
         c = self._kernel_cache
-        return [c["interpolation_cache"], c["_stats"]] + [op.stencil for op in _wtw_ops(c["WtW"])]
+        return [c["interpolation_cache"], c["_stats"], c["_cnt"]] + [op.stencil for op in _wtw_ops(c["WtW"])]

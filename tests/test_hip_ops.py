@@ -118,7 +118,7 @@ def test_spmv_and_kron(d, g, tdt, ndt, tol):
         assert np.abs(outk.double().cpu().numpy() - refk).max() < tol * np.abs(refk).max() * 10
 
 
-@pytest.mark.parametrize("spectral", [False, True])
+@pytest.mark.parametrize("spectral", [False, True, "profile"])
 @pytest.mark.parametrize("d,g", CASES)
 @pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-8), (torch.float32, np.float32, 2e-3)])
 def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral):
@@ -131,6 +131,9 @@ def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral):
     cg_tol = 1e-10 if tdt == torch.float64 else 1e-6
     A = _t(B2.A, tdt); tc = _t(B2.tcol, tdt)
     kw = dict(eigen=grid_ops.kron_eigen(grid, tc), shift=X.shape[0] / grid.m) if spectral else {}
+    if spectral == "profile":      # separable density-profile preconditioner (generalized eigenbasis X, Z)
+        prof = [np.clip(0.2 + np.sin(np.linspace(0.1, 3.0, gq)) ** 2, 1e-2, None) for gq in grid.g]
+        kw = dict(eigen=grid_ops.kron_eigen(grid, tc, profiles=prof), shift=X.shape[0] / grid.m)
     U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=cg_tol, max_iter=500, check_every=5, **kw)
     assert max(res) < cg_tol * 1.01, (it, res)
     assert np.abs(U.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
