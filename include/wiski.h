@@ -151,13 +151,15 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  *     shift = density scale (d_tcol unused).
  * d_U/d_Z [k][m]: solution and its pre-image (U = Kt Z). warm != 0 starts
  * from the given (U, Z) (must satisfy U = Kt Z), else from zero.
- * Stops when every column has ||r||/||rhs|| < tol or at max_iter.
+ * Stops when every column has ||r||/||rhs|| < tol or at max_iter; the host polls the
+ * residual norms after first_check iterations (< 1: check_every) and then every
+ * check_every iterations (each poll is one stream synchronisation).
  * workspace: wiski_pcg_workspace_bytes(...) bytes of device scratch.
  * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
  * be NULL): final relative residuals. */
 int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size);
-int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
-int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

@@ -728,7 +728,8 @@ static int64_t pcg_ws_bytes(int m, int k, int max_iter, int es) {
 template <typename real>
 static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_evec2, const real* d_eval,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
-                    int32_t check_every, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream) {
+                    int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
+                    void* stream) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -796,11 +797,10 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
 
   int it = 0;
   bool done = false;
-  if (warm) {
-    rc = fetch(0);
-    if (rc) return rc;
-    done = converged();
-  }
+  if (first_check < 1) first_check = check_every;
+  if (first_check > max_iter) first_check = max_iter;
+  // host convergence polls: after `first_check` iterations, then every `check_every`
+  auto due = [&](int i) { return i == max_iter || i == first_check || (i > first_check && (i - first_check) % check_every == 0); };
   const bool fused_cg = spectral && wide && spectral_fused_ok<real>(G);
   bool pending = false;   // fused path: update_x of iteration it-1 not applied yet
   auto flush_update = [&]() {
@@ -820,7 +820,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       if (rc) return rc;
       pending = true;
       ++it;
-      if (it % check_every == 0 || it == max_iter) {
+      if (due(it)) {
         flush_update();
         rc = fetch(it);
         if (rc) return rc;
@@ -857,7 +857,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       hipLaunchKernelGGL((k_pcg_update_x<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
                          (const real*)part, nch, d_U, d_Z, r, S);
     ++it;
-    if (it % check_every == 0 || it == max_iter) {
+    if (due(it)) {
       rc = fetch(it);
       if (rc) return rc;
       done = converged();
@@ -922,10 +922,10 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
 }
-int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, s);
 }
-int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, work, wb, iters, relres, s);
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, s);
 }
 }

@@ -62,19 +62,22 @@ class ShardedStatsUpdater:
         m = self.model
         if Y.dim() == 1:
             Y = Y[:, None]
-        if noise is None:
-            noise = torch.ones_like(Y)
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         if world == 1:
             m.condition_on_observations(X, Y, noise, inplace=True)
             return
         delta = self._delta_cache()
-        noise = m._canon_noise(noise, Y)
+        if noise is not None:
+            noise = m._canon_noise(noise, Y)
         halves = m._half_buffers()
         m._absorb(delta, X, Y, noise, init=False, half_delta=halves)
         dev = delta["_stats"].device
-        wsum = (1.0 / noise.to(dev, torch.float64).clamp_min(1e-7)).sum(0)            # [out]
-        count = torch.cat([torch.tensor([float(X.reshape(-1, m._grid.d).shape[0])], dtype=torch.float64, device=dev), wsum])
+        nloc = float(X.reshape(-1, m._grid.d).shape[0])
+        if noise is None:
+            wsum = torch.full((Y.shape[1],), nloc, dtype=torch.float64, device=dev)
+        else:
+            wsum = (1.0 / noise.to(dev, torch.float64).clamp_min(1e-7)).sum(0)        # [out]
+        count = torch.cat([torch.tensor([nloc], dtype=torch.float64, device=dev), wsum])
         small = [delta["interpolation_cache"], delta["_stats"], count] + ([delta["_cnt"]] if "_cnt" in delta else [])
         allreduce_sum_(small + list(halves), self.group)
         c = m._kernel_cache
@@ -84,6 +87,8 @@ class ShardedStatsUpdater:
             c["_cnt"].add_(delta["_cnt"])
         for dst, half in zip(_wtw_ops(c["WtW"]), halves):
             grid_ops.stencil_expand_add(m._grid, half, dst.stencil)
-        m._wsum_dev += count[1:]
-        m.num_data = m.num_data + int(count[0].item())
+        tot = count.tolist()
+        for o in range(len(tot) - 1):
+            m._wsum_host[o] += tot[1 + o]
+        m.num_data = m.num_data + int(tot[0])
         m._dump_caches()

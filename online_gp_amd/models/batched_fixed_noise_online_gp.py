@@ -137,7 +137,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self.has_learnable_noise = learn_additional_noise
 
         self._err = grid_ops.new_err_flag(device)
-        self._wsum_dev = torch.zeros(num_outputs, dtype=torch.float64, device=device)   # sum_p 1/noise_p per output
+        # sum_p 1/noise_p per output: host part (unit-noise updates, exact) + device part (explicit noise tensors)
+        self._wsum_host = [0.0] * num_outputs
+        self._wsum_dev = torch.zeros(num_outputs, dtype=torch.float64, device=device)
+        self._wsum_dev_host = [0.0] * num_outputs
+        self._wsum_dirty = False
         self._pcg_ws = grid_ops.PCGWorkspace()
         self._memo = {}
         self._mean_state = None  # warm-start state of the posterior-mean solve
@@ -203,17 +207,29 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         Y = Y.to(self._device, self._dtype)
         if Y.dim() == 1:
             Y = Y[:, None]
-        noise = noise.to(self._device, self._dtype)
+        n = X.shape[0]
+        unit = noise is None            # unit noise (OnlineSKIRegression, OSR:25,122): no per-point weight tensors at all
+        if unit:
+            if getattr(self, "_ones_cache", None) is None or self._ones_cache.shape[0] < n:
+                self._ones_cache = torch.ones(max(n, 4096), dtype=self._dtype, device=self._device)
+            ones = self._ones_cache[:n]
+        else:
+            noise = noise.to(self._device, self._dtype)
         b = cache["interpolation_cache"]
         stats = cache["_stats"]
         ops = _wtw_ops(cache["WtW"])
-        use_half = half_delta is not None or X.shape[0] >= settings.sym_scatter_min_batch.value()
+        use_half = half_delta is not None or n >= settings.sym_scatter_min_batch.value()
         bufs = half_delta if half_delta is not None else (self._half_buffers() if use_half else None)
+        if getattr(self, "_scratch_stats", None) is None:
+            self._scratch_stats = torch.zeros(2, dtype=torch.float64, device=self._device)
         for o in range(self.num_outputs):
             yo = Y[:, o].contiguous()
-            no = noise[:, o].contiguous()
-            wb = 1.0 / no
-            wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
+            if unit:
+                no = wa = wb = ones
+            else:
+                no = noise[:, o].contiguous()
+                wb = 1.0 / no
+                wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
             if use_half:
                 grid_ops.scatter_stats_sym(self._grid, X, yo, wa, wb, no, b[o, :, 0], bufs[o], stats[o], self._err)
                 if half_delta is None:
@@ -221,24 +237,33 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             else:
                 grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
             if "_cnt" in cache:   # row sums of the increment: W^T wa (y = 1, weight wa), 4^d atomics per point
-                if getattr(self, "_scratch_stats", None) is None:
-                    self._scratch_stats = torch.zeros(2, dtype=torch.float64, device=self._device)
-                    self._ones_cache = None
-                if self._ones_cache is None or self._ones_cache.shape[0] < X.shape[0]:
-                    self._ones_cache = torch.ones(X.shape[0], dtype=self._dtype, device=self._device)
-                grid_ops.scatter_stats(self._grid, X, self._ones_cache[:X.shape[0]], wa, wa, self._ones_cache[:X.shape[0]], cache["_cnt"][o], None,
-                                       self._scratch_stats, self._err)
+                one_n = ones if unit else torch.ones_like(wa)
+                grid_ops.scatter_stats(self._grid, X, one_n, wa, wa, one_n, cache["_cnt"][o], None, self._scratch_stats, self._err)
             if cache is self._kernel_cache or init:
-                self._wsum_dev[o] += wa.sum(dtype=torch.float64)
+                if unit:
+                    self._wsum_host[o] += float(n)
+                else:
+                    self._wsum_dev[o] += wa.sum(dtype=torch.float64)
+                    self._wsum_dirty = True
 
     @property
     def _wsum(self):
-        return self._wsum_dev.tolist()
+        if self._wsum_dirty:
+            self._wsum_dev_host = self._wsum_dev.tolist()
+            self._wsum_dirty = False
+        return [h + d for h, d in zip(self._wsum_host, self._wsum_dev_host)]
 
     def check_bounds(self):
         """Raise like gpytorch's grid check if any point seen so far was outside the
-        grid (the kernels only set a device flag; this is the one host sync)."""
-        if int(self._err.item()) != 0:
+        grid (the kernels only set a device flag; this is the one host sync; the
+        device part of the noise-weight sum rides on the same transfer)."""
+        if self._wsum_dirty:
+            vals = torch.cat([self._err.double(), self._wsum_dev]).tolist()
+            self._wsum_dev_host, self._wsum_dirty = vals[1:], False
+            bad = int(vals[0]) != 0
+        else:
+            bad = int(self._err.item()) != 0
+        if bad:
             self._err.zero_()
             raise RuntimeError("Received data that was out of bounds for the specified grid. "
                                f"Grid bounds were {self.covar_module.grid_bounds}.")
@@ -359,11 +384,22 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                     tcol, s2, _ = hyper[o]
                     Uo = grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2)   # keep U = Kt Z under the new hypers
                 warm = True
-            Uo, Zo = post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm)
+            # warm refreshes poll convergence first where the previous one converged (streaming steps are
+            # alike), every 8th one an iteration earlier, and then after every iteration
+            fc = 0
+            if warm and getattr(self, "_last_iters", None):
+                self._refresh_count = getattr(self, "_refresh_count", 0) + 1
+                probe = getattr(self, "_probe_down", True) or self._refresh_count % 8 == 0
+                fc = max(1, self._last_iters[o] - (1 if probe else 0))
+                post.check_every = 1
+            Uo, Zo = post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm, first_check=fc)
+            if fc:
+                self._probe_down = post.last_iters <= fc and fc > 1      # keep probing while it keeps paying off
             U[o], Z[o] = Uo[0], Zo[0]
             iters.append(post.last_iters)
             posts.append(post)
         self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "ver": ver}
+        self._last_iters = list(iters)
         pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters}
         self._memo["prediction_cache"] = pc
         return pc
@@ -483,9 +519,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         sibling model sharing covar_module / likelihood is returned."""
         if Y.dim() == 1:
             Y = Y[:, None]
-        if noise is None:
-            noise = torch.ones_like(Y)
-        noise = self._canon_noise(noise, Y)
+        if noise is not None:
+            noise = self._canon_noise(noise, Y)
         q = X.reshape(-1, self._grid.d).shape[0]
         if inplace:
             self._absorb(self._kernel_cache, X, Y, noise, init=False)
@@ -501,6 +536,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             num_data=self.num_data + q,
         )
         new_gp._wsum_dev = self._wsum_dev.clone()
+        new_gp._wsum_host = list(self._wsum_host)
+        new_gp._wsum_dev_host = list(self._wsum_dev_host)
+        new_gp._wsum_dirty = self._wsum_dirty
         new_gp._absorb(new_cache, X, Y, noise, init=False)
         if self._mean_state is not None:
             new_gp._mean_state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._mean_state.items()}
@@ -532,6 +570,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         for op in _wtw_ops(cache["WtW"]):
             op.stencil.zero_()
         self._wsum_dev.zero_()
+        self._wsum_host = [0.0] * self.num_outputs
+        self._wsum_dev_host = [0.0] * self.num_outputs
+        self._wsum_dirty = False
         self._memo.pop("precond", None)
         self._absorb(cache, train_inputs, train_targets, noise, init=True)
         self.num_data = train_inputs.reshape(-1, self._grid.d).shape[0]

@@ -107,8 +107,8 @@ class OnlineSKIRegression(torch.nn.Module):
 
         with torch.no_grad():
             features = self.stem(inputs)
-            noise_term = torch.ones_like(targets)
-            self.gp.condition_on_observations(features, targets, noise_term, inplace=True)
+            # noise term == 1 (OSR:122): None selects the unit-noise fast path (no weight tensors)
+            self.gp.condition_on_observations(features, targets, None, inplace=True)
             if any(True for _ in self.stem.modules()):
                 self._raw_inputs = [torch.cat([*self._raw_inputs, inputs])]
                 self.stem.train()

@@ -125,9 +125,10 @@ class spectral_preconditioner(_feature_flag):
 
 
 class cg_check_every(_value_context):
-    """Iterations between host-side convergence checks of wiski_pcg."""
+    """Iterations between host-side convergence checks of wiski_pcg (warm-started refreshes poll
+    first at the iteration count of the previous refresh)."""
 
-    _global_value = 5
+    _global_value = 3
 
 
 class dense_small_grids(_feature_flag):

@@ -37,6 +37,7 @@ class StubModel:
         self.m, self.R = ref.m, ref.R
         self._kernel_cache = self._fresh_cache()
         self._wsum_dev = torch.zeros(1, dtype=torch.float64)
+        self._wsum_host = [0.0]
         self.num_data = 0
         self.dumped = 0
 
@@ -123,7 +124,7 @@ def _worker(rank, world, port, tmpdir):
     ok = (torch.allclose(c["interpolation_cache"], r["interpolation_cache"], atol=1e-12) and
           torch.allclose(c["WtW"].stencil, r["WtW"].stencil, atol=1e-12) and torch.allclose(c["_stats"], r["_stats"], atol=1e-10) and
           model.num_data == 120 and model.dumped == 3 and
-          abs(float(model._wsum_dev[0]) - float((1.0 / N).sum())) < 1e-9)
+          abs(model._wsum_host[0] - float((1.0 / N).sum())) < 1e-9)
     open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
