@@ -88,7 +88,11 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
             real* __restrict__ Arow = A_st + idx_a[t];
             const int obase = center - code_a[t];
 #pragma unroll 4
-            for (int bb = 0; bb < T; ++bb) {
+            for (int bb0 = 0; bb0 < T; ++bb0) {
+              // skew the last-dim digit of b by this lane's own last-dim digit: the 4 lanes that share
+              // (c0, c1) of tap a then target the same stencil offset at 4 consecutive rows, i.e. one
+              // 16-byte run of A -- up to 4 lane-atomics per L2 transaction instead of 1.
+              const int bb = (bb0 & ~3) | ((bb0 + (sub + t * GRP)) & 3);
               int codeb = 0;
 #pragma unroll
               for (int q = 0; q < D; ++q) codeb = codeb * 7 + ((bb >> (2 * (D - 1 - q))) & 3);
