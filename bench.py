@@ -213,10 +213,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, tol)
-        print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)      # the ONE JSON line, last thing written to stdout
 
 
 if __name__ == "__main__":
