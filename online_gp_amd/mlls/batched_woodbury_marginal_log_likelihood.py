@@ -57,15 +57,24 @@ class _WoodburyTerms(torch.autograd.Function):
             ctx.grid, ctx.P, ctx.kap = grid, 1, kap
             ctx.save_for_backward(tcol, Z[0].clone(), U[0].clone(), S_cols, E)
             return bMb, logdet
-        shift = float(model._wsum[o]) / grid.m
+        # same density-profile preconditioner as the posterior refresh (re-solved because the hypers moved)
+        peig, shift = model._precond(o, tcol)
+        if peig is None:
+            peig, shift = eig, float(model._wsum[o]) / grid.m
         tol = settings.cg_tolerance.value() or (1e-7 if dt == torch.float32 else 1e-11)
         kw = dict(tol=tol, max_iter=settings.max_cg_iterations.value(), check_every=settings.cg_check_every.value(), workspace=model._pcg_ws,
-                  eigen=eig, shift=shift)
-        U, Z, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, b[None], **kw)
+                  eigen=peig, shift=shift)
+        # warm start from the last posterior mean: keep the pre-image z, re-derive u = Kt_new z
+        U0 = Z0 = None
+        ms = model._mean_state
+        if ms is not None:
+            Z0 = ms["Z"][o:o + 1].clone()
+            U0 = grid_ops.kron_toeplitz_mm(grid, tcol, Z0, kap)
+        U, Z, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, b[None], U=U0, Z=Z0, warm=U0 is not None, **kw)
         bMb = (b.double() * U[0].double()).sum()
         # probes for tr(S dKt): Rademacher (Hutchinson)
-        gen = torch.Generator(device="cpu").manual_seed(0x5EED + model.num_data)
-        E = (torch.randint(0, 2, (num_trace_samples.value(), m), generator=gen).to(dt) * 2 - 1).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(0x5EED + model.num_data)
+        E = torch.randint(0, 2, (num_trace_samples.value(), m), generator=gen, device=dev).to(dt) * 2 - 1
         P = E.shape[0]
         S_cols = torch.empty_like(E)
         chunk = settings.variance_chunk.value()
