@@ -271,6 +271,130 @@ __global__ __launch_bounds__(256) void k_spmv_reduce(int64_t km, int nch, const 
   }
 }
 
+// ------------------------------------------- stencil SpMM (many right-hand sides) ---
+// Same product for KC columns at once (predictive variances, MLL probes: k = 8..64 columns).
+// The wide SpMV re-reads its v windows from L2 per thread and per "mid" offset; with many
+// columns that traffic (and the A re-read per column group) dominates.  Here a block stages, ONCE per
+// (row block, chunk, column group), the union of all v windows of the chunk -- rows
+// [i0 + off(c0) - Wd, i0 + 1024 + off(c0) + Wd), Wd = 3 * sum_{q>=1} stride_q -- for KC columns
+// in LDS, in a [column][j & 3][j >> 2] layout so that the threads' 4-row groups read it
+// conflict-free at any shift.  A is then streamed once per column group with 16-byte loads
+// (KC = 16: 4 passes over A for 64 columns instead of 8, v traffic cut ~5x).
+template <typename real, int KC, bool DOT>
+__global__ __launch_bounds__(256) void k_stencil_spmm(GridDev<real> G, const real* __restrict__ A_st, const real* __restrict__ V, int k, int nmid,
+                                                      int Wd, int W4, real* __restrict__ part, const real* __restrict__ add, real beta,
+                                                      double* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  real* win = reinterpret_cast<real*>(smem);   // [KC][4][W4]
+  __shared__ int s_off[64];
+  __shared__ double s_red[16];
+  const int m = G.m, d = G.d;
+  const int ch = blockIdx.y;
+  const int c0 = blockIdx.z * KC;
+  const int off_c0 = (ch - 3) * G.stride[0];
+  for (int mid = threadIdx.x; mid < nmid; mid += blockDim.x) {
+    int rem = mid, f = 0;
+    for (int q = d - 2; q >= 1; --q) {
+      const int c = rem % 7;
+      rem /= 7;
+      f += (c - 3) * G.stride[q];
+    }
+    s_off[mid] = f;
+  }
+  const int i0 = blockIdx.x * 1024;
+  const int ws = i0 + off_c0 - Wd;          // flat index of window element 0
+  const int W = 4 * W4;
+  for (int idx = threadIdx.x; idx < W; idx += blockDim.x) {
+    int j = ws + idx;
+    j = j < 0 ? 0 : (j >= m ? m - 1 : j);   // clamped reads only ever meet exact-zero A entries
+    real* dstp = win + (idx & 3) * W4 + (idx >> 2);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) dstp[c * W] = (c0 + c < k) ? V[(int64_t)(c0 + c) * m + j] : (real)0;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int i4 = i0 + 4 * t;
+  const bool live = i4 < m;
+  real acc[KC][4];
+#pragma unroll
+  for (int c = 0; c < KC; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[c][r] = (real)0;
+  if (live) {
+    const real* __restrict__ a_base = A_st + (int64_t)ch * nmid * 7 * m + i4;
+    for (int mid = 0; mid < nmid; ++mid) {
+      const int sh = Wd + s_off[mid] - 3;   // window index of this thread's first needed value is 4t + sh
+      const real* __restrict__ a_mid = a_base + (int64_t)mid * 7 * m;
+      Vec4<real> a[7];
+#pragma unroll
+      for (int c7 = 0; c7 < 7; ++c7) a[c7] = load4<real>(a_mid + (int64_t)c7 * m);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        real wv[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) {
+          const int j = 4 * t + sh + e;
+          wv[e] = win[c * W + (j & 3) * W4 + (j >> 2)];
+        }
+#pragma unroll
+        for (int c7 = 0; c7 < 7; ++c7) {
+          acc[c][0] += a[c7].x * wv[c7 + 0];
+          acc[c][1] += a[c7].y * wv[c7 + 1];
+          acc[c][2] += a[c7].z * wv[c7 + 2];
+          acc[c][3] += a[c7].w * wv[c7 + 3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    double pd = 0;
+    if (live && c0 + c < k) {
+      const int64_t e = (int64_t)(c0 + c) * m + i4;
+      store4<real>(part + ((int64_t)ch * k) * m + e, acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+      if (DOT) {
+        const Vec4<real> v = load4<real>(V + e);
+        pd = (double)v.x * acc[c][0] + (double)v.y * acc[c][1] + (double)v.z * acc[c][2] + (double)v.w * acc[c][3];
+        if (ch == 0 && add) {
+          const Vec4<real> ad = load4<real>(add + e);
+          pd += (double)beta * ((double)v.x * ad.x + (double)v.y * ad.y + (double)v.z * ad.z + (double)v.w * ad.w);
+        }
+      }
+    }
+    if (DOT) {
+      const double tot = block_reduce_sum(pd, s_red);
+      if (threadIdx.x == 0 && c0 + c < k) unsafeAtomicAdd(dots + c0 + c, tot);
+    }
+  }
+}
+
+template <typename real, int KC>
+static int launch_spmm_kc(const GridDev<real>& G, const real* A_st, const real* V, int k, int nmid, real* part, const real* add, real beta,
+                          double* dots, hipStream_t s) {
+  int Wd = 3;
+  for (int q = 1; q < G.d - 1; ++q) Wd += 3 * G.stride[q];
+  const int W4 = ((1024 + 2 * Wd + 3) / 4 + 16) | 1;   // odd word stride between the four residue planes
+  const size_t sh = (size_t)KC * 4 * W4 * sizeof(real);
+  static size_t lds_set[2] = {0, 0};
+  dim3 grd((unsigned)((G.m + 1023) / 1024), (unsigned)spmv_nch(G.d), (unsigned)((k + KC - 1) / KC));
+  if (dots) {
+    if (sh > 48 * 1024 && sh > lds_set[0]) {
+      if (hipFuncSetAttribute((const void*)k_stencil_spmm<real, KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+        return WISKI_E_LAUNCH;
+      lds_set[0] = sh;
+    }
+    hipLaunchKernelGGL((k_stencil_spmm<real, KC, true>), grd, dim3(256), sh, s, G, A_st, V, k, nmid, Wd, W4, part, add, beta, dots);
+  } else {
+    if (sh > 48 * 1024 && sh > lds_set[1]) {
+      if (hipFuncSetAttribute((const void*)k_stencil_spmm<real, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+        return WISKI_E_LAUNCH;
+      lds_set[1] = sh;
+    }
+    hipLaunchKernelGGL((k_stencil_spmm<real, KC, false>), grd, dim3(256), sh, s, G, A_st, V, k, nmid, Wd, W4, part, add, beta, dots);
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 // partial SpMV launcher (requires m % 4 == 0); part holds spmv_nch(d)*k*m reals.
 template <typename real>
 static int launch_spmv4(const GridDev<real>& G, const real* A_st, const real* V, int k, real* part, const real* add, real beta, double* dots,
@@ -278,9 +402,16 @@ static int launch_spmv4(const GridDev<real>& G, const real* A_st, const real* V,
   const int nch = spmv_nch(G.d);
   int nmid = 1;
   for (int q = 1; q < G.d - 1; ++q) nmid *= 7;
+  const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (k >= 8 && (G.d == 2 || G.d == 3) && nmid <= 64 && !prof) {
+    // many right-hand sides: LDS-staged SpMM (fp32: 16 columns per pass, fp64: 8)
+    if constexpr (sizeof(real) == 4) {
+      if (k >= 16) return launch_spmm_kc<real, 16>(G, A_st, V, k, nmid, part, add, beta, dots, s);
+    }
+    return launch_spmm_kc<real, 8>(G, A_st, V, k, nmid, part, add, beta, dots, s);
+  }
   const int kc = k >= 8 ? 8 : (k >= 4 ? 4 : (k >= 2 ? 2 : 1));
   dim3 grd((unsigned)((G.m / 4 + 255) / 256), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
-  const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
 #define SPMV4(KC)                                                                                                              \
   do {                                                                                                                         \

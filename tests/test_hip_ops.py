@@ -107,7 +107,7 @@ def test_spmv_and_kron(d, g, tdt, ndt, tol):
 
     grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
     B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
-    for k in (1, 3, 5):
+    for k in (1, 3, 5, 9, 17, 33):
         V = rng.standard_normal((k, grid.m)).astype(ndt)
         add = rng.standard_normal((k, grid.m)).astype(ndt)
         out = grid_ops.stencil_spmv(grid, _t(B2.A, tdt), _t(V, tdt), _t(add, tdt), 0.7)

@@ -36,7 +36,7 @@ for q in (1024, 16384, N):
     print(f'scatter q={q}: {t*1e6:.1f} us  {q/t:.3e} pt/s')
 b.zero_(); A.zero_(); stats.zero_()
 grid_ops.scatter_stats(grid, X, y, ones, ones, ones, b, A, stats, err)
-for k in (1, 4, 16):
+for k in (1, 4, 16, 64):
     V = torch.randn(k, grid.m, device=dev, dtype=dt)
     t = timeit(lambda: grid_ops.stencil_spmv(grid, A, V), 20)
     print(f'spmv k={k}: {t*1e6:.1f} us  {A.numel()*A.element_size()/t/1e9:.1f} GB/s (A bytes)')
