@@ -153,13 +153,17 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  * from the given (U, Z) (must satisfy U = Kt Z), else from zero.
  * Stops when every column has ||r||/||rhs|| < tol or at max_iter; the host polls the
  * residual norms after first_check iterations (< 1: check_every) and then every
- * check_every iterations (each poll is one stream synchronisation).
+ * check_every iterations.  A poll is a tiny publish kernel writing to host-mapped memory that
+ * the host spins on (no stream synchronisation).  d_err (may be NULL): the out-of-grid flag of
+ * the interp/scatter/gather entry points; its value rides on the last poll into *h_err, so the
+ * caller needs no separate device-to-host read to raise the reference's RuntimeError.
+ * Not re-entrant across host threads (one poll buffer per process).
  * workspace: wiski_pcg_workspace_bytes(...) bytes of device scratch.
  * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
  * be NULL): final relative residuals. */
 int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size);
-int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
-int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, void* stream);
+int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, void* stream);
+int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

@@ -4,6 +4,7 @@
 //   PCG           : (Kt^-1 + A)^-1 RHS     (CG branch of BFN:368-383)
 #include "wiski_common.h"
 
+#include <chrono>
 #include <vector>
 
 // ------------------------------------------------------- profiling hook ---
@@ -712,6 +713,42 @@ static int spectral_mm_impl(const wiski_grid* grid, const real* d_evec, const re
 // -------------------------------------------------------------------- PCG ---
 // scalar slots (double): S[0..k) = ||rhs||^2 ; then per iteration slot
 // it in [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
+// Convergence polling without a stream synchronisation: a one-wave kernel queued behind the
+// iteration copies the residual norms (and the caller's out-of-grid flag) into a host-mapped,
+// coherent buffer and then releases a sequence number; the host spins on it.  A poll costs a few
+// microseconds instead of the ~80 us of hipMemcpyAsync + hipStreamSynchronize + relaunch bubble.
+struct WiskiPoll {
+  double* h = nullptr;       // host view:   [0] = sequence (as int64), [1..k] = rn0, [k+1..2k] = rn, [2k+1] = err flag
+  double* d = nullptr;       // device view of the same pinned allocation
+  int cap = 0;
+  long long seq = 0;
+};
+static WiskiPoll g_poll;
+
+static int poll_reserve(int k) {
+  if (g_poll.cap >= k) return WISKI_OK;
+  if (g_poll.h) (void)hipHostFree(g_poll.h);
+  const int cap = k < 64 ? 64 : k;
+  if (hipHostMalloc((void**)&g_poll.h, (size_t)(2 * cap + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+    return WISKI_E_LAUNCH;
+  if (hipHostGetDevicePointer((void**)&g_poll.d, g_poll.h, 0) != hipSuccess) return WISKI_E_LAUNCH;
+  g_poll.h[0] = 0;
+  g_poll.cap = cap;
+  return WISKI_OK;
+}
+
+__global__ void k_pcg_publish(PcgScal S, int slot, double* __restrict__ poll, const int32_t* __restrict__ err, long long seq) {
+  const int k = S.k;
+  for (int c = threadIdx.x; c < k; c += blockDim.x) {
+    poll[1 + c] = S.rn0()[c];
+    poll[1 + k + c] = S.rn(slot)[c];
+  }
+  if (threadIdx.x == 0) poll[1 + 2 * k] = err ? (double)*err : 0.0;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<long long*>(poll), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
 template <typename real>
 __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, const real* __restrict__ part,
@@ -860,7 +897,7 @@ template <typename real>
 static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_evec2, const real* d_eval,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
-                    void* stream) {
+                    const int32_t* d_err, int32_t* h_err, void* stream) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -914,10 +951,27 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   }
 
   std::vector<double> h_rn0(k), h_rn(k);
+  double err_seen = 0;
+  if (poll_reserve(k) != WISKI_OK) return WISKI_E_LAUNCH;
   auto fetch = [&](int slot) -> int {
-    if (hipMemcpyAsync(h_rn0.data(), S.rn0(), k * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return WISKI_E_LAUNCH;
-    if (hipMemcpyAsync(h_rn.data(), S.rn(slot), k * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return WISKI_E_LAUNCH;
-    if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;
+    const long long seq = ++g_poll.seq;
+    hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, g_poll.d, d_err, seq);
+    if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
+    volatile long long* flag = reinterpret_cast<volatile long long*>(g_poll.h);
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+        if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;   // fallback: should not happen
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return WISKI_E_LAUNCH;
+        break;
+      }
+    }
+    for (int c = 0; c < k; ++c) {
+      h_rn0[c] = g_poll.h[1 + c];
+      h_rn[c] = g_poll.h[1 + k + c];
+    }
+    err_seen = g_poll.h[1 + 2 * k];
     return WISKI_OK;
   };
   auto converged = [&]() {
@@ -1001,6 +1055,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (rc) return rc;
   }
   if (h_iters) *h_iters = it;
+  if (h_err) *h_err = err_seen != 0 ? 1 : 0;
   if (h_relres)
     for (int c = 0; c < k; ++c) h_relres[c] = h_rn0[c] > 0 ? sqrt(h_rn[c] / h_rn0[c]) : 0.0;
   return done ? WISKI_OK : WISKI_E_NOTCONV;
@@ -1053,10 +1108,10 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
 }
-int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, s);
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, s);
 }
-int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, void* s) {
-  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, s);
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, s);
 }
 }

@@ -258,7 +258,7 @@ def kron_eigen(grid, tcol, profiles=None):
 
 
 def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
-        raise_on_fail=False, eigen=None, shift=0.0, first_check=0):
+        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None):
     """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres).
     eigen = (evec, evals) from :func:`kron_eigen` selects the spectral
     preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions."""
@@ -271,6 +271,7 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
     ws = workspace if workspace is not None else PCGWorkspace()
     buf, need = ws.get(grid, k, max_iter, RHS2.dtype, RHS2.device)
     iters = ctypes.c_int32(0)
+    h_err = ctypes.c_int32(0)
     relres = (ctypes.c_double * k)()
     cr = _hip.creal(RHS2.dtype)
     evec, evals, evec2 = (tuple(eigen) + (None,))[:3] if eigen is not None else (None, None, None)
@@ -278,13 +279,17 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
                                           _hip.dptr(evals),
                                           cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
                                           _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
-                                          ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres,
+                                          ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
                                           _hip.stream_ptr(RHS2.device))
     if rc == -4 and not raise_on_fail:
         pass
     else:
         _hip.check(rc, "wiski_pcg")
+    pcg.last_err = int(h_err.value)
     return U, Z, int(iters.value), list(relres)
+
+
+pcg.last_err = 0
 
 
 def kron_toeplitz_grad(grid, tcol, X, Y):

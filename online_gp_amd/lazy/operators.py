@@ -105,7 +105,7 @@ class InducingPosterior(_Operator):
     covariance of the inducing values (batched_fixed_noise_online_gp.py:385-404),
     applied by preconditioned CG (wiski_pcg) instead of through a root."""
 
-    def __init__(self, grid, wtw, tcol, kscale, tol, max_iter, workspace=None, check_every=10, eigen=None, shift=0.0):
+    def __init__(self, grid, wtw, tcol, kscale, tol, max_iter, workspace=None, check_every=10, eigen=None, shift=0.0, err=None):
         self.grid = grid
         self.wtw = wtw
         self.tcol = tcol
@@ -116,6 +116,8 @@ class InducingPosterior(_Operator):
         self.check_every = check_every
         self.eigen = eigen
         self.shift = float(shift)
+        self.err = err            # device out-of-grid flag: its value rides on the solver's convergence poll
+        self.last_err = 0
         self.shape = torch.Size([grid.m, grid.m])
         self.dtype = tcol.dtype
         self.device = tcol.device
@@ -126,8 +128,8 @@ class InducingPosterior(_Operator):
         """RHS [k, m] -> (U, Z) with U = M RHS."""
         U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, tol=self.tol,
                                      max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace, eigen=self.eigen,
-                                     shift=self.shift, first_check=first_check)
-        self.last_iters, self.last_relres = it, res
+                                     shift=self.shift, first_check=first_check, err=self.err)
+        self.last_iters, self.last_relres, self.last_err = it, res, grid_ops.pcg.last_err
         return U, Z
 
     def _matmul(self, rhs):

@@ -334,7 +334,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         eig, shift = self._precond(o, tcol)
         return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
                                  settings.max_cg_iterations.value(), workspace=self._pcg_ws, check_every=settings.cg_check_every.value(),
-                                 eigen=eig, shift=shift)
+                                 eigen=eig, shift=shift, err=self._err)
 
     # --------------------------------------------------------------- caches --
     @property
@@ -358,7 +358,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         pc = self._memo.get("prediction_cache")
         if pc is not None:
             return pc
-        self.check_bounds()
+        if self._use_dense() or self._wsum_dirty:
+            self.check_bounds()          # dense path has no solver poll to ride on; a dirty weight sum needs the read anyway
         out, m = self.num_outputs, self._grid.m
         b = self._kernel_cache["interpolation_cache"]
         hyper = self._hyper()
@@ -398,6 +399,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             U[o], Z[o] = Uo[0], Zo[0]
             iters.append(post.last_iters)
             posts.append(post)
+            if post.last_err:            # out-of-grid flag delivered with the convergence poll (no extra sync)
+                self._err.zero_()
+                raise RuntimeError("Received data that was out of bounds for the specified grid. "
+                                   f"Grid bounds were {self.covar_module.grid_bounds}.")
         self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "ver": ver}
         self._last_iters = list(iters)
         pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters}
