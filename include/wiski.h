@@ -102,6 +102,11 @@ int wiski_scatter_stats_f64(const wiski_grid* grid, const double* d_x, const dou
  * half delta is also what the data-parallel path all-reduces. */
 int wiski_scatter_stats_sym_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, double* d_stats, int32_t* d_err, void* stream);
 int wiski_scatter_stats_sym_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_stats, int32_t* d_err, void* stream);
+/* One-launch form used by the model: as above (half != 0: d_A is the symmetric half delta,
+ * else the full stencil) and additionally d_cnt[m] += W^T wa, the row sums of the increment
+ * (the preconditioner's data-density statistic; d_cnt may be NULL). */
+int wiski_scatter_stats_cnt_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A, int32_t half, float* d_cnt, double* d_stats, int32_t* d_err, void* stream);
+int wiski_scatter_stats_cnt_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A, int32_t half, double* d_cnt, double* d_stats, int32_t* d_err, void* stream);
 int wiski_stencil_expand_add_f32(const wiski_grid* grid, float* d_A_half, float* d_A_st, void* stream);
 int wiski_stencil_expand_add_f64(const wiski_grid* grid, double* d_A_half, double* d_A_st, void* stream);
 

@@ -16,7 +16,8 @@ template <typename real, int D, bool HALF>
 __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const real* __restrict__ x, const real* __restrict__ y,
                                                        const real* __restrict__ wa, const real* __restrict__ wb,
                                                        const real* __restrict__ noise, int64_t n, real* __restrict__ b,
-                                                       real* __restrict__ A_st, double* __restrict__ stats, int32_t* __restrict__ err) {
+                                                       real* __restrict__ A_st, double* __restrict__ stats, int32_t* __restrict__ err,
+                                                       real* __restrict__ cnt) {
   constexpr int T = 1 << (2 * D);
   constexpr int GRP = T < 64 ? T : 64;      // lanes per point
   constexpr int PPB = 256 / GRP;            // points per block pass
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
       for (int t = 0; t < TPL; ++t) {
         if (val_a[t] != (real)0) {
           atomic_add_real(b + idx_a[t], val_a[t] * yp * wbp);
+          if (cnt) atomic_add_real(cnt + idx_a[t], val_a[t] * wap);     // row sums of the increment (preconditioner density model)
           if (A_st) {
             const real va = val_a[t] * wap;
             real* __restrict__ Arow = A_st + idx_a[t];
@@ -163,7 +165,8 @@ static int expand_impl(const wiski_grid* grid, real* d_half, real* d_full, void*
 
 template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
-                        int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false) {
+                        int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
+                        real* d_cnt = nullptr) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -176,8 +179,8 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   dim3 grd((unsigned)blocks);
 #define CALL(DD)                                                                                                                              \
   do {                                                                                                                                        \
-    if (half) hipLaunchKernelGGL((k_scatter_stats<real, DD, true>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err); \
-    else hipLaunchKernelGGL((k_scatter_stats<real, DD, false>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err);   \
+    if (half) hipLaunchKernelGGL((k_scatter_stats<real, DD, true>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt); \
+    else hipLaunchKernelGGL((k_scatter_stats<real, DD, false>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
   } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
 #undef CALL
@@ -197,6 +200,12 @@ int wiski_scatter_stats_sym_f32(const wiski_grid* g, const float* x, const float
 }
 int wiski_scatter_stats_sym_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* stats, int32_t* err, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true);
+}
+int wiski_scatter_stats_cnt_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A, int32_t half, float* cnt, double* stats, int32_t* err, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A, stats, err, s, half != 0, cnt);
+}
+int wiski_scatter_stats_cnt_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A, int32_t half, double* cnt, double* stats, int32_t* err, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A, stats, err, s, half != 0, cnt);
 }
 int wiski_stencil_expand_add_f32(const wiski_grid* g, float* half, float* full, void* s) { return expand_impl<float>(g, half, full, s); }
 int wiski_stencil_expand_add_f64(const wiski_grid* g, double* half, double* full, void* s) { return expand_impl<double>(g, half, full, s); }

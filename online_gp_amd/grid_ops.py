@@ -170,6 +170,16 @@ def scatter_stats_sym(grid, x, y, wa, wb, noise, b, A_half, stats, err):
     _hip.check(rc, "wiski_scatter_stats_sym")
 
 
+def scatter_stats_cnt(grid, x, y, wa, wb, noise, b, A, half, cnt, stats, err):
+    """One launch: (b, A or its half delta, stats) as scatter_stats[_sym] plus cnt += W^T wa."""
+    x = _x2d(x, grid)
+    rc = _hip.fn("wiski_scatter_stats_cnt", x.dtype)(grid.ref, _hip.dptr(x), _hip.dptr(y.contiguous()), _hip.dptr(wa.contiguous()),
+                                                     _hip.dptr(wb.contiguous()), _hip.dptr(noise.contiguous()), ctypes.c_int64(x.shape[0]),
+                                                     _hip.dptr(b), _hip.dptr(A), ctypes.c_int32(int(half)), _hip.dptr(cnt), _hip.dptr(stats),
+                                                     _hip.dptr(err), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_scatter_stats_cnt")
+
+
 def stencil_expand_add(grid, A_half, A_st):
     """A_st += expand(A_half) (delta and its mirror image); A_half is zeroed."""
     rc = _hip.fn("wiski_stencil_expand_add", A_st.dtype)(grid.ref, _hip.dptr(A_half), _hip.dptr(A_st), _hip.stream_ptr(A_st.device))
@@ -258,13 +268,13 @@ def kron_eigen(grid, tcol, profiles=None):
 
 
 def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
-        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None):
+        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None, inplace=False):
     """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres).
     eigen = (evec, evals) from :func:`kron_eigen` selects the spectral
     preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions."""
     RHS2 = RHS.contiguous().reshape(-1, grid.m)
     k = RHS2.shape[0]
-    if U is None or Z is None or not warm:
+    if U is None or Z is None or (not warm and not inplace):
         U = torch.empty_like(RHS2)
         Z = torch.empty_like(RHS2)
         warm = False

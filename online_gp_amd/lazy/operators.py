@@ -124,9 +124,9 @@ class InducingPosterior(_Operator):
         self.last_iters = 0
         self.last_relres = []
 
-    def solve_columns(self, RHS, U=None, Z=None, warm=False, first_check=0):
-        """RHS [k, m] -> (U, Z) with U = M RHS."""
-        U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, tol=self.tol,
+    def solve_columns(self, RHS, U=None, Z=None, warm=False, first_check=0, inplace=False):
+        """RHS [k, m] -> (U, Z) with U = M RHS.  inplace: write into the given U, Z even on a cold start."""
+        U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, inplace=inplace, tol=self.tol,
                                      max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace, eigen=self.eigen,
                                      shift=self.shift, first_check=first_check, err=self.err)
         self.last_iters, self.last_relres, self.last_err = it, res, grid_ops.pcg.last_err

@@ -230,15 +230,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 no = noise[:, o].contiguous()
                 wb = 1.0 / no
                 wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
+            cnt_o = cache["_cnt"][o] if "_cnt" in cache else None     # row sums W^T wa ride on the same launch
             if use_half:
-                grid_ops.scatter_stats_sym(self._grid, X, yo, wa, wb, no, b[o, :, 0], bufs[o], stats[o], self._err)
+                grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], bufs[o], True, cnt_o, stats[o], self._err)
                 if half_delta is None:
                     grid_ops.stencil_expand_add(self._grid, bufs[o], ops[o].stencil)
             else:
-                grid_ops.scatter_stats(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, stats[o], self._err)
-            if "_cnt" in cache:   # row sums of the increment: W^T wa (y = 1, weight wa), 4^d atomics per point
-                one_n = ones if unit else torch.ones_like(wa)
-                grid_ops.scatter_stats(self._grid, X, one_n, wa, wa, one_n, cache["_cnt"][o], None, self._scratch_stats, self._err)
+                grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, False, cnt_o, stats[o], self._err)
             if cache is self._kernel_cache or init:
                 if unit:
                     self._wsum_host[o] += float(n)
@@ -275,8 +273,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         return float(n[o] if n.numel() > 1 else n[0])
 
     def _hyper_version(self):
-        ps = list(self.covar_module.parameters()) + (list(self.likelihood.second_noise_covar.parameters()) if self.has_learnable_noise else [])
-        return tuple((id(p), p._version) for p in ps)
+        ps = self.__dict__.get("_hyper_params")
+        if ps is None:
+            ps = list(self.covar_module.parameters()) + (list(self.likelihood.second_noise_covar.parameters()) if self.has_learnable_noise else [])
+            self.__dict__["_hyper_params"] = ps
+        return tuple(p._version for p in ps)
 
     def _hyper(self):
         """Per-output (tcol on device in the data dtype, sigma2 float); memoised on
@@ -364,8 +365,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         b = self._kernel_cache["interpolation_cache"]
         hyper = self._hyper()
         ver = self._hyper_version()
-        U = torch.empty((out, m), dtype=self._dtype, device=self._device)
-        Z = torch.empty_like(U)
+        ms = self._mean_state
+        if ms is not None and ms["U"].shape == (out, m):
+            U, Z = ms["U"], ms["Z"]                   # refreshed in place by the warm-started solves
+        else:
+            U = torch.empty((out, m), dtype=self._dtype, device=self._device)
+            Z = torch.empty_like(U)
+            ms = None
         iters = []
         posts = []
         for o in range(out):
@@ -377,14 +383,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 iters.append(0)
                 posts.append(post)
                 continue
-            warm = False
-            Uo = Zo = None
-            if self._mean_state is not None:
-                Uo, Zo = self._mean_state["U"][o:o + 1].clone(), self._mean_state["Z"][o:o + 1].clone()
-                if self._mean_state["ver"] != ver:
-                    tcol, s2, _ = hyper[o]
-                    Uo = grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2)   # keep U = Kt Z under the new hypers
-                warm = True
+            warm = ms is not None
+            Uo, Zo = U[o:o + 1], Z[o:o + 1]           # contiguous row views: wiski_pcg updates them in place
+            if warm and ms["ver"] != ver:
+                tcol, s2, _ = hyper[o]
+                Uo.copy_(grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2))   # keep U = Kt Z under the new hypers
             # warm refreshes poll convergence first where the previous one converged (streaming steps are
             # alike), every 8th one an iteration earlier, and then after every iteration
             fc = 0
@@ -393,10 +396,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 probe = getattr(self, "_probe_down", True) or self._refresh_count % 8 == 0
                 fc = max(1, self._last_iters[o] - (1 if probe else 0))
                 post.check_every = 1
-            Uo, Zo = post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm, first_check=fc)
+            post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm, first_check=fc, inplace=True)
             if fc:
                 self._probe_down = post.last_iters <= fc and fc > 1      # keep probing while it keeps paying off
-            U[o], Z[o] = Uo[0], Zo[0]
             iters.append(post.last_iters)
             posts.append(post)
             if post.last_err:            # out-of-grid flag delivered with the convergence poll (no extra sync)
