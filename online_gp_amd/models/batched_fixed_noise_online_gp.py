@@ -151,6 +151,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._absorb(self._kernel_cache, train_inputs, train_targets, train_noise_term, init=True)
         else:
             self._kernel_cache = kernel_cache
+            if "_cnt" in kernel_cache:
+                # hand-over path (bayesopt.py:86-96): recover sum_p 1/noise_p from the row sums (rows of W sum to one)
+                self._wsum_dev = kernel_cache["_cnt"].sum(dim=1, dtype=torch.float64)
+                self._wsum_dirty = True
 
     # ------------------------------------------------------------ helpers --
     @staticmethod

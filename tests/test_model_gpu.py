@@ -176,7 +176,7 @@ def test_botorch_adaptor_batched_posterior_and_cache_handover():
     m1 = m0.condition_on_observations(Xt[10:], yt[10:])
     m2 = OnlineSKIBotorchModel(covar_module=m1.covar_module, kernel_cache=m1._kernel_cache, learn_additional_noise=True,
                                likelihood=m1.likelihood, num_data=m1.num_data)
-    m2._wsum_dev, m2._wsum_host, m2._wsum_dev_host, m2._wsum_dirty = m1._wsum_dev.clone(), list(m1._wsum_host), list(m1._wsum_dev_host), m1._wsum_dirty
+    assert abs(m2._wsum[0] - m1._wsum[0]) < 1e-6 * m1._wsum[0]        # recovered from the row-sum statistic of the cache
     Xq = torch.as_tensor(rng.uniform(0, 1, (4, 3, 3)), device=DEV)
     p1, p2 = m1.posterior(Xq), m2.posterior(Xq)
     assert p1.mean.shape == (4, 3, 1) and p1.variance.shape == (4, 3, 1) and p1.mvn.covariance_matrix.shape == (4, 3, 3)
