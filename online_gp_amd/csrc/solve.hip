@@ -211,6 +211,9 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4(GridDev<real> G, const re
     for (int r = 0; r < 4; ++r) acc[c][r] = (real)0;
   if (live) {
     const real* __restrict__ a_base = A_st + (int64_t)ch * nmid * 7 * m + i4;
+#ifdef WISKI_SPMV_UNROLL
+#pragma unroll WISKI_SPMV_UNROLL
+#endif
     for (int mid = 0; mid < nmid; ++mid) {
       const int base = i4 + s_off[mid] - 3;
       real win[KC][10];
