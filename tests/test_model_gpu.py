@@ -251,3 +251,31 @@ def test_c2_scale_30pow4_fp64_parity():
         mean, var = mvn.mean.cpu().numpy(), mvn.variance.cpu().numpy()
     assert np.abs(mean - mo).max() <= 1e-4 * np.abs(mo).max()
     assert np.abs(var - vo).max() <= 1e-4 * np.abs(vo).max()
+
+
+def test_dirichlet_classifier_wrapper_banana_like():
+    """OnlineSKIClassifier (2-output batch, heteroscedastic Dirichlet noise): batch fit + streaming updates reach the
+    reference's accuracy thresholds (tests/classification/test_ski_classifier.py:33,59: >= 0.85 batch, >= 0.75 online)
+    on a synthetic two-moons-like problem (the Banana data needs the network)."""
+    from online_gp_amd.models import Identity, OnlineSKIClassifier
+
+    rng = np.random.default_rng(0)
+    n = 600
+    lab = rng.integers(0, 2, n)
+    ang = rng.uniform(0, np.pi, n)
+    X = np.stack([np.cos(ang) * (1 - 2 * lab) * 0.5 + 0.25 * (2 * lab - 1), np.sin(ang) * (1 - 2 * lab) * 0.5 + 0.15 * (2 * lab - 1)], 1)
+    X += 0.08 * rng.standard_normal(X.shape)
+    X = np.clip(X, -0.95, 0.95)
+    Xt = torch.as_tensor(X, device=DEV, dtype=torch.float32); yt = torch.as_tensor(lab, device=DEV)
+    clf = OnlineSKIClassifier(Identity(2), Xt[:200], yt[:200], 1e-2, 1e-2, 16, 1.0)
+    recs = clf.fit(Xt[:200], yt[:200], 3)
+    assert len(recs) == 3 and np.isfinite(recs[-1]["train_loss"])
+    acc_batch = clf.predict(Xt[400:]).eq(yt[400:]).float().mean().item()
+    assert acc_batch >= 0.85
+    correct = 0
+    for s in range(200, 400, 20):
+        correct += clf.predict(Xt[s:s + 20]).eq(yt[s:s + 20]).sum().item()
+        clf.update(Xt[s:s + 20], yt[s:s + 20], update_gp=(s % 60 == 0))
+    assert correct / 200 >= 0.75
+    assert clf.gp.num_data == 400 and clf.gp.num_outputs == 2
+    assert clf.predict(Xt[400:]).eq(yt[400:]).float().mean().item() >= 0.85
