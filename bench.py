@@ -187,15 +187,16 @@ def main():
     if rank == 0:
         grid = model._grid
         es = 4 if dtype == torch.float32 else 8
-        # algorithmic bytes of one k=1 stencil SpMV launch: A_st once + v in + out (+ add)
-        spmv_bytes = grid.R * grid.m * es + 3 * grid.m * es
+        # algorithmic bytes of one k=1 stencil SpMV launch: the symmetric half stencil A_h once
+        # (the model's native storage; every entry serves A[i,j] and A[j,i]) + v in + out (+ add)
+        spmv_bytes = (grid.R + 1) // 2 * grid.m * es + 3 * grid.m * es
         n_l = int(launches.value)
         avg_ms = tot_ms.value / max(n_l, 1)
         achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if n_l else 0.0
         traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), if recorded
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "k_stencil_spmv4<%s, 1, true>" % ("float" if args.dtype == "f32" else "double")
+            key = "k_stencil_spmv4_sym<%s, 1, true>" % ("float" if args.dtype == "f32" else "double")
             if args.grid == 50 and d == 3 and key in pmc["kernels"]:
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except Exception:  # noqa: BLE001
@@ -216,7 +217,7 @@ def main():
             "config": {"workload": f"3droad-like synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}",
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": f"dp{world} (stats all-reduce)" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": "k_stencil_spmv (A_st . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_stencil_spmv4_sym (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes},
             "extra": {"cg_iters_per_step_mean": float(np.mean(iters)), "absorb_only_updates_per_s": q / ta,

@@ -120,6 +120,11 @@ int wiski_wt_columns_f64(const wiski_grid* grid, const double* d_x, int64_t n, d
  * d_out[c] = beta * d_add[c] + A_st . d_V[c]   (d_add may be NULL). */
 int wiski_stencil_spmv_f32(const wiski_grid* grid, const float* d_A_st, const float* d_V, int32_t k, const float* d_add, float beta, float* d_out, void* stream);
 int wiski_stencil_spmv_f64(const wiski_grid* grid, const double* d_A_st, const double* d_V, int32_t k, const double* d_add, double beta, double* d_out, void* stream);
+/* Same product on the symmetric half stencil d_A_half [(7^d+1)/2][m] (the layout of
+ * wiski_scatter_stats_sym: only offsets >= centre are stored and every stored entry is used for
+ * A[i,j] and A[j,i]); half the HBM bytes of the full form.  d_out must not alias d_V. */
+int wiski_stencil_spmv_sym_f32(const wiski_grid* grid, const float* d_A_half, const float* d_V, int32_t k, const float* d_add, float beta, float* d_out, void* stream);
+int wiski_stencil_spmv_sym_f64(const wiski_grid* grid, const double* d_A_half, const double* d_V, int32_t k, const double* d_add, double beta, double* d_out, void* stream);
 
 /* a8/a9/a11 -- replaces Kuu @ V (BFN:334-348,363-366) with
  * Kuu = kron_i SymToeplitz(tcol_i): d_out[c] = scale * Kuu d_V[c].
@@ -163,12 +168,14 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  * the interp/scatter/gather entry points; its value rides on the last poll into *h_err, so the
  * caller needs no separate device-to-host read to raise the reference's RuntimeError.
  * Not re-entrant across host threads (one poll buffer per process).
+ * a_sym != 0: d_A_st is the symmetric half stencil [(7^d+1)/2][m] (wiski_stencil_spmv_sym) instead of
+ * the full [7^d][m] one.
  * workspace: wiski_pcg_workspace_bytes(...) bytes of device scratch.
  * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
  * be NULL): final relative residuals. */
 int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size);
-int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, void* stream);
-int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, void* stream);
+int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* stream);
+int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

@@ -49,7 +49,8 @@ extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
 // i; V (k*m reals) is re-read R times but stays L2 / MALL resident.  Entries
 // whose neighbour would leave the grid were never scattered (exact zeros), so
 // clamping the flat neighbour index keeps the loads legal without a branch.
-// DOT: also accumulates dots[c] += sum_i V[c][i] * out[c][i] (CG's p.Hp).
+// DOT: also accumulates dots[c][blockIdx.x % PCG_DOT_SLOTS] += sum_i V[c][i] * out[c][i] (CG's p.Hp, slotted:
+// see PcgScal).
 template <typename real, int KC, bool DOT>
 __global__ __launch_bounds__(256) void k_stencil_spmv(GridDev<real> G, const real* __restrict__ A_st, const real* __restrict__ V,
                                                       int k, const real* __restrict__ add, real beta, real* __restrict__ out,
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv(GridDev<real> G, const rea
       double* s_red = reinterpret_cast<double*>(smem);
       __syncthreads();
       double tot = block_reduce_sum(part, s_red);
-      if (threadIdx.x == 0 && c0 + c < k) unsafeAtomicAdd(dots + c0 + c, tot);
+      if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
     }
   }
 }
@@ -259,18 +260,20 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4(GridDev<real> G, const re
     }
     if (DOT) {
       const double tot = block_reduce_sum(pd, s_red);
-      if (threadIdx.x == 0 && c0 + c < k) unsafeAtomicAdd(dots + c0 + c, tot);
+      if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
     }
   }
 }
 
 // out[c][i] = beta * add[c][i] + sum_ch part[ch][c][i]
+// zl: part[nch-1] is the atomically accumulated partial of the symmetric SpMV; re-zero it once consumed.
 template <typename real>
-__global__ __launch_bounds__(256) void k_spmv_reduce(int64_t km, int nch, const real* __restrict__ part, const real* __restrict__ add, real beta,
-                                                     real* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_spmv_reduce(int64_t km, int nch, real* __restrict__ part, const real* __restrict__ add, real beta,
+                                                     real* __restrict__ out, int zl) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < km; e += (int64_t)gridDim.x * blockDim.x) {
     real r = add ? beta * add[e] : (real)0;
     for (int ch = 0; ch < nch; ++ch) r += part[(int64_t)ch * km + e];
+    if (zl) part[(int64_t)(nch - 1) * km + e] = (real)0;
     out[e] = r;
   }
 }
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmm(GridDev<real> G, const rea
     }
     if (DOT) {
       const double tot = block_reduce_sum(pd, s_red);
-      if (threadIdx.x == 0 && c0 + c < k) unsafeAtomicAdd(dots + c0 + c, tot);
+      if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
     }
   }
 }
@@ -427,6 +430,329 @@ static int launch_spmv4(const GridDev<real>& G, const real* A_st, const real* V,
   else if (kc == 2) SPMV4(2);
   else SPMV4(1);
 #undef SPMV4
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// ------------------------------------- symmetric half-stencil SpMV (native WtW storage) ---
+// A = W^T D^-1 W is symmetric, so only the offsets o >= centre are stored:
+//   A_h[oh][i] = A[i, i + off(c + oh)],  oh = 0 .. (R-1)/2      (the layout k_scatter_stats<HALF> accumulates)
+// and every stored entry is used twice,
+//   out[i]          += A_h[oh][i] * v[i + off]        ("direct")
+//   out[i + off]    += A_h[oh][i] * v[i]              ("transposed", oh > 0)
+// which halves the HBM bytes of the product (and of the model state, and drops the fold pass after a scatter).
+//
+// Generic form (any m, any d): one thread per output row gathers both terms; the transposed one re-reads
+// A_h at row i - off (L2 hits for the small offsets).  Used for m % 4 != 0.
+template <typename real, int KC, bool DOT>
+__global__ __launch_bounds__(256) void k_stencil_spmv_sym(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ V, int k,
+                                                          const real* __restrict__ add, real beta, real* __restrict__ out,
+                                                          double* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_off = reinterpret_cast<int*>(smem);
+  const int R = G.R, m = G.m, d = G.d;
+  const int H = (R + 1) / 2, ctr = (R - 1) / 2;
+  for (int oh = threadIdx.x; oh < H; oh += blockDim.x) {
+    int rem = ctr + oh, f = 0;
+    for (int q = d - 1; q >= 0; --q) {
+      int c = rem % 7;
+      rem /= 7;
+      f += (c - 3) * G.stride[q];
+    }
+    s_off[oh] = f;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * KC;
+  real acc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) acc[c] = (real)0;
+  if (i < m) {
+#pragma unroll 4
+    for (int oh = 0; oh < H; ++oh) {
+      const int off = s_off[oh];
+      const real* __restrict__ a_row = A_h + (int64_t)oh * m;
+      const real a = a_row[i];
+      int j = i + off;
+      j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+      const int jt = i - off;
+      const bool tr = oh > 0 && jt >= 0 && jt < m;
+      const real at = tr ? a_row[jt] : (real)0;
+      const int jtc = tr ? jt : i;
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        if (c0 + c < k) acc[c] += a * V[(int64_t)(c0 + c) * m + j] + at * V[(int64_t)(c0 + c) * m + jtc];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    double part = 0;
+    if (i < m && c0 + c < k) {
+      const int64_t e = (int64_t)(c0 + c) * m + i;
+      real r = acc[c];
+      if (add) r += beta * add[e];
+      out[e] = r;
+      if (DOT) part = (double)V[e] * (double)r;
+    }
+    if (DOT) {
+      double* s_red = reinterpret_cast<double*>(smem);
+      __syncthreads();
+      double tot = block_reduce_sum(part, s_red);
+      if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
+    }
+  }
+}
+
+template <typename real>
+static int launch_spmv_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, const real* add, real beta, real* out, double* dots,
+                           hipStream_t s) {
+  const int kc = k >= 4 ? 4 : (k >= 2 ? 2 : 1);
+  dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)((k + kc - 1) / kc));
+  size_t sh = (size_t)((G.R + 1) / 2) * sizeof(int);
+  if (sh < 16 * sizeof(double)) sh = 16 * sizeof(double);
+#define SPMV(KC)                                                                                                                 \
+  do {                                                                                                                           \
+    if (dots) hipLaunchKernelGGL((k_stencil_spmv_sym<real, KC, true>), grd, dim3(256), sh, s, G, A_h, V, k, add, beta, out, dots); \
+    else hipLaunchKernelGGL((k_stencil_spmv_sym<real, KC, false>), grd, dim3(256), sh, s, G, A_h, V, k, add, beta, out, dots);   \
+  } while (0)
+  if (kc == 4) SPMV(4);
+  else if (kc == 2) SPMV(2);
+  else SPMV(1);
+#undef SPMV
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// Wide form (m % 4 == 0).  As k_stencil_spmv4, a thread owns 4 consecutive rows and streams A_h with
+// 16-byte loads, one "group" (= one value of the leading d-1 stencil digits, 7 innermost offsets; the
+// centre group holds only its 4 non-negative ones) at a time.  The direct term accumulates in registers
+// and is written as one partial vector per chunk of groups (blockIdx.y).  The transposed term of a group
+// lands on the 10-wide row window [i4 + f - 3, i4 + f + 7): it is accumulated in registers across the 7
+// offsets and then added to a *wave-private* LDS window ([j & 3][j >> 2] planes, so the lanes' 4-row
+// groups hit distinct banks at any shift) with plain read-modify-writes in three lane-disjoint phases
+// (window elements 0..3 / 4..7 / 8..9 of lane t are the quads of lanes t / t+1 / t+2: within a phase no
+// two lanes touch the same cell, and a wave's LDS operations execute in order) -- LDS float atomics
+// (ds_add_f32) measured ~0.4 lanes/clk/CU here and would triple the kernel time.  The window is flushed
+// with *coalesced* fire-and-forget global atomics (measured ~300 G lane-atomics/s when the 64 lanes cover
+// 256 contiguous bytes, vs ~40 G/s for scattered ones) into the extra partial vector part[nch], which
+// must be zero on entry and is re-zeroed by whoever consumes the partials.  The window follows the
+// groups: it is flushed whenever the next group's offset leaves [wb, wb + span].  No block barrier is
+// needed in the main loop.
+//   DOT: dots[c] += v . (A v) = sum_i v_i (2 direct_i - diag_i v_i)   (+ beta v.add once)
+static inline int sym_groups(int d) {
+  int np = 1;
+  for (int q = 0; q < d - 1; ++q) np *= 7;
+  return (np + 1) / 2;
+}
+static int g_sym_nch = 0;   // tuning override (WISKI_SYM_NCH)
+static int g_sym_bs = 0;    // tuning override (WISKI_SYM_BLOCK): threads per block of the wide symmetric SpMV
+static inline int sym_block() {
+  if (g_sym_bs == 0) {
+    const char* e = getenv("WISKI_SYM_BLOCK");
+    g_sym_bs = e ? atoi(e) : 128;
+    if (g_sym_bs != 64 && g_sym_bs != 128 && g_sym_bs != 256) g_sym_bs = 128;
+  }
+  return g_sym_bs;
+}
+static inline int sym_nch(int d) {
+  if (g_sym_nch == 0) {
+    const char* e = getenv("WISKI_SYM_NCH");
+    g_sym_nch = e ? atoi(e) : -1;
+  }
+  const int ng = sym_groups(d);
+  int nch = g_sym_nch > 0 ? g_sym_nch : 7;
+  if (nch > 7) nch = 7;
+  if (nch > ng) nch = ng;
+  return nch;
+}
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+#ifndef WISKI_SYM_ABLATE
+#define WISKI_SYM_ABLATE 0   // timing ablations (tools/spmv_probe.py): 1 no LDS accumulation, 3 no global flush atomics
+#endif
+template <typename real, int KC, bool DOT>
+__global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ V, int k,
+                                                           int ng, int nch, int span, int W4, real* __restrict__ part,
+                                                           const real* __restrict__ add, real beta, double* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_off[176];
+  __shared__ double s_red[16];
+  const int m = G.m, d = G.d;
+  const int ch = blockIdx.y;
+  const int c0 = blockIdx.z * KC;
+  const int gA = (int)((int64_t)ch * ng / nch), gB = (int)((int64_t)(ch + 1) * ng / nch);
+  const int cP = ng - 1;                        // prefix code of the centre: (7^(d-1) - 1) / 2
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  real* __restrict__ tw = reinterpret_cast<real*>(smem) + (size_t)wave * KC * 4 * W4;   // this wave's [KC][4][W4] window
+  for (int g = gA + t; g < gB; g += blockDim.x) {
+    int rem = cP + g, f = 0;
+    for (int q = d - 2; q >= 0; --q) {
+      f += (rem % 7 - 3) * G.stride[q];
+      rem /= 7;
+    }
+    s_off[g - gA] = f;
+  }
+  for (int e = lane; e < KC * 4 * W4; e += 64) tw[e] = (real)0;
+  __syncthreads();
+  const int iw0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 256;   // first row of this wave
+  const int i4 = iw0 + 4 * lane;
+  const bool live = i4 < m;
+  const int64_t km = (int64_t)k * m;
+  real* __restrict__ tacc_out = part + (int64_t)nch * km;   // the atomically accumulated partial
+  const int wlen = 256 + span + 10;
+
+  auto flush = [&](int wb) {
+    for (int idx = lane; idx < wlen; idx += 64) {
+      const int j = iw0 + wb - 3 + idx;
+      real* cell = tw + (idx & 3) * W4 + (idx >> 2);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const real v = cell[c * 4 * W4];
+        if (v != (real)0) {
+          cell[c * 4 * W4] = (real)0;
+#if WISKI_SYM_ABLATE != 3
+          if (j >= 0 && j < m && c0 + c < k) atomic_add_real(tacc_out + (int64_t)(c0 + c) * m + j, v);
+#endif
+        }
+      }
+    }
+    wave_lds_fence();
+  };
+
+  real acc[KC][4], dg[KC][4], xo[KC][4];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    Vec4<real> x4;
+    x4.x = x4.y = x4.z = x4.w = (real)0;
+    if (live && c0 + c < k) x4 = load4<real>(V + (int64_t)(c0 + c) * m + i4);
+    xo[c][0] = x4.x; xo[c][1] = x4.y; xo[c][2] = x4.z; xo[c][3] = x4.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[c][r] = dg[c][r] = (real)0;
+  }
+  // one group's operands: 7 x 16 bytes of A_h and the 10-wide window of v.  (Issuing the next group's
+  // loads before consuming the current one was measured: no gain at 50^3 fp32, 10% slower at 30^4 fp64.)
+  struct GroupData {
+    Vec4<real> a[7];
+    real win[KC][10];
+  };
+  auto fetch = [&](int g, GroupData& D) {
+    const int f = s_off[g - gA];
+    const int first = g == 0 ? 3 : 0;       // the centre group stores the innermost digits 3..6 only
+    const real* __restrict__ a_grp = A_h + (g == 0 ? (int64_t)0 : (int64_t)(7 * g - 3) * m) + i4;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) {
+      if (l >= first) D.a[l] = load4<real>(a_grp + (int64_t)(l - first) * m);
+      else D.a[l].x = D.a[l].y = D.a[l].z = D.a[l].w = (real)0;
+    }
+    const int base = i4 + f - 3;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+      int j = base + e;
+      j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) D.win[c][e] = (c0 + c < k) ? V[(int64_t)(c0 + c) * m + j] : (real)0;
+    }
+  };
+  GroupData cur;
+  int wb = s_off[0];
+  for (int g = gA; g < gB; ++g) {
+    const int f = s_off[g - gA];
+    if (f < wb || f - wb > span) {          // uniform: the window moves on
+      flush(wb);
+      wb = f;
+    }
+    if (live) {
+      fetch(g, cur);
+      real tr[KC][10];
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int e = 0; e < 10; ++e) tr[c][e] = (real)0;
+#pragma unroll
+      for (int l = 0; l < 7; ++l) {
+        const Vec4<real> a = cur.a[l];       // exact zeros for the digits the centre group does not store
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          acc[c][0] += a.x * cur.win[c][l + 0];
+          acc[c][1] += a.y * cur.win[c][l + 1];
+          acc[c][2] += a.z * cur.win[c][l + 2];
+          acc[c][3] += a.w * cur.win[c][l + 3];
+          if (g == 0 && l == 3) {           // the diagonal: counted once
+            dg[c][0] = a.x * xo[c][0]; dg[c][1] = a.y * xo[c][1]; dg[c][2] = a.z * xo[c][2]; dg[c][3] = a.w * xo[c][3];
+          } else {
+            tr[c][l + 0] += a.x * xo[c][0];
+            tr[c][l + 1] += a.y * xo[c][1];
+            tr[c][l + 2] += a.z * xo[c][2];
+            tr[c][l + 3] += a.w * xo[c][3];
+          }
+        }
+      }
+#if WISKI_SYM_ABLATE != 1
+      const int w0 = 4 * lane + (f - wb);
+#pragma unroll
+      for (int ph = 0; ph < 3; ++ph) {      // lane-disjoint phases, see the header comment
+#pragma unroll
+        for (int e = 4 * ph; e < (ph == 2 ? 10 : 4 * ph + 4); ++e) {
+          const int idx = w0 + e;
+          real* cell = tw + (idx & 3) * W4 + (idx >> 2);
+#pragma unroll
+          for (int c = 0; c < KC; ++c) cell[c * 4 * W4] += tr[c][e];
+        }
+        wave_lds_fence();
+      }
+#endif
+    }
+  }
+  flush(wb);
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    double pd = 0;
+    if (live && c0 + c < k) {
+      const int64_t e = (int64_t)(c0 + c) * m + i4;
+      store4<real>(part + (int64_t)ch * km + e, acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+      if (DOT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pd += (double)xo[c][r] * (2.0 * (double)acc[c][r] - (double)dg[c][r]);
+        if (ch == 0 && add) {
+          const Vec4<real> ad = load4<real>(add + e);
+          pd += (double)beta * ((double)xo[c][0] * ad.x + (double)xo[c][1] * ad.y + (double)xo[c][2] * ad.z + (double)xo[c][3] * ad.w);
+        }
+      }
+    }
+    if (DOT) {
+      const double tot = block_reduce_sum(pd, s_red);
+      if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
+    }
+  }
+}
+
+// partial SpMV launcher on the half stencil (requires m % 4 == 0).  part holds (sym_nch(d) + 1) * k * m reals;
+// part[sym_nch(d)] must be zero on entry (see the kernel comment).
+template <typename real>
+static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, real* part, const real* add, real beta, double* dots,
+                            hipStream_t s) {
+  const int ng = sym_groups(G.d), nch = sym_nch(G.d);
+  if (ng - (int)((int64_t)(nch - 1) * ng / nch) > 176 || ng > 176 * nch) return WISKI_E_BADARG;
+  const int kc = k >= 4 ? 4 : (k >= 2 ? 2 : 1);
+  // window span: one full cycle of the second-to-last stencil digit, shrunk to fit 48 KB of LDS
+  int span = G.d >= 2 ? 6 * G.stride[G.d - 2] : 0;
+  const int bs = sym_block(), nw = bs / 64;
+  const int cap = (int)(48 * 1024 / (nw * kc * sizeof(real))) - 256 - 32;   // nw wave-private windows per block
+  if (span > cap) span = cap > 0 ? cap : 0;
+  const int W4 = ((256 + span + 10 + 3) / 4) | 1;
+  const size_t sh = (size_t)nw * kc * 4 * W4 * sizeof(real);
+  dim3 grd((unsigned)((G.m + 4 * bs - 1) / (4 * bs)), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
+  const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
+#define SPMV4S(KC)                                                                                                                              \
+  do {                                                                                                                                          \
+    if (dots) hipLaunchKernelGGL((k_stencil_spmv4_sym<real, KC, true>), grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots); \
+    else hipLaunchKernelGGL((k_stencil_spmv4_sym<real, KC, false>), grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);   \
+  } while (0)
+  if (kc == 4) SPMV4S(4);
+  else if (kc == 2) SPMV4S(2);
+  else SPMV4S(1);
+#undef SPMV4S
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
@@ -715,7 +1041,7 @@ static int spectral_mm_impl(const wiski_grid* grid, const real* d_evec, const re
 
 // -------------------------------------------------------------------- PCG ---
 // scalar slots (double): S[0..k) = ||rhs||^2 ; then per iteration slot
-// it in [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
+// it in [0, max_iter]: rho[k], php[k][PCG_DOT_SLOTS], rn[k] (struct PcgScal).  rn of slot 0 = ||r0||^2.
 // Convergence polling without a stream synchronisation: a one-wave kernel queued behind the
 // iteration copies the residual norms (and the caller's out-of-grid flag) into a host-mapped,
 // coherent buffer and then releases a sequence number; the host spins on it.  A poll costs a few
@@ -754,8 +1080,8 @@ __global__ void k_pcg_publish(PcgScal S, int slot, double* __restrict__ poll, co
 
 // r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
 template <typename real>
-__global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, const real* __restrict__ part,
-                                                  int nch, real* __restrict__ r, PcgScal S) {
+__global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, real* __restrict__ part,
+                                                  int nch, int zl, real* __restrict__ r, PcgScal S) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   double a = 0, bsum = 0;
@@ -764,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict_
     const real f = rhs[e];
     real rr = t ? f - t[e] : f;
     for (int ch = 0; ch < nch; ++ch) rr -= part[(int64_t)ch * S.k * m + e];
+    if (zl) part[(int64_t)(nch - 1) * S.k * m + e] = (real)0;
     r[e] = rr;
     a += (double)f * f;
     bsum += (double)rr * rr;
@@ -825,12 +1152,13 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2
 // VEC = 4: 16-byte accesses (requires m % 4 == 0); all partial loads are independent.
 template <typename real, int VEC>
 __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2, const real* __restrict__ p, const real* __restrict__ pt,
-                                                      const real* __restrict__ hp, const real* __restrict__ part, int nch,
+                                                      const real* __restrict__ hp, real* __restrict__ part, int nch, int zl,
                                                       real* __restrict__ u, real* __restrict__ z, real* __restrict__ r, PcgScal S) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   double alpha = 0;
-  const double den = S.php(it)[c];
+  const double den = S.php_sum(it, c);
+  if (blockIdx.x == 0) pcg_dot_clear(S.php(it + 1), c, 1, S.k);   // ring entry of the next SpMV (see PcgScal)
   if (pcg_active(S, it, c, tol2) && den > 0) alpha = S.rho(it)[c] / den;
   const real al = (real)alpha;
   double acc = 0;
@@ -847,14 +1175,15 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
       zv[0] = cz.x; zv[1] = cz.y; zv[2] = cz.z; zv[3] = cz.w;
       rv[0] = cr.x; rv[1] = cr.y; rv[2] = cr.z; rv[3] = cr.w;
       if (nch > 0) {
-        Vec4<real> pp[7];
+        Vec4<real> pp[8];
 #pragma unroll
-        for (int ch = 0; ch < 7; ++ch)
+        for (int ch = 0; ch < 8; ++ch)
           if (ch < nch) pp[ch] = load4<real>(part + (int64_t)ch * km + e);
+        if (zl) store4<real>(part + (int64_t)(nch - 1) * km + e, (real)0, (real)0, (real)0, (real)0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[q] = ptv[q];
 #pragma unroll
-        for (int ch = 0; ch < 7; ++ch)
+        for (int ch = 0; ch < 8; ++ch)
           if (ch < nch) { hv[0] += pp[ch].x; hv[1] += pp[ch].y; hv[2] += pp[ch].z; hv[3] += pp[ch].w; }
       } else {
         const Vec4<real> h4 = load4<real>(hp + e);
@@ -865,6 +1194,7 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
       if (nch > 0) {
         hv[0] = ptv[0];
         for (int ch = 0; ch < nch; ++ch) hv[0] += part[(int64_t)ch * km + e];
+        if (zl) part[(int64_t)(nch - 1) * km + e] = (real)0;
       } else {
         hv[0] = hp[e];
       }
@@ -892,15 +1222,15 @@ static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * 
 
 static int64_t pcg_ws_bytes(int m, int k, int max_iter, int es) {
   int64_t vec = align_up((int64_t)k * m * es, 256);
-  int64_t scal = align_up((int64_t)k * (1 + 3 * (int64_t)(max_iter + 2)) * 8, 256);
-  return (6 + 7 + 6) * vec + scal;
+  int64_t scal = align_up(PcgScal::doubles(k, max_iter) * 8, 256);
+  return (6 + 8 + 6) * vec + scal;
 }
 
 template <typename real>
 static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_evec2, const real* d_eval,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
-                    const int32_t* d_err, int32_t* h_err, void* stream) {
+                    const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* stream) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -920,13 +1250,24 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   real* hp = (real*)(w + 4 * vec);
   real* tmp = (real*)(w + 5 * vec);
   real* part = (real*)(w + 6 * vec);
-  real* ty = (real*)(w + 13 * vec);
-  real* sa = (real*)(w + 15 * vec);
-  real* sb = (real*)(w + 17 * vec);
-  PcgScal S{(double*)(w + 19 * vec), k};
+  real* ty = (real*)(w + 14 * vec);
+  real* sa = (real*)(w + 16 * vec);
+  real* sb = (real*)(w + 18 * vec);
+  PcgScal S{(double*)(w + 20 * vec), k, (double*)(w + 20 * vec) + PcgScal::scalars(k, max_iter)};
   const bool wide = (m % 4) == 0;
-  const int nch = wide ? spmv_nch(G.d) : 0;
-  const int64_t scal_bytes = (int64_t)k * (1 + 3 * (int64_t)(max_iter + 2)) * 8;
+  const bool sym = a_sym != 0;
+  // number of partial vectors the wide SpMV leaves behind; on the half stencil the last one is the
+  // atomically accumulated transposed term: zero here, re-zeroed by every consumer (zl)
+  const int nch = wide ? (sym ? sym_nch(G.d) + 1 : spmv_nch(G.d)) : 0;
+  const int zl = wide && sym ? 1 : 0;
+  if (zl && hipMemsetAsync(part + (int64_t)(nch - 1) * k * m, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+  auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) {
+    return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
+  };
+  auto spmv_narrow = [&](const real* v, const real* add, real beta, real* out, double* dots) {
+    return sym ? launch_spmv_sym<real>(G, d_A, v, k, add, beta, out, dots, s) : launch_spmv<real>(G, d_A, v, k, add, beta, out, dots, s);
+  };
+  const int64_t scal_bytes = PcgScal::doubles(k, max_iter) * 8;
   if (hipMemsetAsync(S.base, 0, scal_bytes, s) != hipSuccess) return WISKI_E_LAUNCH;
   const double tol2 = tol * tol;
   int eb = (m + 255) / 256;
@@ -939,18 +1280,18 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   if (warm) {
     // r0 = rhs - (z + A u)
     if (wide) {
-      rc = launch_spmv4<real>(G, d_A, d_U, k, part, nullptr, (real)0, nullptr, s);
+      rc = spmv_wide(d_U, nullptr, (real)0, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, (const real*)part, nch, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, part, nch, zl, r, S);
     } else {
-      rc = launch_spmv<real>(G, d_A, d_U, k, d_Z, (real)1, hp, nullptr, s);
+      rc = spmv_narrow(d_U, d_Z, (real)1, hp, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (const real*)nullptr, 0, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (real*)nullptr, 0, 0, r, S);
     }
   } else {
     if (hipMemsetAsync(d_U, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
     if (hipMemsetAsync(d_Z, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
-    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (const real*)nullptr, 0, r, S);
+    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, r, S);
   }
 
   std::vector<double> h_rn0(k), h_rn(k);
@@ -994,17 +1335,17 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   auto flush_update = [&]() {
     if (pending) {
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it - 1, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         (const real*)part, nch, d_U, d_Z, r, S);
+                         part, nch, zl, d_U, d_Z, r, S);
       pending = false;
     }
   };
   while (!done && it < max_iter) {
     if (fused_cg) {
       // 4 launches per iteration: [update_x(it-1) + mode-0 fwd] -> slab (+rho) -> [mode-0 bwd + update_p] -> SpMV (+p.Hp)
-      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, (const real*)part, nch,
+      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, part, nch, zl,
                                           d_U, d_Z, S, s);
       if (rc) return rc;
-      rc = launch_spmv4<real>(G, d_A, p, k, part, pt, (real)1, S.php(it), s);
+      rc = spmv_wide(p, pt, (real)1, S.php(it));
       if (rc) return rc;
       pending = true;
       ++it;
@@ -1035,15 +1376,15 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       else hipLaunchKernelGGL((k_pcg_update_p<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)y, (const real*)r, p, pt, S);
     }
     // hp = pt + A p, php(it) = p.hp
-    if (wide) rc = launch_spmv4<real>(G, d_A, p, k, part, pt, (real)1, S.php(it), s);
-    else rc = launch_spmv<real>(G, d_A, p, k, pt, (real)1, hp, S.php(it), s);
+    if (wide) rc = spmv_wide(p, pt, (real)1, S.php(it));
+    else rc = spmv_narrow(p, pt, (real)1, hp, S.php(it));
     if (rc) return rc;
     if (wide)
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         (const real*)part, nch, d_U, d_Z, r, S);
+                         part, nch, zl, d_U, d_Z, r, S);
     else
       hipLaunchKernelGGL((k_pcg_update_x<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         (const real*)part, nch, d_U, d_Z, r, S);
+                         part, nch, zl, d_U, d_Z, r, S);
     ++it;
     if (due(it)) {
       rc = fetch(it);
@@ -1080,7 +1421,32 @@ static int spmv_impl(const wiski_grid* grid, const real* d_A, const real* d_V, i
   if (rc == WISKI_OK) {
     int64_t blocks = (km + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((k_spmv_reduce<real>), dim3((unsigned)blocks), dim3(256), 0, s, km, nch, (const real*)part, d_add, beta, d_out);
+    hipLaunchKernelGGL((k_spmv_reduce<real>), dim3((unsigned)blocks), dim3(256), 0, s, km, nch, part, d_add, beta, d_out, 0);
+    if (hipGetLastError() != hipSuccess) rc = WISKI_E_LAUNCH;
+  }
+  (void)hipFreeAsync(part, s);
+  return rc;
+}
+
+// Same product on the symmetric half stencil A_h [(R+1)/2][m].
+template <typename real>
+static int spmv_sym_impl(const wiski_grid* grid, const real* d_A, const real* d_V, int32_t k, const real* d_add, real beta, real* d_out, void* stream) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_A || !d_V || !d_out || k < 1 || d_out == d_V) return WISKI_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (G.m % 4 != 0) return launch_spmv_sym<real>(G, d_A, d_V, k, d_add, beta, d_out, nullptr, s);
+  const int nch = sym_nch(G.d) + 1;
+  const int64_t km = (int64_t)k * G.m;
+  real* part = nullptr;
+  if (hipMallocAsync((void**)&part, (size_t)nch * km * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;  // stream-ordered scratch
+  if (hipMemsetAsync(part + (int64_t)(nch - 1) * km, 0, (size_t)km * sizeof(real), s) != hipSuccess) rc = WISKI_E_LAUNCH;
+  if (rc == WISKI_OK) rc = launch_spmv4_sym<real>(G, d_A, d_V, k, part, nullptr, (real)0, nullptr, s);
+  if (rc == WISKI_OK) {
+    int64_t blocks = (km + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((k_spmv_reduce<real>), dim3((unsigned)blocks), dim3(256), 0, s, km, nch, part, d_add, beta, d_out, 0);
     if (hipGetLastError() != hipSuccess) rc = WISKI_E_LAUNCH;
   }
   (void)hipFreeAsync(part, s);
@@ -1099,6 +1465,8 @@ static int kron_impl(const wiski_grid* grid, const real* d_tcol, const real* d_V
 extern "C" {
 int wiski_stencil_spmv_f32(const wiski_grid* g, const float* A, const float* V, int32_t k, const float* add, float beta, float* out, void* s) { return spmv_impl<float>(g, A, V, k, add, beta, out, s); }
 int wiski_stencil_spmv_f64(const wiski_grid* g, const double* A, const double* V, int32_t k, const double* add, double beta, double* out, void* s) { return spmv_impl<double>(g, A, V, k, add, beta, out, s); }
+int wiski_stencil_spmv_sym_f32(const wiski_grid* g, const float* A, const float* V, int32_t k, const float* add, float beta, float* out, void* s) { return spmv_sym_impl<float>(g, A, V, k, add, beta, out, s); }
+int wiski_stencil_spmv_sym_f64(const wiski_grid* g, const double* A, const double* V, int32_t k, const double* add, double beta, double* out, void* s) { return spmv_sym_impl<double>(g, A, V, k, add, beta, out, s); }
 int wiski_kron_toeplitz_mm_f32(const wiski_grid* g, const float* tcol, const float* V, int32_t k, float scale, float* tmp, float* out, void* s) { return kron_impl<float>(g, tcol, V, k, scale, tmp, out, s); }
 int wiski_kron_toeplitz_mm_f64(const wiski_grid* g, const double* tcol, const double* V, int32_t k, double scale, double* tmp, double* out, void* s) { return kron_impl<double>(g, tcol, V, k, scale, tmp, out, s); }
 int wiski_kron_toeplitz_grad_f32(const wiski_grid* g, const float* tcol, const float* X, const float* Y, int32_t k, float* tmp, double* grad, void* s) { return kron_grad_impl<float>(g, tcol, X, Y, k, tmp, grad, s); }
@@ -1111,10 +1479,10 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
 }
-int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, void* s) {
-  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, s);
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, s);
 }
-int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, void* s) {
-  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, s);
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, s);
 }
 }

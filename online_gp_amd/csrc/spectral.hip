@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
 template <typename real>
 __global__ __launch_bounds__(128) void k_spec_mode0_fwd_upd(GridDev<real> G, const real* __restrict__ V0, real* __restrict__ r,
                                                            real* __restrict__ dst, int it, int apply, double tol2, const real* __restrict__ p,
-                                                           const real* __restrict__ pt, const real* __restrict__ part, int nch,
+                                                           const real* __restrict__ pt, real* __restrict__ part, int nch, int zl,
                                                            real* __restrict__ u, real* __restrict__ z, PcgScal S) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
@@ -393,7 +393,8 @@ __global__ __launch_bounds__(128) void k_spec_mode0_fwd_upd(GridDev<real> G, con
   const int64_t cm = (int64_t)c * m, km = (int64_t)S.k * m;
   real al = (real)0;
   if (apply) {
-    const double den = S.php(it - 1)[c];
+    const double den = S.php_sum(it - 1, c);
+    if (blockIdx.x == 0) pcg_dot_clear(S.php(it), c, 1, S.k);   // ring entry the SpMV of this iteration accumulates into
     if (pcg_active(S, it - 1, c, tol2) && den > 0) al = (real)(S.rho(it - 1)[c] / den);
   }
   MatrixLoad<real, 128> ml;
@@ -418,6 +419,10 @@ __global__ __launch_bounds__(128) void k_spec_mode0_fwd_upd(GridDev<real> G, con
           const V4<real> pp = lds_read4<real>(part + (int64_t)ch * km + e);
 #pragma unroll
           for (int q = 0; q < 4; ++q) hv.v[q] += pp.v[q];
+        }
+        if (zl) {   // the symmetric SpMV's atomically accumulated partial: consumed, re-zero for the next product
+          real* zp = part + (int64_t)(nch - 1) * km + e;
+          zp[0] = zp[1] = zp[2] = zp[3] = (real)0;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -611,7 +616,7 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 // One CG iteration's preconditioner + vector updates in three launches (see kernels above).
 template <typename real>
 int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
-                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, const real* part, int nch, real* u,
+                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
                              real* z, PcgScal S, hipStream_t s) {
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
   if (!evec2) evec2 = evec;
@@ -634,7 +639,7 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
     slab_lds_set = sh1;
   }
   hipLaunchKernelGGL((k_spec_mode0_fwd_upd<real>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, r, w0, it, apply, tol2, (const real*)p,
-                     (const real*)pt, part, nch, u, z, S);
+                     (const real*)pt, part, nch, zl, u, z, S);
   hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift,
                      (const real*)w0, w1, k, S.rho(it));
   hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, Z0, (const real*)w1, k, it, p, pt, S);
@@ -643,9 +648,9 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
 template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, float*, int, float*,
-                                             float*, int, int, double, float*, float*, const float*, int, float*, float*, PcgScal, hipStream_t);
+                                             float*, int, int, double, float*, float*, float*, int, int, float*, float*, PcgScal, hipStream_t);
 template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, double*, int,
-                                              double*, double*, int, int, double, double*, double*, const double*, int, double*, double*, PcgScal,
+                                              double*, double*, int, int, double, double*, double*, double*, int, int, double*, double*, PcgScal,
                                               hipStream_t);
 template bool spectral_fused_ok<double>(const GridDev<double>&);
 template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int, float*,

@@ -160,14 +160,45 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
 
 // PCG scalar slots (double): [0..k) = ||rhs||^2 ; then per iteration slot it in
 // [0, max_iter]: rho[k], php[k], rn[k].  rn of slot 0 = ||r0||^2.
+// p.Hp is accumulated by one fp64 atomic per SpMV block.  With ~10^3 blocks finishing together, atomics
+// on one address -- or on one 128-byte line -- serialise at the memory side (measured on a 20 us kernel:
+// +16 us with a single address, +7 us with 16 addresses in one line, +0.8 us with 16 addresses on 16
+// lines).  Each column therefore owns PCG_DOT_SLOTS addresses PCG_DOT_STRIDE doubles apart (block b adds
+// to slot b % PCG_DOT_SLOTS) and the consumers sum them.  The slots live in a two-deep ring indexed by
+// the iteration parity: the SpMV of iteration `it` accumulates into ring[it & 1]; the vector update that
+// consumes it (k_pcg_update_x / k_spec_mode0_fwd_upd) clears ring[(it + 1) & 1], whose own reader ran one
+// iteration earlier on the same stream.
+constexpr int PCG_DOT_SLOTS = 16;
+constexpr int PCG_DOT_STRIDE = 16;
+constexpr int PCG_DOT_COL = PCG_DOT_SLOTS * PCG_DOT_STRIDE;   // doubles per column in one ring entry
 struct PcgScal {
   double* base;
   int k;
+  double* ring;     // [2][k][PCG_DOT_COL]
   __host__ __device__ double* rn0() const { return base; }
-  __host__ __device__ double* rho(int it) const { return base + (int64_t)k * (1 + 3 * it); }
-  __host__ __device__ double* php(int it) const { return base + (int64_t)k * (2 + 3 * it); }
-  __host__ __device__ double* rn(int it) const { return base + (int64_t)k * (3 + 3 * it); }
+  __host__ __device__ double* rho(int it) const { return base + (int64_t)k * (1 + 2 * it); }
+  __host__ __device__ double* rn(int it) const { return base + (int64_t)k * (2 + 2 * it); }
+  __host__ __device__ double* php(int it) const { return ring + (int64_t)(it & 1) * k * PCG_DOT_COL; }   // [k][PCG_DOT_COL]
+  __device__ double php_sum(int it, int c) const {
+    const double* q = php(it) + (int64_t)c * PCG_DOT_COL;
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < PCG_DOT_SLOTS; ++j) t += q[j * PCG_DOT_STRIDE];
+    return t;
+  }
+  static int64_t scalars(int k, int max_iter) { return (int64_t)k * (1 + 2 * (int64_t)(max_iter + 2)); }
+  static int64_t doubles(int k, int max_iter) { return scalars(k, max_iter) + 2 * (int64_t)k * PCG_DOT_COL; }
 };
+
+__device__ __forceinline__ void pcg_dot_add(double* dots, int col, double v) {
+  unsafeAtomicAdd(dots + (int64_t)col * PCG_DOT_COL + (blockIdx.x & (PCG_DOT_SLOTS - 1)) * PCG_DOT_STRIDE, v);
+}
+__device__ __forceinline__ void pcg_dot_clear(double* dots_next, int col0, int ncol, int k) {
+  for (int idx = threadIdx.x; idx < ncol * PCG_DOT_COL; idx += blockDim.x) {
+    const int c = col0 + idx / PCG_DOT_COL;
+    if (c < k) dots_next[(int64_t)c * PCG_DOT_COL + idx % PCG_DOT_COL] = 0.0;
+  }
+}
 
 __device__ __forceinline__ bool pcg_active(const PcgScal& S, int it, int c, double tol2) {
   // column still iterating? (rn of the previous slot against the rhs norm)
@@ -185,5 +216,5 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 // Fused CG-iteration front end (d = 3): [apply update_x(it-1)] + mode-0 fwd -> slab (+rho) -> mode-0 bwd (+update_p)
 template <typename real>
 int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
-                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, const real* part, int nch, real* u,
+                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
                              real* z, PcgScal S, hipStream_t s);

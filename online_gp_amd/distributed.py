@@ -40,7 +40,7 @@ class ShardedStatsUpdater:
 
     def _delta_cache(self):
         """Zeroed delta copies of (b, stats); the W^T W delta lives in the model's symmetric
-        half-stencil buffers (half the all-reduce bytes), which the fold pass re-zeroes."""
+        half-stencil delta buffers (half the bytes of a full stencil on the wire)."""
         m = self.model
         if self._delta is None:
             b = torch.zeros_like(m._kernel_cache["interpolation_cache"])
@@ -86,7 +86,11 @@ class ShardedStatsUpdater:
         if "_cnt" in delta and "_cnt" in c:
             c["_cnt"].add_(delta["_cnt"])
         for dst, half in zip(_wtw_ops(c["WtW"]), halves):
-            grid_ops.stencil_expand_add(m._grid, half, dst.stencil)
+            if grid_ops.is_half_stencil(m._grid, dst.stencil):
+                dst.stencil.add_(half)                       # native half storage: plain add
+                half.zero_()
+            else:
+                grid_ops.stencil_expand_add(m._grid, half, dst.stencil)
         tot = count.tolist()
         for o in range(len(tot) - 1):
             m._wsum_host[o] += tot[1 + o]

@@ -196,14 +196,26 @@ def wt_columns(grid, x, err):
     return out
 
 
+def is_half_stencil(grid, A_st):
+    """True for the symmetric half-stencil layout [(R+1)/2, m], False for the full [R, m] one."""
+    rows = A_st.shape[-2]
+    if rows == (grid.R + 1) // 2:
+        return True
+    if rows == grid.R:
+        return False
+    raise ValueError(f"stencil with {rows} rows matches neither the full ({grid.R}) nor the half ({(grid.R + 1) // 2}) layout")
+
+
 def stencil_spmv(grid, A_st, V, add=None, beta=1.0):
+    """A @ V on the block stencil: A_st is either the full [R, m] stencil or the symmetric half [(R+1)/2, m]."""
     V2 = V.contiguous().reshape(-1, grid.m)
     out = torch.empty_like(V2)
     cr = _hip.creal(V2.dtype)
-    rc = _hip.fn("wiski_stencil_spmv", V2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(V2), ctypes.c_int32(V2.shape[0]),
-                                                 _hip.dptr(add.contiguous().reshape(-1, grid.m)) if add is not None else None, cr(beta),
-                                                 _hip.dptr(out), _hip.stream_ptr(V2.device))
-    _hip.check(rc, "wiski_stencil_spmv")
+    name = "wiski_stencil_spmv_sym" if is_half_stencil(grid, A_st) else "wiski_stencil_spmv"
+    rc = _hip.fn(name, V2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(V2), ctypes.c_int32(V2.shape[0]),
+                                 _hip.dptr(add.contiguous().reshape(-1, grid.m)) if add is not None else None, cr(beta),
+                                 _hip.dptr(out), _hip.stream_ptr(V2.device))
+    _hip.check(rc, name)
     return out.reshape(V.shape)
 
 
@@ -290,7 +302,7 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
                                           cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
                                           _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
                                           ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
-                                          _hip.stream_ptr(RHS2.device))
+                                          ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.stream_ptr(RHS2.device))
     if rc == -4 and not raise_on_fail:
         pass
     else:

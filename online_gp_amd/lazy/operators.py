@@ -42,9 +42,12 @@ class _Operator(LazyCovariance):
 
 
 class StencilWtW(_Operator):
-    """W^T D^-1 W in block-stencil form: ``stencil[o, i] = A[i, i + off(o)]`` for
-    the 7^d relative offsets.  Replaces the dense m x m tensor held by the
-    reference's UpdatedRootLazyTensor (updated_root_lazy_tensor.py:42,58)."""
+    """W^T D^-1 W in block-stencil form.  Native storage is the symmetric half
+    ``stencil[oh, i] = A[i, i + off(c + oh)]`` for the (7^d + 1)/2 relative offsets
+    >= the centre c (A is symmetric: every stored entry stands for A[i, j] and
+    A[j, i]); a full ``[7^d, m]`` stencil is accepted too.  Replaces the dense
+    m x m tensor held by the reference's UpdatedRootLazyTensor
+    (updated_root_lazy_tensor.py:42,58)."""
 
     def __init__(self, grid, stencil):
         self.grid = grid
@@ -55,7 +58,19 @@ class StencilWtW(_Operator):
 
     @classmethod
     def zeros(cls, grid, dtype, device):
-        return cls(grid, torch.zeros((grid.R, grid.m), dtype=dtype, device=device))
+        return cls(grid, torch.zeros(((grid.R + 1) // 2, grid.m), dtype=dtype, device=device))
+
+    @property
+    def is_half(self):
+        return grid_ops.is_half_stencil(self.grid, self.stencil)
+
+    def full_stencil(self):
+        """The full [7^d, m] stencil (a copy; diagnostics and tests)."""
+        if not self.is_half:
+            return self.stencil.clone()
+        full = torch.zeros((self.grid.R, self.grid.m), dtype=self.dtype, device=self.device)
+        grid_ops.stencil_expand_add(self.grid, self.stencil.clone(), full)
+        return full
 
     def clone(self):
         return StencilWtW(self.grid, self.stencil.clone())
@@ -68,7 +83,7 @@ class StencilWtW(_Operator):
         return grid_ops.stencil_spmv(self.grid, self.stencil, V).t()
 
     def diag(self):
-        return self.stencil[(self.grid.R - 1) // 2].clone()
+        return self.stencil[0 if self.is_half else (self.grid.R - 1) // 2].clone()
 
 
 class KroneckerToeplitz(_Operator):

@@ -193,7 +193,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         return self._pack_cache(cache["interpolation_cache"].clone(), stats, [op.clone() for op in _wtw_ops(cache["WtW"])], cnt)
 
     def _half_buffers(self):
-        """Per-output symmetric half-stencil delta buffers [(R+1)/2, m] (zero between uses)."""
+        """Per-output symmetric half-stencil delta buffers [(R+1)/2, m] for the data-parallel
+        path (rank-local increment -> all-reduce -> add; zero between uses)."""
         if getattr(self, "_half_delta", None) is None:
             H = (self._grid.R + 1) // 2
             self._half_delta = [torch.zeros((H, self._grid.m), dtype=self._dtype, device=self._device) for _ in range(self.num_outputs)]
@@ -203,10 +204,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """_initialize_caches (:31-60) / _update_cache_dicts (:155-171) fused into
         one scatter launch per output; mutates `cache` in place.
 
-        Batches of >= settings.sym_scatter_min_batch points go through a symmetric
-        half-stencil delta (half the atomics) that is then folded into the full
-        stencil by a streaming pass.  With `half_delta` given (data-parallel path) the
-        W^T W increments are left in those buffers for the caller to all-reduce and fold."""
+        W^T D^-1 W accumulates straight into the symmetric half stencil (T(T+1)/2 atomics
+        per point).  With `half_delta` given (data-parallel path) the increments go to those
+        buffers instead, for the caller to all-reduce and add."""
         X = X.reshape(-1, self._grid.d).to(self._device, self._dtype).contiguous()
         Y = Y.to(self._device, self._dtype)
         if Y.dim() == 1:
@@ -222,8 +222,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         b = cache["interpolation_cache"]
         stats = cache["_stats"]
         ops = _wtw_ops(cache["WtW"])
-        use_half = half_delta is not None or n >= settings.sym_scatter_min_batch.value()
-        bufs = half_delta if half_delta is not None else (self._half_buffers() if use_half else None)
+        dst = half_delta if half_delta is not None else [op.stencil for op in ops]
         if getattr(self, "_scratch_stats", None) is None:
             self._scratch_stats = torch.zeros(2, dtype=torch.float64, device=self._device)
         for o in range(self.num_outputs):
@@ -235,12 +234,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 wb = 1.0 / no
                 wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
             cnt_o = cache["_cnt"][o] if "_cnt" in cache else None     # row sums W^T wa ride on the same launch
-            if use_half:
-                grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], bufs[o], True, cnt_o, stats[o], self._err)
-                if half_delta is None:
-                    grid_ops.stencil_expand_add(self._grid, bufs[o], ops[o].stencil)
-            else:
-                grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], ops[o].stencil, False, cnt_o, stats[o], self._err)
+            half = grid_ops.is_half_stencil(self._grid, dst[o])      # a handed-over cache may carry a full stencil
+            grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], dst[o], half, cnt_o, stats[o], self._err)
             if cache is self._kernel_cache or init:
                 if unit:
                     self._wsum_host[o] += float(n)

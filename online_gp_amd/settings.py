@@ -138,13 +138,6 @@ class dense_small_grids(_feature_flag):
     _state = True
 
 
-class sym_scatter_min_batch(_value_context):
-    """Batches with at least this many points accumulate W^T D^-1 W through the symmetric
-    half-stencil delta (T(T+1)/2 atomics per point + one streaming expand pass)."""
-
-    _global_value = 1024
-
-
 class density_profile_preconditioner(_feature_flag):
     """Model W^T D^-1 W in the CG preconditioner as a kron_q diag(t_q) with t_q the per-dim
     data-density profile (instead of a I): the inducing nodes outside the data box carry no

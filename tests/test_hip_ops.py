@@ -100,17 +100,20 @@ def test_scatter_stats(d, g, tdt, ndt, tol):
     assert np.allclose(stats.cpu().numpy(), B2.c_ld, rtol=max(tol, 1e-12) * 10)
 
 
-@pytest.mark.parametrize("d,g", CASES)
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("d,g", CASES + [(2, 9), (3, 16)])
 @pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
-def test_spmv_and_kron(d, g, tdt, ndt, tol):
+def test_spmv_and_kron(d, g, tdt, ndt, tol, half):
+    """half: the symmetric half-stencil layout (offsets >= centre), the model's native WtW storage."""
     from online_gp_amd import grid_ops
 
     grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
     B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
-    for k in (1, 3, 5, 9, 17, 33):
+    A = _t(B2.A[(grid.R - 1) // 2:] if half else B2.A, tdt)
+    for k in (1, 2, 3, 5, 9, 17, 33):
         V = rng.standard_normal((k, grid.m)).astype(ndt)
         add = rng.standard_normal((k, grid.m)).astype(ndt)
-        out = grid_ops.stencil_spmv(grid, _t(B2.A, tdt), _t(V, tdt), _t(add, tdt), 0.7)
+        out = grid_ops.stencil_spmv(grid, A, _t(V, tdt), _t(add, tdt), 0.7)
         ref = B2.stencil_mv(V.astype(np.float64)) + 0.7 * add.astype(np.float64)
         assert np.abs(out.double().cpu().numpy() - ref).max() < tol * np.abs(ref).max() * 10
         outk = grid_ops.kron_toeplitz_mm(grid, _t(B2.tcol, tdt), _t(V, tdt), 1.3)
@@ -118,10 +121,11 @@ def test_spmv_and_kron(d, g, tdt, ndt, tol):
         assert np.abs(outk.double().cpu().numpy() - refk).max() < tol * np.abs(refk).max() * 10
 
 
+@pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("spectral", [False, True, "profile"])
 @pytest.mark.parametrize("d,g", CASES)
 @pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-8), (torch.float32, np.float32, 2e-3)])
-def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral):
+def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral, half):
     from online_gp_amd import grid_ops
 
     grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
@@ -129,7 +133,7 @@ def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral):
     RHS = np.stack([B2.b, rng.standard_normal(grid.m)])
     Uref, _, _ = B2.solve(RHS, tol=1e-13)
     cg_tol = 1e-10 if tdt == torch.float64 else 1e-6
-    A = _t(B2.A, tdt); tc = _t(B2.tcol, tdt)
+    A = _t(B2.A[(grid.R - 1) // 2:] if half else B2.A, tdt); tc = _t(B2.tcol, tdt)
     kw = dict(eigen=grid_ops.kron_eigen(grid, tc), shift=X.shape[0] / grid.m) if spectral else {}
     if spectral == "profile":      # separable density-profile preconditioner (generalized eigenbasis X, Z)
         prof = [np.clip(0.2 + np.sin(np.linspace(0.1, 3.0, gq)) ** 2, 1e-2, None) for gq in grid.g]
