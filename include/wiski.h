@@ -95,15 +95,22 @@ int wiski_gather_ell_f64(const int32_t* d_idx, const double* d_val, int64_t n, i
 int wiski_scatter_stats_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_st, double* d_stats, int32_t* d_err, void* stream);
 int wiski_scatter_stats_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_st, double* d_stats, int32_t* d_err, void* stream);
 
-/* Same statistics with W^T diag(wa) W accumulated into a symmetric HALF stencil
- * d_A_half[(7^d+1)/2][m] (offsets o >= centre only; half the atomics).  Used as a
- * per-batch delta: wiski_stencil_expand_add folds the delta and its mirror image
- * into the full stencil A_st and zeroes the delta (streaming, no atomics).  The
- * half delta is also what the data-parallel path all-reduces. */
+/* Same statistics with W^T diag(wa) W accumulated into the SYMMETRIC HALF stencil d_A_half --
+ * the model's native WtW storage (replaces the dense m x m tensor of URLT:42,58).  Only stencil
+ * offsets >= the centre are kept ((7^d+1)/2 * m reals: half the atomics of the full form, half the
+ * bytes per product, and the buffer the data-parallel path all-reduces), in the "row-interleaved"
+ * layout: with P the leading d-1 base-7 digits of an offset, s its innermost digit and
+ * g = P - P_centre >= 0,
+ *     g == 0 :  d_A_half[4 i + (s - 3)]                s = 3..6  (s = 3: the diagonal A[i,i])
+ *     g >= 1 :  d_A_half[(7 g - 3) m + 7 i + s]        s = 0..6
+ * holds A[i, i + off(P, s)].  (The 16 innermost-digit combinations of a tap pair then fall into one
+ * 88-byte span, which is what the transaction-bound memory-side atomics want: 72 us vs 208 us per 4096
+ * points at 50^3 against an offset-major half stencil.)  wiski_stencil_expand_add unpacks it into a
+ * full offset-major stencil: A_st += expand(d_A_half), d_A_half = 0. */
 int wiski_scatter_stats_sym_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, double* d_stats, int32_t* d_err, void* stream);
 int wiski_scatter_stats_sym_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_stats, int32_t* d_err, void* stream);
-/* One-launch form used by the model: as above (half != 0: d_A is the symmetric half delta,
- * else the full stencil) and additionally d_cnt[m] += W^T wa, the row sums of the increment
+/* One-launch form used by the model: as above (half != 0: d_A is the symmetric half stencil,
+ * else the full offset-major one) and additionally d_cnt[m] += W^T wa, the row sums of the increment
  * (the preconditioner's data-density statistic; d_cnt may be NULL). */
 int wiski_scatter_stats_cnt_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A, int32_t half, float* d_cnt, double* d_stats, int32_t* d_err, void* stream);
 int wiski_scatter_stats_cnt_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A, int32_t half, double* d_cnt, double* d_stats, int32_t* d_err, void* stream);
@@ -120,9 +127,9 @@ int wiski_wt_columns_f64(const wiski_grid* grid, const double* d_x, int64_t n, d
  * d_out[c] = beta * d_add[c] + A_st . d_V[c]   (d_add may be NULL). */
 int wiski_stencil_spmv_f32(const wiski_grid* grid, const float* d_A_st, const float* d_V, int32_t k, const float* d_add, float beta, float* d_out, void* stream);
 int wiski_stencil_spmv_f64(const wiski_grid* grid, const double* d_A_st, const double* d_V, int32_t k, const double* d_add, double beta, double* d_out, void* stream);
-/* Same product on the symmetric half stencil d_A_half [(7^d+1)/2][m] (the layout of
- * wiski_scatter_stats_sym: only offsets >= centre are stored and every stored entry is used for
- * A[i,j] and A[j,i]); half the HBM bytes of the full form.  d_out must not alias d_V. */
+/* Same product on the symmetric half stencil d_A_half (layout: wiski_scatter_stats_sym); every
+ * stored entry is used for A[i,j] and A[j,i], so a product streams half the HBM bytes of the full
+ * form.  d_out must not alias d_V. */
 int wiski_stencil_spmv_sym_f32(const wiski_grid* grid, const float* d_A_half, const float* d_V, int32_t k, const float* d_add, float beta, float* d_out, void* stream);
 int wiski_stencil_spmv_sym_f64(const wiski_grid* grid, const double* d_A_half, const double* d_V, int32_t k, const double* d_add, double beta, double* d_out, void* stream);
 
@@ -168,8 +175,8 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  * the interp/scatter/gather entry points; its value rides on the last poll into *h_err, so the
  * caller needs no separate device-to-host read to raise the reference's RuntimeError.
  * Not re-entrant across host threads (one poll buffer per process).
- * a_sym != 0: d_A_st is the symmetric half stencil [(7^d+1)/2][m] (wiski_stencil_spmv_sym) instead of
- * the full [7^d][m] one.
+ * a_sym != 0: d_A_st is the symmetric half stencil (wiski_scatter_stats_sym layout) instead of
+ * the full offset-major [7^d][m] one.
  * workspace: wiski_pcg_workspace_bytes(...) bytes of device scratch.
  * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
  * be NULL): final relative residuals. */

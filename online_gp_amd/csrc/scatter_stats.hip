@@ -9,10 +9,9 @@
 // GRP = min(T, 64) lanes cooperate on one point (lane <-> tap a); each lane
 // walks all taps b and issues fire-and-forget L2 atomics on A_st[o(a,b)][idx_a].
 // Tap values are exchanged through LDS (broadcast reads, conflict-free).
-// HALF: A_st is a symmetric half-stencil delta [ (7^d+1)/2 ][m] holding only the offsets
-// o >= centre (pairs with code(b) >= code(a)); T(T+1)/2 atomics per point instead of T^2.
-// k_stencil_expand_add folds it (and its mirror image) into the full stencil.
-template <typename real, int D, bool HALF>
+// This is the full offset-major form A_st[o][i] (all 7^d offsets, T^2 atomics per point); the model itself
+// keeps the symmetric half (k_scatter_stats_sym below: T(T+1)/2 atomics, ~5x faster).
+template <typename real, int D>
 __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const real* __restrict__ x, const real* __restrict__ y,
                                                        const real* __restrict__ wa, const real* __restrict__ wb,
                                                        const real* __restrict__ noise, int64_t n, real* __restrict__ b,
@@ -99,11 +98,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
 #pragma unroll
               for (int q = 0; q < D; ++q) codeb = codeb * 7 + ((bb >> (2 * (D - 1 - q))) & 3);
               const real vb = s_val[loc][bb];
-              if (HALF) {
-                if (codeb >= code_a[t] && vb != (real)0) atomic_add_real(Arow + (int64_t)(codeb - code_a[t]) * G.m, va * vb);
-              } else {
-                if (vb != (real)0) atomic_add_real(Arow + (int64_t)(obase + codeb) * G.m, va * vb);
-              }
+              if (vb != (real)0) atomic_add_real(Arow + (int64_t)(obase + codeb) * G.m, va * vb);
             }
           }
         }
@@ -120,8 +115,140 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
   if (bad) atomicOr(err, 1);
 }
 
-// full[c + oh][i] += half[oh][i];  full[c - oh][i + off(oh)] += half[oh][i] (oh > 0);  half[oh][i] = 0.
-// Pure streaming: every full entry is touched by exactly one (oh, i), so no atomics.
+// Symmetric half-stencil accumulation (the model's native W^T D^-1 W storage), "row-interleaved" layout:
+// with P = the leading d-1 stencil digits of an offset and s its innermost digit, only offsets >= centre
+// are kept, grouped by g = P - P_centre:
+//   group 0      :  A_h[4 i + (s - 3)]                 s = 3..6   (4 reals per row; s = 3 is the diagonal)
+//   group g >= 1 :  A_h[(7 g - 3) m + 7 i + s]         s = 0..6   (7 reals per row)
+// -- (7^d + 1)/2 * m reals in total, the same as a row-major [(7^d+1)/2][m] half stencil.  The layout is
+// chosen for this kernel: one wave per point, lane = (a2, b2, pair slot) with a2/b2 the innermost tap
+// digits of taps a/b, looping over the (prefix_a <= prefix_b) pairs four at a time.  The 16 (a2, b2)
+// combinations of a pair land in one 88-byte span (rows i..i+3 x 7 slots), so a wave instruction touches
+// ~9 cache lines with ~7 lanes each instead of 16 lines with 4 lanes (offset-major layout) -- measured
+// 72 us vs 208 us per 4096 uniform points at 50^3 (the memory-side atomic units are transaction-bound).
+// The stencil SpMV re-tiles the 7-wide rows through LDS (solve.hip).
+template <typename real, int D>
+__global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, const real* __restrict__ x, const real* __restrict__ y,
+                                                           const real* __restrict__ wa, const real* __restrict__ wb,
+                                                           const real* __restrict__ noise, int64_t n, real* __restrict__ b,
+                                                           real* __restrict__ A, double* __restrict__ stats, int32_t* __restrict__ err,
+                                                           real* __restrict__ cnt) {
+  constexpr int T = 1 << (2 * D);
+  constexpr int TP = T / 4;                      // tap prefixes (leading d-1 digits)
+  constexpr int NPAIR = TP * (TP + 1) / 2;       // prefix pairs with code(pb) >= code(pa)
+  constexpr int TPL = T > 64 ? T / 64 : 1;       // taps per lane when filling the per-point tables
+  __shared__ real s_val[4][T];
+  __shared__ int s_idx[4][T];
+  __shared__ int s_pair[NPAIR];                  // pa | pb << 8 | g << 16
+  __shared__ int s_scan[4];
+  __shared__ double s_red[16];
+  const int lane = threadIdx.x & 63, loc = threadIdx.x >> 6;
+  {  // compact list of the valid prefix pairs (block-cooperative stream compaction)
+    int running = 0;
+    for (int base = 0; base < TP * TP; base += 256) {
+      const int idx = base + threadIdx.x;
+      const int pa = idx / TP, pb = idx % TP;
+      int ca = 0, cb = 0;
+#pragma unroll
+      for (int q = 0; q < D - 1; ++q) {
+        ca = ca * 7 + ((pa >> (2 * (D - 2 - q))) & 3);
+        cb = cb * 7 + ((pb >> (2 * (D - 2 - q))) & 3);
+      }
+      const bool ok = idx < TP * TP && cb >= ca;
+      const unsigned long long mask = __ballot(ok);
+      if (lane == 0) s_scan[loc] = __popcll(mask);
+      __syncthreads();
+      int off = running;
+      for (int w = 0; w < loc; ++w) off += s_scan[w];
+      if (ok) s_pair[off + __popcll(mask & ((1ull << lane) - 1ull))] = pa | (pb << 8) | ((cb - ca) << 16);
+      running += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+      __syncthreads();
+    }
+  }
+  double c_acc = 0, ld_acc = 0;
+  bool bad = false;
+  const int64_t m = G.m;
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < n; base += (int64_t)gridDim.x * 4) {
+    const int64_t p = base + loc;
+    const bool valid = p < n;
+    int j0[D];
+    real w[D][4];
+    real yp = 0, wap = 0, wbp = 0;
+    if (valid) {
+      real xp[D];
+#pragma unroll
+      for (int q = 0; q < D; ++q) xp[q] = x[p * D + q];
+      if (!point_stencil<real, D>(G, xp, j0, w)) bad = true;
+      yp = y[p];
+      wap = wa[p];
+      wbp = wb[p];
+      if (lane == 0) {
+        c_acc += (double)yp * (double)yp * (double)wbp;
+        ld_acc += log((double)noise[p]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        j0[q] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[q][c] = 0;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPL; ++t) {
+      const int a = lane + t * 64;
+      if (a < T) {
+        int flat = 0;
+        real v = (real)1;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          const int c = (a >> (2 * (D - 1 - q))) & 3;
+          flat += (j0[q] + c) * G.stride[q];
+          v *= w[q][c];
+        }
+        s_val[loc][a] = v;
+        s_idx[loc][a] = flat;
+        if (valid && v != (real)0) {
+          atomic_add_real(b + flat, v * yp * wbp);
+          if (cnt) atomic_add_real(cnt + flat, v * wap);     // row sums of the increment (preconditioner density model)
+        }
+      }
+    }
+    __syncthreads();
+    if (valid && A) {
+      const int a2 = lane & 3, b2 = (lane >> 2) & 3, ps = lane >> 4;
+#pragma unroll 2
+      for (int t0 = 0; t0 < NPAIR; t0 += 4) {
+        const int t = t0 + ps;
+        if (t < NPAIR) {
+          const int pk = s_pair[t];
+          const int g = pk >> 16;
+          const int a = (pk & 0xff) * 4 + a2;
+          const real v = wap * s_val[loc][a] * s_val[loc][((pk >> 8) & 0xff) * 4 + b2];
+          const int64_t row = s_idx[loc][a];
+          if (g == 0) {
+            if (b2 >= a2 && v != (real)0) atomic_add_real(A + row * 4 + (b2 - a2), v);
+          } else if (v != (real)0) {
+            atomic_add_real(A + (int64_t)(7 * g - 3) * m + row * 7 + (b2 - a2 + 3), v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double c_tot = block_reduce_sum(c_acc, s_red);
+  double ld_tot = block_reduce_sum(ld_acc, s_red);
+  if (threadIdx.x == 0 && (c_tot != 0 || ld_tot != 0)) {
+    unsafeAtomicAdd(stats + 0, c_tot);
+    unsafeAtomicAdd(stats + 1, ld_tot);
+  }
+  if (bad) atomicOr(err, 1);
+}
+
+// Unpacks the row-interleaved half stencil into a full offset-major stencil full[o][i] = A[i, i + off(o)]
+// (diagnostics, tests, and models handed a full-stencil cache):
+//   full[c + oh][i] += h(oh, i);  full[c - oh][i + off(oh)] += h(oh, i) (oh > 0);  h(oh, i) = 0.
+// Every full entry is touched by exactly one (oh, i), so no atomics.
 template <typename real>
 __global__ __launch_bounds__(256) void k_stencil_expand_add(GridDev<real> G, real* __restrict__ half, real* __restrict__ full) {
   const int m = G.m, d = G.d;
@@ -133,18 +260,20 @@ __global__ __launch_bounds__(256) void k_stencil_expand_add(GridDev<real> G, rea
     off += (rem % 7 - 3) * G.stride[q];
     rem /= 7;
   }
-  real* __restrict__ h = half + (int64_t)oh * m;
+  const int g = oh < 4 ? 0 : (oh - 4) / 7 + 1;
+  real* __restrict__ h = oh < 4 ? half + oh : half + (int64_t)(7 * g - 3) * m + (oh - 4) % 7;
+  const int hs = oh < 4 ? 4 : 7;
   real* __restrict__ fd = full + (int64_t)(c + oh) * m;
   real* __restrict__ fm = full + (int64_t)(c - oh) * m;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    const real v = h[i];
+    const real v = h[(int64_t)i * hs];
     if (v != (real)0) {
       fd[i] += v;
       if (oh > 0) {
         const int j = i + off;
         if (j >= 0 && j < m) fm[j] += v;
       }
-      h[i] = (real)0;
+      h[(int64_t)i * hs] = (real)0;
     }
   }
 }
@@ -172,15 +301,15 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   if (rc) return rc;
   if (n == 0) return WISKI_OK;
   if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
-  const int grp = G.T < 64 ? G.T : 64;
+  const int grp = half ? 64 : (G.T < 64 ? G.T : 64);
   const int64_t ppb = 256 / grp;
   int64_t blocks = (n + ppb - 1) / ppb;
   if (blocks > 256 * 8) blocks = 256 * 8;
   dim3 grd((unsigned)blocks);
 #define CALL(DD)                                                                                                                              \
   do {                                                                                                                                        \
-    if (half) hipLaunchKernelGGL((k_scatter_stats<real, DD, true>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt); \
-    else hipLaunchKernelGGL((k_scatter_stats<real, DD, false>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
+    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt); \
+    else hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
   } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
 #undef CALL

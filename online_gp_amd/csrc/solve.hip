@@ -435,12 +435,14 @@ static int launch_spmv4(const GridDev<real>& G, const real* A_st, const real* V,
 }
 
 // ------------------------------------- symmetric half-stencil SpMV (native WtW storage) ---
-// A = W^T D^-1 W is symmetric, so only the offsets o >= centre are stored:
-//   A_h[oh][i] = A[i, i + off(c + oh)],  oh = 0 .. (R-1)/2      (the layout k_scatter_stats<HALF> accumulates)
+// A = W^T D^-1 W is symmetric, so only the offsets o >= centre are stored, a(oh, i) = A[i, i + off(c + oh)],
+// oh = 0 .. (R-1)/2, in the row-interleaved layout k_scatter_stats_sym accumulates (scatter_stats.hip):
+//   oh < 4            : A_h[4 i + oh]                          (group 0: innermost digits 3..6 of the centre prefix)
+//   oh = 7 g - 3 + s  : A_h[(7 g - 3) m + 7 i + s]             (group g >= 1, s = 0..6)
 // and every stored entry is used twice,
-//   out[i]          += A_h[oh][i] * v[i + off]        ("direct")
-//   out[i + off]    += A_h[oh][i] * v[i]              ("transposed", oh > 0)
-// which halves the HBM bytes of the product (and of the model state, and drops the fold pass after a scatter).
+//   out[i]          += a(oh, i) * v[i + off]        ("direct")
+//   out[i + off]    += a(oh, i) * v[i]              ("transposed", oh > 0)
+// which halves the HBM bytes of the product (and of the model state).
 //
 // Generic form (any m, any d): one thread per output row gathers both terms; the transposed one re-reads
 // A_h at row i - off (L2 hits for the small offsets).  Used for m % 4 != 0.
@@ -449,9 +451,11 @@ __global__ __launch_bounds__(256) void k_stencil_spmv_sym(GridDev<real> G, const
                                                           const real* __restrict__ add, real beta, real* __restrict__ out,
                                                           double* __restrict__ dots) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_off = reinterpret_cast<int*>(smem);
   const int R = G.R, m = G.m, d = G.d;
   const int H = (R + 1) / 2, ctr = (R - 1) / 2;
+  int64_t* s_base = reinterpret_cast<int64_t*>(smem);        // a(oh, i) = A_h[s_base[oh] + i * s_str[oh]]
+  int* s_off = reinterpret_cast<int*>(s_base + H);
+  int* s_str = s_off + H;
   for (int oh = threadIdx.x; oh < H; oh += blockDim.x) {
     int rem = ctr + oh, f = 0;
     for (int q = d - 1; q >= 0; --q) {
@@ -460,6 +464,9 @@ __global__ __launch_bounds__(256) void k_stencil_spmv_sym(GridDev<real> G, const
       f += (c - 3) * G.stride[q];
     }
     s_off[oh] = f;
+    const int g = oh < 4 ? 0 : (oh - 4) / 7 + 1;
+    s_base[oh] = oh < 4 ? (int64_t)oh : (int64_t)(7 * g - 3) * m + (oh - 4) % 7;
+    s_str[oh] = oh < 4 ? 4 : 7;
   }
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,13 +478,14 @@ __global__ __launch_bounds__(256) void k_stencil_spmv_sym(GridDev<real> G, const
 #pragma unroll 4
     for (int oh = 0; oh < H; ++oh) {
       const int off = s_off[oh];
-      const real* __restrict__ a_row = A_h + (int64_t)oh * m;
-      const real a = a_row[i];
+      const real* __restrict__ a_row = A_h + s_base[oh];
+      const int64_t st = s_str[oh];
+      const real a = a_row[i * st];
       int j = i + off;
       j = j < 0 ? 0 : (j >= m ? m - 1 : j);
       const int jt = i - off;
       const bool tr = oh > 0 && jt >= 0 && jt < m;
-      const real at = tr ? a_row[jt] : (real)0;
+      const real at = tr ? a_row[jt * st] : (real)0;
       const int jtc = tr ? jt : i;
 #pragma unroll
       for (int c = 0; c < KC; ++c)
@@ -495,8 +503,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv_sym(GridDev<real> G, const
       if (DOT) part = (double)V[e] * (double)r;
     }
     if (DOT) {
-      double* s_red = reinterpret_cast<double*>(smem);
-      __syncthreads();
+      __shared__ double s_red[16];
       double tot = block_reduce_sum(part, s_red);
       if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
     }
@@ -508,8 +515,7 @@ static int launch_spmv_sym(const GridDev<real>& G, const real* A_h, const real* 
                            hipStream_t s) {
   const int kc = k >= 4 ? 4 : (k >= 2 ? 2 : 1);
   dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)((k + kc - 1) / kc));
-  size_t sh = (size_t)((G.R + 1) / 2) * sizeof(int);
-  if (sh < 16 * sizeof(double)) sh = 16 * sizeof(double);
+  const size_t sh = (size_t)((G.R + 1) / 2) * (sizeof(int64_t) + 2 * sizeof(int));
 #define SPMV(KC)                                                                                                                 \
   do {                                                                                                                           \
     if (dots) hipLaunchKernelGGL((k_stencil_spmv_sym<real, KC, true>), grd, dim3(256), sh, s, G, A_h, V, k, add, beta, out, dots); \
@@ -583,7 +589,9 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
   const int gA = (int)((int64_t)ch * ng / nch), gB = (int)((int64_t)(ch + 1) * ng / nch);
   const int cP = ng - 1;                        // prefix code of the centre: (7^(d-1) - 1) / 2
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  real* __restrict__ tw = reinterpret_cast<real*>(smem) + (size_t)wave * KC * 4 * W4;   // this wave's [KC][4][W4] window
+  constexpr int STAGE = 7 * 256;                // reals of one group tile of a wave
+  real* __restrict__ stage = reinterpret_cast<real*>(smem) + (size_t)wave * (STAGE + KC * 4 * W4);   // this wave's A tile
+  real* __restrict__ tw = stage + STAGE;                                                           // and its [KC][4][W4] window
   for (int g = gA + t; g < gB; g += blockDim.x) {
     int rem = cP + g, f = 0;
     for (int q = d - 2; q >= 0; --q) {
@@ -629,20 +637,54 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[c][r] = dg[c][r] = (real)0;
   }
-  // one group's operands: 7 x 16 bytes of A_h and the 10-wide window of v.  (Issuing the next group's
-  // loads before consuming the current one was measured: no gain at 50^3 fp32, 10% slower at 30^4 fp64.)
+  // one group's operands: 4 rows x 7 innermost offsets of A_h and the 10-wide window of v.  A_h keeps a
+  // row's 7 offsets adjacent (the scatter's layout), so the wave reads its 256 rows x 7 reals as one
+  // contiguous span with fully coalesced 16-byte loads, parks it in a wave-private LDS tile and reads it
+  // back row-wise: lane t gets the 28 reals of rows 4t..4t+3 (7 x ds_read_b128, stride 112 B: bank-
+  // conflict free).  (Issuing the next group's loads before consuming the current one was measured on the
+  // offset-major predecessor of this kernel: no gain at 50^3 fp32, 10% slower at 30^4 fp64.)
   struct GroupData {
-    Vec4<real> a[7];
+    Vec4<real> a[7];       // a[s].{x,y,z,w} = rows i4..i4+3 at innermost offset digit s
     real win[KC][10];
   };
+  const int nrows = m - iw0 < 256 ? m - iw0 : 256;      // rows of this wave inside the grid (multiple of 4, may be <= 0)
   auto fetch = [&](int g, GroupData& D) {
     const int f = s_off[g - gA];
-    const int first = g == 0 ? 3 : 0;       // the centre group stores the innermost digits 3..6 only
-    const real* __restrict__ a_grp = A_h + (g == 0 ? (int64_t)0 : (int64_t)(7 * g - 3) * m) + i4;
+    if (g == 0) {
+      // centre group: 4 reals per row (digits 3..6), rows i4..i4+3 are 16 contiguous reals
+      Vec4<real> q[4];
 #pragma unroll
-    for (int l = 0; l < 7; ++l) {
-      if (l >= first) D.a[l] = load4<real>(a_grp + (int64_t)(l - first) * m);
-      else D.a[l].x = D.a[l].y = D.a[l].z = D.a[l].w = (real)0;
+      for (int r = 0; r < 4; ++r) {
+        if (live) q[r] = load4<real>(A_h + (int64_t)4 * i4 + 4 * r);
+        else q[r].x = q[r].y = q[r].z = q[r].w = (real)0;
+      }
+#pragma unroll
+      for (int l = 0; l < 3; ++l) D.a[l].x = D.a[l].y = D.a[l].z = D.a[l].w = (real)0;
+      D.a[3].x = q[0].x; D.a[3].y = q[1].x; D.a[3].z = q[2].x; D.a[3].w = q[3].x;
+      D.a[4].x = q[0].y; D.a[4].y = q[1].y; D.a[4].z = q[2].y; D.a[4].w = q[3].y;
+      D.a[5].x = q[0].z; D.a[5].y = q[1].z; D.a[5].z = q[2].z; D.a[5].w = q[3].z;
+      D.a[6].x = q[0].w; D.a[6].y = q[1].w; D.a[6].z = q[2].w; D.a[6].w = q[3].w;
+    } else {
+      const real* __restrict__ src = A_h + (int64_t)(7 * g - 3) * m + (int64_t)7 * iw0;
+      Vec4<real> ld[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int e = 4 * (64 * j + lane);
+        if (e < 7 * nrows) ld[j] = load4<real>(src + e);
+        else ld[j].x = ld[j].y = ld[j].z = ld[j].w = (real)0;
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) store4<real>(stage + 4 * (64 * j + lane), ld[j].x, ld[j].y, ld[j].z, ld[j].w);
+      wave_lds_fence();
+      real v[28];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const Vec4<real> t4 = load4<real>(stage + 28 * lane + 4 * j);
+        v[4 * j + 0] = t4.x; v[4 * j + 1] = t4.y; v[4 * j + 2] = t4.z; v[4 * j + 3] = t4.w;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int l = 0; l < 7; ++l) { D.a[l].x = v[l]; D.a[l].y = v[7 + l]; D.a[l].z = v[14 + l]; D.a[l].w = v[21 + l]; }
     }
     const int base = i4 + f - 3;
 #pragma unroll
@@ -661,8 +703,8 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
       flush(wb);
       wb = f;
     }
+    if (nrows > 0) fetch(g, cur);         // wave-cooperative (all lanes), rows past the grid read as zeros
     if (live) {
-      fetch(g, cur);
       real tr[KC][10];
 #pragma unroll
       for (int c = 0; c < KC; ++c)
@@ -737,15 +779,23 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
   // window span: one full cycle of the second-to-last stencil digit, shrunk to fit 48 KB of LDS
   int span = G.d >= 2 ? 6 * G.stride[G.d - 2] : 0;
   const int bs = sym_block(), nw = bs / 64;
-  const int cap = (int)(48 * 1024 / (nw * kc * sizeof(real))) - 256 - 32;   // nw wave-private windows per block
+  // per wave: a 7 x 256 tile of A_h plus kc windows; the windows are shrunk to keep a block within 64 KB
+  const int cap = (int)((64 * 1024 / (nw * sizeof(real)) - 7 * 256) / kc) - 256 - 32;
   if (span > cap) span = cap > 0 ? cap : 0;
   const int W4 = ((256 + span + 10 + 3) / 4) | 1;
-  const size_t sh = (size_t)nw * kc * 4 * W4 * sizeof(real);
+  const size_t sh = (size_t)nw * (7 * 256 + kc * 4 * W4) * sizeof(real);
   dim3 grd((unsigned)((G.m + 4 * bs - 1) / (4 * bs)), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
   const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
 #define SPMV4S(KC)                                                                                                                              \
   do {                                                                                                                                          \
+    static size_t lds_set[2] = {0, 0};   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                \
+    const int di = dots ? 1 : 0;                                                                                                                \
+    if (sh > 48 * 1024 && sh > lds_set[di]) {                                                                                                   \
+      const void* fn = dots ? (const void*)k_stencil_spmv4_sym<real, KC, true> : (const void*)k_stencil_spmv4_sym<real, KC, false>;             \
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return WISKI_E_LAUNCH;                   \
+      lds_set[di] = sh;                                                                                                                         \
+    }                                                                                                                                           \
     if (dots) hipLaunchKernelGGL((k_stencil_spmv4_sym<real, KC, true>), grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots); \
     else hipLaunchKernelGGL((k_stencil_spmv4_sym<real, KC, false>), grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);   \
   } while (0)

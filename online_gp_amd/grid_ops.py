@@ -206,8 +206,32 @@ def is_half_stencil(grid, A_st):
     raise ValueError(f"stencil with {rows} rows matches neither the full ({grid.R}) nor the half ({(grid.R + 1) // 2}) layout")
 
 
+def half_stencil_from_offset_major(grid, A_om):
+    """Offset-major half stencil ``A_om[oh, i] = A[i, i + off(c + oh)]`` ([(R+1)/2, m], e.g. the upper half of
+    the oracle's full stencil) -> the native row-interleaved layout of wiski_scatter_stats_sym (same shape,
+    different memory order: see include/wiski.h)."""
+    H, m = A_om.shape
+    flat = torch.empty(H * m, dtype=A_om.dtype, device=A_om.device)
+    flat[:4 * m] = A_om[:4].t().reshape(-1)
+    if H > 4:
+        flat[4 * m:] = A_om[4:].reshape(-1, 7, m).transpose(1, 2).reshape(-1)
+    return flat.view(H, m)
+
+
+def half_stencil_to_offset_major(grid, A_h):
+    """Inverse of :func:`half_stencil_from_offset_major`."""
+    H, m = A_h.shape
+    flat = A_h.reshape(-1)
+    out = torch.empty((H, m), dtype=A_h.dtype, device=A_h.device)
+    out[:4] = flat[:4 * m].view(m, 4).t()
+    if H > 4:
+        out[4:] = flat[4 * m:].view(-1, m, 7).transpose(1, 2).reshape(H - 4, m)
+    return out
+
+
 def stencil_spmv(grid, A_st, V, add=None, beta=1.0):
-    """A @ V on the block stencil: A_st is either the full [R, m] stencil or the symmetric half [(R+1)/2, m]."""
+    """A @ V on the block stencil: A_st is either the full offset-major [R, m] stencil or the symmetric half
+    ([(R+1)/2, m] reals in the native row-interleaved layout)."""
     V2 = V.contiguous().reshape(-1, grid.m)
     out = torch.empty_like(V2)
     cr = _hip.creal(V2.dtype)

@@ -42,11 +42,14 @@ class _Operator(LazyCovariance):
 
 
 class StencilWtW(_Operator):
-    """W^T D^-1 W in block-stencil form.  Native storage is the symmetric half
-    ``stencil[oh, i] = A[i, i + off(c + oh)]`` for the (7^d + 1)/2 relative offsets
-    >= the centre c (A is symmetric: every stored entry stands for A[i, j] and
-    A[j, i]); a full ``[7^d, m]`` stencil is accepted too.  Replaces the dense
-    m x m tensor held by the reference's UpdatedRootLazyTensor
+    """W^T D^-1 W in block-stencil form.  Native storage is the symmetric half: the
+    (7^d + 1)/2 relative offsets >= the centre (A is symmetric: every stored entry
+    stands for A[i, j] and A[j, i]) as ``(7^d + 1)/2 * m`` reals in the
+    row-interleaved layout of ``wiski_scatter_stats_sym`` (include/wiski.h) -- the
+    ``[(7^d + 1)/2, m]`` shape of ``stencil`` only carries the size, its rows are
+    not offsets; ``grid_ops.half_stencil_to_offset_major`` converts.  A full
+    offset-major ``[7^d, m]`` stencil is accepted too.  Replaces the dense m x m
+    tensor held by the reference's UpdatedRootLazyTensor
     (updated_root_lazy_tensor.py:42,58)."""
 
     def __init__(self, grid, stencil):
@@ -83,7 +86,9 @@ class StencilWtW(_Operator):
         return grid_ops.stencil_spmv(self.grid, self.stencil, V).t()
 
     def diag(self):
-        return self.stencil[0 if self.is_half else (self.grid.R - 1) // 2].clone()
+        if self.is_half:                      # group 0 of the interleaved layout: 4 reals per row, the first is A[i, i]
+            return self.stencil.reshape(-1)[0:4 * self.grid.m:4].clone()
+        return self.stencil[(self.grid.R - 1) // 2].clone()
 
 
 class KroneckerToeplitz(_Operator):

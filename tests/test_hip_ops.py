@@ -109,7 +109,9 @@ def test_spmv_and_kron(d, g, tdt, ndt, tol, half):
 
     grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
     B2.absorb(X.astype(np.float64), y.astype(np.float64), noise.astype(np.float64), init=True)
-    A = _t(B2.A[(grid.R - 1) // 2:] if half else B2.A, tdt)
+    A = _t(B2.A, tdt)
+    if half:
+        A = grid_ops.half_stencil_from_offset_major(grid, A[(grid.R - 1) // 2:].contiguous())
     for k in (1, 2, 3, 5, 9, 17, 33):
         V = rng.standard_normal((k, grid.m)).astype(ndt)
         add = rng.standard_normal((k, grid.m)).astype(ndt)
@@ -133,7 +135,9 @@ def test_pcg_against_oracle_and_warm_start(d, g, tdt, ndt, tol, spectral, half):
     RHS = np.stack([B2.b, rng.standard_normal(grid.m)])
     Uref, _, _ = B2.solve(RHS, tol=1e-13)
     cg_tol = 1e-10 if tdt == torch.float64 else 1e-6
-    A = _t(B2.A[(grid.R - 1) // 2:] if half else B2.A, tdt); tc = _t(B2.tcol, tdt)
+    A = _t(B2.A, tdt); tc = _t(B2.tcol, tdt)
+    if half:
+        A = grid_ops.half_stencil_from_offset_major(grid, A[(grid.R - 1) // 2:].contiguous())
     kw = dict(eigen=grid_ops.kron_eigen(grid, tc), shift=X.shape[0] / grid.m) if spectral else {}
     if spectral == "profile":      # separable density-profile preconditioner (generalized eigenbasis X, Z)
         prof = [np.clip(0.2 + np.sin(np.linspace(0.1, 3.0, gq)) ** 2, 1e-2, None) for gq in grid.g]
@@ -167,7 +171,7 @@ def test_wt_columns():
 @pytest.mark.parametrize("d,g", CASES)
 @pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
 def test_symmetric_half_scatter_and_expand(d, g, tdt, ndt, tol):
-    """half-stencil delta + streaming fold == direct full-stencil scatter == oracle."""
+    """symmetric half-stencil scatter (row-interleaved layout) + unpack == direct full-stencil scatter == oracle."""
     from online_gp_amd import grid_ops
 
     grid, X, y, noise, B2, rng = _setup(d, g, tdt, ndt)
@@ -181,7 +185,11 @@ def test_symmetric_half_scatter_and_expand(d, g, tdt, ndt, tol):
     w = _t(1.0 / noise.astype(np.float64), tdt)
     grid_ops.scatter_stats_sym(grid, _t(X, tdt), _t(y, tdt), w, w, _t(noise, tdt), b, half, stats, err)
     c = (grid.R - 1) // 2
-    assert np.abs(half.double().cpu().numpy() - B2.A[c:]).max() < tol * np.abs(B2.A).max() * 10
+    half_om = grid_ops.half_stencil_to_offset_major(grid, half)
+    assert np.abs(half_om.double().cpu().numpy() - B2.A[c:]).max() < tol * np.abs(B2.A).max() * 10
+    assert torch.equal(grid_ops.half_stencil_from_offset_major(grid, half_om), half)      # layout converters are inverses
+    diag = half.reshape(-1)[0:4 * grid.m:4]
+    assert np.abs(diag.double().cpu().numpy() - B2.A[c]).max() < tol * np.abs(B2.A).max() * 10
     grid_ops.stencil_expand_add(grid, half, full)
     assert float(half.abs().max()) == 0.0
     assert np.abs(full.double().cpu().numpy() - B2.A).max() < tol * np.abs(B2.A).max() * 10

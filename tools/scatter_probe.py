@@ -24,3 +24,4 @@ for name, X in (("uniform", torch.rand(q, 3, device=dev) * 2 - 1), ("one cell", 
     tf = tm(lambda: grid_ops.scatter_stats(grid, X, y, ones, ones, ones, b, full, stats, err))
     print(f"{name:15s} half {th:7.1f} us   full {tf:7.1f} us")
 print("expand", tm(lambda: grid_ops.stencil_expand_add(grid, half, full)), "us (after zeroing: nothing to fold)")
+
