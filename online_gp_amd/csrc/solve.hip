@@ -1128,22 +1128,55 @@ __global__ void k_pcg_publish(PcgScal S, int slot, double* __restrict__ poll, co
   if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<long long*>(poll), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
+// One launch instead of two hipMemsetAsync (each costs ~5 us of stream time): zero the scalar block and,
+// on the half-stencil path, the atomically accumulated partial vector.
 template <typename real>
+__global__ __launch_bounds__(256) void k_pcg_zero(double* __restrict__ scal, int64_t nscal, real* __restrict__ vec, int64_t nvec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = i; e < nscal; e += stride) scal[e] = 0.0;
+  for (int64_t e = i; e < nvec; e += stride) vec[e] = (real)0;
+}
+
+// r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
+// VEC = 4: 16-byte accesses (requires m % 4 == 0), all loads of a thread independent.
+template <typename real, int VEC>
 __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, real* __restrict__ part,
                                                   int nch, int zl, real* __restrict__ r, PcgScal S) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
+  const int64_t km = (int64_t)S.k * m;
   double a = 0, bsum = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < m; i += gridDim.x * blockDim.x * VEC) {
     const int64_t e = (int64_t)c * m + i;
-    const real f = rhs[e];
-    real rr = t ? f - t[e] : f;
-    for (int ch = 0; ch < nch; ++ch) rr -= part[(int64_t)ch * S.k * m + e];
-    if (zl) part[(int64_t)(nch - 1) * S.k * m + e] = (real)0;
-    r[e] = rr;
-    a += (double)f * f;
-    bsum += (double)rr * rr;
+    real f[VEC], rr[VEC];
+    if constexpr (VEC == 4) {
+      const Vec4<real> f4 = load4<real>(rhs + e);
+      f[0] = f4.x; f[1] = f4.y; f[2] = f4.z; f[3] = f4.w;
+      Vec4<real> t4;
+      t4.x = t4.y = t4.z = t4.w = (real)0;
+      if (t) t4 = load4<real>(t + e);
+      Vec4<real> pp[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch)
+        if (ch < nch) pp[ch] = load4<real>(part + (int64_t)ch * km + e);
+      if (zl) store4<real>(part + (int64_t)(nch - 1) * km + e, (real)0, (real)0, (real)0, (real)0);
+      rr[0] = f[0] - t4.x; rr[1] = f[1] - t4.y; rr[2] = f[2] - t4.z; rr[3] = f[3] - t4.w;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch)
+        if (ch < nch) { rr[0] -= pp[ch].x; rr[1] -= pp[ch].y; rr[2] -= pp[ch].z; rr[3] -= pp[ch].w; }
+      store4<real>(r + e, rr[0], rr[1], rr[2], rr[3]);
+    } else {
+      f[0] = rhs[e];
+      rr[0] = t ? f[0] - t[e] : f[0];
+      for (int ch = 0; ch < nch; ++ch) rr[0] -= part[(int64_t)ch * km + e];
+      if (zl) part[(int64_t)(nch - 1) * km + e] = (real)0;
+      r[e] = rr[0];
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      a += (double)f[q] * f[q];
+      bsum += (double)rr[q] * rr[q];
+    }
   }
   a = block_reduce_sum(a, s_red);
   bsum = block_reduce_sum(bsum, s_red);
@@ -1310,15 +1343,18 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   // atomically accumulated transposed term: zero here, re-zeroed by every consumer (zl)
   const int nch = wide ? (sym ? sym_nch(G.d) + 1 : spmv_nch(G.d)) : 0;
   const int zl = wide && sym ? 1 : 0;
-  if (zl && hipMemsetAsync(part + (int64_t)(nch - 1) * k * m, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
   auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) {
     return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
   };
   auto spmv_narrow = [&](const real* v, const real* add, real beta, real* out, double* dots) {
     return sym ? launch_spmv_sym<real>(G, d_A, v, k, add, beta, out, dots, s) : launch_spmv<real>(G, d_A, v, k, add, beta, out, dots, s);
   };
-  const int64_t scal_bytes = PcgScal::doubles(k, max_iter) * 8;
-  if (hipMemsetAsync(S.base, 0, scal_bytes, s) != hipSuccess) return WISKI_E_LAUNCH;
+  {
+    const int64_t nscal = PcgScal::doubles(k, max_iter), nvec = zl ? (int64_t)k * m : 0;
+    int64_t zb = ((nscal > nvec ? nscal : nvec) + 255) / 256;
+    if (zb > 1024) zb = 1024;
+    hipLaunchKernelGGL((k_pcg_zero<real>), dim3((unsigned)zb), dim3(256), 0, s, S.base, nscal, part + (int64_t)(nch > 0 ? nch - 1 : 0) * k * m, nvec);
+  }
   const double tol2 = tol * tol;
   int eb = (m + 255) / 256;
   if (eb > 1024) eb = 1024;
@@ -1332,16 +1368,16 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (wide) {
       rc = spmv_wide(d_U, nullptr, (real)0, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, part, nch, zl, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, part, nch, zl, r, S);
     } else {
       rc = spmv_narrow(d_U, d_Z, (real)1, hp, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (real*)nullptr, 0, 0, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (real*)nullptr, 0, 0, r, S);
     }
   } else {
     if (hipMemsetAsync(d_U, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
     if (hipMemsetAsync(d_Z, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
-    hipLaunchKernelGGL((k_pcg_init<real>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, r, S);
+    hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, r, S);
   }
 
   std::vector<double> h_rn0(k), h_rn(k);

@@ -24,6 +24,9 @@ __device__ long long g_spec_dbg[16];
 #define SPEC_STAMP(i) do {} while (0)
 #endif
 #ifndef SPEC_ABLATE
+#ifndef SPEC_ST
+#define SPEC_ST 32   // fibre-tile width of the mode-0 kernels (columns of the [g0][g1 g2] view per block)
+#endif
 #define SPEC_ABLATE 0   // micro-benchmark hook (tools/ubench): 1 = skip LDS products, 2 = skip transposed LDS writes
 #endif
 
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(128) void k_spec_mode0(GridDev<real> G, const real*
                                                     const real* __restrict__ rvec, int dot_c0, double* __restrict__ dots) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
-  constexpr int ST = 32;
+  constexpr int ST = SPEC_ST;
   const int g0 = G.g[0], S = G.stride[0], m = G.m;
   const int P0 = (g0 + 3) & ~3;
   real* sF = reinterpret_cast<real*>(smem);   // [P0][P0]
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(128) void k_spec_mode0_fwd_upd(GridDev<real> G, con
                                                            real* __restrict__ u, real* __restrict__ z, PcgScal S) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
-  constexpr int ST = 32;
+  constexpr int ST = SPEC_ST;
   const int g0 = G.g[0], Sf = G.stride[0], m = G.m;
   const int P0 = (g0 + 3) & ~3;
   real* sF = reinterpret_cast<real*>(smem);
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(128) void k_spec_mode0_bwd_updp(GridDev<real> G, co
                                                             const real* __restrict__ src, int k, int it, real* __restrict__ p,
                                                             real* __restrict__ pt, PcgScal S) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ST = 32;
+  constexpr int ST = SPEC_ST;
   const int g0 = G.g[0], Sf = G.stride[0], m = G.m;
   const int P0 = (g0 + 3) & ~3;
   real* sF = reinterpret_cast<real*>(smem);
@@ -593,9 +596,9 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
   const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
   const int PM = P1 > P2 ? P1 : P2;
   const int S = G.stride[0];
-  const size_t sh0 = (size_t)(P0 * P0 + P0 * 32) * sizeof(real);
+  const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
   const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
-  const unsigned sx = (unsigned)((S + 31) / 32);
+  const unsigned sx = (unsigned)((S + SPEC_ST - 1) / SPEC_ST);
   static size_t slab_lds_set = 0;   // per instantiation; raise the dynamic-LDS limit once
   if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
     if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
@@ -629,9 +632,9 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
   const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
   const int PM = P1 > P2 ? P1 : P2;
   const int Sf = G.stride[0];
-  const size_t sh0 = (size_t)(P0 * P0 + P0 * 32) * sizeof(real);
+  const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
   const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
-  const unsigned sx = (unsigned)((Sf + 31) / 32);
+  const unsigned sx = (unsigned)((Sf + SPEC_ST - 1) / SPEC_ST);
   static size_t slab_lds_set = 0;   // per instantiation; raise the dynamic-LDS limit once
   if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
     if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)

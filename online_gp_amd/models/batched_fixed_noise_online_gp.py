@@ -301,14 +301,17 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """(eigen tuple, shift) of wiski_pcg's preconditioner (Kt^-1 + a kron_q diag(t_q))^-1.
         t_q = per-dim marginal of the row sums of W^T D^-1 W (the data-density profile: the
         grid nodes outside the data box carry no data), a = total mass / prod_q sum(t_q).
-        The d small generalized eigenproblems are re-solved only when the hyper-parameters
-        change or the data volume has grown by 30 %; `a` follows the stream exactly."""
+        The d small generalized eigenproblems are re-solved when the hyper-parameters change,
+        or when -- checked each time the data volume has grown by 30 % -- the normalised density
+        profile has moved by more than settings.precond_profile_drift (a stationary stream keeps
+        its eigenbasis); `a` follows the stream exactly."""
         if settings.spectral_preconditioner.off():
             return None, 0.0
         ver = self._hyper_version()
         st = self._memo.setdefault("precond", {}).get(o)
         wsum = float(self._wsum[o])
-        if st is None or st["ver"] != ver or wsum > 1.3 * st["wsum"] or wsum < 0.5 * st["wsum"]:
+        stale = st is None or st["ver"] != ver
+        if stale or wsum > 1.3 * st["wsum"] or wsum < 0.5 * st["wsum"]:
             profiles, norm = None, float(self._grid.m)
             cnt = self._kernel_cache.get("_cnt") if settings.density_profile_preconditioner.on() else None
             if cnt is not None and wsum > 0:
@@ -322,9 +325,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                         t = t.clip(1e-2, None)
                         profiles.append(t)
                         norm *= float(t.sum())
-            eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles)
-            st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm}
-            self._memo["precond"][o] = st
+            old = None if stale else st.get("profiles")
+            if (old is not None and profiles is not None and
+                    max(float(abs(a - b).max()) for a, b in zip(profiles, old)) <= settings.precond_profile_drift.value()):
+                st["wsum"] = wsum                      # same density shape: keep the eigenbasis, only the scale moves
+            else:
+                eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles)
+                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles}
+                self._memo["precond"][o] = st
         return st["eig"], wsum / st["norm"]
 
     def _posterior_op(self, o):

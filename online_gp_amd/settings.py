@@ -138,6 +138,13 @@ class dense_small_grids(_feature_flag):
     _state = True
 
 
+class precond_profile_drift(_value_context):
+    """Largest change of the normalised per-dimension data-density profile (entries in [0.01, 1]) the
+    CG preconditioner tolerates before its generalized eigenbasis is recomputed."""
+
+    _global_value = 0.1
+
+
 class density_profile_preconditioner(_feature_flag):
     """Model W^T D^-1 W in the CG preconditioner as a kron_q diag(t_q) with t_q the per-dim
     data-density profile (instead of a I): the inducing nodes outside the data box carry no
