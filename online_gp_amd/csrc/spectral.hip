@@ -373,123 +373,7 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
   SPEC_STAMP(5);
 }
 
-// ------------------------------------------- fused CG front end (mode 0) ---
-// Forward mode 0 with the previous iteration's vector update folded into the tile
-// load (each element of r belongs to exactly one (fibre-tile, column) block):
-//   apply != 0:  alpha = rho(it-1)/php(it-1);  u += alpha p;  z += alpha pt;
-//                r -= alpha (pt + sum_ch part[ch]);  rn(it) += |r|^2     -- k_pcg_update_x of iteration it-1
-//   then dst = V0^T r (tile product).
-template <typename real>
-__global__ __launch_bounds__(128) void k_spec_mode0_fwd_upd(GridDev<real> G, const real* __restrict__ V0, real* __restrict__ r,
-                                                           real* __restrict__ dst, int it, int apply, double tol2, const real* __restrict__ p,
-                                                           const real* __restrict__ pt, real* __restrict__ part, int nch, int zl,
-                                                           real* __restrict__ u, real* __restrict__ z, PcgScal S) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double s_red[16];
-  constexpr int ST = SPEC_ST;
-  const int g0 = G.g[0], Sf = G.stride[0], m = G.m;
-  const int P0 = (g0 + 3) & ~3;
-  real* sF = reinterpret_cast<real*>(smem);
-  real* sIn = sF + P0 * P0;
-  const int c = blockIdx.y;
-  const int s0 = blockIdx.x * ST;
-  const int64_t cm = (int64_t)c * m, km = (int64_t)S.k * m;
-  real al = (real)0;
-  if (apply) {
-    const double den = S.php_sum(it - 1, c);
-    if (blockIdx.x == 0) pcg_dot_clear(S.php(it), c, 1, S.k);   // ring entry the SpMV of this iteration accumulates into
-    if (pcg_active(S, it - 1, c, tol2) && den > 0) al = (real)(S.rho(it - 1)[c] / den);
-  }
-  MatrixLoad<real, 128> ml;
-  ml.issue(V0, g0);
-  constexpr int NV = (64 * (ST / 4) + 127) / 128;
-  V4<real> tin[NV];
-  double rn_part = 0;
-#pragma unroll
-  for (int itv = 0; itv < NV; ++itv) {
-    const int t = threadIdx.x + itv * 128;
-    const int b = t / (ST / 4), q4 = (t - b * (ST / 4)) * 4;
-    V4<real> rv;
-    rv.v[0] = rv.v[1] = rv.v[2] = rv.v[3] = (real)0;
-    if (b < g0 && s0 + q4 < Sf) {
-      const int64_t e = cm + (int64_t)b * Sf + s0 + q4;
-      rv = lds_read4<real>(r + e);
-      if (apply) {
-        const V4<real> pv = lds_read4<real>(p + e), ptv = lds_read4<real>(pt + e);
-        V4<real> uv = lds_read4<real>(u + e), zv = lds_read4<real>(z + e);
-        V4<real> hv = ptv;
-        for (int ch = 0; ch < nch; ++ch) {
-          const V4<real> pp = lds_read4<real>(part + (int64_t)ch * km + e);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hv.v[q] += pp.v[q];
-        }
-        if (zl) {   // the symmetric SpMV's atomically accumulated partial: consumed, re-zero for the next product
-          real* zp = part + (int64_t)(nch - 1) * km + e;
-          zp[0] = zp[1] = zp[2] = zp[3] = (real)0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          uv.v[q] += al * pv.v[q];
-          zv.v[q] += al * ptv.v[q];
-          rv.v[q] -= al * hv.v[q];
-          rn_part += (double)rv.v[q] * (double)rv.v[q];
-        }
-        if constexpr (sizeof(real) == 4) {
-          *reinterpret_cast<float4*>(u + e) = make_float4(uv.v[0], uv.v[1], uv.v[2], uv.v[3]);
-          *reinterpret_cast<float4*>(z + e) = make_float4(zv.v[0], zv.v[1], zv.v[2], zv.v[3]);
-          *reinterpret_cast<float4*>(r + e) = make_float4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
-        } else {
-          *reinterpret_cast<double2*>(u + e) = make_double2(uv.v[0], uv.v[1]); *reinterpret_cast<double2*>(u + e + 2) = make_double2(uv.v[2], uv.v[3]);
-          *reinterpret_cast<double2*>(z + e) = make_double2(zv.v[0], zv.v[1]); *reinterpret_cast<double2*>(z + e + 2) = make_double2(zv.v[2], zv.v[3]);
-          *reinterpret_cast<double2*>(r + e) = make_double2(rv.v[0], rv.v[1]); *reinterpret_cast<double2*>(r + e + 2) = make_double2(rv.v[2], rv.v[3]);
-        }
-      }
-    }
-    tin[itv] = rv;
-  }
-  for (int e = threadIdx.x; e < P0 * P0; e += 128) sF[e] = (real)0;
-  __syncthreads();
-  ml.commit(sF, g0, P0);
-#pragma unroll
-  for (int itv = 0; itv < NV; ++itv) {
-    const int t = threadIdx.x + itv * 128;
-    const int b = t / (ST / 4), q4 = (t - b * (ST / 4)) * 4;
-    if (b < P0) {
-      real* d = sIn + b * ST + q4;
-      d[0] = tin[itv].v[0]; d[1] = tin[itv].v[1]; d[2] = tin[itv].v[2]; d[3] = tin[itv].v[3];
-    }
-  }
-  __syncthreads();
-  if (apply) {
-    const double tot = block_reduce_sum(rn_part, s_red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(S.rn(it) + c, tot);
-  }
-  const int nty = ST / 4, ntx = P0 / 4;
-  const int t = threadIdx.x;
-  if (t < ntx * nty) {
-    const int tx = t / nty, ty = t - tx * nty;
-    real acc[4][4];
-    tile_product<real>(sF, P0, sIn, ST, P0, tx, ty, acc);
-    const int sidx = s0 + 4 * ty;
-    if (sidx < Sf) {
-      real* __restrict__ dc = dst + cm;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = 4 * tx + i;
-        if (x < g0) {
-          const int64_t e = (int64_t)x * Sf + sidx;
-          if constexpr (sizeof(real) == 4) {
-            *reinterpret_cast<float4*>(dc + e) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-          } else {
-            *reinterpret_cast<double2*>(dc + e) = make_double2(acc[i][0], acc[i][1]);
-            *reinterpret_cast<double2*>(dc + e + 2) = make_double2(acc[i][2], acc[i][3]);
-          }
-        }
-      }
-    }
-  }
-}
-
+// ------------------------------------------- fused CG back end (mode 0) ---
 // Backward mode 0 on 2k columns with the direction update folded into the store:
 //   columns [0,k):  t = V0 (.)  ->  pt = t + beta pt      columns [k,2k):  y = V0 (.)  ->  p = y + beta p
 //   beta = rho(it)/rho(it-1) (0 at it == 0); t and y themselves are never written.   -- k_pcg_update_p
@@ -616,11 +500,13 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
-// One CG iteration's preconditioner + vector updates in three launches (see kernels above).
+// One CG iteration's preconditioner + direction update in three launches: mode-0 forward, slab (+ rho),
+// mode-0 backward with p / pt updated in the store.  (Folding the previous iteration's u/z/r update into
+// the forward kernel's tile load was measured slower than a separate k_pcg_update_x launch: its 79 blocks
+// serialise 13 dependent vector loads per thread, 20.6 us against 5.5 + 7.5 us.)
 template <typename real>
-int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
-                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
-                             real* z, PcgScal S, hipStream_t s) {
+int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, const real* r,
+                             int k, real* w0, real* w1, int it, real* p, real* pt, PcgScal S, hipStream_t s) {
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
   if (!evec2) evec2 = evec;
   const real* V0 = evec;
@@ -641,8 +527,8 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
       return WISKI_E_LAUNCH;
     slab_lds_set = sh1;
   }
-  hipLaunchKernelGGL((k_spec_mode0_fwd_upd<real>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, r, w0, it, apply, tol2, (const real*)p,
-                     (const real*)pt, part, nch, zl, u, z, S);
+  hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, V0, 0, 0, r, w0, (const real*)nullptr, 0,
+                     (double*)nullptr);
   hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift,
                      (const real*)w0, w1, k, S.rho(it));
   hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, Z0, (const real*)w1, k, it, p, pt, S);
@@ -650,11 +536,10 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
 }
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
-template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, float*, int, float*,
-                                             float*, int, int, double, float*, float*, float*, int, int, float*, float*, PcgScal, hipStream_t);
-template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, double*, int,
-                                              double*, double*, int, int, double, double*, double*, double*, int, int, double*, double*, PcgScal,
-                                              hipStream_t);
+template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int,
+                                             float*, float*, int, float*, float*, PcgScal, hipStream_t);
+template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, const double*,
+                                              int, double*, double*, int, double*, double*, PcgScal, hipStream_t);
 template bool spectral_fused_ok<double>(const GridDev<double>&);
 template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int, float*,
                                           float*, float*, double*, hipStream_t);

@@ -166,7 +166,7 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
 // lines).  Each column therefore owns PCG_DOT_SLOTS addresses PCG_DOT_STRIDE doubles apart (block b adds
 // to slot b % PCG_DOT_SLOTS) and the consumers sum them.  The slots live in a two-deep ring indexed by
 // the iteration parity: the SpMV of iteration `it` accumulates into ring[it & 1]; the vector update that
-// consumes it (k_pcg_update_x / k_spec_mode0_fwd_upd) clears ring[(it + 1) & 1], whose own reader ran one
+// consumes it (k_pcg_update_x) clears ring[(it + 1) & 1], whose own reader ran one
 // iteration earlier on the same stream.
 constexpr int PCG_DOT_SLOTS = 16;
 constexpr int PCG_DOT_STRIDE = 16;
@@ -215,6 +215,5 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 
 // Fused CG-iteration front end (d = 3): [apply update_x(it-1)] + mode-0 fwd -> slab (+rho) -> mode-0 bwd (+update_p)
 template <typename real>
-int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
-                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
-                             real* z, PcgScal S, hipStream_t s);
+int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, const real* r,
+                             int k, real* w0, real* w1, int it, real* p, real* pt, PcgScal S, hipStream_t s);

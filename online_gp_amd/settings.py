@@ -140,9 +140,10 @@ class dense_small_grids(_feature_flag):
 
 class precond_profile_drift(_value_context):
     """Largest change of the normalised per-dimension data-density profile (entries in [0.01, 1]) the
-    CG preconditioner tolerates before its generalized eigenbasis is recomputed."""
+    CG preconditioner tolerates before its generalized eigenbasis is recomputed (the estimate itself
+    carries ~10 % sampling noise at 2e4 points on a 50-node axis)."""
 
-    _global_value = 0.1
+    _global_value = 0.2
 
 
 class density_profile_preconditioner(_feature_flag):
