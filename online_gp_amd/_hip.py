@@ -88,8 +88,25 @@ def dptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None):
+    """The caller's current HIP stream on `device` (a torch.device, index or None = current device)."""
+    if _raw_stream is not None:                      # ~0.3 us instead of ~3 us through torch.cuda.current_stream
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = torch.device(device).index
+            if idx is None:
+                idx = torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_fn_cache = {}
 
 
 def suffix(dtype):
@@ -105,4 +122,8 @@ def creal(dtype):
 
 
 def fn(name, dtype):
-    return getattr(lib(), name + suffix(dtype))
+    key = (name, dtype)
+    f = _fn_cache.get(key)
+    if f is None:
+        f = _fn_cache[key] = getattr(lib(), name + suffix(dtype))
+    return f

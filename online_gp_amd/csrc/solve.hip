@@ -573,6 +573,13 @@ static inline int sym_nch(int d) {
 
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+#ifdef WISKI_SYM_TIMING   // phase stamps of one mid-grid wave (tools/spmv_probe.py --timing)
+__device__ long long g_sym_dbg[32];
+#define SYM_STAMP(i) do { if (lane == 0 && wave == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) g_sym_dbg[i] = wall_clock64(); } while (0)
+extern "C" int wiski_sym_dbg(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sym_dbg), sizeof(long long) * 32) == hipSuccess ? 0 : -1; }
+#else
+#define SYM_STAMP(i) do {} while (0)
+#endif
 #ifndef WISKI_SYM_ABLATE
 #define WISKI_SYM_ABLATE 0   // timing ablations (tools/spmv_probe.py): 1 no LDS accumulation, 3 no global flush atomics
 #endif
@@ -600,8 +607,10 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
     }
     s_off[g - gA] = f;
   }
+  SYM_STAMP(0);
   for (int e = lane; e < KC * 4 * W4; e += 64) tw[e] = (real)0;
   __syncthreads();
+  SYM_STAMP(1);
   const int iw0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 256;   // first row of this wave
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;
@@ -704,6 +713,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
       wb = f;
     }
     if (nrows > 0) fetch(g, cur);         // wave-cooperative (all lanes), rows past the grid read as zeros
+    SYM_STAMP(2 + 3 * (g - gA));
     if (live) {
       real tr[KC][10];
 #pragma unroll
@@ -729,6 +739,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
           }
         }
       }
+      SYM_STAMP(3 + 3 * (g - gA));
 #if WISKI_SYM_ABLATE != 1
       const int w0 = 4 * lane + (f - wb);
 #pragma unroll
@@ -743,9 +754,12 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
         wave_lds_fence();
       }
 #endif
+      SYM_STAMP(4 + 3 * (g - gA));
     }
   }
+  SYM_STAMP(20);
   flush(wb);
+  SYM_STAMP(21);
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     double pd = 0;
@@ -766,6 +780,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
       if (threadIdx.x == 0 && c0 + c < k) pcg_dot_add(dots, c0 + c, tot);
     }
   }
+  SYM_STAMP(22);
 }
 
 // partial SpMV launcher on the half stencil (requires m % 4 == 0).  part holds (sym_nch(d) + 1) * k * m reals;

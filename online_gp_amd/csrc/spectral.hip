@@ -373,6 +373,242 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
   SPEC_STAMP(5);
 }
 
+// -------------------------------------------------- slab, fp32 on the matrix cores ---
+// The same four products as k_spec_slab for real = float, on v_mfma_f32_16x16x4_f32 (exact fp32).
+// Every product is Out[x][y] = sum_b A[x][b] B[b][y] on a 64 x 64 padded tile; the 4 waves each own
+// a 32 x 32 quadrant (2 x 2 MFMA tiles, as wiski_gemm).  An MFMA needs one LDS word per operand and
+// lane (vs 8 x 16 B per 64 FMAs in the register-tile version), so the LDS latency that bounded the
+// scalar kernel (~2.3 us per product at one wave per SIMD) no longer does.
+//   P2  C2[i1'][i2]  = sum_i1  V1[i1][i1']  X[i1][i2]          A = V1^T (row-wise reads), B = X
+//   P3  C3[i1'][i2'] = sum_i2  C2[i1'][i2]  V2[i2][i2']         A = C2,  B = V2          then * f_h(lam)
+//   P5  C5[i1'][i2]  = sum_i2' C3[i1'][i2'] bV2[i2][i2']        A = C3,  B = bV2^T
+//   P6  out[i1][i2]  = sum_i1' bV1[i1][i1'] C5[i1'][i2]         A = bV1, B = C5
+// (bV = Z for the t-half of a generalized eigenbasis, else V).  Two LDS row strides keep every operand
+// read bank-conflict free: LDT = 80 (16 mod 64) for operands whose 16-lane groups read a row
+// (B[b][y], A^T[b][x]); LDN = 68 (4 mod 64) for operands whose lanes walk a column (A[x][b], B^T[y][b]).
+// Out-of-range rows / columns are loaded as exact zeros, so the padded products are exact.
+using spec_f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int SPEC_LDT = 80, SPEC_LDN = 68;
+
+template <bool A_NAT, bool B_NAT, int KS>
+__device__ __forceinline__ void spec_mfma_product(const float* __restrict__ pa, const float* __restrict__ pb, int wr, int wc, int lane,
+                                                  spec_f32x4 acc[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.f;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const float* qa = A_NAT ? pa + (wr * 32 + l15) * SPEC_LDN + l4 : pa + l4 * SPEC_LDT + wr * 32 + l15;
+  const float* qb = B_NAT ? pb + (wc * 32 + l15) * SPEC_LDN + l4 : pb + l4 * SPEC_LDT + wc * 32 + l15;
+  constexpr int SA = A_NAT ? 1 : SPEC_LDT, TA = A_NAT ? 16 * SPEC_LDN : 16;   // step per k, step per 16-row tile
+  constexpr int SB = B_NAT ? 1 : SPEC_LDT, TB = B_NAT ? 16 * SPEC_LDN : 16;
+  // KS = (padded inner dimension) / 4 is a compile-time constant (the zero padding makes a larger KS exact):
+  // every operand word is read up front (4 KS registers), so the LDS latency is paid once and the 4 KS MFMAs
+  // issue back to back.  (A run-time trip count turned this into one branch + s_waitcnt lgkmcnt(0) per step.)
+  float af[KS][2], bf[KS][2];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    af[i][0] = qa[4 * i * SA]; af[i][1] = qa[4 * i * SA + TA];
+    bf[i][0] = qb[4 * i * SB]; bf[i][1] = qb[4 * i * SB + TB];
+  }
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[i][0], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[i][1], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i][0], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i][1], acc[1][1], 0, 0, 0);
+  }
+}
+
+// rows x cols compact row-major matrix -> LDS image [64][ld] with exact-zero padding, no integer division and
+// no separate zero fill: thread (r, c) mapping, 64 / VW threads per padded row, VW-wide loads and LDS stores
+// (VW = 2 needs even `cols`: rows are then 8-byte aligned).  issue() only loads, commit() only stores.
+template <int VW>
+struct SpecTile {
+  static constexpr int TPR = 64 / VW;          // threads per row
+  static constexpr int RPP = 256 / TPR;        // rows per pass
+  static constexpr int NP = 64 / RPP;          // passes
+  float v[NP][VW];
+  __device__ __forceinline__ void issue(const float* __restrict__ M, int rows, int cols) {
+    const int r0 = threadIdx.x / TPR, c0 = (threadIdx.x % TPR) * VW;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = r0 + RPP * p;
+      const bool ok = r < rows && c0 < cols;
+      const float* q = M + (ok ? r * cols + c0 : 0);
+      if constexpr (VW == 2) {
+        const float2 x = *reinterpret_cast<const float2*>(q);
+        v[p][0] = ok ? x.x : 0.f;
+        v[p][1] = ok ? x.y : 0.f;
+      } else {
+        const float x = *q;
+        v[p][0] = ok ? x : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(float* __restrict__ dst, int ld) const {
+    const int r0 = threadIdx.x / TPR, c0 = (threadIdx.x % TPR) * VW;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float* d = dst + (r0 + RPP * p) * ld + c0;
+      if constexpr (VW == 2) *reinterpret_cast<float2*>(d) = make_float2(v[p][0], v[p][1]);
+      else *d = v[p][0];
+    }
+  }
+};
+
+template <int KS, int VW>
+__global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
+                                                        const float* __restrict__ Z1, const float* __restrict__ Z2,
+                                                        const float* __restrict__ evals, float kscale, float shift,
+                                                        const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double s_red[16];
+  __shared__ float sE[128];                       // eigenvalues of dims 1 | 2, zero padded to 64 each
+  float* bufA = reinterpret_cast<float*>(smem);   // [64][80]: X, later C3 (stride LDN)
+  float* bufB = bufA + 64 * SPEC_LDT;             // [64][80]: C2 (stride LDN), later C5 (stride LDT)
+  float* sV1 = bufB + 64 * SPEC_LDT;              // [b][x], stride LDT
+  float* sV2 = sV1 + 64 * SPEC_LDT;               // [b][y], stride LDT
+  float* sB1 = sV2 + 64 * SPEC_LDT;               // bV1[x][b], stride LDN
+  float* sB2 = sB1 + 64 * SPEC_LDN;               // bV2[y][b], stride LDN
+  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2], m = G.m;
+  const int i0 = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const bool alt = (h == 0) && (Z1 != V1 || Z2 != V2);   // block-uniform
+  SPEC_STAMP(0);
+  SpecTile<VW> tX, tV1, tV2, tB1, tB2;
+  tX.issue(src + (int64_t)c * m + (int64_t)i0 * g1 * g2, g1, g2);
+  tV1.issue(V1, g1, g1);
+  tV2.issue(V2, g2, g2);
+  tB1.issue(alt ? Z1 : V1, g1, g1);
+  tB2.issue(alt ? Z2 : V2, g2, g2);
+  if (t < 128) {
+    const int q = t & 63;
+    float ev = 0.f;
+    if (t < 64 ? q < g1 : q < g2) ev = evals[t < 64 ? g0 + q : g0 + g1 + q];
+    sE[t] = ev;
+  }
+  const float l0 = kscale * evals[i0];
+  SPEC_STAMP(6);
+  tX.commit(bufA, SPEC_LDT);           // every image is written in full (padding = zeros); bufB is first written by P2
+  tV1.commit(sV1, SPEC_LDT);
+  tV2.commit(sV2, SPEC_LDT);
+  tB1.commit(sB1, SPEC_LDN);
+  tB2.commit(sB2, SPEC_LDN);
+  SPEC_STAMP(7);
+  __syncthreads();
+  SPEC_STAMP(1);
+  spec_f32x4 acc[2][2];
+  const int l15 = lane & 15, l4 = lane >> 4;
+  auto store_tiles = [&](float* __restrict__ out, int ld) {       // C fragments -> out[row][col], row-major with stride ld
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(wr * 32 + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
+  };
+  // P2: A = V1^T (sV1 [b][x]), B = X (bufA [b][y])  -> C2 natural (bufB, stride LDN)
+  spec_mfma_product<false, false, KS>(sV1, bufA, wr, wc, lane, acc);
+  store_tiles(bufB, SPEC_LDN);
+  __syncthreads();
+  SPEC_STAMP(2);
+  // P3: A = C2 (bufB natural), B = V2 (sV2 [b][y]) -> scaled C3 natural (bufA, stride LDN)
+  spec_mfma_product<true, false, KS>(bufB, sV2, wr, wc, lane, acc);
+  float rho_lane = 0.f;   // 16 terms per lane in fp32, the cross-lane / cross-block sum in fp64
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const float e2 = sE[64 + wc * 32 + cc * 16 + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float lam = l0 * sE[wr * 32 + a * 16 + l4 * 4 + r] * e2;
+        const float f1 = __frcp_rn(1.f + shift * lam);
+        const float v = acc[a][cc][r];
+        rho_lane += (lam * f1) * v * v;   // r^T P r in the eigenbasis (padding: lam = 0)
+        acc[a][cc][r] = v * (h == 0 ? f1 : lam * f1);
+      }
+    }
+  store_tiles(bufA, SPEC_LDN);
+  if (rho != nullptr && h == 1) {   // block-uniform
+    const double tot = block_reduce_sum((double)rho_lane, s_red);
+    if (t == 0) unsafeAtomicAdd(rho + c, tot);
+  }
+  __syncthreads();
+  SPEC_STAMP(3);
+  // P5: A = C3 (bufA natural), B = bV2^T (sB2 [y][b]) -> C5 [b = i1'][y = i2] (bufB, stride LDT)
+  spec_mfma_product<true, true, KS>(bufA, sB2, wr, wc, lane, acc);
+  store_tiles(bufB, SPEC_LDT);
+  __syncthreads();
+  SPEC_STAMP(4);
+  // P6: A = bV1 (sB1 natural), B = C5 (bufB [b][y]) -> global
+  spec_mfma_product<true, false, KS>(sB1, bufB, wr, wc, lane, acc);
+  float* __restrict__ os = dst + ((int64_t)h * k + c) * m + (int64_t)i0 * g1 * g2;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = wr * 32 + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
+        if (x < g1 && y < g2) os[x * g2 + y] = acc[a][cc][r];
+      }
+  SPEC_STAMP(5);
+}
+
+constexpr size_t SPEC_SLAB_MFMA_LDS = (size_t)(4 * 64 * SPEC_LDT + 2 * 64 * SPEC_LDN) * sizeof(float);
+
+// slab launch: fp32 on the matrix cores, fp64 on the register-tile kernel
+template <typename real>
+static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, const real* Z1, const real* Z2, const real* evals, real kscale,
+                       real shift, const real* src, real* dst, int k, double* rho, hipStream_t s) {
+  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
+  if constexpr (sizeof(real) == 4) {
+    const int gm = g1 > g2 ? g1 : g2;
+    const bool even = g1 % 2 == 0 && g2 % 2 == 0;      // 8-byte loads need 8-byte aligned rows
+#define SLAB_MFMA2(KS, VW)                                                                                                                     \
+  do {                                                                                                                                         \
+    static bool lds_set = false;   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                      \
+    if (!lds_set) {                                                                                                                            \
+      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPEC_SLAB_MFMA_LDS) !=   \
+          hipSuccess)                                                                                                                          \
+        return WISKI_E_LAUNCH;                                                                                                                 \
+      lds_set = true;                                                                                                                          \
+    }                                                                                                                                          \
+    hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1, Z2,    \
+                       evals, kscale, shift, src, dst, k, rho);                                                                                \
+  } while (0)
+#define SLAB_MFMA(KS)              \
+  do {                             \
+    if (even) SLAB_MFMA2(KS, 2);   \
+    else SLAB_MFMA2(KS, 1);        \
+  } while (0)
+    if (gm <= 16) SLAB_MFMA(4);          // inner dimension padded to 16 / 32 / 48 / 52 / 64
+    else if (gm <= 32) SLAB_MFMA(8);
+    else if (gm <= 48) SLAB_MFMA(12);
+    else if (gm <= 52) SLAB_MFMA(13);
+    else SLAB_MFMA(16);
+#undef SLAB_MFMA
+#undef SLAB_MFMA2
+  } else {
+    const int P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
+    const int PM = P1 > P2 ? P1 : P2;
+    const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
+    static size_t slab_lds_set = 0;   // raise the dynamic-LDS limit once
+    if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
+      if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
+        return WISKI_E_LAUNCH;
+      slab_lds_set = sh1;
+    }
+    hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift, src, dst,
+                       k, rho);
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 // ------------------------------------------- fused CG back end (mode 0) ---
 // Backward mode 0 on 2k columns with the direction update folded into the store:
 //   columns [0,k):  t = V0 (.)  ->  pt = t + beta pt      columns [k,2k):  y = V0 (.)  ->  p = y + beta p
@@ -478,23 +714,14 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
   const real* Z1 = evec2 + g0 * g0;
   const real* Z2 = Z1 + g1 * g1;
   const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
-  const int PM = P1 > P2 ? P1 : P2;
   const int S = G.stride[0];
   const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
-  const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
   const unsigned sx = (unsigned)((S + SPEC_ST - 1) / SPEC_ST);
-  static size_t slab_lds_set = 0;   // per instantiation; raise the dynamic-LDS limit once
-  if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
-    if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
-      return WISKI_E_LAUNCH;
-    slab_lds_set = sh1;
-  }
   // forward mode 0: w0 = V0^T r
   hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, V0, 0, 0, r, w0, (const real*)nullptr, 0,
                      (double*)nullptr);
   // slab: forward modes 1,2 + scaling + backward modes 2,1 -> w1 = [half 0 | half 1]
-  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift,
-                     (const real*)w0, w1, k, (double*)nullptr);
+  if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, (double*)nullptr, s)) return rc;
   // backward mode 0 on 2k columns, rho += r . y for the second half
   hipLaunchKernelGGL((k_spec_mode0<real, true>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, Z0, V0, k, 1, (const real*)w1, ty, r, k, rho);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
@@ -516,21 +743,12 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
   const real* Z1 = evec2 + g0 * g0;
   const real* Z2 = Z1 + g1 * g1;
   const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
-  const int PM = P1 > P2 ? P1 : P2;
   const int Sf = G.stride[0];
   const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
-  const size_t sh1 = (size_t)(2 * PM * PM + 2 * (P1 * P1 + P2 * P2) + P1 + P2) * sizeof(real);
   const unsigned sx = (unsigned)((Sf + SPEC_ST - 1) / SPEC_ST);
-  static size_t slab_lds_set = 0;   // per instantiation; raise the dynamic-LDS limit once
-  if (sh1 > 48 * 1024 && sh1 > slab_lds_set) {
-    if (hipFuncSetAttribute((const void*)k_spec_slab<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
-      return WISKI_E_LAUNCH;
-    slab_lds_set = sh1;
-  }
   hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, V0, 0, 0, r, w0, (const real*)nullptr, 0,
                      (double*)nullptr);
-  hipLaunchKernelGGL((k_spec_slab<real>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), sh1, s, G, V1, V2, Z1, Z2, evals, kscale, shift,
-                     (const real*)w0, w1, k, S.rho(it));
+  if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, S.rho(it), s)) return rc;
   hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, Z0, (const real*)w1, k, it, p, pt, S);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }

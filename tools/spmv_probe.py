@@ -59,3 +59,25 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def timing_dump():
+    """With a -DWISKI_SYM_TIMING build (WISKI_HIP_SO=...): phase stamps (100 MHz wall clock) of one mid-grid wave."""
+    lib = _hip.lib()
+    if not hasattr(lib, "wiski_sym_dbg"):
+        return
+    buf = (ctypes.c_longlong * 32)()
+    lib.wiski_sym_dbg(buf)
+    v = list(buf)
+    t0 = v[0]
+    names = {0: "start", 1: "LDS zero + barrier", 20: "loop end", 21: "flush", 22: "end"}
+    for i in range(4):
+        names[2 + 3 * i] = f"g{i} fetch"; names[3 + 3 * i] = f"g{i} fma"; names[4 + 3 * i] = f"g{i} lds rmw"
+    prev = t0
+    for i in sorted(names):
+        if v[i] >= t0 and v[i] > 0:
+            print(f"  {names[i]:20s} +{(v[i] - prev) * 10:6d} ns   (t = {(v[i] - t0) * 10} ns)")
+            prev = v[i]
+
+
+timing_dump()

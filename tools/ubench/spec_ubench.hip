@@ -19,7 +19,7 @@ int main() {
     for (int it = 0; it < reps + 2; ++it) {
       if (flush) hipMemsetAsync(big, 0, bigN, 0);
       hipEventRecord(e0, 0);
-      launch_spectral_fused<float>(G, evec, evals, 1.4f, 3.0f, r, k, w0, w1, ty, rho, 0);
+      launch_spectral_fused<float>(G, evec, evec, evals, 1.4f, 3.0f, r, k, w0, w1, ty, rho, 0);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) tot += ms;
     }
@@ -29,6 +29,7 @@ int main() {
   long long h_dbg[16];
   hipMemcpyFromSymbol(h_dbg, HIP_SYMBOL(g_spec_dbg), sizeof(h_dbg));
   for (int i = 1; i < 6; ++i) printf("slab phase %d: %lld cycles\n", i, h_dbg[i] - h_dbg[i - 1]);
+  printf("load phase: issue %lld | commit %lld | barrier %lld\n", h_dbg[6] - h_dbg[0], h_dbg[7] - h_dbg[6], h_dbg[1] - h_dbg[7]);
 #endif
   return 0;
 }
