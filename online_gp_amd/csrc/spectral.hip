@@ -559,6 +559,167 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const 
   SPEC_STAMP(5);
 }
 
+// ----------------------------------------------- mode 0, fp32 on the matrix cores ---
+// dst[c][x, s] = sum_b A[x][b] src[c][b, s] for a tile of 32 fibres s, A = V0^T (forward) or V0 (backward):
+// one 64 x 32 x (4 KS) product per block, the 4 waves own 32 x 16 output sub-tiles (2 MFMA tiles each).
+//   MODE 0: plain store (+ optional dots[c - dot_c0] += rvec . dst for c >= dot_c0)       -- k_spec_mode0
+//   MODE 1: CG direction update folded into the store, 2k columns                         -- k_spec_mode0_bwd_updp
+template <int KS, int VW, int MODE>
+__global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const float* __restrict__ Va, const float* __restrict__ Vb, int split,
+                                                         int transposed, const float* __restrict__ src, float* __restrict__ dst,
+                                                         const float* __restrict__ rvec, int dot_c0, double* __restrict__ dots, int k, int it,
+                                                         float* __restrict__ p, float* __restrict__ pt, PcgScal S) {
+  __shared__ __attribute__((aligned(16))) float sF[64 * SPEC_LDT];    // V0 image, row stride LDT (forward) or LDN (backward)
+  __shared__ __attribute__((aligned(16))) float sIn[64 * SPEC_LDT];   // src tile [b][s], 32 of LDT columns used
+  __shared__ double s_red[16];
+  const int g0 = G.g[0], Sf = G.stride[0], m = G.m;
+  const int cc = blockIdx.y;
+  const int s0 = blockIdx.x * 32;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const float* __restrict__ V0;
+  int c = cc;
+  float bt = 0.f;
+  if (MODE == 1) {                       // columns [0, k): pt-half with Z0 (= Va); [k, 2k): p-half with X0 (= Vb)
+    const int half = cc / k;
+    c = cc - half * k;
+    V0 = half == 0 ? Va : Vb;
+    if (it > 0) {
+      const double den = S.rho(it - 1)[c];
+      bt = (float)(den > 0 ? S.rho(it)[c] / den : 0.0);
+    }
+  } else {
+    V0 = cc < split ? Va : Vb;           // generalized eigenbasis: t-half and y-half use different factors
+  }
+  const float* __restrict__ sc = src + (int64_t)cc * m;
+  SpecTile<VW> tV;
+  tV.issue(V0, g0, g0);
+  float4 tin[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int b = (t >> 3) + 32 * q, q4 = (t & 7) * 4;
+    const bool ok = b < g0 && s0 + q4 < Sf;                  // Sf % 4 == 0 (precondition of the fused path)
+    tin[q] = *reinterpret_cast<const float4*>(sc + (ok ? (int64_t)b * Sf + s0 + q4 : 0));
+    if (!ok) tin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  tV.commit(sF, transposed ? SPEC_LDN : SPEC_LDT);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(sIn + ((t >> 3) + 32 * q) * SPEC_LDT + (t & 7) * 4) = tin[q];
+  __syncthreads();
+  spec_f32x4 acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+  {
+    const float* qb = sIn + l4 * SPEC_LDT + wc * 16 + l15;
+    float af[KS][2], bf[KS];
+    if (transposed) {                    // A[x][b] = V0[x][b], lanes walk a column (stride LDN)
+      const float* qa = sF + (wr * 32 + l15) * SPEC_LDN + l4;
+#pragma unroll
+      for (int i = 0; i < KS; ++i) { af[i][0] = qa[4 * i]; af[i][1] = qa[4 * i + 16 * SPEC_LDN]; }
+    } else {                             // A[x][b] = V0[b][x], 16-lane groups read a row (stride LDT)
+      const float* qa = sF + l4 * SPEC_LDT + wr * 32 + l15;
+#pragma unroll
+      for (int i = 0; i < KS; ++i) { af[i][0] = qa[4 * i * SPEC_LDT]; af[i][1] = qa[4 * i * SPEC_LDT + 16]; }
+    }
+#pragma unroll
+    for (int i = 0; i < KS; ++i) bf[i] = qb[4 * i * SPEC_LDT];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[i], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i], acc[1], 0, 0, 0);
+    }
+  }
+  const int sidx = s0 + wc * 16 + l15;
+  const bool dot = MODE == 0 && dots != nullptr && cc >= dot_c0;   // block-uniform
+  float part = 0.f;
+  if (sidx < Sf) {
+    float* __restrict__ tgt = MODE == 1 ? (cc < k ? pt : p) + (int64_t)c * m : dst + (int64_t)cc * m;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = wr * 32 + a * 16 + l4 * 4 + r;
+        if (x < g0) {
+          const int64_t e = (int64_t)x * Sf + sidx;
+          float o = acc[a][r];
+          if (MODE == 1 && it > 0) o += bt * tgt[e];
+          tgt[e] = o;
+          if (dot) part += rvec[(int64_t)(cc - dot_c0) * m + e] * o;
+        }
+      }
+  }
+  if (dot) {
+    const double tot = block_reduce_sum((double)part, s_red);
+    if (t == 0) unsafeAtomicAdd(dots + (cc - dot_c0), tot);
+  }
+}
+
+// KS / VW dispatch shared by the fp32 MFMA kernels: inner dimension padded to 16 / 32 / 48 / 52 / 64;
+// 8-byte tile loads when the matrix rows are 8-byte aligned (even g)
+#define SPEC_DISPATCH_KS_VW(gmax, even, CALL) \
+  do {                                        \
+    if (even) {                               \
+      if ((gmax) <= 16) CALL(4, 2);           \
+      else if ((gmax) <= 32) CALL(8, 2);      \
+      else if ((gmax) <= 48) CALL(12, 2);     \
+      else if ((gmax) <= 52) CALL(13, 2);     \
+      else CALL(16, 2);                       \
+    } else {                                  \
+      if ((gmax) <= 16) CALL(4, 1);           \
+      else if ((gmax) <= 32) CALL(8, 1);      \
+      else if ((gmax) <= 48) CALL(12, 1);     \
+      else if ((gmax) <= 52) CALL(13, 1);     \
+      else CALL(16, 1);                       \
+    }                                         \
+  } while (0)
+
+template <typename real>
+__global__ void k_spec_mode0_bwd_updp(GridDev<real> G, const real* __restrict__ X0, const real* __restrict__ Z0, const real* __restrict__ src, int k,
+                                      int it, real* __restrict__ p, real* __restrict__ pt, PcgScal S);   // defined below
+
+// mode-0 launch: fp32 on the matrix cores (256 threads), fp64 on the register-tile kernels (128 threads)
+template <typename real, bool DOT>
+static int launch_mode0(const GridDev<real>& G, const real* Va, const real* Vb, int split, int transposed, const real* src, real* dst, int ncols,
+                        const real* rvec, int dot_c0, double* dots, hipStream_t s) {
+  const int g0 = G.g[0], Sf = G.stride[0];
+  if constexpr (sizeof(real) == 4) {
+    dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)ncols);
+#define M0(KS, VW)                                                                                                                          \
+  hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 0>), grd, dim3(256), 0, s, G, Va, Vb, split, transposed, src, dst, rvec, dot_c0,            \
+                     DOT ? dots : (double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, PcgScal{nullptr, 0, nullptr})
+    SPEC_DISPATCH_KS_VW(g0, g0 % 2 == 0, M0);
+#undef M0
+  } else {
+    const int P0 = (g0 + 3) & ~3;
+    const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
+    hipLaunchKernelGGL((k_spec_mode0<real, DOT>), dim3((unsigned)((Sf + SPEC_ST - 1) / SPEC_ST), (unsigned)ncols), dim3(128), sh0, s, G, Va, Vb, split,
+                       transposed, src, dst, rvec, dot_c0, dots);
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+template <typename real>
+static int launch_mode0_bwd_updp(const GridDev<real>& G, const real* X0, const real* Z0, const real* src, int k, int it, real* p, real* pt,
+                                 PcgScal S, hipStream_t s) {
+  const int g0 = G.g[0], Sf = G.stride[0];
+  if constexpr (sizeof(real) == 4) {
+    dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)(2 * k));
+#define M1(KS, VW)                                                                                                                       \
+  hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 1>), grd, dim3(256), 0, s, G, Z0, X0, 0, 1, src, (float*)nullptr, (const float*)nullptr, 0, \
+                     (double*)nullptr, k, it, p, pt, S)
+    SPEC_DISPATCH_KS_VW(g0, g0 % 2 == 0, M1);
+#undef M1
+  } else {
+    const int P0 = (g0 + 3) & ~3;
+    const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
+    hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3((unsigned)((Sf + SPEC_ST - 1) / SPEC_ST), (unsigned)(2 * k)), dim3(128), sh0, s, G, X0, Z0,
+                       src, k, it, p, pt, S);
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 constexpr size_t SPEC_SLAB_MFMA_LDS = (size_t)(4 * 64 * SPEC_LDT + 2 * 64 * SPEC_LDN) * sizeof(float);
 
 // slab launch: fp32 on the matrix cores, fp64 on the register-tile kernel
@@ -713,18 +874,12 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
   const real* Z0 = evec2;
   const real* Z1 = evec2 + g0 * g0;
   const real* Z2 = Z1 + g1 * g1;
-  const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
-  const int S = G.stride[0];
-  const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
-  const unsigned sx = (unsigned)((S + SPEC_ST - 1) / SPEC_ST);
   // forward mode 0: w0 = V0^T r
-  hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, V0, 0, 0, r, w0, (const real*)nullptr, 0,
-                     (double*)nullptr);
+  if (int rc = launch_mode0<real, false>(G, V0, V0, 0, 0, r, w0, k, (const real*)nullptr, 0, (double*)nullptr, s)) return rc;
   // slab: forward modes 1,2 + scaling + backward modes 2,1 -> w1 = [half 0 | half 1]
   if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, (double*)nullptr, s)) return rc;
   // backward mode 0 on 2k columns, rho += r . y for the second half
-  hipLaunchKernelGGL((k_spec_mode0<real, true>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, Z0, V0, k, 1, (const real*)w1, ty, r, k, rho);
-  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+  return launch_mode0<real, true>(G, Z0, V0, k, 1, (const real*)w1, ty, 2 * k, r, k, rho, s);
 }
 
 // One CG iteration's preconditioner + direction update in three launches: mode-0 forward, slab (+ rho),
@@ -742,15 +897,9 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
   const real* Z0 = evec2;
   const real* Z1 = evec2 + g0 * g0;
   const real* Z2 = Z1 + g1 * g1;
-  const int P0 = (g0 + 3) & ~3, P1 = (g1 + 3) & ~3, P2 = (g2 + 3) & ~3;
-  const int Sf = G.stride[0];
-  const size_t sh0 = (size_t)(P0 * P0 + P0 * SPEC_ST) * sizeof(real);
-  const unsigned sx = (unsigned)((Sf + SPEC_ST - 1) / SPEC_ST);
-  hipLaunchKernelGGL((k_spec_mode0<real, false>), dim3(sx, (unsigned)k), dim3(128), sh0, s, G, V0, V0, 0, 0, r, w0, (const real*)nullptr, 0,
-                     (double*)nullptr);
+  if (int rc = launch_mode0<real, false>(G, V0, V0, 0, 0, r, w0, k, (const real*)nullptr, 0, (double*)nullptr, s)) return rc;
   if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, S.rho(it), s)) return rc;
-  hipLaunchKernelGGL((k_spec_mode0_bwd_updp<real>), dim3(sx, (unsigned)(2 * k)), dim3(128), sh0, s, G, V0, Z0, (const real*)w1, k, it, p, pt, S);
-  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+  return launch_mode0_bwd_updp<real>(G, V0, Z0, (const real*)w1, k, it, p, pt, S, s);
 }
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
