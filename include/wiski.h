@@ -110,10 +110,15 @@ int wiski_scatter_stats_f64(const wiski_grid* grid, const double* d_x, const dou
 int wiski_scatter_stats_sym_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, double* d_stats, int32_t* d_err, void* stream);
 int wiski_scatter_stats_sym_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_stats, int32_t* d_err, void* stream);
 /* One-launch form used by the model: as above (half != 0: d_A is the symmetric half stencil,
- * else the full offset-major one) and additionally d_cnt[m] += W^T wa, the row sums of the increment
- * (the preconditioner's data-density statistic; d_cnt may be NULL). */
-int wiski_scatter_stats_cnt_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A, int32_t half, float* d_cnt, double* d_stats, int32_t* d_err, void* stream);
-int wiski_scatter_stats_cnt_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A, int32_t half, double* d_cnt, double* d_stats, int32_t* d_err, void* stream);
+ * else the full offset-major one) and additionally
+ *   d_cnt[m] += W^T wa      the row sums of the increment (the preconditioner's data-density statistic;
+ *                           d_cnt may be NULL)
+ *   d_res[m] += W^T (wb y - wa (W d_u))      (d_u / d_res: both or neither; half form only)
+ * the residual carry-over: if d_res held b - z - A u for the current solution (u, z) of
+ * (Kt^-1 + A) u = b, it still does after the increment, so the next wiski_pcg warm start (warm = 2)
+ * needs no A u product. */
+int wiski_scatter_stats_cnt_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A, int32_t half, float* d_cnt, const float* d_u, float* d_res, double* d_stats, int32_t* d_err, void* stream);
+int wiski_scatter_stats_cnt_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A, int32_t half, double* d_cnt, const double* d_u, double* d_res, double* d_stats, int32_t* d_err, void* stream);
 int wiski_stencil_expand_add_f32(const wiski_grid* grid, float* d_A_half, float* d_A_st, void* stream);
 int wiski_stencil_expand_add_f64(const wiski_grid* grid, double* d_A_half, double* d_A_st, void* stream);
 
@@ -177,12 +182,16 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  * Not re-entrant across host threads (one poll buffer per process).
  * a_sym != 0: d_A_st is the symmetric half stencil (wiski_scatter_stats_sym layout) instead of
  * the full offset-major [7^d][m] one.
+ * d_R (k*m reals, may be NULL): caller-owned residual buffer used instead of workspace scratch; on return
+ * it holds rhs - Z - A U for the returned (U, Z).  warm = 2 (needs d_R): d_R already holds that residual
+ * for the incoming (U, Z) -- kept current across streaming updates by wiski_scatter_stats_cnt's d_res --
+ * so the solve starts without an A U product.
  * workspace: wiski_pcg_workspace_bytes(...) bytes of device scratch.
  * h_iters (host, may be NULL): iterations run; h_relres (host, k doubles, may
  * be NULL): final relative residuals. */
 int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max_iter, int32_t elem_size);
-int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* stream);
-int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* stream);
+int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream);
+int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

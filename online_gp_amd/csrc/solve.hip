@@ -1154,9 +1154,10 @@ __global__ __launch_bounds__(256) void k_pcg_zero(double* __restrict__ scal, int
 
 // r = rhs - t - sum_ch part[ch] (t / part may be NULL); rn0 += rhs^2 ; rn(0) += r^2
 // VEC = 4: 16-byte accesses (requires m % 4 == 0), all loads of a thread independent.
+// given != 0: r already holds the residual (carried over by the caller, warm = 2); only the norms are formed.
 template <typename real, int VEC>
 __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict__ rhs, const real* __restrict__ t, real* __restrict__ part,
-                                                  int nch, int zl, real* __restrict__ r, PcgScal S) {
+                                                  int nch, int zl, int given, real* __restrict__ r, PcgScal S) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   const int64_t km = (int64_t)S.k * m;
@@ -1167,6 +1168,10 @@ __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict_
     if constexpr (VEC == 4) {
       const Vec4<real> f4 = load4<real>(rhs + e);
       f[0] = f4.x; f[1] = f4.y; f[2] = f4.z; f[3] = f4.w;
+      if (given) {
+        const Vec4<real> r4 = load4<real>(r + e);
+        rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+      } else {
       Vec4<real> t4;
       t4.x = t4.y = t4.z = t4.w = (real)0;
       if (t) t4 = load4<real>(t + e);
@@ -1180,12 +1185,17 @@ __global__ __launch_bounds__(256) void k_pcg_init(int m, const real* __restrict_
       for (int ch = 0; ch < 8; ++ch)
         if (ch < nch) { rr[0] -= pp[ch].x; rr[1] -= pp[ch].y; rr[2] -= pp[ch].z; rr[3] -= pp[ch].w; }
       store4<real>(r + e, rr[0], rr[1], rr[2], rr[3]);
+      }
     } else {
       f[0] = rhs[e];
-      rr[0] = t ? f[0] - t[e] : f[0];
-      for (int ch = 0; ch < nch; ++ch) rr[0] -= part[(int64_t)ch * km + e];
-      if (zl) part[(int64_t)(nch - 1) * km + e] = (real)0;
-      r[e] = rr[0];
+      if (given) {
+        rr[0] = r[e];
+      } else {
+        rr[0] = t ? f[0] - t[e] : f[0];
+        for (int ch = 0; ch < nch; ++ch) rr[0] -= part[(int64_t)ch * km + e];
+        if (zl) part[(int64_t)(nch - 1) * km + e] = (real)0;
+        r[e] = rr[0];
+      }
     }
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
@@ -1328,7 +1338,7 @@ template <typename real>
 static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_evec2, const real* d_eval,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
-                    const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* stream) {
+                    const int32_t* d_err, int32_t* h_err, int32_t a_sym, real* d_R, void* stream) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -1341,7 +1351,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   const int m = G.m;
   const int64_t vec = align_up((int64_t)k * m * sizeof(real), 256);
   char* w = (char*)d_work;
-  real* r = (real*)(w + 0 * vec);
+  real* r = d_R ? d_R : (real*)(w + 0 * vec);   // caller-owned residual: survives the call (carry-over for warm = 2)
   real* y = (real*)(w + 1 * vec);
   real* p = (real*)(w + 2 * vec);
   real* pt = (real*)(w + 3 * vec);
@@ -1378,21 +1388,26 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   if (vb < 1) vb = 1;
   dim3 vgrid((unsigned)vb, (unsigned)k);   // one 16-byte group per thread
 
-  if (warm) {
+  if (warm == 2) {
+    // r0 carried over by the caller in d_R (wiski_scatter_stats_cnt's d_res): no A u product
+    if (!d_R) return WISKI_E_BADARG;
+    if (wide) hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, 1, r, S);
+    else hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, 1, r, S);
+  } else if (warm) {
     // r0 = rhs - (z + A u)
     if (wide) {
       rc = spmv_wide(d_U, nullptr, (real)0, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, part, nch, zl, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, part, nch, zl, 0, r, S);
     } else {
       rc = spmv_narrow(d_U, d_Z, (real)1, hp, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (real*)nullptr, 0, 0, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)hp, (real*)nullptr, 0, 0, 0, r, S);
     }
   } else {
     if (hipMemsetAsync(d_U, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
     if (hipMemsetAsync(d_Z, 0, (size_t)k * m * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
-    hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, r, S);
+    hipLaunchKernelGGL((k_pcg_init<real, 1>), egrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, 0, r, S);
   }
 
   std::vector<double> h_rn0(k), h_rn(k);
@@ -1580,10 +1595,10 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
 }
-int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* s) {
-  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, s);
+int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s);
 }
-int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, void* s) {
-  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, s);
+int wiski_pcg_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* R, void* s) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s);
 }
 }

@@ -71,6 +71,8 @@ class ShardedStatsUpdater:
             noise = m._canon_noise(noise, Y)
         halves = m._half_buffers()
         m._absorb(delta, X, Y, noise, init=False, half_delta=halves)
+        if getattr(m, "_mean_state", None) is not None:
+            m._mean_state["R_ok"] = False            # the carried-over residual does not see the all-reduced increment
         dev = delta["_stats"].device
         nloc = float(X.reshape(-1, m._grid.d).shape[0])
         if noise is None:

@@ -170,13 +170,14 @@ def scatter_stats_sym(grid, x, y, wa, wb, noise, b, A_half, stats, err):
     _hip.check(rc, "wiski_scatter_stats_sym")
 
 
-def scatter_stats_cnt(grid, x, y, wa, wb, noise, b, A, half, cnt, stats, err):
-    """One launch: (b, A or its half delta, stats) as scatter_stats[_sym] plus cnt += W^T wa."""
+def scatter_stats_cnt(grid, x, y, wa, wb, noise, b, A, half, cnt, stats, err, u=None, res=None):
+    """One launch: (b, A full or symmetric half, stats) as scatter_stats[_sym] plus cnt += W^T wa and, with
+    (u, res) given, the residual carry-over res += W^T (wb y - wa (W u))."""
     x = _x2d(x, grid)
     rc = _hip.fn("wiski_scatter_stats_cnt", x.dtype)(grid.ref, _hip.dptr(x), _hip.dptr(y.contiguous()), _hip.dptr(wa.contiguous()),
                                                      _hip.dptr(wb.contiguous()), _hip.dptr(noise.contiguous()), ctypes.c_int64(x.shape[0]),
-                                                     _hip.dptr(b), _hip.dptr(A), ctypes.c_int32(int(half)), _hip.dptr(cnt), _hip.dptr(stats),
-                                                     _hip.dptr(err), _hip.stream_ptr(x.device))
+                                                     _hip.dptr(b), _hip.dptr(A), ctypes.c_int32(int(half)), _hip.dptr(cnt), _hip.dptr(u), _hip.dptr(res),
+                                                     _hip.dptr(stats), _hip.dptr(err), _hip.stream_ptr(x.device))
     _hip.check(rc, "wiski_scatter_stats_cnt")
 
 
@@ -304,16 +305,20 @@ def kron_eigen(grid, tcol, profiles=None):
 
 
 def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
-        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None, inplace=False):
+        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None, inplace=False, R=None):
     """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres).
     eigen = (evec, evals) from :func:`kron_eigen` selects the spectral
-    preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions."""
+    preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions.
+    R [k, m] (optional, contiguous): caller-owned residual buffer, left holding RHS - Z - A U;
+    warm=2 starts from the residual already in R (see wiski.h) instead of forming A U."""
     RHS2 = RHS.contiguous().reshape(-1, grid.m)
     k = RHS2.shape[0]
     if U is None or Z is None or (not warm and not inplace):
         U = torch.empty_like(RHS2)
         Z = torch.empty_like(RHS2)
         warm = False
+    if int(warm) == 2 and R is None:
+        raise ValueError("warm=2 needs the carried-over residual R")
     ws = workspace if workspace is not None else PCGWorkspace()
     buf, need = ws.get(grid, k, max_iter, RHS2.dtype, RHS2.device)
     iters = ctypes.c_int32(0)
@@ -326,7 +331,7 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
                                           cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
                                           _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
                                           ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
-                                          ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.stream_ptr(RHS2.device))
+                                          ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.dptr(R), _hip.stream_ptr(RHS2.device))
     if rc == -4 and not raise_on_fail:
         pass
     else:

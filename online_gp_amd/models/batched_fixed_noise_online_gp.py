@@ -223,6 +223,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         stats = cache["_stats"]
         ops = _wtw_ops(cache["WtW"])
         dst = half_delta if half_delta is not None else [op.stencil for op in ops]
+        # residual carry-over: while the posterior-mean state (U, Z, R = b - Z - A U) is current, the scatter
+        # keeps R exact under the increment, and the next refresh starts without an A U product
+        ms = self._mean_state
+        mine = cache is self._kernel_cache
+        carry = (mine and half_delta is None and not init and ms is not None and ms.get("R_ok", False)
+                 and settings.residual_carry_over.on())
+        if mine and ms is not None and not carry:
+            ms["R_ok"] = False
         if getattr(self, "_scratch_stats", None) is None:
             self._scratch_stats = torch.zeros(2, dtype=torch.float64, device=self._device)
         for o in range(self.num_outputs):
@@ -235,7 +243,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 wa = wb if init else 1.0 / no.clamp_min(1e-7)   # clamp_min(1e-7)**0.5 of :163, squared
             cnt_o = cache["_cnt"][o] if "_cnt" in cache else None     # row sums W^T wa ride on the same launch
             half = grid_ops.is_half_stencil(self._grid, dst[o])      # a handed-over cache may carry a full stencil
-            grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], dst[o], half, cnt_o, stats[o], self._err)
+            if carry and not half:
+                carry = ms["R_ok"] = False
+            grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], dst[o], half, cnt_o, stats[o], self._err,
+                                       u=ms["U"][o] if carry else None, res=ms["R"][o] if carry else None)
             if cache is self._kernel_cache or init:
                 if unit:
                     self._wsum_host[o] += float(n)
@@ -374,10 +385,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         ver = self._hyper_version()
         ms = self._mean_state
         if ms is not None and ms["U"].shape == (out, m):
-            U, Z = ms["U"], ms["Z"]                   # refreshed in place by the warm-started solves
+            U, Z, R = ms["U"], ms["Z"], ms["R"]       # refreshed in place by the warm-started solves
         else:
             U = torch.empty((out, m), dtype=self._dtype, device=self._device)
             Z = torch.empty_like(U)
+            R = torch.empty_like(U)
             ms = None
         iters = []
         posts = []
@@ -391,10 +403,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 posts.append(post)
                 continue
             warm = ms is not None
-            Uo, Zo = U[o:o + 1], Z[o:o + 1]           # contiguous row views: wiski_pcg updates them in place
+            Uo, Zo, Ro = U[o:o + 1], Z[o:o + 1], R[o:o + 1]   # contiguous row views: wiski_pcg updates them in place
+            carried = warm and ms.get("R_ok", False)
             if warm and ms["ver"] != ver:
                 tcol, s2, _ = hyper[o]
                 Uo.copy_(grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2))   # keep U = Kt Z under the new hypers
+                carried = False
             # warm refreshes poll convergence first where the previous one converged (streaming steps are
             # alike), every 8th one an iteration earlier, and then after every iteration
             fc = 0
@@ -403,7 +417,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 probe = getattr(self, "_probe_down", True) or self._refresh_count % 8 == 0
                 fc = max(1, self._last_iters[o] - (1 if probe else 0))
                 post.check_every = 1
-            post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=warm, first_check=fc, inplace=True)
+            # warm = 2: R was kept equal to b - Z - A U by the scatter launches since the last solve (recomputed
+            # from scratch every 16th refresh so that fp rounding of the recursion cannot accumulate)
+            if carried and getattr(self, "_refresh_count", 0) % 16 == 0:
+                carried = False
+            post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=2 if carried else warm, first_check=fc, inplace=True, R=Ro)
             if fc:
                 self._probe_down = post.last_iters <= fc and fc > 1      # keep probing while it keeps paying off
             iters.append(post.last_iters)
@@ -412,7 +430,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 self._err.zero_()
                 raise RuntimeError("Received data that was out of bounds for the specified grid. "
                                    f"Grid bounds were {self.covar_module.grid_bounds}.")
-        self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "ver": ver}
+        self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "R": R, "R_ok": True, "ver": ver}
         self._last_iters = list(iters)
         pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters}
         self._memo["prediction_cache"] = pc
@@ -556,6 +574,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         new_gp._absorb(new_cache, X, Y, noise, init=False)
         if self._mean_state is not None:
             new_gp._mean_state = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._mean_state.items()}
+            new_gp._mean_state["R_ok"] = False          # the copied residual predates the increment just absorbed
         if not self.training:
             new_gp.eval()
         return new_gp

@@ -138,6 +138,13 @@ class dense_small_grids(_feature_flag):
     _state = True
 
 
+class residual_carry_over(_feature_flag):
+    """Keep the posterior-mean residual b - z - A u current inside the scatter launches of streaming updates, so
+    that the warm-started refresh needs no A u product (recomputed from scratch every 16th refresh)."""
+
+    _state = True
+
+
 class precond_profile_drift(_value_context):
     """Largest change of the normalised per-dimension data-density profile (entries in [0.01, 1]) the
     CG preconditioner tolerates before its generalized eigenbasis is recomputed (the estimate itself

@@ -279,3 +279,48 @@ def test_dirichlet_classifier_wrapper_banana_like():
     assert correct / 200 >= 0.75
     assert clf.gp.num_data == 400 and clf.gp.num_outputs == 2
     assert clf.predict(Xt[400:]).eq(yt[400:]).float().mean().item() >= 0.85
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+def test_residual_carry_over_tracks_true_residual(dtype, tol):
+    """Streaming refreshes that start from the scatter-maintained residual (warm = 2) stay on the true residual
+    b - z - A u and give the same posterior as refreshes that recompute it (and as the data-space oracle)."""
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    torch.manual_seed(1)
+    d, g, n0, q, steps = 3, 12, 300, 64, 20      # 20 > 16: crosses one from-scratch recomputation
+    X = torch.rand(n0 + q * steps, d, device=DEV, dtype=dtype) * 2 - 1
+    y = (torch.sin(2 * X[:, 0]) + X[:, 1] * X[:, 2] + 0.1 * torch.randn(X.shape[0], device=DEV, dtype=dtype))[:, None]
+    noise = torch.rand_like(y) + 0.5
+
+    def run(carry):
+        with settings.residual_carry_over(carry), settings.cg_tolerance(1e-10 if dtype == torch.float64 else 1e-6), \
+                settings.dense_small_grids(False), torch.no_grad():
+            model = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], noise[:n0], grid_bounds=torch.tensor([[-1.1, 1.1]] * d), grid_size=g,
+                                          learn_additional_noise=True).eval()
+            used = 0
+            for s in range(steps):
+                sl = slice(n0 + s * q, n0 + (s + 1) * q)
+                model.prediction_cache                                   # refresh (warm from the 2nd step on)
+                used += int(bool(model._mean_state["R_ok"]))
+                model.condition_on_observations(X[sl], y[sl], noise[sl], inplace=True)
+                assert model._mean_state["R_ok"] == carry
+            pc = model.prediction_cache
+            ms = model._mean_state
+            c = model._kernel_cache
+            true_r = c["interpolation_cache"][0, :, 0] - ms["Z"][0] - grid_ops.stencil_spmv(model._grid, c["WtW"].stencil, ms["U"][0:1])[0]
+            return model, pc["pred_mean"][0, :, 0].clone(), ms["R"][0].clone(), true_r
+
+    m1, mean1, r1, true1 = run(True)
+    m0, mean0, _, _ = run(False)
+    scale = float(m1._kernel_cache["interpolation_cache"].abs().max())
+    assert float((r1 - true1).abs().max()) < tol * scale * 50          # the carried residual is the true residual
+    assert float((mean1 - mean0).abs().max()) < tol * 50 * float(mean0.abs().max())
+    Xs = X[:32]
+    O = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, sigma2=float(m1.likelihood.second_noise.detach())).fit(
+        X.double().cpu().numpy(), y[:, 0].double().cpu().numpy(), noise[:, 0].double().cpu().numpy())
+    mo, _ = O.predict(Xs.double().cpu().numpy())
+    with settings.skip_posterior_variances(True), settings.dense_small_grids(False), torch.no_grad():
+        mh = m1(Xs).mean.double().cpu().numpy()
+    assert np.abs(mh - mo).max() <= RTOL[dtype] * np.abs(mo).max()
