@@ -74,8 +74,8 @@ def cpu_baseline(args, tol):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="streamed points per step per GPU (q)")
     ap.add_argument("--grid", type=int, default=50)
     ap.add_argument("--dim", type=int, default=3)
