@@ -92,10 +92,18 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    # self-test hook for 1-GPU boxes: WISKI_BENCH_BACKEND=gloo puts every rank on cuda:0 and uses gloo, so that the
+    # N > 1 code path can be exercised without a second device (never used for reported numbers)
+    selftest = os.environ.get("WISKI_BENCH_BACKEND") == "gloo"
+    if selftest:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if selftest:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from online_gp_amd import _hip, settings
     from online_gp_amd.distributed import ShardedStatsUpdater
@@ -112,7 +120,7 @@ def main():
     gb = torch.tensor([[-1.1, 1.1]] * d)
     model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
     model.eval()
-    upd = ShardedStatsUpdater(model)
+    upd = ShardedStatsUpdater(model, equal_shards=True)   # every rank streams q points per step
     lib = _hip.lib()
 
     def step(t):
@@ -216,7 +224,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"3droad-like synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}",
-                       "batch_per_gpu": q, "global_batch": q * world, "parallelism": f"dp{world} (stats all-reduce)" if world > 1 else "single"},
+                       "batch_per_gpu": q, "global_batch": q * world, "parallelism": (f"dp{world} (" + ("shard all-gather + replicated scatter" if upd.last_exchange == "points"
+                                                          else "all-reduce of the half-stencil statistics") + ")") if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_stencil_spmv4_sym (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes},

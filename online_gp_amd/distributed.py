@@ -8,6 +8,10 @@ all-reduce(SUM) (RCCL over xGMI; gloo in the CPU tests) makes the delta global,
 and every rank adds it into its replica of the statistics.  Roots / solves are
 then computed redundantly per rank (they do not add).
 
+When a step's shards are small the same sum is cheaper to form redundantly: the ranks all-gather the
+raw points (q * (d + 2) reals each) and every rank scatters all of them -- (N - 1) extra scatter passes
+against an all-reduce of the whole half stencil.  ``exchange="auto"`` picks per call.
+
 The reference has no distributed code; this is the one collective of the path.
 """
 import torch
@@ -33,10 +37,54 @@ class ShardedStatsUpdater:
     noise_all, inplace=True)`` on every rank, where *_all is the concatenation of
     all ranks' shards."""
 
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, exchange="auto", equal_shards=False):
+        """exchange: "stats" (all-reduce the statistics deltas), "points" (all-gather the shards, scatter them all
+        on every rank) or "auto" (the cheaper of the two by a simple cost model).  The point exchange needs the same
+        shard length on every rank; ``equal_shards=True`` promises that (no size check), otherwise the sizes are
+        compared first (one tiny all-reduce + host read) and unequal shards fall back to the statistics exchange."""
+        if exchange not in ("auto", "stats", "points"):
+            raise ValueError("exchange must be 'auto', 'stats' or 'points'")
         self.model = model
         self.group = group
+        self.exchange = exchange
+        self.equal_shards = equal_shards
         self._delta = None
+        self.last_exchange = None
+
+    def _use_points(self, q, world, dev):
+        """Same decision on every rank: exchange the points iff the shards have equal length and the (world - 1)
+        redundant scatter passes (~1e11 lane-atomics/s) are cheaper than the stencil all-reduce (~1e11 B/s)."""
+        if self.exchange == "stats":
+            return False
+        m = self.model
+        if not self.equal_shards:
+            t = torch.tensor([float(q), -float(q)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            hi, neg_lo = t.tolist()
+            if hi != -neg_lo:
+                return False
+        if self.exchange == "points":
+            return True
+        grid = m._grid
+        T = 4 ** grid.d
+        atomics = world * q * (T * (T + 1) // 2) * m.num_outputs
+        stencil_bytes = 2 * ((grid.R + 1) // 2) * grid.m * m.num_outputs * (4 if m._dtype == torch.float32 else 8)
+        return atomics < stencil_bytes
+
+    def _update_points(self, X, Y, noise, world):
+        m = self.model
+        dev = m._device
+        d = m._grid.d
+        X2 = X.reshape(-1, d).to(dev, m._dtype)
+        cols = [X2, Y.to(dev, m._dtype)] + ([noise.to(dev, m._dtype)] if noise is not None else [])
+        packed = torch.cat(cols, dim=1).contiguous()
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(parts, packed, group=self.group)
+        allp = torch.cat(parts, dim=0)
+        out = Y.shape[1]
+        Xa, Ya = allp[:, :d].contiguous(), allp[:, d:d + out].contiguous()
+        Na = allp[:, d + out:].contiguous() if noise is not None else None
+        m.condition_on_observations(Xa, Ya, Na, inplace=True)
 
     def _delta_cache(self):
         """Zeroed delta copies of (b, stats); the W^T W delta lives in the model's symmetric
@@ -66,9 +114,15 @@ class ShardedStatsUpdater:
         if world == 1:
             m.condition_on_observations(X, Y, noise, inplace=True)
             return
-        delta = self._delta_cache()
         if noise is not None:
             noise = m._canon_noise(noise, Y)
+        q = X.reshape(-1, m._grid.d).shape[0]
+        if self._use_points(q, world, m._kernel_cache["_stats"].device):
+            self.last_exchange = "points"
+            self._update_points(X, Y, noise, world)
+            return
+        self.last_exchange = "stats"
+        delta = self._delta_cache()
         halves = m._half_buffers()
         m._absorb(delta, X, Y, noise, init=False, half_delta=halves)
         if getattr(m, "_mean_state", None) is not None:

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _Grid:
     d = 2
     R = 49
+    m = 64
 
 
 class _StubOp:
@@ -33,6 +34,8 @@ class StubModel:
         self.cp = cport
         self.gb, self.g = gb, g
         self._grid = _Grid()
+        self._dtype = torch.float64
+        self._device = torch.device("cpu")
         self.num_outputs = 1
         ref = cport.MatrixFreeWISKI(gb, g)
         self.m, self.R = ref.m, ref.R
@@ -91,19 +94,34 @@ def _worker(rank, world, port, tmpdir):
     X = torch.from_numpy(rng.uniform(-1, 1, (3, 40, 2)))          # 3 steps x 40 points, split over ranks
     Y = torch.from_numpy(rng.standard_normal((3, 40, 1)))
     N = torch.from_numpy(rng.uniform(0.5, 2.0, (3, 40, 1)))
-    model = StubModel(gb, g)
-    upd = ShardedStatsUpdater(model)
-    for s in range(3):
-        sl = slice(rank * 20, (rank + 1) * 20)
-        upd.update(X[s, sl], Y[s, sl], N[s, sl])
     ref = StubModel(gb, g)
     for s in range(3):
         ref.condition_on_observations(X[s], Y[s], N[s])
-    c, r = model._kernel_cache, ref._kernel_cache
-    ok = (torch.allclose(c["interpolation_cache"], r["interpolation_cache"], atol=1e-12) and
-          torch.allclose(c["WtW"].stencil, r["WtW"].stencil, atol=1e-12) and torch.allclose(c["_stats"], r["_stats"], atol=1e-10) and
-          model.num_data == 120 and model.dumped == 3 and
-          abs(model._wsum_host[0] - float((1.0 / N).sum())) < 1e-9)
+    r = ref._kernel_cache
+    ok = True
+    # "stats": all-reduce of the deltas; "points": all-gather of the shards + redundant scatter; "auto" picks one
+    for mode, expect in (("stats", "stats"), ("points", "points"), ("auto", None)):
+        model = StubModel(gb, g)
+        upd = ShardedStatsUpdater(model, exchange=mode)
+        for s in range(3):
+            sl = slice(rank * 20, (rank + 1) * 20)
+            upd.update(X[s, sl], Y[s, sl], N[s, sl])
+        c = model._kernel_cache
+        ok = ok and (torch.allclose(c["interpolation_cache"], r["interpolation_cache"], atol=1e-12) and
+                     torch.allclose(c["WtW"].stencil, r["WtW"].stencil, atol=1e-12) and torch.allclose(c["_stats"], r["_stats"], atol=1e-10) and
+                     model.num_data == 120 and (expect is None or upd.last_exchange == expect))
+        if mode == "stats":
+            ok = ok and model.dumped == 3 and abs(model._wsum_host[0] - float((1.0 / N).sum())) < 1e-9
+    # unequal shard lengths: the point exchange must fall back to the statistics exchange (same result)
+    model = StubModel(gb, g)
+    upd = ShardedStatsUpdater(model, exchange="points")
+    cut = 15 if rank == 0 else 25
+    sl = slice(0, 15) if rank == 0 else slice(15, 40)
+    upd.update(X[0, sl], Y[0, sl], N[0, sl])
+    one = StubModel(gb, g)
+    one.condition_on_observations(X[0], Y[0], N[0])
+    ok = ok and upd.last_exchange == "stats" and torch.allclose(model._kernel_cache["WtW"].stencil, one._kernel_cache["WtW"].stencil, atol=1e-12) \
+        and model.num_data == 40 and cut > 0
     open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()

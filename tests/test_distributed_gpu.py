@@ -1,5 +1,5 @@
-"""GPU (one device, two processes, gloo): the real HIP data-parallel path -- half-stencil delta scatter,
-all-reduce, streaming fold -- equals single-process accumulation of the concatenated shards."""
+"""GPU (one device, two processes, gloo): the real HIP data-parallel paths -- half-stencil delta scatter +
+all-reduce, and shard all-gather + redundant scatter -- equal single-process accumulation of the concatenated shards."""
 import os
 import socket
 import sys
@@ -27,25 +27,30 @@ def _worker(rank, world, port, tmpdir):
     X = torch.as_tensor(rng.uniform(-1, 1, (40 + 3 * 2048, 3)), device=dev, dtype=torch.float32)
     y = torch.sin(2 * X[:, :1]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=torch.float32)
     gb = torch.tensor([[-1.1, 1.1]] * 3)
-    model = FixedNoiseOnlineSKIGP(X[:40], y[:40], None, grid_bounds=gb, grid_size=12, learn_additional_noise=True)
-    model.eval()
-    upd = ShardedStatsUpdater(model)
-    for s in range(3):
-        lo = 40 + s * 2048 + rank * 1024
-        upd.update(X[lo:lo + 1024], y[lo:lo + 1024])                       # unit noise, half-stencil delta + all-reduce + fold
     ref = FixedNoiseOnlineSKIGP(X[:40], y[:40], None, grid_bounds=gb, grid_size=12, learn_additional_noise=True)
     ref.eval()
     for s in range(3):
         lo = 40 + s * 2048
         ref.condition_on_observations(X[lo:lo + 2048], y[lo:lo + 2048], inplace=True)
-    a, b = model._kernel_cache, ref._kernel_cache
+    b = ref._kernel_cache
     sc = float(b["WtW"].stencil.abs().max())
-    ok = ((a["WtW"].stencil - b["WtW"].stencil).abs().max().item() < 1e-4 * sc and
-          (a["interpolation_cache"] - b["interpolation_cache"]).abs().max().item() < 1e-4 * float(b["interpolation_cache"].abs().max()) and
-          torch.allclose(a["_stats"], b["_stats"], rtol=1e-6) and torch.allclose(a["_cnt"], b["_cnt"], rtol=1e-4, atol=1e-4) and
-          model.num_data == ref.num_data == 40 + 3 * 2048 and abs(model._wsum[0] - ref._wsum[0]) < 1e-6)
     Xs = X[:16]
-    ok = ok and torch.allclose(model(Xs).mean, ref(Xs).mean, rtol=1e-3, atol=1e-4)
+    ok = True
+    for mode in ("stats", "points"):      # all-reduce of the half-stencil delta / all-gather of the shards + redundant scatter
+        model = FixedNoiseOnlineSKIGP(X[:40], y[:40], None, grid_bounds=gb, grid_size=12, learn_additional_noise=True)
+        model.eval()
+        upd = ShardedStatsUpdater(model, exchange=mode)
+        for s in range(3):
+            lo = 40 + s * 2048 + rank * 1024
+            upd.update(X[lo:lo + 1024], y[lo:lo + 1024])                   # unit noise
+            model.prediction_cache                                          # refresh between updates (exercises the carried residual)
+        a = model._kernel_cache
+        ok = ok and ((a["WtW"].stencil - b["WtW"].stencil).abs().max().item() < 1e-4 * sc and
+                     (a["interpolation_cache"] - b["interpolation_cache"]).abs().max().item() < 1e-4 * float(b["interpolation_cache"].abs().max()) and
+                     torch.allclose(a["_stats"], b["_stats"], rtol=1e-6) and torch.allclose(a["_cnt"], b["_cnt"], rtol=1e-4, atol=1e-4) and
+                     model.num_data == ref.num_data == 40 + 3 * 2048 and abs(model._wsum[0] - ref._wsum[0]) < 1e-6 and
+                     upd.last_exchange == mode)
+        ok = ok and torch.allclose(model(Xs).mean, ref(Xs).mean, rtol=1e-3, atol=1e-4)
     open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
