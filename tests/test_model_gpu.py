@@ -324,3 +324,44 @@ def test_residual_carry_over_tracks_true_residual(dtype, tol):
     with settings.skip_posterior_variances(True), settings.dense_small_grids(False), torch.no_grad():
         mh = m1(Xs).mean.double().cpu().numpy()
     assert np.abs(mh - mo).max() <= RTOL[dtype] * np.abs(mo).max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_empty_batches_and_colliding_points(dtype):
+    """Edge cases of the streaming update: an empty batch changes nothing; a batch of identical points (every atomic of
+    the scatter collides) and a batch on the grid-box corners (one-hot boundary cells) match the data-space oracle."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    torch.manual_seed(3)
+    d, g = 3, 12
+    gb = [[-1.1, 1.1]] * d
+    X0 = torch.rand(200, d, device=DEV, dtype=dtype) * 2 - 1
+    f = lambda X: (torch.sin(2 * X[:, 0]) + X[:, 1] * X[:, 2])[:, None]
+    y0 = f(X0) + 0.1 * torch.randn(200, 1, device=DEV, dtype=dtype)
+    with settings.dense_small_grids(False), settings.cg_tolerance(1e-10 if dtype == torch.float64 else 1e-6), torch.no_grad():
+        model = FixedNoiseOnlineSKIGP(X0, y0, None, grid_bounds=torch.tensor(gb), grid_size=g, learn_additional_noise=True).eval()
+        model.prediction_cache
+        before = {k: v.clone() for k, v in (("b", model._kernel_cache["interpolation_cache"]), ("A", model._kernel_cache["WtW"].stencil),
+                                            ("s", model._kernel_cache["_stats"]))}
+        model.condition_on_observations(X0[:0], y0[:0], inplace=True)                 # empty batch
+        assert model.num_data == 200
+        assert torch.equal(before["b"], model._kernel_cache["interpolation_cache"]) and torch.equal(before["A"], model._kernel_cache["WtW"].stencil)
+        assert torch.equal(before["s"], model._kernel_cache["_stats"])
+        xd = torch.tensor([[0.3, -0.2, 0.55]], device=DEV, dtype=dtype).repeat(777, 1)   # 777 copies of one point
+        yd = f(xd) + 0.1 * torch.randn(777, 1, device=DEV, dtype=dtype)
+        corners = torch.tensor([[sx * 1.1, sy * 1.1, sz * 1.1] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], device=DEV, dtype=dtype)
+        yc = f(corners)
+        model.condition_on_observations(xd, yd, inplace=True)
+        model.prediction_cache
+        model.condition_on_observations(corners, yc, inplace=True)
+        Xs = torch.cat([X0[:24], xd[:1], corners[:2]])
+        mvn = model(Xs)
+        mean, var = mvn.mean.double().cpu().numpy(), mvn.variance.double().cpu().numpy()
+    Xall = torch.cat([X0, xd, corners]).double().cpu().numpy()
+    yall = torch.cat([y0, yd, yc])[:, 0].double().cpu().numpy()
+    O = dataspace.DataSpaceGP(gb, g, sigma2=float(model.likelihood.second_noise.detach())).fit(Xall, yall, np.ones(Xall.shape[0]))
+    mo, vo = O.predict(Xs.double().cpu().numpy())
+    assert model.num_data == 200 + 777 + 8
+    assert np.abs(mean - mo).max() <= RTOL[dtype] * np.abs(mo).max()
+    assert np.abs(var - vo).max() <= RTOL[dtype] * np.abs(vo).max()
