@@ -38,9 +38,12 @@ class _WoodburyTerms(torch.autograd.Function):
         A = model._kernel_cache["WtW"]
         A = A.ops[o] if hasattr(A, "ops") else A
         b = model._kernel_cache["interpolation_cache"][o, :, 0]
-        eig = grid_ops.kron_eigen(grid, tcol)
         m = grid.m
-        if model._use_dense():
+        dense = model._use_dense()
+        # plain eigenbasis of Kt: the dense factor and the SLQ logdet need it; the streaming hyper step
+        # (skip_logdet_forward, large grid) does not -- 3 host eigh + an upload saved per step
+        eig = grid_ops.kron_eigen(grid, tcol) if (dense or want_logdet) else None
+        if dense:
             # small grid: everything from the dense factor, exact trace (S = A - A M A by Woodbury)
             from ..lazy.dense_woodbury import DenseInducingPosterior
 
@@ -60,7 +63,7 @@ class _WoodburyTerms(torch.autograd.Function):
         # same density-profile preconditioner as the posterior refresh (re-solved because the hypers moved)
         peig, shift = model._precond(o, tcol)
         if peig is None:
-            peig, shift = eig, float(model._wsum[o]) / grid.m
+            peig, shift = (eig if eig is not None else grid_ops.kron_eigen(grid, tcol)), float(model._wsum[o]) / grid.m
         tol = settings.cg_tolerance.value() or (1e-7 if dt == torch.float32 else 1e-11)
         kw = dict(tol=tol, max_iter=settings.max_cg_iterations.value(), check_every=settings.cg_check_every.value(), workspace=model._pcg_ws,
                   eigen=peig, shift=shift)
