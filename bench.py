@@ -228,7 +228,11 @@ def main():
                                                           else "all-reduce of the half-stencil statistics") + ")") if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_stencil_spmv4_sym (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes},
+                         "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
+                         # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
+                         # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
+                         "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es,
+                         "full_stencil_equivalent_frac": ((grid.R * grid.m * es + 2 * grid.m * es) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if n_l else 0.0},
             "extra": {"cg_iters_per_step_mean": float(np.mean(iters)), "absorb_only_updates_per_s": q / ta,
                       "variance_ms_per_64_queries": tv * 1e3, "step_ms_q1": small[1], "step_ms_q64": small[64], "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
         }

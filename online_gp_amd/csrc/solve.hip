@@ -653,8 +653,9 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
   // row's 7 offsets adjacent (the scatter's layout), so the wave reads its 256 rows x 7 reals as one
   // contiguous span with fully coalesced 16-byte loads, parks it in a wave-private LDS tile and reads it
   // back row-wise: lane t gets the 28 reals of rows 4t..4t+3 (7 x ds_read_b128, stride 112 B: bank-
-  // conflict free).  (Issuing the next group's loads before consuming the current one was measured on the
-  // offset-major predecessor of this kernel: no gain at 50^3 fp32, 10% slower at 30^4 fp64.)
+  // conflict free).  (Issuing the next group's loads before consuming the current one was measured twice -- on the
+  // offset-major predecessor and on this kernel, v window first so that vmcnt can retire it alone: 158 VGPRs,
+  // 23.3 us at best (5 chunks) against 23.9 us without; not kept.)
   struct GroupData {
     Vec4<real> a[7];       // a[s].{x,y,z,w} = rows i4..i4+3 at innermost offset digit s
   };
