@@ -313,16 +313,23 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         t_q = per-dim marginal of the row sums of W^T D^-1 W (the data-density profile: the
         grid nodes outside the data box carry no data), a = total mass / prod_q sum(t_q).
         The d small generalized eigenproblems are re-solved when the hyper-parameters change,
-        or when -- checked each time the data volume has grown by 30 % -- the normalised density
-        profile has moved by more than settings.precond_profile_drift (a stationary stream keeps
-        its eigenbasis); `a` follows the stream exactly."""
+        or when the normalised density profile has moved by more than
+        settings.precond_profile_drift (a stationary stream keeps its eigenbasis).  The profile is
+        looked at (3 small reductions + one host read, ~0.15 ms) each time the data volume has
+        doubled, or as soon as a warm refresh needs 2 more CG iterations than the first one after
+        the last re-solve did -- the symptom of a stale basis; `a` follows the stream exactly."""
         if settings.spectral_preconditioner.off():
             return None, 0.0
         ver = self._hyper_version()
         st = self._memo.setdefault("precond", {}).get(o)
         wsum = float(self._wsum[o])
         stale = st is None or st["ver"] != ver
-        if stale or wsum > 1.3 * st["wsum"] or wsum < 0.5 * st["wsum"]:
+        its = (getattr(self, "_last_iters", None) or [0] * (o + 1))[o]
+        if not stale:
+            if st.get("it0") is None and its > 0:
+                st["it0"] = its                          # iteration level of this basis when it was fresh
+            slow = st.get("it0") is not None and its >= st["it0"] + 2 and wsum > 1.1 * st["wsum"]
+        if stale or wsum > 2.0 * st["wsum"] or wsum < 0.5 * st["wsum"] or slow:
             profiles, norm = None, float(self._grid.m)
             cnt = self._kernel_cache.get("_cnt") if settings.density_profile_preconditioner.on() else None
             if cnt is not None and wsum > 0:
@@ -340,9 +347,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             if (old is not None and profiles is not None and
                     max(float(abs(a - b).max()) for a, b in zip(profiles, old)) <= settings.precond_profile_drift.value()):
                 st["wsum"] = wsum                      # same density shape: keep the eigenbasis, only the scale moves
+                st["it0"] = None
             else:
                 eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles)
-                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles}
+                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles, "it0": None}
                 self._memo["precond"][o] = st
         return st["eig"], wsum / st["norm"]
 
