@@ -38,10 +38,22 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synth_stream(n, d, seed, device, dtype):
-    """S3 of SURVEY.md 8d: X ~ U(-1,1)^3, y = sin(2 pi x0) cos(pi x1) + 0.5 x2 + 0.1 N(0,1), standardised."""
+def synth_stream(n, d, seed, device, dtype, kind="uniform"):
+    """S3 of SURVEY.md 8d: X ~ U(-1,1)^3, y = sin(2 pi x0) cos(pi x1) + 0.5 x2 + 0.1 N(0,1), standardised.
+    kind="clustered": the road-like variant of 8d -- points along 64 random poly-lines (8 segments each, the same
+    lines for every seed) with sigma = 0.02 jitter, so that many points of a batch share grid cells."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    X = torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1
+    if kind == "clustered":
+        gl = torch.Generator(device="cpu").manual_seed(12345)
+        knots = torch.rand(64, 9, d, generator=gl, dtype=torch.float64) * 1.8 - 0.9        # 64 lines x 9 knots
+        line = torch.randint(0, 64, (n,), generator=g)
+        t = torch.rand(n, generator=g, dtype=torch.float64) * 8
+        seg = t.floor().clamp(max=7).long()
+        fr = (t - seg)[:, None]
+        X = (1 - fr) * knots[line, seg] + fr * knots[line, seg + 1] + 0.02 * torch.randn(n, d, generator=g, dtype=torch.float64)
+        X = X.clamp(-1.0, 1.0)
+    else:
+        X = torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1
     y = torch.sin(2 * np.pi * X[:, 0]) * torch.cos(np.pi * X[:, 1 % d]) + 0.5 * X[:, (2 % d)] + 0.1 * torch.randn(n, generator=g, dtype=torch.float64)
     y = (y - y.mean()) / y.std()
     return X.to(device, dtype), y.to(device, dtype)[:, None]
@@ -82,6 +94,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--n-init", type=int, default=21743, help="5%% of 434874 (init_ratio of the reference config)")
     ap.add_argument("--tol", type=float, default=None, help="CG relative-residual tolerance")
+    ap.add_argument("--stream", default="uniform", choices=["uniform", "clustered"], help="synthetic stream of SURVEY.md 8d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
@@ -115,8 +128,8 @@ def main():
     K, Wm, q, d = args.steps, args.warmup, args.batch, args.dim
 
     # identical init on every rank (replicated statistics), rank-local stream shards
-    X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype)
-    Xs, ys = synth_stream((K + Wm + 1) * q, d, 1000 + rank, dev, dtype)
+    X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
+    Xs, ys = synth_stream((K + Wm + 1) * q, d, 1000 + rank, dev, dtype, args.stream)
     gb = torch.tensor([[-1.1, 1.1]] * d)
     model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
     model.eval()
@@ -222,7 +235,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"3droad-like synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
+            "config": {"workload": ("clustered (64 poly-lines, sigma 0.02) " if args.stream == "clustered" else "") + f"3droad-like synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}",
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": (f"dp{world} (" + ("shard all-gather + replicated scatter" if upd.last_exchange == "points"
                                                           else "all-reduce of the half-stencil statistics") + ")") if world > 1 else "single"},
