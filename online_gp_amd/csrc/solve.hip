@@ -597,9 +597,6 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
   const int cP = ng - 1;                        // prefix code of the centre: (7^(d-1) - 1) / 2
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int STAGE = 7 * 256;                // reals of one group tile of a wave
-  // columns whose v / transposed-term windows are live together.  Sub-blocking (CB < KC, the A tile kept in
-  // registers across sub-blocks) was measured slower: CB = 2 of KC = 4 in fp64 1.8x, KC = 8 / CB = 4 in fp32 1.3x.
-  constexpr int CB = KC;
   real* __restrict__ stage = reinterpret_cast<real*>(smem) + (size_t)wave * (STAGE + KC * 4 * W4);   // this wave's A tile
   real* __restrict__ tw = stage + STAGE;                                                           // and its [KC][4][W4] window
   for (int g = gA + t; g < gB; g += blockDim.x) {
@@ -655,9 +652,11 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
   // back row-wise: lane t gets the 28 reals of rows 4t..4t+3 (7 x ds_read_b128, stride 112 B: bank-
   // conflict free).  (Issuing the next group's loads before consuming the current one was measured twice -- on the
   // offset-major predecessor and on this kernel, v window first so that vmcnt can retire it alone: 158 VGPRs,
-  // 23.3 us at best (5 chunks) against 23.9 us without; not kept.)
+  // 23.3 us at best (5 chunks) against 23.9 us without; not kept.  Mind the register budget: 120 VGPRs keep 4 waves
+  // per SIMD = 16 per CU for the 13.3 this grid wants; a refactor that cost 130 made the kernel 28% slower.)
   struct GroupData {
     Vec4<real> a[7];       // a[s].{x,y,z,w} = rows i4..i4+3 at innermost offset digit s
+    real win[KC][10];
   };
   const int nrows = m - iw0 < 256 ? m - iw0 : 256;      // rows of this wave inside the grid (multiple of 4, may be <= 0)
   auto fetch = [&](int g, GroupData& D) {
@@ -698,6 +697,14 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 #pragma unroll
       for (int l = 0; l < 7; ++l) { D.a[l].x = v[l]; D.a[l].y = v[7 + l]; D.a[l].z = v[14 + l]; D.a[l].w = v[21 + l]; }
     }
+    const int base = i4 + f - 3;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+      int j = base + e;
+      j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) D.win[c][e] = (c0 + c < k) ? V[(int64_t)(c0 + c) * m + j] : (real)0;
+    }
   };
   GroupData cur;
   int wb = s_off[0];
@@ -710,62 +717,45 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
     if (nrows > 0) fetch(g, cur);         // wave-cooperative (all lanes), rows past the grid read as zeros
     SYM_STAMP(2 + 3 * (g - gA));
     if (live) {
-      // columns in sub-blocks of CB: the A tile stays in registers for all KC columns (one pass over A_h per KC
-      // columns), while only CB windows of v and CB transposed-term windows are live at a time
-      const int base = i4 + f - 3;
+      real tr[KC][10];
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int e = 0; e < 10; ++e) tr[c][e] = (real)0;
+#pragma unroll
+      for (int l = 0; l < 7; ++l) {
+        const Vec4<real> a = cur.a[l];       // exact zeros for the digits the centre group does not store
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          acc[c][0] += a.x * cur.win[c][l + 0];
+          acc[c][1] += a.y * cur.win[c][l + 1];
+          acc[c][2] += a.z * cur.win[c][l + 2];
+          acc[c][3] += a.w * cur.win[c][l + 3];
+          if (g == 0 && l == 3) {           // the diagonal: counted once
+            dg[c][0] = a.x * xo[c][0]; dg[c][1] = a.y * xo[c][1]; dg[c][2] = a.z * xo[c][2]; dg[c][3] = a.w * xo[c][3];
+          } else {
+            tr[c][l + 0] += a.x * xo[c][0];
+            tr[c][l + 1] += a.y * xo[c][1];
+            tr[c][l + 2] += a.z * xo[c][2];
+            tr[c][l + 3] += a.w * xo[c][3];
+          }
+        }
+      }
+      SYM_STAMP(3 + 3 * (g - gA));
+#if WISKI_SYM_ABLATE != 1
       const int w0 = 4 * lane + (f - wb);
 #pragma unroll
-      for (int cb = 0; cb < KC; cb += CB) {
-        real win[CB][10], tr[CB][10];
+      for (int ph = 0; ph < 3; ++ph) {      // lane-disjoint phases, see the header comment
 #pragma unroll
-        for (int e = 0; e < 10; ++e) {
-          int j = base + e;
-          j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+        for (int e = 4 * ph; e < (ph == 2 ? 10 : 4 * ph + 4); ++e) {
+          const int idx = w0 + e;
+          real* cell = tw + (idx & 3) * W4 + (idx >> 2);
 #pragma unroll
-          for (int c = 0; c < CB; ++c) {
-#if WISKI_SYM_ABLATE == 4
-            win[c][e] = (real)(j & 7);          // timing ablation: no v-window loads
-#else
-            win[c][e] = (c0 + cb + c < k) ? V[(int64_t)(c0 + cb + c) * m + j] : (real)0;
-#endif
-            tr[c][e] = (real)0;
-          }
+          for (int c = 0; c < KC; ++c) cell[c * 4 * W4] += tr[c][e];
         }
-#pragma unroll
-        for (int l = 0; l < 7; ++l) {
-          const Vec4<real> a = cur.a[l];       // exact zeros for the digits the centre group does not store
-#pragma unroll
-          for (int c = 0; c < CB; ++c) {
-            acc[cb + c][0] += a.x * win[c][l + 0];
-            acc[cb + c][1] += a.y * win[c][l + 1];
-            acc[cb + c][2] += a.z * win[c][l + 2];
-            acc[cb + c][3] += a.w * win[c][l + 3];
-            if (g == 0 && l == 3) {           // the diagonal: counted once
-              dg[cb + c][0] = a.x * xo[cb + c][0]; dg[cb + c][1] = a.y * xo[cb + c][1];
-              dg[cb + c][2] = a.z * xo[cb + c][2]; dg[cb + c][3] = a.w * xo[cb + c][3];
-            } else {
-              tr[c][l + 0] += a.x * xo[cb + c][0];
-              tr[c][l + 1] += a.y * xo[cb + c][1];
-              tr[c][l + 2] += a.z * xo[cb + c][2];
-              tr[c][l + 3] += a.w * xo[cb + c][3];
-            }
-          }
-        }
-        if (cb == 0) SYM_STAMP(3 + 3 * (g - gA));
-#if WISKI_SYM_ABLATE != 1
-#pragma unroll
-        for (int ph = 0; ph < 3; ++ph) {      // lane-disjoint phases, see the header comment
-#pragma unroll
-          for (int e = 4 * ph; e < (ph == 2 ? 10 : 4 * ph + 4); ++e) {
-            const int idx = w0 + e;
-            real* cell = tw + (idx & 3) * W4 + (idx >> 2);
-#pragma unroll
-            for (int c = 0; c < CB; ++c) cell[(cb + c) * 4 * W4] += tr[c][e];
-          }
-          wave_lds_fence();
-        }
-#endif
+        wave_lds_fence();
       }
+#endif
       SYM_STAMP(4 + 3 * (g - gA));
     }
   }
@@ -802,7 +792,8 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
                             hipStream_t s) {
   const int ng = sym_groups(G.d), nch = sym_nch(G.d);
   if (ng - (int)((int64_t)(nch - 1) * ng / nch) > 176 || ng > 176 * nch) return WISKI_E_BADARG;
-  // columns per pass over A_h (8 per pass was measured: 344 / 488 VGPRs leave one wave per SIMD, 1.3x / 2.2x slower)
+  // columns per pass over A_h (8 per pass, with the v / transposed windows of 4 live at a time, was measured:
+  // 344 / 488 VGPRs leave one wave per SIMD, 1.3x / 2.2x slower)
   const int kc = k >= 4 ? 4 : (k >= 2 ? 2 : 1);
   // window span: one full cycle of the second-to-last stencil digit, shrunk to fit 48 KB of LDS
   int span = G.d >= 2 ? 6 * G.stride[G.d - 2] : 0;
