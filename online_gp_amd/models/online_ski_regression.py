@@ -5,7 +5,7 @@ import torch
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
 from .. import settings
-from ..mlls import BatchedWoodburyMarginalLogLikelihood, sm_partial_mll
+from ..mlls import BatchedWoodburyMarginalLogLikelihood, mll_feature_surrogate, sm_partial_mll
 from .batched_fixed_noise_online_gp import FixedNoiseOnlineSKIGP
 
 
@@ -79,6 +79,9 @@ class OnlineSKIRegression(torch.nn.Module):
             self.gp_optimizer.zero_grad()
             train_dist = self.gp(features)
             loss = -self.mll(train_dist, targets).sum()
+            if features.requires_grad and self.gp._use_dense():
+                # joint stem + GP training (OSR:80-112): d(-MLL)/d features, written out (mlls/feature_gradient.py)
+                loss = loss + mll_feature_surrogate(self.gp, features, targets)
             loss.backward()
             self.stem_optimizer.step()
             self.gp_optimizer.step()

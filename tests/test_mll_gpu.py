@@ -198,3 +198,48 @@ def test_learned_stem_streaming_update_runs():
     assert (stem[0].weight.detach() - w0).abs().max() > 0
     rmse, nll = r.evaluate(Xt[300:], yt[300:])
     assert np.isfinite(rmse) and np.isfinite(nll)
+
+
+def test_mll_feature_gradient_matches_finite_differences_and_fit_trains_the_stem():
+    """d(-MLL)/d features (mlls/feature_gradient.py: joint stem + GP training of OSR.fit, OSR:80-112) against central
+    differences of the MLL itself, single- and multi-output with heteroscedastic noise; then fit() moves a LinearStem."""
+    from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood, mll_feature_surrogate
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP, LinearStem, OnlineSKIRegression
+
+    rng = np.random.default_rng(5)
+    n, d, out = 36, 2, 2
+    X = torch.as_tensor(rng.uniform(-0.9, 0.9, (n, d)), device=DEV)
+    Y = torch.as_tensor(np.stack([np.sin(2 * X[:, 0].cpu().numpy()) + X[:, 1].cpu().numpy(), np.cos(X[:, 0].cpu().numpy() * X[:, 1].cpu().numpy())], 1)
+                        + 0.1 * rng.standard_normal((n, out)), device=DEV)
+    N = torch.as_tensor(rng.uniform(0.5, 1.5, (n, out)), device=DEV)
+    gb = torch.tensor([[-1.1, 1.1]] * d)
+
+    def neg_mll(Xq):
+        m = FixedNoiseOnlineSKIGP(Xq, Y, N, grid_bounds=gb, grid_size=8, learn_additional_noise=True).double()
+        mll = BatchedWoodburyMarginalLogLikelihood(m.likelihood, m)
+        m.train()
+        return m, -mll(m(Xq), Y).sum()
+
+    Xg = X.clone().requires_grad_(True)
+    m, loss = neg_mll(Xg.detach())
+    surr = mll_feature_surrogate(m, Xg, Y, N)
+    assert abs(float(surr.detach())) == 0.0
+    surr.backward()
+    g = Xg.grad.cpu().numpy()
+    eps = 1e-5
+    for (i, j) in [(0, 0), (7, 1), (20, 0), (35, 1)]:
+        Xp, Xm = X.clone(), X.clone()
+        Xp[i, j] += eps; Xm[i, j] -= eps
+        fd = (float(neg_mll(Xp)[1]) - float(neg_mll(Xm)[1])) / (2 * eps)
+        assert abs(g[i, j] - fd) < 1e-5 * max(1.0, abs(fd)), (i, j, g[i, j], fd)
+
+    # fit(): the stem parameters receive gradients and move; the training loss goes down
+    torch.manual_seed(0)
+    Xh = torch.randn(120, 5, device=DEV, dtype=torch.float32)
+    yh = (torch.tanh(Xh[:, :1] - 0.5 * Xh[:, 1:2]) + 0.05 * torch.randn(120, 1, device=DEV))
+    stem = LinearStem(5, 2)
+    model = OnlineSKIRegression(stem, Xh, yh, 5e-2, 8, 1.0)
+    w0 = [p.detach().clone() for p in model.stem.parameters()]
+    rec = model.fit(Xh, yh, 15)
+    assert any((p.detach() - q).abs().max() > 1e-4 for p, q in zip(model.stem.parameters(), w0))
+    assert rec[-1]["train_loss"] < rec[0]["train_loss"]
