@@ -32,6 +32,32 @@ class DenseInducingPosterior(_Operator):
         self.dense = grid_ops.gemm(T, T, ta=True)                                                # M = T^T T
         self.logdet = grid_ops.chol_logdet(self.chol)
         self.last_iters, self.last_relres = 0, []
+        self.updates = 0          # rank-q updates applied since the last fresh factorisation
+
+    def rank_update(self, wtw_new, x, wa, err):
+        """Posterior for the statistics A + W(x)^T diag(wa) W(x), from this one, in O(m^2 q):
+            M' = M - M W^T (diag(1/wa) + W M W^T)^-1 W M,
+            logdet(I + Kt A') = logdet(I + Kt A) + logdet(diag(wa)) + logdet(diag(1/wa) + W M W^T)
+        -- the posterior-space counterpart of the reference's rank-q root update (URLT:69-119), used by
+        condition_on_observations / fantasies in the dense regime instead of a fresh O(m^3) factor."""
+        grid = self.grid
+        new = object.__new__(DenseInducingPosterior)
+        new.grid, new.wtw, new.tcol, new.kscale, new.eigen = grid, wtw_new, self.tcol, self.kscale, self.eigen
+        new.shape, new.dtype, new.device = self.shape, self.dtype, self.device
+        new.chol = None
+        MW = grid_ops.gather_rows(grid, x, self.dense, err)               # [q, m]: rows w_p^T M
+        W = grid_ops.wt_columns(grid, x, err)                             # [q, m]
+        S = grid_ops.gemm(MW, W, tb=True)                                 # W M W^T
+        S = 0.5 * (S + S.t())
+        S.diagonal().add_(1.0 / wa)
+        L = grid_ops.psd_safe_cholesky(S.contiguous())
+        C = grid_ops.trsm_(L, MW.clone(), trans=False)                    # L^-1 W M
+        new.dense = self.dense.clone()
+        grid_ops.gemm(C, C, ta=True, alpha=-1.0, beta=1.0, C=new.dense)   # M - (W M)^T S^-1 (W M)
+        new.logdet = self.logdet + grid_ops.chol_logdet(L) + torch.log(wa.double()).sum()
+        new.last_iters, new.last_relres = 0, []
+        new.updates = self.updates + 1
+        return new
 
     def solve_columns(self, RHS, U=None, Z=None, warm=False):
         """RHS [k, m] -> U = M RHS (rows), Z = Kt^-1 U is not tracked in the dense path."""

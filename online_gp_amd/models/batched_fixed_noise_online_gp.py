@@ -382,6 +382,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """pred_mean = (Kt^-1 + A)^-1 W^T D^-1 y  [out, m, 1]   (:368-383), and the
         lazy pred_cov operator(s).  The mean solve is warm-started from the
         previous solution (U, Z) after every streaming update."""
+        self._apply_pending_rank_update()
         pc = self._memo.get("prediction_cache")
         if pc is not None:
             return pc
@@ -440,7 +441,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                                    f"Grid bounds were {self.covar_module.grid_bounds}.")
         self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "R": R, "R_ok": True, "ver": ver}
         self._last_iters = list(iters)
-        pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters}
+        pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters, "ver": ver}
         self._memo["prediction_cache"] = pc
         return pc
 
@@ -488,6 +489,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
 
     def _dump_caches(self):
         self._memo.pop("prediction_cache", None)
+        self._memo.pop("pending_rank_update", None)
         self._memo.pop("root_space", None)
         # "hyper" (Toeplitz columns + Kronecker eigenbasis) is keyed on the parameters' version
         # counters and survives streaming updates: only a hyper-parameter change invalidates it
@@ -562,10 +564,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if noise is not None:
             noise = self._canon_noise(noise, Y)
         q = X.reshape(-1, self._grid.d).shape[0]
+        old_pc = self._rank_update_source(q)
         if inplace:
             self._absorb(self._kernel_cache, X, Y, noise, init=False)
             self.num_data = self.num_data + q
             self._dump_caches()
+            self._seed_rank_updated_cache(self, old_pc, X, noise, Y)
             return None
         new_cache = self._clone_cache(self._kernel_cache)
         new_gp = type(self)(
@@ -585,7 +589,58 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             new_gp._mean_state["R_ok"] = False          # the copied residual predates the increment just absorbed
         if not self.training:
             new_gp.eval()
+        self._seed_rank_updated_cache(new_gp, old_pc, X, noise, Y)
         return new_gp
+
+    def _rank_update_source(self, q):
+        """The cached dense posterior(s), if a rank-q Woodbury update of them is valid and cheaper than a fresh factor:
+        dense regime, cache built for the current hyper-parameters, 0 < q <= m / 8, fewer than 64 stacked updates."""
+        if q == 0 or not self._use_dense() or q > self._grid.m // 8 or settings.dense_rank_updates.off():
+            return None
+        self._apply_pending_rank_update()
+        pc = self._memo.get("prediction_cache")
+        if pc is None or pc.get("ver") != self._hyper_version():
+            return None
+        posts = pc["pred_cov"].ops if self.num_outputs > 1 else [pc["pred_cov"]]
+        if not all(isinstance(p, DenseInducingPosterior) and p.updates < 64 for p in posts):
+            return None
+        return posts
+
+    @staticmethod
+    def _seed_rank_updated_cache(target, old_posts, X, noise, Y):
+        """Note on `target` (self or the sibling model) that its prediction cache can be obtained from `old_posts` by a
+        rank-q update.  Applied lazily by the next prediction_cache request; dropped if the caches are dumped first
+        (e.g. by a hyper-parameter step), so a BO loop that refits after every update pays nothing for it."""
+        if old_posts is None:
+            return
+        X = X.reshape(-1, target._grid.d).to(target._device, target._dtype).contiguous()
+        was = []
+        for o in range(target.num_outputs):
+            if noise is None:
+                was.append(torch.ones(X.shape[0], dtype=target._dtype, device=target._device))
+            else:
+                was.append(1.0 / noise.to(target._device, target._dtype)[:, o].clamp_min(1e-7))
+        target._memo["pending_rank_update"] = (old_posts, X, was, target._hyper_version())
+
+    def _apply_pending_rank_update(self):
+        pend = self._memo.pop("pending_rank_update", None)
+        if pend is None or "prediction_cache" in self._memo:
+            return
+        old_posts, X, was, ver = pend
+        if ver != self._hyper_version():
+            return
+        self.check_bounds()         # as a fresh dense factor would: raise for out-of-grid inputs before trusting the update
+        b = self._kernel_cache["interpolation_cache"]
+        out = self.num_outputs
+        posts, U = [], torch.empty((out, self._grid.m), dtype=self._dtype, device=self._device)
+        ops = _wtw_ops(self._kernel_cache["WtW"])
+        for o in range(out):
+            post = old_posts[o].rank_update(ops[o], X, was[o], self._err)
+            U[o] = post.solve_columns(b[o, :, 0][None])[0][0]
+            posts.append(post)
+        self._last_iters = [0] * out
+        self._memo["prediction_cache"] = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts),
+                                          "cg_iters": [0] * out, "ver": ver}
 
     def get_fantasy_model(self, inputs, targets, noise_term=None, **kwargs):
         """Single-batch fantasy: condition a copy on (inputs, targets).  The

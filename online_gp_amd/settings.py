@@ -138,6 +138,13 @@ class dense_small_grids(_feature_flag):
     _state = True
 
 
+class dense_rank_updates(_feature_flag):
+    """Dense regime: condition_on_observations / fantasies update the cached posterior matrix by a rank-q Woodbury
+    step (O(m^2 q)) instead of re-factorising (O(m^3)); a fresh factor is taken after 64 stacked updates."""
+
+    _state = True
+
+
 class residual_carry_over(_feature_flag):
     """Keep the posterior-mean residual b - z - A u current inside the scatter launches of streaming updates, so
     that the warm-started refresh needs no A u product (recomputed from scratch every 16th refresh)."""

@@ -116,3 +116,48 @@ def test_dense_path_matches_pcg_path_and_exposes_root_space(dtype, rt):
                 assert torch.allclose(Q, Q.t(), atol=1e-3 if dtype == torch.float32 else 1e-9)
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= rt * b.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)])
+def test_rank_q_posterior_updates_match_a_fresh_factor(dtype, tol):
+    """Dense regime: condition_on_observations (in place and functional, single and multi-output, heteroscedastic)
+    updates the cached posterior matrix by Woodbury rank-q steps; mean, variance and logdet equal a fresh factorisation."""
+    from online_gp_amd import settings
+    from online_gp_amd.lazy.dense_woodbury import DenseInducingPosterior
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    torch.manual_seed(2)
+    d, g, n0, q, steps, out = 2, 12, 60, 5, 6, 2
+    X = torch.rand(n0 + q * steps, d, device="cuda", dtype=dtype) * 2 - 1
+    Y = torch.stack([torch.sin(2 * X[:, 0]) + X[:, 1], torch.cos(X[:, 0] * X[:, 1])], 1) + 0.1 * torch.randn(X.shape[0], out, device="cuda", dtype=dtype)
+    N = torch.rand_like(Y) + 0.5
+    gb = torch.tensor([[-1.1, 1.1]] * d)
+    Xs = X[:40]
+
+    def moments(model):
+        with torch.no_grad():
+            mvn = model(Xs)
+        return mvn.mean, mvn.variance
+
+    with torch.no_grad():
+        fun = FixedNoiseOnlineSKIGP(X[:n0], Y[:n0], N[:n0], grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        inp = FixedNoiseOnlineSKIGP(X[:n0], Y[:n0], N[:n0], grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        moments(fun); moments(inp)                                   # build the dense caches
+        for s in range(steps):
+            sl = slice(n0 + s * q, n0 + (s + 1) * q)
+            fun = fun.condition_on_observations(X[sl], Y[sl], N[sl])            # functional (fantasy-style)
+            inp.condition_on_observations(X[sl], Y[sl], N[sl], inplace=True)
+            for m_ in (fun, inp):
+                assert "pending_rank_update" in m_._memo                                          # applied lazily ...
+                pc = m_.prediction_cache
+                assert all(p.updates == s + 1 for p in pc["pred_cov"].ops)                        # ... by a rank update, not a fresh factor
+        with settings.dense_rank_updates(False):
+            ref = FixedNoiseOnlineSKIGP(X, Y, N, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        mr, vr = moments(ref)
+        for m_ in (fun, inp):
+            mm, vv = moments(m_)
+            assert float((mm - mr).abs().max()) < tol * float(mr.abs().max())
+            assert float((vv - vr).abs().max()) < tol * float(vr.abs().max())
+            for o, p in enumerate(m_._memo["prediction_cache"]["pred_cov"].ops):
+                fresh = ref._memo["prediction_cache"]["pred_cov"].ops[o]
+                assert isinstance(p, DenseInducingPosterior) and abs(float(p.logdet) - float(fresh.logdet)) < max(tol, 1e-6) * abs(float(fresh.logdet)) * 10

@@ -38,7 +38,22 @@ def run(name, d, g, gb, nu, q, steps, hetero):
         torch.cuda.synchronize(); t3 = time.perf_counter()
         if s >= 2:
             t_fit += t1 - t0; t_acq += t2 - t1; t_cond += t3 - t2
+    # fantasy-style use (look-ahead acquisitions, qNIPV): condition a sibling on q candidate points and read its posterior,
+    # hyper-parameters fixed -- rank-q Woodbury update of the cached posterior matrix vs a fresh factor per fantasy
+    from online_gp_amd import settings
+    fant = {}
+    with torch.no_grad():
+        model.eval(); model.posterior(torch.rand(4, q, d, device=dev)).mean
+        for name_, flag in (("rank_update", True), ("fresh_factor", False)):
+            with settings.dense_rank_updates(flag):
+                torch.cuda.synchronize(); tf = time.perf_counter()
+                for _ in range(10):
+                    xf = torch.rand(q, d, device=dev)
+                    fm = model.condition_on_observations(xf, torch.zeros(q, 1, device=dev), noise[:q])
+                    _ = fm.posterior(torch.rand(64, q, d, device=dev)).variance
+                torch.cuda.synchronize(); fant[name_] = (time.perf_counter() - tf) / 10 * 1e3
     n = steps - 2
+    print(json.dumps({"config": name + " -- fantasy + posterior, ms each", **fant}))
     print(json.dumps({"config": name, "m": g ** d, "q": q, "fit_ms": t_fit / n * 1e3, "acqf_20_posteriors_ms": t_acq / n * 1e3,
                       "condition_ms": t_cond / n * 1e3, "num_data": model.num_data}))
 
