@@ -126,78 +126,157 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
-// -------------------------------------------------------------- Cholesky ---
+// ------------------------------------------------------------ Cholesky ---
+// Blocked right-looking lower Cholesky, NB = 64.  The O(n^3) work is the trailing update on the MFMA GEMM; at the
+// sizes of the dense regime (n <= 2048) the run time is the latency of the 2 n / NB small steps in between, so those
+// are kept short: the diagonal block is factorised AND inverted by one workgroup in LDS, and every triangular solve
+// against a diagonal block -- the panel of the factorisation, both sweeps of wiski_trsm -- is a tile product with
+// that explicit 64 x 64 inverse instead of a per-row / per-column substitution.
+//   k_potrf_diag   : A11 -> L11 (in place) and L11^-1 (scratch), one wave, rows in registers
+//   k_apply_inv    : 64-row or 64-column tiles  T <- T Linv^T (right) | Linv T | Linv^T T (left), in place
 constexpr int NB = 64;
 
-// In-place Cholesky of one nb x nb diagonal block (nb <= 64) held in LDS.
-// info != 0 when a non-positive pivot was met (the caller adds jitter and retries,
-// as psd_safe_cholesky does for the reference -- URLT:5).
+// Column c of the inverse of the lower-triangular 64 x 64 matrix in sM (LDS), by forward substitution on e_c with the
+// whole column in registers (compile-time indices, fully unrolled: 2016 FMAs fed by broadcast LDS reads).
 template <typename real>
-__global__ __launch_bounds__(256) void k_potrf_diag(int nb, real* __restrict__ A, int lda, int32_t* __restrict__ info) {
-  __shared__ real sL[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < nb * nb; e += 256) sL[e / nb][e % nb] = A[(int64_t)(e / nb) * lda + (e % nb)];
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    const real piv = sL[k][k];
-    if (!(piv > (real)0)) {
-      if (tid == 0) atomicOr(info, 1);
-    }
-    const real d = sqrt(piv > (real)0 ? piv : (real)1);
-    __syncthreads();
-    if (tid == 0) sL[k][k] = d;
-    for (int i = k + 1 + tid; i < nb; i += 256) sL[i][k] /= d;
-    __syncthreads();
-    const int rem = nb - k - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-      if (j <= i) sL[i][j] -= sL[i][k] * sL[j][k];
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < nb * nb; e += 256) {
-    const int i = e / nb, j = e % nb;
-    A[(int64_t)i * lda + j] = j <= i ? sL[i][j] : (real)0;
+__device__ __forceinline__ void tri_inv_column(const real (*sM)[NB + 1], int c, real x[NB]) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) x[i] = i == c ? (real)1 : (real)0;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const real xk = x[k] / sM[k][k];          // rows k < c: x[k] == 0 stays 0
+    x[k] = xk;
+#pragma unroll
+    for (int i = k + 1; i < NB; ++i) x[i] -= sM[i][k] * xk;
   }
 }
 
-// Panel: X L11^T = A21  ->  rows of A21 (below the nb x nb block L11) overwritten by X.
-// One thread per row, L11 broadcast from LDS, the row kept in LDS column-major.
+// One wave factorises the diagonal block: lane t owns row t in registers; per step the pivot comes by a lane read and
+// column k is published through LDS for broadcast reads (no block barrier chain, no integer division).  The inverse of
+// the factor follows from the same wave (tri_inv_column).  nb < 64 is padded with an identity block.
 template <typename real>
-__global__ __launch_bounds__(64) void k_trsm_panel(int rows, int nb, const real* __restrict__ L11, int ldl, real* __restrict__ A21, int lda) {
-  __shared__ real sL[NB][NB + 1];
-  __shared__ real sX[NB][64 + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < nb * nb; e += 64) sL[e / nb][e % nb] = L11[(int64_t)(e / nb) * ldl + (e % nb)];
-  const int r = blockIdx.x * 64 + tid;
+__global__ __launch_bounds__(64) void k_potrf_diag(int nb, real* __restrict__ A, int lda, real* __restrict__ Linv, int32_t* __restrict__ info) {
+  __shared__ real sM[NB][NB + 1];
+  __shared__ real sCol[NB];
+  const int t = threadIdx.x;
+  for (int r = 0; r < NB; ++r) sM[r][t] = (r < nb && t < nb) ? A[(int64_t)r * lda + t] : (r == t ? (real)1 : (real)0);   // coalesced rows
   __syncthreads();
-  if (r < rows) {
-    for (int j = 0; j < nb; ++j) sX[j][tid] = A21[(int64_t)r * lda + j];
-    for (int j = 0; j < nb; ++j) {
-      real sacc = sX[j][tid];
-      for (int k = 0; k < j; ++k) sacc -= sX[k][tid] * sL[j][k];
-      sX[j][tid] = sacc / sL[j][j];
+  real row[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) row[j] = sM[t][j];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const real piv = __shfl(row[k], k, 64);
+    if (!(piv > (real)0)) bad = true;
+    const real d = sqrt(piv > (real)0 ? piv : (real)1);
+    const real lk = t > k ? row[k] / d : (t == k ? d : (real)0);
+    row[k] = lk;
+    __syncthreads();                 // previous step's readers of sCol are done
+    sCol[t] = lk;
+    __syncthreads();
+    if (t > k) {
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j) row[j] -= lk * sCol[j];      // entries j > t are never used (upper triangle)
     }
-    for (int j = 0; j < nb; ++j) A21[(int64_t)r * lda + j] = sX[j][tid];
+  }
+  if (bad && t == 0) atomicOr(info, 1);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NB; ++j) sM[t][j] = j <= t ? row[j] : (real)0;
+  __syncthreads();
+  for (int r = 0; r < nb; ++r)
+    if (t < nb) A[(int64_t)r * lda + t] = sM[r][t];
+  real x[NB];
+  tri_inv_column<real>(sM, t, x);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NB; ++i) sM[i][t] = x[i];                      // column t of the inverse
+  __syncthreads();
+  for (int r = 0; r < NB; ++r) Linv[r * NB + t] = sM[r][t];          // [64][64] dense, identity-padded
+}
+
+// Inverses of all diagonal blocks of an existing factor (wiski_trsm): block b of the grid handles L[b*64.., b*64..].
+template <typename real>
+__global__ __launch_bounds__(64) void k_tri_inv_blocks(int n, const real* __restrict__ L, int ldl, real* __restrict__ Linv) {
+  __shared__ real sM[NB][NB + 1];
+  const int b = blockIdx.x, i0 = b * NB, t = threadIdx.x;
+  const int nb = n - i0 < NB ? n - i0 : NB;
+  for (int r = 0; r < NB; ++r) sM[r][t] = (r < nb && t < nb && t <= r) ? L[(int64_t)(i0 + r) * ldl + i0 + t] : (r == t ? (real)1 : (real)0);
+  __syncthreads();
+  real x[NB];
+  tri_inv_column<real>(sM, t, x);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NB; ++i) sM[i][t] = x[i];
+  __syncthreads();
+  real* out = Linv + (int64_t)b * NB * NB;
+  for (int r = 0; r < NB; ++r) out[r * NB + t] = sM[r][t];
+}
+
+// In-place tile product with a 64 x 64 inverse block Linv (row-major, lower triangular, identity-padded):
+//   MODE 0 (right):  T [rows x nb]  <- T Linv^T          (panel of the factorisation: X L11^T = A21)
+//   MODE 1 (left) :  T [nb x cols]  <- Linv T            (forward sweep:  L11 X = B)
+//   MODE 2 (left) :  T [nb x cols]  <- Linv^T T          (backward sweep: L11^T X = B)
+// One block per 64 rows (MODE 0) or 64 columns (MODE 1, 2); 256 threads, 16 outputs each.
+template <typename real, int MODE>
+__global__ __launch_bounds__(256) void k_apply_inv(int ext, int nb, const real* __restrict__ Linv, real* __restrict__ T, int ldt) {
+  __shared__ real sI[NB][NB + 1];
+  __shared__ real sT[NB][NB + 1];
+  const int tid = threadIdx.x;
+  const int o0 = blockIdx.x * NB;                        // first row (MODE 0) / column (MODE 1, 2) of this tile
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    sI[i][j] = Linv[e];
+    real v = (real)0;
+    if (MODE == 0) { if (o0 + i < ext && j < nb) v = T[(int64_t)(o0 + i) * ldt + j]; }
+    else { if (i < nb && o0 + j < ext) v = T[(int64_t)i * ldt + o0 + j]; }
+    sT[i][j] = v;
+  }
+  __syncthreads();
+  const int i = tid >> 2, j0 = (tid & 3) * 16;
+  real acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = (real)0;
+  for (int k = 0; k < NB; ++k) {
+    if (MODE == 0) {                                     // out[i][j] = sum_k T[i][k] Linv[j][k]
+      const real t = sT[i][k];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += t * sI[j0 + u][k];
+    } else {                                             // out[i][j] = sum_k Linv[i][k] T[k][j]   (MODE 2: Linv[k][i])
+      const real l = MODE == 1 ? sI[i][k] : sI[k][i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += l * sT[k][j0 + u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int j = j0 + u;
+    if (MODE == 0) { if (o0 + i < ext && j < nb) T[(int64_t)(o0 + i) * ldt + j] = acc[u]; }
+    else { if (i < nb && o0 + j < ext) T[(int64_t)i * ldt + o0 + j] = acc[u]; }
   }
 }
 
 template <typename real>
 static int potrf_impl(int n, real* d_A, int lda, int32_t* d_info, hipStream_t s) {
   if (n < 1 || !d_A || !d_info || lda < n) return WISKI_E_BADARG;
-  for (int j = 0; j < n; j += NB) {
+  real* linv = nullptr;
+  if (hipMallocAsync((void**)&linv, (size_t)NB * NB * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;   // stream-ordered scratch
+  int rc = WISKI_OK;
+  for (int j = 0; j < n && rc == WISKI_OK; j += NB) {
     const int nb = n - j < NB ? n - j : NB;
     real* Ajj = d_A + (int64_t)j * lda + j;
-    hipLaunchKernelGGL((k_potrf_diag<real>), dim3(1), dim3(256), 0, s, nb, Ajj, lda, d_info);
+    hipLaunchKernelGGL((k_potrf_diag<real>), dim3(1), dim3(64), 0, s, nb, Ajj, lda, linv, d_info);
     const int rows = n - j - nb;
     if (rows > 0) {
       real* A21 = d_A + (int64_t)(j + nb) * lda + j;
-      hipLaunchKernelGGL((k_trsm_panel<real>), dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, rows, nb, (const real*)Ajj, lda, A21, lda);
+      hipLaunchKernelGGL((k_apply_inv<real, 0>), dim3((unsigned)((rows + NB - 1) / NB)), dim3(256), 0, s, rows, nb, (const real*)linv, A21, lda);
       real* A22 = d_A + (int64_t)(j + nb) * lda + (j + nb);
-      int rc = launch_gemm<real>(0, 1, rows, rows, nb, (real)-1, A21, lda, A21, lda, (real)1, A22, lda, s);   // A22 -= L21 L21^T
-      if (rc) return rc;
+      rc = launch_gemm<real>(0, 1, rows, rows, nb, (real)-1, A21, lda, A21, lda, (real)1, A22, lda, s);   // A22 -= L21 L21^T
     }
   }
+  (void)hipFreeAsync(linv, s);
+  if (rc) return rc;
   // zero the strict upper triangle (the trailing updates wrote it)
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
@@ -211,59 +290,38 @@ __global__ __launch_bounds__(256) void k_zero_upper(int n, real* __restrict__ A,
 }
 
 // --------------------------------------------------------------- TRSM ---
-// Diagonal-block solves for nrhs columns: one thread per right-hand side.
-//   trans == 0:  L11 X = B   (forward) ; trans == 1:  L11^T X = B  (backward)
-template <typename real>
-__global__ __launch_bounds__(64) void k_trsm_diag(int nb, int nrhs, int trans, const real* __restrict__ L11, int ldl, real* __restrict__ Bm, int ldb) {
-  __shared__ real sL[NB][NB + 1];
-  __shared__ real sX[NB][64 + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < nb * nb; e += 64) sL[e / nb][e % nb] = L11[(int64_t)(e / nb) * ldl + (e % nb)];
-  const int c = blockIdx.x * 64 + tid;
-  __syncthreads();
-  if (c < nrhs) {
-    for (int j = 0; j < nb; ++j) sX[j][tid] = Bm[(int64_t)j * ldb + c];
-    if (!trans) {
-      for (int j = 0; j < nb; ++j) {
-        real sacc = sX[j][tid];
-        for (int k = 0; k < j; ++k) sacc -= sL[j][k] * sX[k][tid];
-        sX[j][tid] = sacc / sL[j][j];
-      }
-    } else {
-      for (int j = nb - 1; j >= 0; --j) {
-        real sacc = sX[j][tid];
-        for (int k = j + 1; k < nb; ++k) sacc -= sL[k][j] * sX[k][tid];
-        sX[j][tid] = sacc / sL[j][j];
-      }
-    }
-    for (int j = 0; j < nb; ++j) Bm[(int64_t)j * ldb + c] = sX[j][tid];
-  }
-}
-
-// Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; L lower n x n, B n x nrhs.
+// Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; L lower n x n, B n x nrhs.  Right-looking: block row I
+// is finished with the explicit inverse of its diagonal block (k_apply_inv), then ALL remaining block rows are updated
+// at once -- a GEMM with a long M and K = 64 that fills the chip, instead of one 64-row GEMM with a long K per step.
 template <typename real>
 static int trsm_impl(int trans, int n, int nrhs, const real* d_L, int ldl, real* d_B, int ldb, hipStream_t s) {
   if (n < 1 || nrhs < 1 || !d_L || !d_B || ldl < n || ldb < nrhs) return WISKI_E_BADARG;
   const int nblk = (n + NB - 1) / NB;
-  for (int bi = 0; bi < nblk; ++bi) {
+  real* linv = nullptr;
+  if (hipMallocAsync((void**)&linv, (size_t)nblk * NB * NB * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+  hipLaunchKernelGGL((k_tri_inv_blocks<real>), dim3((unsigned)nblk), dim3(64), 0, s, n, d_L, ldl, linv);
+  const unsigned ctiles = (unsigned)((nrhs + NB - 1) / NB);
+  int rc = WISKI_OK;
+  for (int bi = 0; bi < nblk && rc == WISKI_OK; ++bi) {
     const int I = trans ? nblk - 1 - bi : bi;
     const int i0 = I * NB;
     const int nb = n - i0 < NB ? n - i0 : NB;
     real* BI = d_B + (int64_t)i0 * ldb;
-    if (!trans && i0 > 0) {
-      // B_I -= L[I, 0:i0] X[0:i0]
-      int rc = launch_gemm<real>(0, 0, nb, nrhs, i0, (real)-1, d_L + (int64_t)i0 * ldl, ldl, d_B, ldb, (real)1, BI, ldb, s);
-      if (rc) return rc;
-    } else if (trans && i0 + nb < n) {
-      // B_I -= L[i0+nb:, I]^T X[i0+nb:]
-      const int rest = n - i0 - nb;
-      int rc = launch_gemm<real>(1, 0, nb, nrhs, rest, (real)-1, d_L + (int64_t)(i0 + nb) * ldl + i0, ldl, d_B + (int64_t)(i0 + nb) * ldb, ldb,
-                                 (real)1, BI, ldb, s);
-      if (rc) return rc;
+    const real* inv = linv + (int64_t)I * NB * NB;
+    if (!trans) {
+      hipLaunchKernelGGL((k_apply_inv<real, 1>), dim3(ctiles), dim3(256), 0, s, nrhs, nb, inv, BI, ldb);
+      const int below = n - i0 - nb;
+      if (below > 0)     // B[i0+nb:, :] -= L[i0+nb:, I] X_I
+        rc = launch_gemm<real>(0, 0, below, nrhs, nb, (real)-1, d_L + (int64_t)(i0 + nb) * ldl + i0, ldl, BI, ldb, (real)1,
+                               d_B + (int64_t)(i0 + nb) * ldb, ldb, s);
+    } else {
+      hipLaunchKernelGGL((k_apply_inv<real, 2>), dim3(ctiles), dim3(256), 0, s, nrhs, nb, inv, BI, ldb);
+      if (i0 > 0)        // B[0:i0, :] -= L[I, 0:i0]^T X_I
+        rc = launch_gemm<real>(1, 0, i0, nrhs, nb, (real)-1, d_L + (int64_t)i0 * ldl, ldl, BI, ldb, (real)1, d_B, ldb, s);
     }
-    hipLaunchKernelGGL((k_trsm_diag<real>), dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, nb, nrhs, trans,
-                       d_L + (int64_t)i0 * ldl + i0, ldl, BI, ldb);
   }
+  (void)hipFreeAsync(linv, s);
+  if (rc) return rc;
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
