@@ -998,19 +998,29 @@ static int launch_spectral_precond(const GridDev<real>& G, const real* evec, con
 template <typename real>
 __global__ __launch_bounds__(256) void k_lag_correlate(int g, int post, int m, int k, const real* __restrict__ X, const real* __restrict__ Yq,
                                                        double* __restrict__ out) {
+  // out[lag] += sum_c sum_{e} X[c][e] * Yq[c][e with mode-q index j],  lag = |i(e) - j|.
+  // One thread per element e and block.y per chunk of LAG_CK columns: the thread keeps its x values of the chunk in
+  // registers, reduces over the columns in fp64 registers and issues ONE LDS atomic per (e, j) -- not one per (e, j, c):
+  // the dense-regime MLL calls this with k = m + 1 columns, where the per-column atomics cost 2.5 ms per call.
+  constexpr int LAG_CK = 32;
   __shared__ double s_bins[256];
   for (int l = threadIdx.x; l < g; l += blockDim.x) s_bins[l] = 0.0;
   __syncthreads();
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * LAG_CK;
   if (e < m) {
     const int i = (e / post) % g;
-    for (int c = 0; c < k; ++c) {
-      const double x = (double)X[(int64_t)c * m + e];
-      const real* __restrict__ src = Yq + (int64_t)c * m + (e - i * post);
-      for (int j = 0; j < g; ++j) {
-        const int lag = i > j ? i - j : j - i;
-        atomicAdd(&s_bins[lag], x * (double)src[(int64_t)j * post]);
-      }
+    real xr[LAG_CK];
+#pragma unroll
+    for (int cc = 0; cc < LAG_CK; ++cc) xr[cc] = c0 + cc < k ? X[(int64_t)(c0 + cc) * m + e] : (real)0;
+    const real* __restrict__ src = Yq + (int64_t)c0 * m + (e - i * post);
+    for (int j = 0; j < g; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < LAG_CK; ++cc)
+        if (c0 + cc < k) acc += (double)xr[cc] * (double)src[(int64_t)cc * m + (int64_t)j * post];
+      const int lag = i > j ? i - j : j - i;
+      atomicAdd(&s_bins[lag], acc);
     }
   }
   __syncthreads();
@@ -1048,8 +1058,8 @@ static int kron_grad_impl(const wiski_grid* grid, const real* d_tcol, const real
       }
       off2 += G.g[r];
     }
-    hipLaunchKernelGGL((k_lag_correlate<real>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, G.g[q], G.stride[q], m, k, d_X, src,
-                       d_grad + toff);
+    hipLaunchKernelGGL((k_lag_correlate<real>), dim3((unsigned)((m + 255) / 256), (unsigned)((k + 31) / 32)), dim3(256), 0, s, G.g[q], G.stride[q],
+                       m, k, d_X, src, d_grad + toff);
     toff += G.g[q];
   }
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
