@@ -120,3 +120,24 @@ def test_product_code_never_imports_the_oracle():
     for f in glob.glob(os.path.join(ROOT, "online_gp_amd", "**", "*.py"), recursive=True):
         src = open(f).read()
         assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_half_stencil_layout_converters_roundtrip_on_cpu():
+    """The row-interleaved half-stencil layout (include/wiski.h) against its definition, on the host:
+    group 0 is A_h[4 i + (s - 3)], group g >= 1 is A_h[(7 g - 3) m + 7 i + s] for the offset-major row oh = 7 g - 3 + s."""
+    import torch
+
+    from online_gp_amd import grid_ops
+
+    for d, g in ((1, 9), (2, 6), (3, 5)):
+        grid = grid_ops.GridSpec([[-1.0, 1.0]] * d, g)
+        H, m = (grid.R + 1) // 2, grid.m
+        om = torch.arange(H * m, dtype=torch.float64).reshape(H, m)            # om[oh, i] = oh * m + i
+        nat = grid_ops.half_stencil_from_offset_major(grid, om)
+        assert nat.shape == (H, m) and torch.equal(grid_ops.half_stencil_to_offset_major(grid, nat), om)
+        flat = nat.reshape(-1)
+        for i in (0, 1, m // 2, m - 1):
+            for oh in range(H):
+                pos = 4 * i + oh if oh < 4 else (7 * ((oh - 4) // 7 + 1) - 3) * m + 7 * i + (oh - 4) % 7
+                assert flat[pos] == oh * m + i
+        assert grid_ops.is_half_stencil(grid, nat) and not grid_ops.is_half_stencil(grid, torch.zeros(grid.R, m))
