@@ -209,3 +209,31 @@ def test_gather_rows_row_major_operand(d, g, tdt, ndt, tol):
     ref = B2.gather(X.astype(np.float64), Vr.T.astype(np.float64))
     assert out.shape == (37, 11) and int(err.item()) == 0
     assert np.abs(out.double().cpu().numpy() - ref).max() < tol * np.abs(ref).max() * 10
+
+
+@pytest.mark.parametrize("gs", [(9, 8, 12), (8, 9, 12), (20, 17, 12), (33, 8, 8), (12, 50, 6), (8, 8, 53)])
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float32, np.float32, 2e-3), (torch.float64, np.float64, 1e-8)])
+def test_fused_spectral_pcg_on_anisotropic_grids(gs, tdt, ndt, tol):
+    """d = 3 grids with unequal, odd and > 48-node axes: every inner-dimension padding (16/32/48/52/64) and both tile-load
+    widths of the fp32 MFMA preconditioner kernels, and the fp64 register-tile ones, against the oracle solve."""
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(11)
+    gb = [[-1.1, 1.1]] * 3
+    grid = grid_ops.GridSpec(gb, list(gs))
+    assert grid.m % 4 == 0                                   # fused path precondition (16-byte fibre loads)
+    n = 400
+    X = rng.uniform(-1.0, 1.0, (n, 3)); y = rng.standard_normal(n); noise = rng.uniform(0.5, 2.0, n)
+    B2 = cport.MatrixFreeWISKI(gb, list(gs), sigma2=0.5, dtype=np.float64)
+    B2.absorb(X, y, noise, init=True)
+    RHS = np.stack([B2.b, rng.standard_normal(grid.m)])
+    Uref, _, _ = B2.solve(RHS, tol=1e-13)
+    A = grid_ops.half_stencil_from_offset_major(grid, _t(B2.A, tdt)[(grid.R - 1) // 2:].contiguous())
+    tc = _t(B2.tcol, tdt)
+    prof = [np.clip(0.3 + np.cos(np.linspace(0.0, 2.5, gq)) ** 2, 1e-2, None) for gq in grid.g]
+    cg_tol = 1e-10 if tdt == torch.float64 else 1e-6
+    for kw in (dict(eigen=grid_ops.kron_eigen(grid, tc), shift=n / grid.m),
+               dict(eigen=grid_ops.kron_eigen(grid, tc, profiles=prof), shift=n / grid.m)):
+        U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=cg_tol, max_iter=500, check_every=5, **kw)
+        assert max(res) < cg_tol * 1.01, (it, res)
+        assert np.abs(U.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
