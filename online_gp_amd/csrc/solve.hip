@@ -1471,9 +1471,13 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   };
   while (!done && it < max_iter) {
     if (fused_cg) {
-      // 5 launches per iteration: update_x(it-1) -> mode-0 fwd -> slab (+rho) -> [mode-0 bwd + update_p] -> SpMV (+p.Hp)
-      flush_update();
-      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, p, pt, S, s);
+      // fp32: 4 launches per iteration: [update_x(it-1) + mode-0 fwd] -> slab (+rho) -> [mode-0 bwd + update_p] -> SpMV (+p.Hp)
+      // fp64: the update is its own launch (5 per iteration)
+      constexpr bool fuse_upd = sizeof(real) == 4;
+      if (!fuse_upd) flush_update();
+      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, part, nch, zl,
+                                          d_U, d_Z, S, s);
+      pending = false;
       if (rc) return rc;
       rc = spmv_wide(p, pt, (real)1, S.php(it));
       if (rc) return rc;

@@ -564,11 +564,18 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const 
 // one 64 x 32 x (4 KS) product per block, the 4 waves own 32 x 16 output sub-tiles (2 MFMA tiles each).
 //   MODE 0: plain store (+ optional dots[c - dot_c0] += rvec . dst for c >= dot_c0)       -- k_spec_mode0
 //   MODE 1: CG direction update folded into the store, 2k columns                         -- k_spec_mode0_bwd_updp
+//   MODE 2: forward product of the residual with the PREVIOUS iteration's vector update folded into the tile load
+//           (apply != 0:  alpha = rho(it-1) / p.Hp(it-1);  u += alpha p;  z += alpha pt;  r -= alpha (pt + sum_ch part[ch]);
+//           rn(it) += |r|^2 -- k_pcg_update_x; every element of r belongs to exactly one (fibre tile, column) block).
+//           With 256 threads a thread updates 2 x 4 elements: all 2 x 13 vector loads of a thread are independent and
+//           in flight together (the 128-thread register-tile predecessor serialised 4 such rounds and lost to a
+//           separate update launch; this one saves that launch).
 template <int KS, int VW, int MODE>
 __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const float* __restrict__ Va, const float* __restrict__ Vb, int split,
                                                          int transposed, const float* __restrict__ src, float* __restrict__ dst,
                                                          const float* __restrict__ rvec, int dot_c0, double* __restrict__ dots, int k, int it,
-                                                         float* __restrict__ p, float* __restrict__ pt, PcgScal S) {
+                                                         float* __restrict__ p, float* __restrict__ pt, PcgScal S, int apply, double tol2,
+                                                         float* __restrict__ part, int nch, int zl, float* __restrict__ u, float* __restrict__ z) {
   __shared__ __attribute__((aligned(16))) float sF[64 * SPEC_LDT];    // V0 image, row stride LDT (forward) or LDN (backward)
   __shared__ __attribute__((aligned(16))) float sIn[64 * SPEC_LDT];   // src tile [b][s], 32 of LDT columns used
   __shared__ double s_red[16];
@@ -591,16 +598,50 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
   } else {
     V0 = cc < split ? Va : Vb;           // generalized eigenbasis: t-half and y-half use different factors
   }
-  const float* __restrict__ sc = src + (int64_t)cc * m;
   SpecTile<VW> tV;
   tV.issue(V0, g0, g0);
   float4 tin[2];
+  float al = 0.f;
+  if (MODE == 2 && apply) {
+    const double den = S.php_sum(it - 1, cc);
+    if (blockIdx.x == 0) pcg_dot_clear(S.php(it), cc, 1, S.k);   // ring entry the SpMV of this iteration accumulates into
+    if (pcg_active(S, it - 1, cc, tol2) && den > 0) al = (float)(S.rho(it - 1)[cc] / den);
+  }
+  float rn_part = 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int b = (t >> 3) + 32 * q, q4 = (t & 7) * 4;
     const bool ok = b < g0 && s0 + q4 < Sf;                  // Sf % 4 == 0 (precondition of the fused path)
-    tin[q] = *reinterpret_cast<const float4*>(sc + (ok ? (int64_t)b * Sf + s0 + q4 : 0));
+    const int64_t e = (int64_t)cc * m + (ok ? (int64_t)b * Sf + s0 + q4 : 0);
+    tin[q] = *reinterpret_cast<const float4*>(src + e);
     if (!ok) tin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 2 && apply && ok) {
+      const int64_t km = (int64_t)S.k * m;
+      const float4 pv = *reinterpret_cast<const float4*>(p + e), ptv = *reinterpret_cast<const float4*>(pt + e);
+      float4 uv = *reinterpret_cast<const float4*>(u + e), zv = *reinterpret_cast<const float4*>(z + e);
+      float4 pp[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch)
+        if (ch < nch) pp[ch] = *reinterpret_cast<const float4*>(part + (int64_t)ch * km + e);
+      if (zl) *reinterpret_cast<float4*>(part + (int64_t)(nch - 1) * km + e) = make_float4(0.f, 0.f, 0.f, 0.f);   // consumed: re-zero
+      float4 hv = ptv;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch)
+        if (ch < nch) { hv.x += pp[ch].x; hv.y += pp[ch].y; hv.z += pp[ch].z; hv.w += pp[ch].w; }
+      uv.x += al * pv.x; uv.y += al * pv.y; uv.z += al * pv.z; uv.w += al * pv.w;
+      zv.x += al * ptv.x; zv.y += al * ptv.y; zv.z += al * ptv.z; zv.w += al * ptv.w;
+      float4 rv = tin[q];
+      rv.x -= al * hv.x; rv.y -= al * hv.y; rv.z -= al * hv.z; rv.w -= al * hv.w;
+      rn_part += rv.x * rv.x + rv.y * rv.y + rv.z * rv.z + rv.w * rv.w;
+      *reinterpret_cast<float4*>(u + e) = uv;
+      *reinterpret_cast<float4*>(z + e) = zv;
+      *reinterpret_cast<float4*>(const_cast<float*>(src) + e) = rv;
+      tin[q] = rv;
+    }
+  }
+  if (MODE == 2 && apply) {                                  // block-uniform
+    const double tot = block_reduce_sum((double)rn_part, s_red);
+    if (t == 0) unsafeAtomicAdd(S.rn(it) + cc, tot);
   }
   tV.commit(sF, transposed ? SPEC_LDN : SPEC_LDT);
 #pragma unroll
@@ -633,7 +674,7 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
   }
   const int sidx = s0 + wc * 16 + l15;
   const bool dot = MODE == 0 && dots != nullptr && cc >= dot_c0;   // block-uniform
-  float part = 0.f;
+  float dpart = 0.f;
   if (sidx < Sf) {
     float* __restrict__ tgt = MODE == 1 ? (cc < k ? pt : p) + (int64_t)c * m : dst + (int64_t)cc * m;
 #pragma unroll
@@ -646,12 +687,12 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
           float o = acc[a][r];
           if (MODE == 1 && it > 0) o += bt * tgt[e];
           tgt[e] = o;
-          if (dot) part += rvec[(int64_t)(cc - dot_c0) * m + e] * o;
+          if (dot) dpart += rvec[(int64_t)(cc - dot_c0) * m + e] * o;
         }
       }
   }
   if (dot) {
-    const double tot = block_reduce_sum((double)part, s_red);
+    const double tot = block_reduce_sum((double)dpart, s_red);
     if (t == 0) unsafeAtomicAdd(dots + (cc - dot_c0), tot);
   }
 }
@@ -688,7 +729,8 @@ static int launch_mode0(const GridDev<real>& G, const real* Va, const real* Vb, 
     dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)ncols);
 #define M0(KS, VW)                                                                                                                          \
   hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 0>), grd, dim3(256), 0, s, G, Va, Vb, split, transposed, src, dst, rvec, dot_c0,            \
-                     DOT ? dots : (double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, PcgScal{nullptr, 0, nullptr})
+                     DOT ? dots : (double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, PcgScal{nullptr, 0, nullptr}, 0, 0.0,         \
+                     (float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr)
     SPEC_DISPATCH_KS_VW(g0, g0 % 2 == 0, M0);
 #undef M0
   } else {
@@ -700,6 +742,19 @@ static int launch_mode0(const GridDev<real>& G, const real* Va, const real* Vb, 
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+// forward mode 0 of the residual with the previous iteration's vector update folded in (fp32 only)
+static int launch_mode0_fwd_upd(const GridDev<float>& G, const float* V0, float* r, float* dst, int k, int it, int apply, double tol2, float* p,
+                                float* pt, float* part, int nch, int zl, float* u, float* z, PcgScal S, hipStream_t s) {
+  const int g0 = G.g[0], Sf = G.stride[0];
+  dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)k);
+#define M2(KS, VW)                                                                                                                        \
+  hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 2>), grd, dim3(256), 0, s, G, V0, V0, 0, 0, (const float*)r, dst, (const float*)nullptr, 0, \
+                     (double*)nullptr, k, it, p, pt, S, apply, tol2, part, nch, zl, u, z)
+  SPEC_DISPATCH_KS_VW(g0, g0 % 2 == 0, M2);
+#undef M2
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 template <typename real>
 static int launch_mode0_bwd_updp(const GridDev<real>& G, const real* X0, const real* Z0, const real* src, int k, int it, real* p, real* pt,
                                  PcgScal S, hipStream_t s) {
@@ -708,7 +763,7 @@ static int launch_mode0_bwd_updp(const GridDev<real>& G, const real* X0, const r
     dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)(2 * k));
 #define M1(KS, VW)                                                                                                                       \
   hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 1>), grd, dim3(256), 0, s, G, Z0, X0, 0, 1, src, (float*)nullptr, (const float*)nullptr, 0, \
-                     (double*)nullptr, k, it, p, pt, S)
+                     (double*)nullptr, k, it, p, pt, S, 0, 0.0, (float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr)
     SPEC_DISPATCH_KS_VW(g0, g0 % 2 == 0, M1);
 #undef M1
   } else {
@@ -882,14 +937,14 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
   return launch_mode0<real, true>(G, Z0, V0, k, 1, (const real*)w1, ty, 2 * k, r, k, rho, s);
 }
 
-// One CG iteration's preconditioner + direction update in three launches: mode-0 forward, slab (+ rho),
-// mode-0 backward with p / pt updated in the store.  (Folding the previous iteration's u/z/r update into
-// the forward kernel's tile load was measured slower than a separate k_pcg_update_x launch: its 79 blocks
-// serialise 13 dependent vector loads per thread, 20.6 us against 5.5 + 7.5 us.)
+// One CG iteration's preconditioner + vector updates in three launches: mode-0 forward (fp32: with the previous
+// iteration's u / z / r update folded into its tile load when `apply`), slab (+ rho), mode-0 backward with p / pt updated
+// in the store.  fp64 callers apply the update with a separate k_pcg_update_x launch and pass apply = 0.
 template <typename real>
-int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, const real* r,
-                             int k, real* w0, real* w1, int it, real* p, real* pt, PcgScal S, hipStream_t s) {
-  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
+int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
+                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
+                             real* z, PcgScal S, hipStream_t s) {
+  const int g0 = G.g[0], g1 = G.g[1];
   if (!evec2) evec2 = evec;
   const real* V0 = evec;
   const real* V1 = evec + g0 * g0;
@@ -897,16 +952,22 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
   const real* Z0 = evec2;
   const real* Z1 = evec2 + g0 * g0;
   const real* Z2 = Z1 + g1 * g1;
-  if (int rc = launch_mode0<real, false>(G, V0, V0, 0, 0, r, w0, k, (const real*)nullptr, 0, (double*)nullptr, s)) return rc;
+  if constexpr (sizeof(real) == 4) {
+    if (int rc = launch_mode0_fwd_upd(G, V0, r, w0, k, it, apply, tol2, p, pt, part, nch, zl, u, z, S, s)) return rc;
+  } else {
+    if (apply) return WISKI_E_BADARG;
+    if (int rc = launch_mode0<real, false>(G, V0, V0, 0, 0, (const real*)r, w0, k, (const real*)nullptr, 0, (double*)nullptr, s)) return rc;
+  }
   if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, S.rho(it), s)) return rc;
   return launch_mode0_bwd_updp<real>(G, V0, Z0, (const real*)w1, k, it, p, pt, S, s);
 }
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
-template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int,
-                                             float*, float*, int, float*, float*, PcgScal, hipStream_t);
-template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, const double*,
-                                              int, double*, double*, int, double*, double*, PcgScal, hipStream_t);
+template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, float*, int, float*,
+                                             float*, int, int, double, float*, float*, float*, int, int, float*, float*, PcgScal, hipStream_t);
+template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, double*, int,
+                                              double*, double*, int, int, double, double*, double*, double*, int, int, double*, double*, PcgScal,
+                                              hipStream_t);
 template bool spectral_fused_ok<double>(const GridDev<double>&);
 template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int, float*,
                                           float*, float*, double*, hipStream_t);

@@ -215,5 +215,6 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 
 // Fused CG-iteration front end (d = 3): [apply update_x(it-1)] + mode-0 fwd -> slab (+rho) -> mode-0 bwd (+update_p)
 template <typename real>
-int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, const real* r,
-                             int k, real* w0, real* w1, int it, real* p, real* pt, PcgScal S, hipStream_t s);
+int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
+                             int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
+                             real* z, PcgScal S, hipStream_t s);
