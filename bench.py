@@ -193,6 +193,18 @@ def main():
                 model.prediction_cache
             torch.cuda.synchronize()
             small[qs] = (time.perf_counter() - tq) / 10 * 1e3
+        # large-batch throughput (SURVEY.md 8d lists q = 16384): the same full step, 6 steps of fresh points
+        qL = 16384
+        XL, yL = synth_stream(7 * qL, d, 5000 + rank, dev, dtype, args.stream)
+        for i in range(7):
+            if i == 1:
+                torch.cuda.synchronize(); tL = time.perf_counter()
+            xq, yq = XL[i * qL:(i + 1) * qL], yL[i * qL:(i + 1) * qL]
+            model(xq).mean
+            model.condition_on_observations(xq, yq, inplace=True)
+            model.prediction_cache
+        torch.cuda.synchronize()
+        large_rate = 6 * qL / (time.perf_counter() - tL)
     with settings.cg_tolerance(tol), torch.no_grad():
         xv = Xs[:64]
         model(Xs[64:128]).variance                 # warm the 64-column PCG workspace (first call allocates ~0.8 GB)
@@ -247,7 +259,7 @@ def main():
                          "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es,
                          "full_stencil_equivalent_frac": ((grid.R * grid.m * es + 2 * grid.m * es) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if n_l else 0.0},
             "extra": {"cg_iters_per_step_mean": float(np.mean(iters)), "absorb_only_updates_per_s": q / ta,
-                      "variance_ms_per_64_queries": tv * 1e3, "step_ms_q1": small[1], "step_ms_q64": small[64], "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
+                      "variance_ms_per_64_queries": tv * 1e3, "step_ms_q1": small[1], "step_ms_q64": small[64], "updates_per_s_q16384": large_rate, "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, tol)
