@@ -4,7 +4,10 @@
 //   PCG           : (Kt^-1 + A)^-1 RHS     (CG branch of BFN:368-383)
 #include "wiski_common.h"
 
+#include <hip/hip_ext.h>
+
 #include <chrono>
+#include <cstdlib>
 #include <vector>
 
 // ------------------------------------------------------- profiling hook ---
@@ -559,7 +562,7 @@ static inline int sym_block() {
   }
   return g_sym_bs;
 }
-static inline int sym_nch(int d) {
+static inline int sym_nch_lds(int d) {
   if (g_sym_nch == 0) {
     const char* e = getenv("WISKI_SYM_NCH");
     g_sym_nch = e ? atoi(e) : -1;
@@ -746,13 +749,22 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
       const int w0 = 4 * lane + (f - wb);
 #pragma unroll
       for (int ph = 0; ph < 3; ++ph) {      // lane-disjoint phases, see the header comment
+        // the cells of a phase are distinct: read them all, then write them all (written as `cell += x` the
+        // compiler serialises one LDS round trip per element)
+        constexpr int NE[3] = {4, 4, 2};
+        real* cell[4];
+        real old[KC][4];
 #pragma unroll
-        for (int e = 4 * ph; e < (ph == 2 ? 10 : 4 * ph + 4); ++e) {
-          const int idx = w0 + e;
-          real* cell = tw + (idx & 3) * W4 + (idx >> 2);
+        for (int u = 0; u < NE[ph]; ++u) {
+          const int idx = w0 + 4 * ph + u;
+          cell[u] = tw + (idx & 3) * W4 + (idx >> 2);
 #pragma unroll
-          for (int c = 0; c < KC; ++c) cell[c * 4 * W4] += tr[c][e];
+          for (int c = 0; c < KC; ++c) old[c][u] = cell[u][c * 4 * W4];
         }
+#pragma unroll
+        for (int u = 0; u < NE[ph]; ++u)
+#pragma unroll
+          for (int c = 0; c < KC; ++c) cell[u][c * 4 * W4] = old[c][u] + tr[c][4 * ph + u];
         wave_lds_fence();
       }
 #endif
@@ -785,12 +797,76 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
   SYM_STAMP(22);
 }
 
-// partial SpMV launcher on the half stencil (requires m % 4 == 0).  part holds (sym_nch(d) + 1) * k * m reals;
-// part[sym_nch(d)] must be zero on entry (see the kernel comment).
+#include "spmv_sym_dma.h"
+
+// Which wide half-stencil kernel serves (G, k): the LDS-DMA pipelined one (d = 3, fp32, one right-hand side; 4 chunks)
+// or the LDS-window one (anything else with m % 4 == 0; up to 7 chunks).  WISKI_SYM_DMA=0 forces the latter,
+// WISKI_SYM_DMA_NST sets the ring depth (2 or 3) and WISKI_SYM_DMA_PARTS the work split (4..7): A/B hooks for
+// tools/spmv_probe.py.
+static int g_sym_dma = -1, g_sym_dma_nst = 0, g_sym_dma_parts = 6;
+template <typename real>
+static inline bool sym_use_dma(const GridDev<real>& G, int k) {
+  if constexpr (sizeof(real) != 4) return false;
+  if (g_sym_dma < 0) {
+    const char* e = getenv("WISKI_SYM_DMA");
+    g_sym_dma = e ? atoi(e) : 1;
+    const char* n = getenv("WISKI_SYM_DMA_NST");
+    g_sym_dma_nst = n ? atoi(n) : 2;
+    if (g_sym_dma_nst != 2 && g_sym_dma_nst != 3) g_sym_dma_nst = 2;
+    const char* pp = getenv("WISKI_SYM_DMA_PARTS");
+    g_sym_dma_parts = pp ? atoi(pp) : 6;
+    if (g_sym_dma_parts < 4 || g_sym_dma_parts > 7) g_sym_dma_parts = 6;
+  }
+  return g_sym_dma != 0 && G.d == 3 && k == 1 && (G.m % 4) == 0 && symdma_lds_bytes(G.g[2], g_sym_dma_nst) <= 64 * 1024;
+}
+// number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
+template <typename real>
+static inline int sym_nch(const GridDev<real>& G, int k) { return sym_use_dma<real>(G, k) ? g_sym_dma_parts : sym_nch_lds(G.d); }
+
+// One launch with optional per-dispatch timing: in profiling mode the start/stop events are attached to the
+// kernel's own dispatch packet (hipExtLaunchKernelGGL), so their difference is the kernel's execution time --
+// a hipEventRecord bracket adds ~3 us of marker-packet latency to a 20 us kernel.
+template <typename F, typename... Args>
+static inline void launch_timed(F kern, dim3 grd, dim3 blk, size_t sh, hipStream_t s, Args... args) {
+  if (g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) {
+    hipEvent_t e0 = g_prof.ev[g_prof.used], e1 = g_prof.ev[g_prof.used + 1];
+    g_prof.used += 2;
+    hipExtLaunchKernelGGL(kern, grd, blk, (unsigned)sh, s, e0, e1, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kern, grd, blk, sh, s, args...);
+  }
+}
+
+// partial SpMV launcher on the half stencil (requires m % 4 == 0).  part holds (sym_nch(G, k) + 1) * k * m reals;
+// part[sym_nch(G, k)] must be zero on entry (see the kernel comments).
 template <typename real>
 static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, real* part, const real* add, real beta, double* dots,
                             hipStream_t s) {
-  const int ng = sym_groups(G.d), nch = sym_nch(G.d);
+  if constexpr (sizeof(real) == 4) {
+    if (sym_use_dma<real>(G, k)) {
+      const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
+      const size_t sh = symdma_lds_bytes(G.g[2], g_sym_dma_nst);
+      dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)g_sym_dma_parts);
+#define SYMDMA(NST, DOT)                                                                                                          \
+  do {                                                                                                                            \
+    static size_t lds_set = 0;                                                                                                    \
+    if (sh > 48 * 1024 && sh > lds_set) {                                                                                         \
+      if (hipFuncSetAttribute((const void*)k_spmv_sym_dma<NST, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) \
+        return WISKI_E_LAUNCH;                                                                                                    \
+      lds_set = sh;                                                                                                               \
+    }                                                                                                                             \
+    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots);                       \
+  } while (0)
+      if (g_sym_dma_nst == 3) {
+        if (dots) SYMDMA(3, true); else SYMDMA(3, false);
+      } else {
+        if (dots) SYMDMA(2, true); else SYMDMA(2, false);
+      }
+#undef SYMDMA
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
+  }
+  const int ng = sym_groups(G.d), nch = sym_nch_lds(G.d);
   if (ng - (int)((int64_t)(nch - 1) * ng / nch) > 176 || ng > 176 * nch) return WISKI_E_BADARG;
   // columns per pass over A_h (8 per pass, with the v / transposed windows of 4 live at a time, was measured:
   // 344 / 488 VGPRs leave one wave per SIMD, 1.3x / 2.2x slower)
@@ -804,8 +880,6 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
   const int W4 = ((256 + span + 10 + 3) / 4) | 1;
   const size_t sh = (size_t)nw * (7 * 256 + kc * 4 * W4) * sizeof(real);
   dim3 grd((unsigned)((G.m + 4 * bs - 1) / (4 * bs)), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
-  const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
 #define SPMV4S(KC)                                                                                                                              \
   do {                                                                                                                                          \
     static size_t lds_set[2] = {0, 0};   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                \
@@ -815,14 +889,13 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return WISKI_E_LAUNCH;                   \
       lds_set[di] = sh;                                                                                                                         \
     }                                                                                                                                           \
-    if (dots) hipLaunchKernelGGL((k_stencil_spmv4_sym<real, KC, true>), grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots); \
-    else hipLaunchKernelGGL((k_stencil_spmv4_sym<real, KC, false>), grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);   \
+    if (dots) launch_timed(k_stencil_spmv4_sym<real, KC, true>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);  \
+    else launch_timed(k_stencil_spmv4_sym<real, KC, false>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);      \
   } while (0)
   if (kc == 4) SPMV4S(4);
   else if (kc == 2) SPMV4S(2);
   else SPMV4S(1);
 #undef SPMV4S
-  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
@@ -1380,7 +1453,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   const bool sym = a_sym != 0;
   // number of partial vectors the wide SpMV leaves behind; on the half stencil the last one is the
   // atomically accumulated transposed term: zero here, re-zeroed by every consumer (zl)
-  const int nch = wide ? (sym ? sym_nch(G.d) + 1 : spmv_nch(G.d)) : 0;
+  const int nch = wide ? (sym ? sym_nch<real>(G, k) + 1 : spmv_nch(G.d)) : 0;
   const int zl = wide && sym ? 1 : 0;
   auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) {
     return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
@@ -1571,7 +1644,7 @@ static int spmv_sym_impl(const wiski_grid* grid, const real* d_A, const real* d_
   if (!d_A || !d_V || !d_out || k < 1 || d_out == d_V) return WISKI_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (G.m % 4 != 0) return launch_spmv_sym<real>(G, d_A, d_V, k, d_add, beta, d_out, nullptr, s);
-  const int nch = sym_nch(G.d) + 1;
+  const int nch = sym_nch<real>(G, k) + 1;
   const int64_t km = (int64_t)k * G.m;
   real* part = nullptr;
   if (hipMallocAsync((void**)&part, (size_t)nch * km * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;  // stream-ordered scratch

@@ -237,3 +237,28 @@ def test_fused_spectral_pcg_on_anisotropic_grids(gs, tdt, ndt, tol):
         U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=cg_tol, max_iter=500, check_every=5, **kw)
         assert max(res) < cg_tol * 1.01, (it, res)
         assert np.abs(U.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
+
+
+@pytest.mark.parametrize("gs", [(6, 10, 14), (8, 5, 9), (4, 4, 4), (20, 24, 50), (5, 7, 64)])
+def test_half_stencil_spmv_dma_kernel_on_3d_grids(gs):
+    """fp32, d = 3, one right-hand side takes the LDS-DMA pipelined kernel (csrc/spmv_sym_dma.h): ragged
+    last row block, odd innermost sizes, windows wider than a row block; against the C oracle's full-stencil product."""
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(3)
+    gb = [[-1.1, 1.1]] * 3
+    grid = grid_ops.GridSpec(gb, list(gs))
+    assert grid.m % 4 == 0
+    n = 500
+    X = rng.uniform(-1.1, 1.1, (n, 3))
+    y = rng.standard_normal(n)
+    noise = rng.uniform(0.5, 2.0, n)
+    B2 = cport.MatrixFreeWISKI(gb, list(gs), sigma2=0.5, dtype=np.float64)
+    B2.absorb(X, y, noise, init=True)
+    A = grid_ops.half_stencil_from_offset_major(grid, _t(B2.A, torch.float32)[(grid.R - 1) // 2:].contiguous())
+    for rep in range(2):
+        V = rng.standard_normal((1, grid.m))
+        add = rng.standard_normal((1, grid.m))
+        out = grid_ops.stencil_spmv(grid, A, _t(V, torch.float32), _t(add, torch.float32), -0.3)
+        ref = B2.stencil_mv(V) - 0.3 * add
+        assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
