@@ -177,9 +177,12 @@ int wiski_kron_spectral_mm_f64(const wiski_grid* grid, const double* d_evec, con
  * residual norms after first_check iterations (< 1: check_every) and then every
  * check_every iterations.  A poll is a tiny publish kernel writing to host-mapped memory that
  * the host spins on (no stream synchronisation).  d_err (may be NULL): the out-of-grid flag of
- * the interp/scatter/gather entry points; its value rides on the last poll into *h_err, so the
- * caller needs no separate device-to-host read to raise the reference's RuntimeError.
- * Not re-entrant across host threads (one poll buffer per process).
+ * the interp/scatter/gather entry points; its raw value (bit 0: some point was outside the grid; bits 1..:
+ * number of training points the scatter kernels dropped for that reason) rides on the last poll into
+ * *h_err, so the caller needs no separate device-to-host read to raise the reference's RuntimeError.
+ * Host threads: the poll buffer is per device and held under a mutex for the duration of a solve, so
+ * concurrent solves on one device from several host threads serialise (the calling thread's current
+ * device must be the one the pointers live on).
  * a_sym != 0: d_A_st is the symmetric half stencil (wiski_scatter_stats_sym layout) instead of
  * the full offset-major [7^d][m] one.
  * d_R (k*m reals, may be NULL): caller-owned residual buffer used instead of workspace scratch; on return
@@ -211,9 +214,16 @@ int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* d_L, in
 int wiski_logdiag_f32(int32_t n, const float* d_A, int32_t lda, double* d_out, void* stream);
 int wiski_logdiag_f64(int32_t n, const double* d_A, int32_t lda, double* d_out, void* stream);
 
-/* Measurement hook (bench.py roofline leg): brackets every stencil-SpMV launch
- * with HIP events on the launch stream.  wiski_prof_stop returns the summed
- * kernel time and launch count; synchronise the stream before calling it. */
+/* Value of a device int32 flag after everything already queued on `stream`, without a stream
+ * synchronisation (a one-thread publish kernel + a host spin on pinned memory, a few microseconds once the
+ * queue has drained).  Used for the out-of-grid flag after a query gather, where the reference raises
+ * immediately (gpytorch's grid bounds check behind BFN:205). */
+int wiski_read_flag(const int32_t* d_flag, int32_t* h_value, void* stream);
+
+/* Measurement hook (bench.py roofline leg): every half-stencil SpMV launch gets a start/stop event pair
+ * attached to its own dispatch packet (hipExtLaunchKernel), i.e. the kernel's execution time as rocprofv3
+ * reports it, on the stream it runs on.  wiski_prof_stop returns the summed kernel time and launch count;
+ * synchronise the stream before calling it. */
 int wiski_prof_start(int32_t max_launches);
 int wiski_prof_stop(double* total_ms, int64_t* launches);
 

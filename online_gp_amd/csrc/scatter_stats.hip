@@ -42,11 +42,17 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
       real xp[D];
 #pragma unroll
       for (int q = 0; q < D; ++q) xp[q] = x[p * D + q];
-      if (!point_stencil<real, D>(G, xp, j0, w)) bad = true;
+      // a point outside the grid raises the flag and contributes nothing at all (zero weights; no y^2 / log-noise
+      // term either, so a caller that catches the error keeps statistics that agree with A and b)
+      const bool inside = point_stencil<real, D>(G, xp, j0, w);
+      if (!inside) {
+        bad = true;
+        if (sub == 0) atomicAdd(err, 2);      // bits 1..: number of training points dropped (bit 0: any point outside)
+      }
       yp = y[p];
       wap = wa[p];
       wbp = wb[p];
-      if (sub == 0) {
+      if (sub == 0 && inside) {
         c_acc += (double)yp * (double)yp * (double)wbp;
         ld_acc += log((double)noise[p]);
       }
@@ -178,11 +184,17 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
       real xp[D];
 #pragma unroll
       for (int q = 0; q < D; ++q) xp[q] = x[p * D + q];
-      if (!point_stencil<real, D>(G, xp, j0, w)) bad = true;
+      // a point outside the grid raises the flag and contributes nothing at all (zero weights; no y^2 / log-noise
+      // term either, so a caller that catches the error keeps statistics that agree with A and b)
+      const bool inside = point_stencil<real, D>(G, xp, j0, w);
+      if (!inside) {
+        bad = true;
+        if (lane == 0) atomicAdd(err, 2);      // bits 1..: number of training points dropped (bit 0: any point outside)
+      }
       yp = y[p];
       wap = wa[p];
       wbp = wb[p];
-      if (lane == 0) {
+      if (lane == 0 && inside) {
         c_acc += (double)yp * (double)yp * (double)wbp;
         ld_acc += log((double)noise[p]);
       }

@@ -8,6 +8,8 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 // ------------------------------------------------------- profiling hook ---
@@ -1204,17 +1206,60 @@ struct WiskiPoll {
   int cap = 0;
   long long seq = 0;
 };
-static WiskiPoll g_poll;
+// One poll buffer per device, handed out under a mutex and owned by the calling solve until it returns (a
+// second host thread solving on the same device waits its turn instead of interleaving sequence numbers).
+static std::mutex g_poll_mu;
+static std::map<int, WiskiPoll> g_polls;
 
-static int poll_reserve(int k) {
-  if (g_poll.cap >= k) return WISKI_OK;
-  if (g_poll.h) (void)hipHostFree(g_poll.h);
+static int poll_reserve(WiskiPoll& P, int k) {
+  if (P.cap >= k) return WISKI_OK;
+  if (P.h) (void)hipHostFree(P.h);
   const int cap = k < 64 ? 64 : k;
-  if (hipHostMalloc((void**)&g_poll.h, (size_t)(2 * cap + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+  if (hipHostMalloc((void**)&P.h, (size_t)(2 * cap + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) !=
+      hipSuccess)
     return WISKI_E_LAUNCH;
-  if (hipHostGetDevicePointer((void**)&g_poll.d, g_poll.h, 0) != hipSuccess) return WISKI_E_LAUNCH;
-  g_poll.h[0] = 0;
-  g_poll.cap = cap;
+  if (hipHostGetDevicePointer((void**)&P.d, P.h, 0) != hipSuccess) return WISKI_E_LAUNCH;
+  P.h[0] = 0;
+  P.cap = cap;
+  return WISKI_OK;
+}
+
+// spin until the device has released sequence number `seq` into the poll buffer (20 s fallback: stream sync)
+static int poll_wait(WiskiPoll& P, long long seq, hipStream_t s) {
+  volatile long long* flag = reinterpret_cast<volatile long long*>(P.h);
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+      if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;   // fallback: should not happen
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return WISKI_E_LAUNCH;
+      break;
+    }
+  }
+  return WISKI_OK;
+}
+
+__global__ void k_publish_flag(const int32_t* __restrict__ flag, double* __restrict__ poll, long long seq) {
+  poll[1] = (double)*flag;
+  __threadfence_system();
+  __hip_atomic_store(reinterpret_cast<long long*>(poll), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Value of a device int32 flag once everything queued on `stream` before this call has run, without a stream
+// synchronisation (the caller's out-of-grid flag after a gather: models/batched_fixed_noise_online_gp.py).
+extern "C" int wiski_read_flag(const int32_t* d_flag, int32_t* h_value, void* stream) {
+  if (!d_flag || !h_value) return WISKI_E_BADARG;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return WISKI_E_LAUNCH;
+  std::lock_guard<std::mutex> lock(g_poll_mu);
+  WiskiPoll& P = g_polls[dev];
+  if (poll_reserve(P, 1) != WISKI_OK) return WISKI_E_LAUNCH;
+  const long long seq = ++P.seq;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, s, d_flag, P.d, seq);
+  if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
+  if (int rc = poll_wait(P, seq, s)) return rc;
+  *h_value = (int32_t)P.h[1];
   return WISKI_OK;
 }
 
@@ -1499,26 +1544,21 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
 
   std::vector<double> h_rn0(k), h_rn(k);
   double err_seen = 0;
-  if (poll_reserve(k) != WISKI_OK) return WISKI_E_LAUNCH;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return WISKI_E_LAUNCH;
+  std::lock_guard<std::mutex> poll_lock(g_poll_mu);
+  WiskiPoll& P = g_polls[dev];
+  if (poll_reserve(P, k) != WISKI_OK) return WISKI_E_LAUNCH;
   auto fetch = [&](int slot) -> int {
-    const long long seq = ++g_poll.seq;
-    hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, g_poll.d, d_err, seq);
+    const long long seq = ++P.seq;
+    hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq);
     if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
-    volatile long long* flag = reinterpret_cast<volatile long long*>(g_poll.h);
-    const auto t0 = std::chrono::steady_clock::now();
-    long spins = 0;
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-      if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-        if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;   // fallback: should not happen
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return WISKI_E_LAUNCH;
-        break;
-      }
-    }
+    if (int prc = poll_wait(P, seq, s)) return prc;
     for (int c = 0; c < k; ++c) {
-      h_rn0[c] = g_poll.h[1 + c];
-      h_rn[c] = g_poll.h[1 + k + c];
+      h_rn0[c] = P.h[1 + c];
+      h_rn[c] = P.h[1 + k + c];
     }
-    err_seen = g_poll.h[1 + 2 * k];
+    err_seen = P.h[1 + 2 * k];
     return WISKI_OK;
   };
   auto converged = [&]() {
@@ -1606,7 +1646,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (rc) return rc;
   }
   if (h_iters) *h_iters = it;
-  if (h_err) *h_err = err_seen != 0 ? 1 : 0;
+  if (h_err) *h_err = (int32_t)err_seen;   // raw flag word: bit 0 = any point outside the grid, bits 1.. = count of such training points
   if (h_relres)
     for (int c = 0; c < k; ++c) h_relres[c] = h_rn0[c] > 0 ? sqrt(h_rn[c] / h_rn0[c]) : 0.0;
   return done ? WISKI_OK : WISKI_E_NOTCONV;

@@ -5,6 +5,7 @@ the HIP kernels under csrc/.
 """
 import ctypes
 import math
+import warnings
 
 import torch
 
@@ -64,6 +65,14 @@ class GridSpec:
 
 def new_err_flag(device):
     return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def read_flag(flag):
+    """Host value of a device int32 flag after everything queued so far on the current stream (no stream sync)."""
+    val = ctypes.c_int32(0)
+    rc = _hip.lib().wiski_read_flag(_hip.dptr(flag), ctypes.byref(val), _hip.stream_ptr(flag.device))
+    _hip.check(rc, "wiski_read_flag")
+    return int(val.value)
 
 
 def _x2d(x, grid):
@@ -333,14 +342,19 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
                                           ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
                                           ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.dptr(R), _hip.stream_ptr(RHS2.device))
     if rc == -4 and not raise_on_fail:
-        pass
+        # gpytorch emits a NumericalWarning when CG stops at max_cg_iterations; callers also see it in `relres`
+        warnings.warn(f"wiski_pcg stopped at max_iter={max_iter} with relative residual {max(relres):.3e} (tolerance {tol:.1e})",
+                      RuntimeWarning)
+        pcg.last_converged = False
     else:
         _hip.check(rc, "wiski_pcg")
+        pcg.last_converged = True
     pcg.last_err = int(h_err.value)
     return U, Z, int(iters.value), list(relres)
 
 
 pcg.last_err = 0
+pcg.last_converged = True
 
 
 def kron_toeplitz_grad(grid, tcol, X, Y):

@@ -15,8 +15,8 @@ returns the first columns of the d symmetric-Toeplitz Kronecker factors
 import math
 
 import torch
-from torch.nn.functional import softplus
 
+from .constraints import Positive
 from .grid_ops import GridSpec
 
 
@@ -28,23 +28,36 @@ def inv_softplus(x):
 class Kernel(torch.nn.Module):
     has_lengthscale = False
 
-    def __init__(self, ard_num_dims=None, batch_shape=torch.Size([]), **kwargs):
+    def __init__(self, ard_num_dims=None, batch_shape=torch.Size([]), lengthscale_prior=None, lengthscale_constraint=None, **kwargs):
         super().__init__()
+        if kwargs:       # an option silently dropped here would change the fit without a trace
+            raise TypeError(f"{type(self).__name__}: unsupported keyword argument(s) {sorted(kwargs)}")
         self.ard_num_dims = ard_num_dims
         self.batch_shape = torch.Size(batch_shape) if not isinstance(batch_shape, int) else torch.Size([batch_shape])
+        self._wiski_priors = {}
         if self.has_lengthscale:
             nd = 1 if ard_num_dims is None else ard_num_dims
             self.register_parameter("raw_lengthscale", torch.nn.Parameter(torch.zeros(self.batch_shape + torch.Size([1, nd]))))
+            self.raw_lengthscale_constraint = lengthscale_constraint if lengthscale_constraint is not None else Positive()
+            if lengthscale_prior is not None:
+                self.register_prior("lengthscale_prior", lengthscale_prior, lambda: self.lengthscale)
+        elif lengthscale_prior is not None or lengthscale_constraint is not None:
+            raise TypeError(f"{type(self).__name__} has no lengthscale")
+
+    def register_prior(self, name, prior, closure):
+        """`closure()` -> the constrained value `prior` scores; the MLL adds prior.log_prob(closure()).sum() (BWM:48-49)."""
+        self.add_module(name, prior)
+        self._wiski_priors[name] = (prior, closure)
 
     @property
     def lengthscale(self):
-        return softplus(self.raw_lengthscale) if self.has_lengthscale else None
+        return self.raw_lengthscale_constraint.transform(self.raw_lengthscale) if self.has_lengthscale else None
 
     @lengthscale.setter
     def lengthscale(self, value):
         v = torch.as_tensor(value, dtype=torch.float64).expand(self.raw_lengthscale.shape)
         with torch.no_grad():
-            self.raw_lengthscale.copy_(inv_softplus(v).to(self.raw_lengthscale))
+            self.raw_lengthscale.copy_(self.raw_lengthscale_constraint.inverse_transform(v).to(self.raw_lengthscale))
 
     # k(r), r = |x - x'| / lengthscale
     def profile(self, r):
@@ -88,20 +101,23 @@ class MaternKernel(Kernel):
 
 
 class ScaleKernel(Kernel):
-    def __init__(self, base_kernel, batch_shape=torch.Size([]), **kwargs):
-        super().__init__(batch_shape=batch_shape)
+    def __init__(self, base_kernel, batch_shape=torch.Size([]), outputscale_prior=None, outputscale_constraint=None, **kwargs):
+        super().__init__(batch_shape=batch_shape, **kwargs)
         self.base_kernel = base_kernel
         self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(self.batch_shape)))
+        self.raw_outputscale_constraint = outputscale_constraint if outputscale_constraint is not None else Positive()
+        if outputscale_prior is not None:
+            self.register_prior("outputscale_prior", outputscale_prior, lambda: self.outputscale)
 
     @property
     def outputscale(self):
-        return softplus(self.raw_outputscale)
+        return self.raw_outputscale_constraint.transform(self.raw_outputscale)
 
     @outputscale.setter
     def outputscale(self, value):
         v = torch.as_tensor(value, dtype=torch.float64).expand(self.raw_outputscale.shape)
         with torch.no_grad():
-            self.raw_outputscale.copy_(inv_softplus(v).to(self.raw_outputscale))
+            self.raw_outputscale.copy_(self.raw_outputscale_constraint.inverse_transform(v).to(self.raw_outputscale))
 
     def lag_column(self, dim, lags, batch_index=None):
         s = self.outputscale
@@ -132,7 +148,7 @@ class GridInterpolationKernel(Kernel):
     base kernel.  ``grid_size`` counts gpytorch's two extension points per dim."""
 
     def __init__(self, base_kernel, grid_size, num_dims=None, grid_bounds=None, **kwargs):
-        super().__init__()
+        super().__init__(**kwargs)
         if grid_bounds is None:
             raise RuntimeError("grid_bounds must be given (the data are not kept)")
         gb = torch.as_tensor(grid_bounds, dtype=torch.float64).reshape(-1, 2)

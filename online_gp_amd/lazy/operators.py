@@ -151,6 +151,7 @@ class InducingPosterior(_Operator):
                                      max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace, eigen=self.eigen,
                                      shift=self.shift, first_check=first_check, err=self.err, R=R)
         self.last_iters, self.last_relres, self.last_err = it, res, grid_ops.pcg.last_err
+        self.last_converged = grid_ops.pcg.last_converged
         return U, Z
 
     def _matmul(self, rhs):

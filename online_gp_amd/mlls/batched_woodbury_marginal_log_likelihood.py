@@ -18,6 +18,7 @@ import math
 import torch
 
 from .. import grid_ops, settings
+from ..priors import named_priors
 
 
 class num_trace_samples(settings._value_context):
@@ -176,6 +177,10 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
             ld = cache["_stats"][o, 1]
             inv_quad = (c - bMb) / s2                                               # BWM:34,43
             final = n * math.log(2 * math.pi) + n * torch.log(s2)                   # BWM:40-47 (log sigma2 = 0 when fixed)
-            out.append(-0.5 * (inv_quad + logdet_q + ld + final) / n)              # BWM:49-51
+            out.append(-0.5 * (inv_quad + logdet_q + ld + final))                  # BWM:46
         res = torch.stack(out)
+        # registered hyper-parameter priors: + sum of log-densities, before the division by n (BWM:48-51)
+        for _, prior, closure in named_priors(self):
+            res = res + prior.log_prob(closure()).sum().to(res)
+        res = res / n
         return res[0] if model.num_outputs == 1 else res

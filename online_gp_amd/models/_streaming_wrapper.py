@@ -186,7 +186,7 @@ class StreamingSKIWrapper(torch.nn.Module):
             return mll_feature_surrogate(self.gp, feats, gp_targets.to(feats.dtype), None if noise is None else noise.to(feats.dtype))
         if not self._warned_no_stem_grad:
             warnings.warn(
-                f"fit(): the inducing grid has {self.gp.grid.m} nodes (> settings.max_cholesky_size); the MLL gradient with respect "
+                f"fit(): the inducing grid has {self.gp._grid.m} nodes (> settings.max_cholesky_size); the MLL gradient with respect "
                 "to the stem features is only implemented in the dense regime, so the stem parameters are NOT trained by fit() here "
                 "(update() still trains them through the streaming partial MLL).", RuntimeWarning)
             self._warned_no_stem_grad = True

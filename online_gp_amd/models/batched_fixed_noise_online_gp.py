@@ -268,13 +268,29 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if self._wsum_dirty:
             vals = torch.cat([self._err.double(), self._wsum_dev]).tolist()
             self._wsum_dev_host, self._wsum_dirty = vals[1:], False
-            bad = int(vals[0]) != 0
+            flag = int(vals[0])
         else:
-            bad = int(self._err.item()) != 0
-        if bad:
-            self._err.zero_()
-            raise RuntimeError("Received data that was out of bounds for the specified grid. "
-                               f"Grid bounds were {self.covar_module.grid_bounds}.")
+            flag = int(self._err.item())
+        if flag:
+            self._raise_out_of_bounds(flag)
+
+    def _raise_out_of_bounds(self, flag):
+        """`flag` is the raw device word: bit 0 = some point (query or training) was outside the grid, bits 1.. = number
+        of *training* points the scatter dropped.  Dropped points contributed nothing to A, b, y^T D^-1 y or log|D|
+        (scatter_stats.hip), so taking them out of `num_data` and of the noise-weight sum leaves statistics that
+        describe exactly the points that were absorbed -- a caller may catch the error and carry on."""
+        dropped = flag >> 1
+        self._err.zero_()
+        if dropped:
+            self.num_data = self.num_data - dropped
+            cnt = self._kernel_cache.get("_cnt")
+            if cnt is not None:                       # row sums of W^T D^-1 W: sum_i cnt_i = sum over absorbed points of 1/noise
+                self._wsum_dev = cnt.sum(dim=1, dtype=torch.float64)
+                self._wsum_host = [0.0] * self.num_outputs
+                self._wsum_dirty = True
+            self._dump_caches()
+        raise RuntimeError("Received data that was out of bounds for the specified grid. "
+                           f"Grid bounds were {self.covar_module.grid_bounds}.")
 
     def _sigma2(self, o=0):
         if not self.has_learnable_noise:
@@ -402,6 +418,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             ms = None
         iters = []
         posts = []
+        converged = True
         for o in range(out):
             post = self._posterior_op(o)
             if isinstance(post, DenseInducingPosterior):
@@ -436,10 +453,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             iters.append(post.last_iters)
             posts.append(post)
             if post.last_err:            # out-of-grid flag delivered with the convergence poll (no extra sync)
-                self._err.zero_()
-                raise RuntimeError("Received data that was out of bounds for the specified grid. "
-                                   f"Grid bounds were {self.covar_module.grid_bounds}.")
-        self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "R": R, "R_ok": True, "ver": ver}
+                self._mean_state = None if ms is None else dict(ms, R_ok=False)
+                self._raise_out_of_bounds(post.last_err)
+            converged = converged and getattr(post, "last_converged", True)
+        # a solve that stopped at max_cg_iterations (warned about in grid_ops.pcg) leaves a residual that is not small:
+        # do not carry it into the next refresh as if it were
+        self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "R": R, "R_ok": converged, "ver": ver}
         self._last_iters = list(iters)
         pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters, "ver": ver}
         self._memo["prediction_cache"] = pc
@@ -532,6 +551,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         n = Xf.shape[0]
         pc = self.prediction_cache
         mean = grid_ops.gather(grid, Xf, pc["pred_mean"][..., 0], self._err)      # [n, out]   left_interp, :206-210
+        if settings.deferred_bounds_check.off():
+            flag = grid_ops.read_flag(self._err)       # gpytorch raises inside this call for queries outside the grid
+            if flag:
+                self._raise_out_of_bounds(flag)
         if settings.skip_posterior_variances.on():
             covs = None
         else:

@@ -81,6 +81,15 @@ class skip_logdet_forward(_feature_flag):
     _state = False
 
 
+class deferred_bounds_check(_feature_flag):
+    """Query points outside the inducing grid: off (default) = the posterior call itself raises, as gpytorch's grid
+    check does (one flag read per call: a publish kernel + a host spin behind the gather).  On = the device flag is
+    only looked at with the next solver poll / ``check_bounds()`` -- for streaming loops that evaluate and update in
+    lock-step and would rather not wait for the gather before queueing the update."""
+
+    _state = False
+
+
 class use_toeplitz(_feature_flag):
     _state = True
 

@@ -141,3 +141,45 @@ def test_half_stencil_layout_converters_roundtrip_on_cpu():
                 pos = 4 * i + oh if oh < 4 else (7 * ((oh - 4) // 7 + 1) - 3) * m + 7 * i + (oh - 4) % 7
                 assert flat[pos] == oh * m + i
         assert grid_ops.is_half_stencil(grid, nat) and not grid_ops.is_half_stencil(grid, torch.zeros(grid.R, m))
+
+
+def test_constraints_and_priors_follow_gpytorch_parameterisation():
+    """Advisor finding r1: kernel kwargs must not be swallowed.  Interval / GreaterThan / Positive transforms, prior
+    log-densities, registration through the kernel constructors as the reference's BO driver passes them
+    (experiments/bayesopt/bayesopt.py:69-77), and a TypeError for anything unknown."""
+    import math
+
+    import pytest
+    import torch
+
+    from online_gp_amd.constraints import GreaterThan, Interval, Positive
+    from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, RBFKernel, ScaleKernel
+    from online_gp_amd.priors import GammaPrior, named_priors
+
+    raw = torch.zeros(3, dtype=torch.float64)
+    assert torch.allclose(Positive().transform(raw), torch.full((3,), math.log(2.0), dtype=torch.float64))
+    assert torch.allclose(GreaterThan(1e-4).transform(raw), torch.full((3,), math.log(2.0) + 1e-4, dtype=torch.float64))
+    iv = Interval(1e-4, 12.0)
+    assert torch.allclose(iv.transform(raw), torch.full((3,), 0.5 * (12.0 + 1e-4), dtype=torch.float64))
+    for c in (Positive(), GreaterThan(0.3), iv):
+        v = torch.tensor([0.5, 1.7, 11.0], dtype=torch.float64)
+        assert torch.allclose(c.transform(c.inverse_transform(v)), v, rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        iv.inverse_transform(torch.tensor(13.0))
+    # Gamma(3, 6) log-density at 0.5: 3 log 6 - lgamma(3) + 2 log 0.5 - 3
+    lp = float(GammaPrior(3.0, 6.0).log_prob(torch.tensor(0.5, dtype=torch.float64)))
+    assert abs(lp - (3 * math.log(6.0) - math.lgamma(3.0) + 2 * math.log(0.5) - 3.0)) < 1e-12
+    k = ScaleKernel(MaternKernel(nu=2.5, ard_num_dims=3, lengthscale_prior=GammaPrior(3.0, 6.0), lengthscale_constraint=Interval(1e-4, 12.0)),
+                    outputscale_prior=GammaPrior(2.0, 0.15), outputscale_constraint=Interval(1e-4, 12.0))
+    cov = GridInterpolationKernel(k, grid_size=10, num_dims=3, grid_bounds=[[0.0, 1.0]] * 3)
+    assert abs(float(k.outputscale.detach()) - 6.00005) < 1e-5 and abs(float(k.base_kernel.lengthscale.detach()[0, 0]) - 6.00005) < 1e-5
+    k.base_kernel.lengthscale = 0.7
+    assert torch.allclose(k.base_kernel.lengthscale.double(), torch.full((1, 3), 0.7, dtype=torch.float64), rtol=1e-6)
+    names = sorted(n for n, _, _ in named_priors(cov))
+    assert names == ["base_kernel.base_kernel.lengthscale_prior", "base_kernel.outputscale_prior"]
+    total = sum(float(p.log_prob(c()).sum()) for _, p, c in named_priors(cov))
+    assert math.isfinite(total)
+    with pytest.raises(TypeError):
+        RBFKernel(ard_num_dims=2, lengthscale_prio=GammaPrior(3.0, 6.0))
+    with pytest.raises(TypeError):
+        ScaleKernel(RBFKernel(), outputscale_priors=None, foo=1)

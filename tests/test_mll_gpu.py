@@ -243,3 +243,44 @@ def test_mll_feature_gradient_matches_finite_differences_and_fit_trains_the_stem
     rec = model.fit(Xh, yh, 15)
     assert any((p.detach() - q).abs().max() > 1e-4 for p, q in zip(model.stem.parameters(), w0))
     assert rec[-1]["train_loss"] < rec[0]["train_loss"]
+
+
+def test_mll_adds_registered_priors_before_dividing_by_n():
+    """BWM:48-51: res += sum_priors log p(theta); res /= n.  The reference's BO kernel (Matern-5/2, Gamma priors, Interval
+    constraints, experiments/bayesopt/bayesopt.py:69-77): value = prior-free MLL at the same hyper-parameters + log-priors / n,
+    and the hyper-parameter gradients pick up the prior term."""
+    from online_gp_amd.constraints import Interval
+    from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, ScaleKernel
+    from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+    from online_gp_amd.priors import GammaPrior
+
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0, 1, (30, 2)); y = np.cos(3 * X[:, 0]) * X[:, 1]
+    Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+    gb = torch.tensor([[0.0, 1.0]] * 2)
+
+    def build(with_priors):
+        kw_l = dict(lengthscale_prior=GammaPrior(3.0, 6.0)) if with_priors else {}
+        kw_s = dict(outputscale_prior=GammaPrior(2.0, 0.15)) if with_priors else {}
+        base = ScaleKernel(MaternKernel(nu=2.5, ard_num_dims=2, lengthscale_constraint=Interval(1e-4, 12.0), **kw_l),
+                           outputscale_constraint=Interval(1e-4, 12.0), **kw_s)
+        cov = GridInterpolationKernel(base, grid_size=8, num_dims=2, grid_bounds=gb)
+        base.outputscale = 1.3
+        base.base_kernel.lengthscale = torch.tensor([0.4, 0.9])
+        m = FixedNoiseOnlineSKIGP(Xt, yt, torch.ones_like(yt), covar_module=cov, learn_additional_noise=True).to(DEV)
+        m.train()
+        return m, BatchedWoodburyMarginalLogLikelihood(m.likelihood, m)
+
+    m0, mll0 = build(False)
+    m1, mll1 = build(True)
+    v0, v1 = mll0(None, None), mll1(None, None)
+    ls, osc = m1.covar_module.base_kernel.base_kernel.lengthscale.detach().double(), m1.covar_module.base_kernel.outputscale.detach().double()
+    lp = torch.distributions.Gamma(3.0, 6.0).log_prob(ls.cpu()).sum() + torch.distributions.Gamma(2.0, 0.15).log_prob(osc.cpu()).sum()
+    assert abs(float(v1.detach()) - float(v0.detach()) - float(lp) / 30) < 1e-6      # raw parameters are fp32
+    v0.backward(); v1.backward()
+    g0 = m0.covar_module.base_kernel.raw_outputscale.grad; g1 = m1.covar_module.base_kernel.raw_outputscale.grad
+    # d/d raw of log Gamma(2, 0.15)(s) / n with s = lo + (hi - lo) sigmoid(raw)
+    s = float(osc); dsdraw = (s - 1e-4) * (12.0 - s) / (12.0 - 1e-4)
+    want = ((2.0 - 1.0) / s - 0.15) * dsdraw / 30
+    assert abs(float(g1 - g0) - want) < 1e-6

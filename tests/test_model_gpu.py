@@ -131,6 +131,52 @@ def test_out_of_bounds_raises_like_gpytorch():
         model(x[:2]).mean
 
 
+@pytest.mark.parametrize("g", [8, 24])     # 8^2: dense factor; 24^3 > max_cholesky_size: PCG path (flag rides on the solver poll)
+def test_out_of_grid_points_leave_consistent_statistics(g):
+    """Advisor finding r1: (a) a query outside the grid raises inside the posterior call, not at the next update;
+    (b) a training point outside the grid is dropped whole -- no y^2 / log-noise / num_data / weight-sum residue -- so
+    a caller that catches the error keeps a model that equals the oracle on the points inside the grid."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    d = 2 if g == 8 else 3
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 1, (60, d)); y = np.sin(3 * X.sum(1)); nz = rng.uniform(0.5, 1.5, 60)
+    Xt = torch.as_tensor(X, device=DEV); yt = torch.as_tensor(y, device=DEV)[:, None]; nt = torch.as_tensor(nz, device=DEV)[:, None]
+    gb = [[0.0, 1.0]] * d
+    model = FixedNoiseOnlineSKIGP(Xt[:40], yt[:40], nt[:40], grid_bounds=torch.tensor(gb), grid_size=g, learn_additional_noise=True)
+    model.eval()
+    # (a) query outside: raises here, and the model is untouched
+    bad_q = Xt[:3].clone(); bad_q[1, 0] = 7.0
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        model(bad_q)
+    m_ok = model(Xt[40:45]).mean
+    assert torch.isfinite(m_ok).all() and model.num_data == 40
+    with settings.deferred_bounds_check(True):          # deferred mode: the flag waits for the next poll / check_bounds
+        model(bad_q)
+        with pytest.raises(RuntimeError, match="out of bounds"):
+            model.check_bounds()
+    # (b) a batch with two points outside: the error surfaces at the next posterior request, the 18 good points stay in
+    xb = Xt[40:].clone(); xb[3, 1] = -4.0; xb[11, 0] = 2.5
+    model.condition_on_observations(xb, yt[40:], nt[40:], inplace=True)
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        model(Xt[:2]).mean
+    assert model.num_data == 58
+    keep = np.ones(60, bool); keep[[43, 51]] = False
+    s2 = float(model.likelihood.second_noise.detach())
+    ell = model.covar_module.base_kernel.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1)
+    osc = float(model.covar_module.base_kernel.outputscale)
+    O = dataspace.DataSpaceGP(gb, g, "rbf", ell, osc, s2).fit(X[keep], y[keep], nz[keep])
+    mo, vo = O.predict(X[:7])
+    mvn = model(Xt[:7])
+    assert np.abs(mvn.mean.cpu().numpy() - mo).max() < 1e-6 * np.abs(mo).max()
+    assert np.abs(mvn.variance.cpu().numpy() - vo).max() < 1e-6 * np.abs(vo).max()
+    stats = model._kernel_cache["response_cache"].reshape(-1).cpu().numpy()
+    assert abs(stats[0] - np.sum(y[keep] ** 2 / nz[keep])) < 1e-9 * abs(stats[0])
+    assert abs(float(model._kernel_cache["D_logdet"].reshape(-1)[0]) - np.log(nz[keep]).sum()) < 1e-9 * 60
+    assert abs(model._wsum[0] - np.sum(1.0 / nz[keep])) < 1e-9 * 60
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_online_ski_regression_wrapper(dtype):
     """OnlineSKIRegression surface (OSR:16-197): grid bounds +0.1, noise == 1, predict adds sigma2."""
