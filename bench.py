@@ -8,21 +8,31 @@ evaluate-then-update order of the reference's driver
 
   1. predictive mean of the incoming batch        (fused gather, wiski_gather)
   2. absorb the batch into the statistics          (wiski_scatter_stats; with
-     N > 1 GPUs each rank absorbs its own q points and the deltas are
-     all-reduced over RCCL -- weak scaling)
+     N > 1 GPUs each rank absorbs its own q points and the ranks exchange --
+     weak scaling)
   3. refresh the inducing posterior mean           (wiski_pcg, warm-started)
 
-Hyper-parameters are fixed ("no hyper steps"); predictive
-variances are not part of the timed step (their latency per 64-query chunk is
-reported in `extra`).  Inputs are resident in HBM before the timed region.
+Hyper-parameters are fixed ("no hyper steps") and predictive
+variances are not part of the headline step; the reference-fidelity step
+(evaluate mean AND variance -> Adam step on the MLL -> condition) is timed
+separately and reported in `extra.reference_step_ms_q*`.  Inputs are resident
+in HBM before the timed region.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the stencil
-SpMV of the CG, HBM-bound, timed live with HIP events on its launch stream)
-and `cpu_baseline` (the C oracle port on a bounded sample, rank 0, N=1 only).
+Timing: W warm-up steps, then R back-to-back *blocks* of exactly K steps, every
+block bracketed by a barrier + torch.cuda.synchronize() on both sides and
+reduced with MAX over ranks; `ms_per_step` / `value` come from the MEDIAN block
+(R is chosen so that the timed region lasts >= ~0.3 s: a single 20-step block is
+8 ms, one scheduler hiccup would move it by double digits).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the half-stencil
+SpMV of the CG, HBM-bound; per-dispatch HIP events on its launch stream),
+`roofline_secondary` (statistics scatter, ELL gather) and `cpu_baseline` (the
+OpenMP port of the same step on all host cores, rank 0, N=1 only).
 """
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -59,34 +69,77 @@ def synth_stream(n, d, seed, device, dtype, kind="uniform"):
     return X.to(device, dtype), y.to(device, dtype)[:, None]
 
 
-def cpu_baseline(args, tol):
-    """Time the C oracle (scalar port, 1 core) on a bounded sample of the same workload."""
-    from oracle import cport, spec
+def cpu_baseline(args, tol, budget_s=20.0, max_steps=24):
+    """The same step (predictive mean of the batch -> absorb -> warm-started refresh; same grid, q, init, dtype,
+    tolerance) by the OpenMP port on all host cores: oracle/baseline.py.  Bounded sample: steps until `budget_s`."""
+    from oracle import baseline, spec
 
-    cport.build()
+    baseline.build()
     ndt = np.float32 if args.dtype == "f32" else np.float64
-    n_init, q, steps = 8192, 2048, 5
-    Xt, yt = synth_stream(n_init + q * (steps + 1), args.dim, 0, "cpu", torch.float64)
-    X, y = Xt.numpy(), yt.numpy()[:, 0]
-    B2 = cport.MatrixFreeWISKI([[-1.1, 1.1]] * args.dim, args.grid, sigma2=spec.SOFTPLUS0 + 1e-4, dtype=ndt)
-    B2.absorb(X[:n_init], y[:n_init], init=True)
-    B2.refresh(tol, 2000)
+    q = args.batch
+    Xt, yt = synth_stream(args.n_init, args.dim, 0, "cpu", torch.float64, args.stream)
+    Xs, ys = synth_stream(q * max_steps, args.dim, 1000, "cpu", torch.float64, args.stream)
+    B = baseline.StreamingBaseline([[-1.1, 1.1]] * args.dim, args.grid, sigma2=spec.SOFTPLUS0 + 1e-4, dtype=ndt)
+    B.absorb(Xt.numpy(), yt.numpy()[:, 0])
+    B.refresh(tol)                                  # cold solve on the init data (not timed), as on the GPU leg
+    X, y = Xs.numpy(), ys.numpy()[:, 0]
+    steps, iters = 0, []
     t0 = time.perf_counter()
-    for s in range(steps):
-        lo = n_init + s * q
-        B2.predict_mean(X[lo:lo + q], tol)
-        B2.absorb(X[lo:lo + q], y[lo:lo + q])
-        B2.refresh(tol, 2000)   # the C port has no warm start: cold solve per step
+    while steps < max_steps and (steps < 3 or time.perf_counter() - t0 < budget_s):
+        lo = steps * q
+        B.predict_mean(X[lo:lo + q])
+        B.absorb(X[lo:lo + q], y[lo:lo + q])
+        it, _ = B.refresh(tol)
+        iters.append(it)
+        steps += 1
     dt = time.perf_counter() - t0
-    return {"value": steps * q / dt, "unit": "updates/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} steps of q={q} after a {n_init}-point init, same grid/dtype/tolerance, cold CG per step, "
-                      f"scalar C oracle (oracle/wiski_oracle.c), {dt:.1f} s"}
+    return {"value": steps * q / dt, "unit": "updates/s", "cores": baseline.num_threads(), "kind": "port",
+            "sample": f"{steps} steps of q={q} after the {args.n_init}-point init (same grid / dtype / tolerance / warm starts as the GPU leg), "
+                      f"OpenMP C port on {baseline.num_threads()} threads of {os.cpu_count()} logical CPUs, Kt-preconditioned CG "
+                      f"({np.mean(iters):.0f} iterations per step; the GPU library's density-profile preconditioner is not ported), {dt:.1f} s"}
+
+
+def dense_reference_timings(dev):
+    """SURVEY.md 8(d) last bullet: the faithful dense restatement of the reference algorithm (B1, oracle/dense_reference.py,
+    numpy/LAPACK on the host) beside the GPU's dense regime, at the reference's own grid sizes: one streamed point
+    (condition_on_observations) followed by mean + variance at 16 queries."""
+    from oracle import dense_reference
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    out = {}
+    for name, d, g in (("m256_16x16", 2, 16), ("m1000_10x10x10", 3, 10)):
+        rng = np.random.default_rng(0)
+        n0, nst = 64, 12
+        X = rng.uniform(-1, 1, (n0 + nst, d)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(n0 + nst)
+        Xq = rng.uniform(-1, 1, (16, d))
+        gb = [[-1.1, 1.1]] * d
+        B1 = dense_reference.DenseWISKI(gb, g, sigma2=0.6932)
+        B1.set_train_data(X[:n0], y[:n0], np.ones(n0))
+        B1.predict(Xq)
+        t0 = time.perf_counter()
+        for i in range(nst):
+            B1.condition_on_observations(X[n0 + i:n0 + i + 1], y[n0 + i:n0 + i + 1])
+            B1.predict(Xq)
+        cpu_ms = (time.perf_counter() - t0) / nst * 1e3
+        Xt = torch.as_tensor(X, device=dev); yt = torch.as_tensor(y, device=dev)[:, None]; Xqt = torch.as_tensor(Xq, device=dev)
+        m = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], torch.ones_like(yt[:n0]), grid_bounds=torch.tensor(gb), grid_size=g, learn_additional_noise=True)
+        m.eval()
+        with torch.no_grad():
+            mv = m(Xqt); mv.mean, mv.variance
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(nst):
+                m.condition_on_observations(Xt[n0 + i:n0 + i + 1], yt[n0 + i:n0 + i + 1], inplace=True)
+                mv = m(Xqt); mv.mean, mv.variance
+            torch.cuda.synchronize()
+        out[name] = {"gpu_ms_per_point": (time.perf_counter() - t0) / nst * 1e3, "cpu_dense_reference_ms_per_point": cpu_ms}
+    out["note"] = "fp64; CPU = oracle/dense_reference.py (dense W^T, m x m WtW, SVD root update, Cholesky of Q; numpy/LAPACK threads of the host)"
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="streamed points per step per GPU (q)")
     ap.add_argument("--grid", type=int, default=50)
@@ -95,7 +148,9 @@ def main():
     ap.add_argument("--n-init", type=int, default=21743, help="5%% of 434874 (init_ratio of the reference config)")
     ap.add_argument("--tol", type=float, default=None, help="CG relative-residual tolerance")
     ap.add_argument("--stream", default="uniform", choices=["uniform", "clustered"], help="synthetic stream of SURVEY.md 8d")
+    ap.add_argument("--blocks", type=int, default=0, help="number of timed K-step blocks (0 = enough for ~0.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extras (profiling runs)")
     ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
 
@@ -118,149 +173,266 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from online_gp_amd import _hip, settings
+    from online_gp_amd import _hip, grid_ops, settings
     from online_gp_amd.distributed import ShardedStatsUpdater
-    from online_gp_amd.kernels import GridInterpolationKernel, RBFKernel, ScaleKernel
-    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP, Identity, OnlineSKIRegression
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     tol = args.tol if args.tol is not None else (1e-4 if dtype == torch.float32 else 1e-8)
     K, Wm, q, d = args.steps, args.warmup, args.batch, args.dim
-
-    # identical init on every rank (replicated statistics), rank-local stream shards
-    X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
-    Xs, ys = synth_stream((K + Wm + 1) * q, d, 1000 + rank, dev, dtype, args.stream)
-    gb = torch.tensor([[-1.1, 1.1]] * d)
-    model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
-    model.eval()
-    upd = ShardedStatsUpdater(model, equal_shards=True)   # every rank streams q points per step
     lib = _hip.lib()
-
-    def step(t):
-        xb, yb = Xs[t * q:(t + 1) * q], ys[t * q:(t + 1) * q]
-        mean = model(xb).mean                      # 1. evaluate
-        upd.update(xb, yb)                         # 2. absorb (+ all-reduce of the deltas when N > 1)
-        pc = model.prediction_cache                # 3. refresh
-        return mean, pc["cg_iters"][0]
+    gb = torch.tensor([[-1.1, 1.1]] * d)
+    if args.check_every:
+        settings.cg_check_every._set_value(args.check_every)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.check_every:
-        settings.cg_check_every._set_value(args.check_every)
-    with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), torch.no_grad():
-        model.prediction_cache                     # cold solve on the init data (not timed)
-        for t in range(Wm):
-            step(t)
-        barrier()
-        # roofline leg: HIP events bracket every stencil-SpMV launch of every 4th timed step (each bracket costs
-        # ~6 us of stream time on both sides of the kernel, so sampling keeps the timed region honest)
-        iters = []
-        tot_ms_sum, launches_sum = 0.0, 0
-        t0 = time.perf_counter()
-        for t in range(Wm, Wm + K):
-            sampled = (t - Wm) % 4 == 0
-            if sampled:
-                lib.wiski_prof_start(ctypes.c_int32(4096))
-            _, it = step(t)
-            iters.append(it)
-            if sampled:
-                # no synchronisation needed: step() returned from the solver's convergence poll, which is ordered
-                # after every bracketed SpMV on the same stream
-                tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
-                lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl))
-                tot_ms_sum += tms.value
-                launches_sum += int(nl.value)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        tot_ms, launches = ctypes.c_double(tot_ms_sum), ctypes.c_int64(launches_sum)
+    def run_stream(kind, exchange, blocks, seed0, profile):
+        """Fresh model on the init data, W warm-up steps, then `blocks` timed blocks of K steps on fresh points.
+        Returns (model, per-block seconds [MAX over ranks], CG iterations per step, SpMV event ms, SpMV launches)."""
+        X0, y0 = synth_stream(args.n_init, d, seed0, dev, dtype, kind)        # identical init on every rank
+        model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
+        model.eval()
+        upd = ShardedStatsUpdater(model, equal_shards=True, exchange=exchange)   # every rank streams q points per step
 
-        # un-timed extras: absorb-only rate, variance latency, parity of the streamed model vs the oracle
-        xb, yb = Xs[(Wm + K) * q:(Wm + K + 1) * q], ys[(Wm + K) * q:(Wm + K + 1) * q]
-        torch.cuda.synchronize(); ta = time.perf_counter()
-        model.condition_on_observations(xb, yb, inplace=True)
-        torch.cuda.synchronize(); ta = time.perf_counter() - ta
-        # small-batch latencies (the reference driver streams with batch_size 1, config/regression.yaml:22)
-        small = {}
-        for qs in (1, 64):
-            torch.cuda.synchronize(); tq = time.perf_counter()
+        def step(xb, yb):
+            mean = model(xb).mean                      # 1. evaluate
+            upd.update(xb, yb)                         # 2. absorb (+ exchange between the ranks when N > 1)
+            pc = model.prediction_cache                # 3. refresh
+            return mean, pc["cg_iters"][0]
+
+        model.prediction_cache                         # cold solve on the init data (not timed)
+        Xw, yw = synth_stream(max(Wm, 1) * q, d, seed0 + 1000 + rank, dev, dtype, kind)
+        lib.wiski_prof_start(ctypes.c_int32(256))      # creates the event pool outside the timed region
+        lib.wiski_prof_stop(None, None)
+        tw = float("inf")
+        for t in range(Wm):                            # un-timed warm-up; the fastest step sizes the number of blocks
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            step(Xw[t * q:(t + 1) * q], yw[t * q:(t + 1) * q])
+            torch.cuda.synchronize(); tw = min(tw, time.perf_counter() - t0)
+        R = blocks
+        if R <= 0:                                      # same R on every rank: >= ~0.3 s of timed blocks, <= 2400 steps
+            est = torch.tensor([tw if Wm > 0 else 4e-4], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(est, op=dist.ReduceOp.MAX)
+            R = int(max(5, math.ceil(0.3 / max(float(est.item()) * K, 1e-6))))
+            R = max(3, min(R, 2400 // max(K, 1)))
+        Xs, ys = synth_stream(R * K * q, d, seed0 + 2000 + rank, dev, dtype, kind)
+        block_s, iters = [], []
+        ms_sum, n_launch = 0.0, 0
+        for r in range(R):
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(K):
+                t = r * K + k
+                sampled = profile and t % 4 == 0        # per-dispatch events on every SpMV launch of every 4th step
+                if sampled:
+                    lib.wiski_prof_start(ctypes.c_int32(256))
+                _, it = step(Xs[t * q:(t + 1) * q], ys[t * q:(t + 1) * q])
+                iters.append(it)
+                if sampled:
+                    # step() returned from the solver's convergence poll, which is ordered after every SpMV of the step
+                    tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+                    lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl))
+                    ms_sum += tms.value
+                    n_launch += int(nl.value)
+            barrier()
+            block_s.append(time.perf_counter() - t0)
+        bt = torch.tensor(block_s, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        return model, upd, bt.tolist(), iters, ms_sum, n_launch
+
+    with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), torch.no_grad():
+        # headline: the configured stream; N > 1: the exchange the cost model picks ("auto")
+        model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=True)
+        R = len(block_s)
+        med = float(np.median(block_s))
+        extra = {"blocks": R, "block_ms_first_median_last_min": [block_s[0] * 1e3, med * 1e3, block_s[-1] * 1e3, min(block_s) * 1e3],
+                 "timed_region_s": float(np.sum(block_s)), "cg_iters_per_step_mean": float(np.mean(iters)),
+                 "points_absorbed_at_end": int(model.num_data)}
+        exchange_used = upd.last_exchange
+
+        if world > 1 and not args.no_extras:
+            # both exchanges, timed the same way (VERDICT r1 5d): the point exchange divides no work (every rank scatters
+            # all N q points and solves), the statistics all-reduce is the north-star form
+            for ex in ("points", "stats"):
+                _, _, bs, its, _, _ = run_stream(args.stream, ex, max(3, R // 4), 0, profile=False)
+                extra[f"updates_per_s_exchange_{ex}"] = world * K * q / float(np.median(bs))
+                extra[f"cg_iters_exchange_{ex}"] = float(np.mean(its))
+
+        if world == 1 and not args.no_extras:
+            # second value: the road-like clustered stream of SURVEY 8d (3droad IS road-like)
+            other = "clustered" if args.stream == "uniform" else "uniform"
+            _, _, bs, its, _, _ = run_stream(other, "auto", max(3, R // 3), 7, profile=False)
+            extra[f"{other}_stream_updates_per_s"] = K * q / float(np.median(bs))
+            extra[f"{other}_stream_cg_iters_per_step_mean"] = float(np.mean(its))
+
+            # absorb-only rate and the scatter kernel by itself (torch events on the launch stream)
+            Xe, ye = synth_stream(12 * q, d, 4242, dev, dtype, args.stream)
+            torch.cuda.synchronize(); ta = time.perf_counter()
+            for i in range(4):
+                model.condition_on_observations(Xe[i * q:(i + 1) * q], ye[i * q:(i + 1) * q], inplace=True)
+            torch.cuda.synchronize(); ta = (time.perf_counter() - ta) / 4
+            extra["absorb_only_updates_per_s"] = q / ta
+            grid = model._grid
+            half = torch.zeros(((grid.R + 1) // 2, grid.m), device=dev, dtype=dtype)
+            bvec = torch.zeros(grid.m, device=dev, dtype=dtype)
+            st = torch.zeros(2, device=dev, dtype=torch.float64)
+            ones = torch.ones(q, device=dev, dtype=dtype)
+            errf = grid_ops.new_err_flag(dev)
+            grid_ops.scatter_stats_sym(grid, Xe[:q], ye[:q, 0].contiguous(), ones, ones, ones, bvec, half, st, errf)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(8):
+                grid_ops.scatter_stats_sym(grid, Xe[(i + 4) * q:(i + 5) * q], ye[(i + 4) * q:(i + 5) * q, 0].contiguous(), ones, ones, ones, bvec, half, st, errf)
+            e1.record(); torch.cuda.synchronize()
+            sc_us = e0.elapsed_time(e1) / 8 * 1e3
+            es = 4 if dtype == torch.float32 else 8
+            T = grid.T
+            sc_bytes = ((d + 2) + 2 * T + T * (T + 1)) * es       # SURVEY 8(d): read (d + 2 out) s, RMW 2 T s (W^T y), RMW T (T + 1) s (symmetric WtW)
+            # the ELL form of the predictive interpolated MVM (north_star's "CSR/COO sparse interpolation SpMM"): idx/val streamed
+            nq = 1 << 20
+            Xq = torch.rand((nq, d), device=dev, dtype=dtype) * 2 - 1
+            idx, val = grid_ops.interp(grid, Xq, errf)
+            mu = model.prediction_cache["pred_mean"][0, :, 0].contiguous()
+            grid_ops.gather_ell(idx, val, mu)
+            e0.record()
             for i in range(10):
-                xq, yq = Xs[i * qs:(i + 1) * qs], ys[i * qs:(i + 1) * qs]
-                model(xq).mean
-                model.condition_on_observations(xq, yq, inplace=True)
-                model.prediction_cache
-            torch.cuda.synchronize()
-            small[qs] = (time.perf_counter() - tq) / 10 * 1e3
-        # large-batch throughput (SURVEY.md 8d lists q = 16384): the same full step, 6 steps of fresh points
-        qL = 16384
-        XL, yL = synth_stream(7 * qL, d, 5000 + rank, dev, dtype, args.stream)
-        for i in range(7):
-            if i == 1:
-                torch.cuda.synchronize(); tL = time.perf_counter()
-            xq, yq = XL[i * qL:(i + 1) * qL], yL[i * qL:(i + 1) * qL]
-            model(xq).mean
-            model.condition_on_observations(xq, yq, inplace=True)
-            model.prediction_cache
-        torch.cuda.synchronize()
-        large_rate = 6 * qL / (time.perf_counter() - tL)
-    with settings.cg_tolerance(tol), torch.no_grad():
-        xv = Xs[:64]
-        model(Xs[64:128]).variance                 # warm the 64-column PCG workspace (first call allocates ~0.8 GB)
-        torch.cuda.synchronize(); tv = time.perf_counter()
-        var = model(xv).variance
-        torch.cuda.synchronize(); tv = time.perf_counter() - tv
+                grid_ops.gather_ell(idx, val, mu)
+            e1.record(); torch.cuda.synchronize()
+            ell_us = e0.elapsed_time(e1) / 10 * 1e3
+            ell_bytes = nq * (T * (4 + es) + es)
+            e0.record()
+            for i in range(10):
+                grid_ops.gather(grid, Xq, mu, errf)
+            e1.record(); torch.cuda.synchronize()
+            fused_us = e0.elapsed_time(e1) / 10 * 1e3
+            roofline_secondary = [
+                {"kernel": "k_scatter_stats_sym (statistics scatter of q points; memory-side atomics)", "bound": "hbm",
+                 "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "avg_launch_us": sc_us, "algorithmic_bytes_per_point": sc_bytes, "points_per_s": q / (sc_us * 1e-6),
+                 "lane_atomics_per_s": q * (T * (T + 1) // 2 + 2 * T) / (sc_us * 1e-6), "timing": "torch.cuda.Event bracket around 8 launches"},
+                {"kernel": "k_gather_ell (predictive interpolated MVM from stored idx/val, 2^20 query rows)", "bound": "hbm",
+                 "achieved": ell_bytes / (ell_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ell_bytes / (ell_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "avg_launch_us": ell_us, "algorithmic_bytes_per_row": T * (4 + es) + es,
+                 "fused_form_rows_per_s": nq / (fused_us * 1e-6), "note": "the product path uses the fused form (weights recomputed from x, 16 B/row)",
+                 "timing": "torch.cuda.Event bracket around 10 launches"},
+            ]
+        else:
+            roofline_secondary = None
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    if world == 1 and not args.no_extras:
+        # predictive variances: latency of one 64-query chunk (one 64-column PCG solve) and the reference-fidelity step
+        with settings.cg_tolerance(tol), torch.no_grad():
+            Xv, _ = synth_stream(128, d, 99, dev, dtype, args.stream)
+            model(Xv[64:128]).variance                 # warm the 64-column PCG workspace (first call allocates ~0.8 GB)
+            torch.cuda.synchronize(); tv = time.perf_counter()
+            model(Xv[:64]).variance
+            torch.cuda.synchronize(); tv = time.perf_counter() - tv
+        extra["variance_ms_per_64_queries"] = tv * 1e3
+        del model
+        torch.cuda.empty_cache()
+        # the reference's timed step at full fidelity (experiments/regression.py:48-54, OSR:56-146): evaluate = predictive
+        # mean AND variance (rmse, nll) of the incoming batch, update = one Adam step on the Woodbury MLL + condition
+        X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
+        Xr, yr = synth_stream(4096, d, 31337, dev, dtype, args.stream)
+        with settings.cg_tolerance(tol):
+            reg = OnlineSKIRegression(Identity(d), X0, y0, 1e-3, args.grid, 1.0)
+            for qs, nst in ((1, 6), (64, 4), (1024, 3)):
+                ts = []
+                for i in range(nst):
+                    xb, yb = Xr[i * qs:(i + 1) * qs], yr[i * qs:(i + 1) * qs]
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    reg.evaluate(xb, yb)
+                    reg.update(xb, yb)
+                    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                extra[f"reference_step_ms_q{qs}"] = float(np.median(ts[1:])) * 1e3
+                extra[f"reference_step_updates_per_s_q{qs}"] = qs / float(np.median(ts[1:]))
+            # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
+            gp = reg.gp
+            with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():
+                for qs in (1, 64):
+                    torch.cuda.synchronize(); tq = time.perf_counter()
+                    for i in range(10):
+                        xq, yq = Xr[2048 + i * qs:2048 + (i + 1) * qs], yr[2048 + i * qs:2048 + (i + 1) * qs]
+                        gp(xq).mean
+                        gp.condition_on_observations(xq, yq, inplace=True)
+                        gp.prediction_cache
+                    torch.cuda.synchronize()
+                    extra[f"step_ms_q{qs}"] = (time.perf_counter() - tq) / 10 * 1e3
+                # large-batch throughput (SURVEY.md 8d lists q = 16384): the same full step, 6 steps of fresh points
+                qL = 16384
+                XL, yL = synth_stream(7 * qL, d, 5000, dev, dtype, args.stream)
+                for i in range(7):
+                    if i == 1:
+                        torch.cuda.synchronize(); tL = time.perf_counter()
+                    gp(XL[i * qL:(i + 1) * qL]).mean
+                    gp.condition_on_observations(XL[i * qL:(i + 1) * qL], yL[i * qL:(i + 1) * qL], inplace=True)
+                    gp.prediction_cache
+                torch.cuda.synchronize()
+                extra["updates_per_s_q16384"] = 6 * qL / (time.perf_counter() - tL)
+            del reg, gp
+            torch.cuda.empty_cache()
+        extra["dense_regime"] = dense_reference_timings(dev)
 
     if rank == 0:
-        grid = model._grid
+        from online_gp_amd.grid_ops import GridSpec
+
+        grid = GridSpec(gb, args.grid)
         es = 4 if dtype == torch.float32 else 8
         # algorithmic bytes of one k=1 stencil SpMV launch (SURVEY.md 8d): the symmetric half stencil A_h once
         # (the model's native storage; every entry serves A[i,j] and A[j,i]) + v in + out (+ add)
         spmv_bytes = (grid.R + 1) // 2 * grid.m * es + 3 * grid.m * es
-        n_l = int(launches.value)
-        avg_ms = tot_ms.value / max(n_l, 1)
-        achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if n_l else 0.0
-        traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), if recorded
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "k_stencil_spmv4_sym<%s, 1, true>" % ("float" if args.dtype == "f32" else "double")
-            if args.grid == 50 and d == 3 and key in pmc["kernels"]:
-                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            traffic = None
+        avg_ms = spmv_ms / max(spmv_n, 1)
+        achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        dma = dtype == torch.float32 and d == 3 and grid.m % 4 == 0 and os.environ.get("WISKI_SYM_DMA", "1") != "0"
+        kname = "k_spmv_sym_dma<2, true>" if dma else "k_stencil_spmv4_sym<%s, 1, true>" % ("float" if args.dtype == "f32" else "double")
+        # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (tools/pmc_traffic.py),
+        # NOT in this run -- read back from the committed profile and labelled with its source
+        traffic, traffic_source = None, None
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if args.grid == 50 and d == 3 and kname in pmc["kernels"]:
+                    traffic, traffic_source = pmc["kernels"][kname]["hbm_bytes_per_launch"], "profiles/" + fn + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    break
+            except Exception:  # noqa: BLE001
+                pass
+        par = "single"
+        if world > 1:
+            par = f"dp{world} (" + ("shard all-gather + replicated scatter: divides no work, every rank scatters all N q points and solves"
+                                    if exchange_used == "points" else "all-reduce of the half-stencil statistics") + ")"
         res = {
             "metric": "streaming updates/sec (WISKI, 50^3 inducing grid)",
-            "value": world * K * q / elapsed,
+            "value": world * K * q / med,
             "unit": "updates/s",
             "n_gpus": world,
             "steps": K,
             "warmup": Wm,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": med / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": ("clustered (64 poly-lines, sigma 0.02) " if args.stream == "clustered" else "") + f"3droad-like synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
-                                   f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}",
-                       "batch_per_gpu": q, "global_batch": q * world, "parallelism": (f"dp{world} (" + ("shard all-gather + replicated scatter" if upd.last_exchange == "points"
-                                                          else "all-reduce of the half-stencil statistics") + ")") if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": "k_stencil_spmv4_sym (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": n_l, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
+                                   f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}; median of {R} timed blocks of {K} steps",
+                       "batch_per_gpu": q, "global_batch": q * world, "parallelism": par},
+            "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "launches": spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
+                         "timing": "start/stop HIP events attached to each SpMV dispatch (hipExtLaunchKernel) on its launch stream, every 4th timed step",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
-                         "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es,
-                         "full_stencil_equivalent_frac": ((grid.R * grid.m * es + 2 * grid.m * es) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if n_l else 0.0},
-            "extra": {"cg_iters_per_step_mean": float(np.mean(iters)), "absorb_only_updates_per_s": q / ta,
-                      "variance_ms_per_64_queries": tv * 1e3, "step_ms_q1": small[1], "step_ms_q64": small[64], "updates_per_s_q16384": large_rate, "spmv_time_share": tot_ms.value * 1e-3 / elapsed},
+                         "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es},
+            "extra": extra,
         }
+        if roofline_secondary:
+            res["roofline_secondary"] = roofline_secondary
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, tol)
     if world > 1:

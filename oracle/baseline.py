@@ -1,0 +1,95 @@
+"""TEST INFRASTRUCTURE -- ctypes front-end of the multi-threaded CPU baseline (oracle/wiski_baseline_omp.c).
+
+The timed ``cpu_baseline`` of bench.py (kind "port"): the matrix-free WISKI streaming step -- predictive mean of the
+incoming batch, absorb, warm-started refresh of the inducing posterior mean -- on all host cores, at the same grid /
+batch / init / tolerance as the GPU leg.  Checked against the scalar oracle (cport.py) in tests/test_oracle.py.
+Never imported by online_gp_amd."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import spec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libwiski_baseline.so")
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("wiski_baseline_omp.c", "wiski_baseline_omp_impl.h")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_build/libwiski_baseline.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def num_threads():
+    return int(lib().wb_num_threads())
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class StreamingBaseline:
+    """Single-output matrix-free WISKI state; full 7^d block stencil, Kt-preconditioned CG with warm starts."""
+
+    def __init__(self, grid_bounds, grid_size, kind="rbf", lengthscale=spec.SOFTPLUS0, outputscale=spec.SOFTPLUS0, sigma2=1.0,
+                 dtype=np.float32):
+        self.dt = np.dtype(dtype)
+        self.sfx = "_f64" if self.dt == np.float64 else "_f32"
+        self.creal = ctypes.c_double if self.dt == np.float64 else ctypes.c_float
+        g0, h, g = spec.make_grid(grid_bounds, grid_size)
+        self.g0, self.h, self.g = g0.astype(self.dt), h.astype(self.dt), g.astype(np.int32)
+        self.d, self.m = len(g), int(np.prod(g))
+        self.tcol = np.concatenate(spec.toeplitz_columns(kind, h, g, lengthscale, outputscale)).astype(self.dt)
+        self.sigma2 = float(sigma2)
+        self.b = np.zeros(self.m, self.dt)
+        self.A = np.zeros((7 ** self.d, self.m), self.dt)
+        self.c_ld = np.zeros(2, np.float64)
+        self.u = np.zeros(self.m, self.dt)
+        self.z = np.zeros(self.m, self.dt)
+        self.solved = False
+        self.num_data = 0
+
+    def _fn(self, name):
+        f = getattr(lib(), name + self.sfx)
+        f.restype = ctypes.c_int
+        return f
+
+    def absorb(self, X, y, noise=None):
+        X = np.ascontiguousarray(X, self.dt).reshape(-1, self.d)
+        y = np.ascontiguousarray(y, self.dt).reshape(-1)
+        n = X.shape[0]
+        noise = np.ones(n, self.dt) if noise is None else np.ascontiguousarray(noise, self.dt).reshape(-1)
+        rc = self._fn("wb_absorb")(_p(X), _p(y), _p(noise), ctypes.c_long(n), self.d, _p(self.g0), _p(self.h), _p(self.g),
+                                   ctypes.c_long(self.m), _p(self.b), _p(self.A), _p(self.c_ld))
+        if rc:
+            raise RuntimeError("Received data that was out of bounds for the specified grid.")
+        self.num_data += n
+
+    def refresh(self, tol, max_iter=5000):
+        """u = (Kt^-1 + A)^-1 b, warm-started from the previous (u, z); returns (iterations, relative residual)."""
+        res = ctypes.c_double(0)
+        it = self._fn("wb_pcg")(_p(self.A), _p(self.tcol), self.d, _p(self.g), ctypes.c_long(self.m), self.creal(1.0 / self.sigma2),
+                                _p(self.b), int(self.solved), ctypes.c_double(tol), max_iter, _p(self.u), _p(self.z), ctypes.byref(res))
+        self.solved = True
+        return it, float(res.value)
+
+    def predict_mean(self, Xs):
+        Xs = np.ascontiguousarray(Xs, self.dt).reshape(-1, self.d)
+        out = np.empty(Xs.shape[0], self.dt)
+        rc = self._fn("wb_gather")(_p(Xs), ctypes.c_long(Xs.shape[0]), self.d, _p(self.g0), _p(self.h), _p(self.g), _p(self.u), _p(out))
+        if rc:
+            raise RuntimeError("Received data that was out of bounds for the specified grid.")
+        return out

@@ -127,3 +127,28 @@ def test_float32_port_close_to_float64(oracle_lib):
         B2.absorb(X, y, init=True)
         res.append(B2.predict_mean(X[:9], 1e-6 if dt == np.float32 else 1e-12))
     assert np.abs(res[0] - res[1]).max() < 1e-3 * np.abs(res[0]).max()
+
+
+def test_openmp_baseline_matches_scalar_oracle():
+    """bench.py's cpu_baseline (oracle/baseline.py: OpenMP, warm-started CG) against the scalar checker (cport.py)."""
+    from oracle import baseline, cport
+
+    rng = np.random.default_rng(7)
+    gb = [[-1.1, 1.1]] * 3
+    X = rng.uniform(-1, 1, (600, 3)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(600); nz = rng.uniform(0.5, 2.0, 600)
+    for dt, tol in ((np.float64, 1e-9), (np.float32, 2e-4)):
+        B = baseline.StreamingBaseline(gb, 10, sigma2=0.7, dtype=dt)
+        C = cport.MatrixFreeWISKI(gb, 10, sigma2=0.7, dtype=np.float64)
+        for lo in (0, 200, 400):                    # three streaming steps, warm starts on the second and third
+            B.absorb(X[lo:lo + 200], y[lo:lo + 200], nz[lo:lo + 200])
+            C.absorb(X[lo:lo + 200], y[lo:lo + 200], nz[lo:lo + 200], init=(lo == 0))
+            it, res = B.refresh(1e-10 if dt == np.float64 else 1e-6)
+            assert res < (1e-9 if dt == np.float64 else 1e-5) and it > 0
+        assert np.abs(B.A.astype(np.float64) - C.A).max() < tol * np.abs(C.A).max()
+        assert np.abs(B.b.astype(np.float64) - C.b).max() < tol * np.abs(C.b).max()
+        assert np.allclose(B.c_ld, C.c_ld, rtol=1e-10 if dt == np.float64 else 1e-6)
+        C.refresh(1e-12)
+        ref = C.predict_mean(X[:50], 1e-12)
+        got = B.predict_mean(X[:50]).astype(np.float64)
+        assert np.abs(got - ref).max() < (1e-7 if dt == np.float64 else 5e-4) * np.abs(ref).max()
+    assert baseline.num_threads() >= 1
