@@ -214,6 +214,17 @@ int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* d_L, in
 int wiski_logdiag_f32(int32_t n, const float* d_A, int32_t lda, double* d_out, void* stream);
 int wiski_logdiag_f64(int32_t n, const double* d_A, int32_t lda, double* d_out, void* stream);
 
+/* a6 -- replaces UpdatedRootLazyTensor.collect_vector (URLT:69-119): in-place rank-q update of a root /
+ * inverse-root pair.  On entry L L^T = A and R^T L = I (R = L^-T), both [m][r] row-major with leading
+ * dimensions ldl / ldr; V [m][q] (ldv) holds the new columns (W^T scaled by 1/sqrt(noise), BFN:163-168).  On
+ * return L L^T = A + V V^T and R^T L = I.  O(m r q) on the MFMA GEMM through the thin factor of
+ * p = R^T V (the reference builds a full r x r U: O(m r^2)); the q x q eigenproblem of p^T p is solved on
+ * the host, so the call synchronises the stream.  L differs from the reference's L U S~ by a right orthogonal
+ * factor.  d_ws: wiski_root_update_workspace_elems(m, r, q) reals of device scratch. */
+int64_t wiski_root_update_workspace_elems(int32_t m, int32_t r, int32_t q);
+int wiski_root_update_f32(int32_t m, int32_t r, int32_t q, float* d_L, int32_t ldl, float* d_R, int32_t ldr, const float* d_V, int32_t ldv, float* d_ws, int64_t ws_elems, void* stream);
+int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* d_L, int32_t ldl, double* d_R, int32_t ldr, const double* d_V, int32_t ldv, double* d_ws, int64_t ws_elems, void* stream);
+
 /* Value of a device int32 flag after everything already queued on `stream`, without a stream
  * synchronisation (a one-thread publish kernel + a host spin on pinned memory, a few microseconds once the
  * queue has drained).  Used for the out-of-grid flag after a query gather, where the reference raises

@@ -62,6 +62,8 @@ def lib():
         if alt:
             _lib = ctypes.CDLL(alt)
             _lib.wiski_pcg_workspace_bytes.restype = ctypes.c_int64
+            if hasattr(_lib, "wiski_root_update_workspace_elems"):
+                _lib.wiski_root_update_workspace_elems.restype = ctypes.c_int64
             return _lib
         if not os.path.exists(_SO):
             raise WiskiError(
@@ -70,6 +72,8 @@ def lib():
             )
         _lib = ctypes.CDLL(_SO)
         _lib.wiski_pcg_workspace_bytes.restype = ctypes.c_int64
+    if hasattr(_lib, "wiski_root_update_workspace_elems"):
+        _lib.wiski_root_update_workspace_elems.restype = ctypes.c_int64
     return _lib
 
 

@@ -9,6 +9,9 @@
 // All matrices are row-major with explicit leading dimensions.
 #include "wiski_common.h"
 
+#include <cmath>
+#include <vector>
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
@@ -353,6 +356,110 @@ static int logdiag_impl(int n, const real* d_A, int lda, double* d_out, void* st
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+// ----------------------------------------------------------------- root update (a6) ---
+// Rank-q update of a root / inverse-root pair, replacing UpdatedRootLazyTensor.collect_vector (URLT:69-119):
+// given L, R with L L^T = A and R^T L = I (R = L^-T), and the new columns V [m, q], produce L', R' with
+// L' L'^T = A + V V^T and R'^T L' = I.  The reference takes the full SVD p = R^T V = U S W^T with an r x r U and
+// forms L U S~, R U S~^-1, S~ = diag(sqrt(S^2 + 1), 1...): O(m r^2).  The same Gram matrices follow from the thin
+// factor U_q = p W S^-1 of the q x q eigenproblem p^T p = W S^2 W^T:
+//   L' = L + (L U_q) diag(sqrt(S^2+1) - 1) U_q^T      R' = R + (R U_q) diag(1/sqrt(S^2+1) - 1) U_q^T
+// i.e. L' = L (I + p p^T)^{1/2}, O(m r q) on the MFMA GEMM; L' differs from the reference's L U S~ by a right
+// orthogonal factor (roots are only defined up to one).  The q x q eigenproblem is solved on the host (cyclic
+// Jacobi, fp64): one small device-to-host copy and a stream synchronisation per update.
+static void jacobi_eigh(int n, std::vector<double>& a, std::vector<double>& v) {   // a (row-major, symmetric) -> eigenvalues on its diagonal
+  v.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) (i == j ? diag : off) += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    if (off <= 1e-30 * (diag > 0 ? diag : 1.0)) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; ++k) {            // columns p, q
+          const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+          a[(size_t)k * n + p] = c * akp - sn * akq;
+          a[(size_t)k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {            // rows p, q
+          const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+          a[(size_t)p * n + k] = c * apk - sn * aqk;
+          a[(size_t)q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = v[(size_t)k * n + p], vkq = v[(size_t)k * n + q];
+          v[(size_t)k * n + p] = c * vkp - sn * vkq;
+          v[(size_t)k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+template <typename real>
+__global__ __launch_bounds__(256) void k_scale_cols(int rows, int cols, real* __restrict__ X, int ldx, const real* __restrict__ sc) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)rows * cols) X[(e / cols) * ldx + e % cols] *= sc[e % cols];
+}
+
+int64_t root_update_ws_elems(int m, int r, int q) { return (int64_t)r * q * 2 + (int64_t)q * q * 2 + (int64_t)m * q + 2 * (int64_t)q; }
+
+template <typename real>
+static int root_update_impl(int m, int r, int q, real* d_L, int ldl, real* d_R, int ldr, const real* d_V, int ldv, real* d_ws, int64_t ws_elems,
+                            void* stream) {
+  if (m < 1 || r < 1 || q < 1 || !d_L || !d_R || !d_V || !d_ws || ws_elems < root_update_ws_elems(m, r, q)) return WISKI_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  real* p = d_ws;                       // [r, q]
+  real* Uq = p + (int64_t)r * q;        // [r, q]
+  real* gram = Uq + (int64_t)r * q;     // [q, q]
+  real* coef = gram + (int64_t)q * q;   // [q, q]
+  real* T = coef + (int64_t)q * q;      // [m, q]
+  real* sc = T + (int64_t)m * q;        // [2 q]
+  int rc = launch_gemm<real>(1, 0, r, q, m, (real)1, d_R, ldr, d_V, ldv, (real)0, p, q, s);              // p = R^T V        URLT:79
+  if (rc) return rc;
+  rc = launch_gemm<real>(1, 0, q, q, r, (real)1, p, q, p, q, (real)0, gram, q, s);                       // p^T p
+  if (rc) return rc;
+  std::vector<real> hg((size_t)q * q);
+  if (hipMemcpyAsync(hg.data(), gram, sizeof(real) * q * q, hipMemcpyDeviceToHost, s) != hipSuccess) return WISKI_E_LAUNCH;
+  if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;
+  std::vector<double> a((size_t)q * q), vec;
+  for (size_t i = 0; i < a.size(); ++i) a[i] = (double)hg[i];
+  for (int i = 0; i < q; ++i)
+    for (int j = i + 1; j < q; ++j) a[(size_t)i * q + j] = a[(size_t)j * q + i] = 0.5 * (a[(size_t)i * q + j] + a[(size_t)j * q + i]);
+  jacobi_eigh(q, a, vec);
+  double smax = 0;
+  for (int j = 0; j < q; ++j) smax = a[(size_t)j * q + j] > smax ? a[(size_t)j * q + j] : smax;
+  std::vector<real> hcoef((size_t)q * q, (real)0), hsc((size_t)2 * q, (real)0);
+  for (int j = 0; j < q; ++j) {
+    const double s2 = a[(size_t)j * q + j];
+    if (!(s2 > 1e-14 * (smax > 1e-300 ? smax : 1e-300))) continue;      // directions already in the null space of p: no change
+    const double is = 1.0 / sqrt(s2), sp = sqrt(s2 + 1.0);
+    for (int i = 0; i < q; ++i) hcoef[(size_t)i * q + j] = (real)(vec[(size_t)i * q + j] * is);          // W S^-1
+    hsc[j] = (real)(sp - 1.0);
+    hsc[q + j] = (real)(1.0 / sp - 1.0);
+  }
+  if (hipMemcpyAsync(coef, hcoef.data(), sizeof(real) * q * q, hipMemcpyHostToDevice, s) != hipSuccess) return WISKI_E_LAUNCH;
+  if (hipMemcpyAsync(sc, hsc.data(), sizeof(real) * 2 * q, hipMemcpyHostToDevice, s) != hipSuccess) return WISKI_E_LAUNCH;
+  rc = launch_gemm<real>(0, 0, r, q, q, (real)1, p, q, coef, q, (real)0, Uq, q, s);                      // U_q = p W S^-1 (orthonormal columns)
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)(((int64_t)m * q + 255) / 256);
+  for (int which = 0; which < 2; ++which) {
+    real* X = which == 0 ? d_L : d_R;
+    const int ldx = which == 0 ? ldl : ldr;
+    rc = launch_gemm<real>(0, 0, m, q, r, (real)1, X, ldx, Uq, q, (real)0, T, q, s);                     // X U_q
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_scale_cols<real>), dim3(blocks), dim3(256), 0, s, m, q, T, q, sc + which * q);
+    rc = launch_gemm<real>(0, 1, m, r, q, (real)1, T, q, Uq, q, (real)1, X, ldx, s);                     // X += (X U_q) diag(.) U_q^T
+    if (rc) return rc;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;     // the host staging buffers above go out of scope
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 extern "C" {
 int wiski_gemm_f32(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc, void* s) {
   if (!A || !B || !C || K < 0) return WISKI_E_BADARG;
@@ -368,4 +475,7 @@ int wiski_trsm_f32(int32_t trans, int32_t n, int32_t nrhs, const float* L, int32
 int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* L, int32_t ldl, double* B, int32_t ldb, void* s) { return trsm_impl<double>(trans, n, nrhs, L, ldl, B, ldb, (hipStream_t)s); }
 int wiski_logdiag_f32(int32_t n, const float* A, int32_t lda, double* out, void* s) { return logdiag_impl<float>(n, A, lda, out, s); }
 int wiski_logdiag_f64(int32_t n, const double* A, int32_t lda, double* out, void* s) { return logdiag_impl<double>(n, A, lda, out, s); }
+int64_t wiski_root_update_workspace_elems(int32_t m, int32_t r, int32_t q) { return root_update_ws_elems(m, r, q); }
+int wiski_root_update_f32(int32_t m, int32_t r, int32_t q, float* L, int32_t ldl, float* R, int32_t ldr, const float* V, int32_t ldv, float* ws, int64_t ws_elems, void* s) { return root_update_impl<float>(m, r, q, L, ldl, R, ldr, V, ldv, ws, ws_elems, s); }
+int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* L, int32_t ldl, double* R, int32_t ldr, const double* V, int32_t ldv, double* ws, int64_t ws_elems, void* s) { return root_update_impl<double>(m, r, q, L, ldl, R, ldr, V, ldv, ws, ws_elems, s); }
 }

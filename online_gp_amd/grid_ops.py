@@ -36,6 +36,15 @@ class GridSpec:
         delta = [(hi - lo) / (gi - 2) for (lo, hi), gi in zip(gb, g)]
         self.g0 = [lo - dl for (lo, hi), dl in zip(gb, delta)]
         self.h = [((hi + dl) - g0) / (gi - 1) for (lo, hi), dl, g0, gi in zip(gb, delta, self.g0, g)]
+        from . import settings
+
+        if settings.float32_grid.on():          # gpytorch's float32 grid, promoted
+            for q, ((lo, hi), gi) in enumerate(zip(gb, g)):
+                dl = torch.tensor(hi - lo, dtype=torch.float32) / (gi - 2)
+                pts = torch.linspace(float(torch.tensor(lo, dtype=torch.float32) - dl), float(torch.tensor(hi, dtype=torch.float32) + dl), gi,
+                                     dtype=torch.float32)
+                self.g0[q] = float(pts[0])
+                self.h[q] = float(pts[1] - pts[0])
         self.m = int(math.prod(g))
         self.T = 4 ** d
         self.R = 7 ** d
@@ -436,6 +445,23 @@ def trsm_(L, B, trans=False):
                                         ctypes.c_int32(L.shape[1]), _hip.dptr(B), ctypes.c_int32(B.shape[1]), _hip.stream_ptr(L.device))
     _hip.check(rc, "wiski_trsm")
     return B
+
+
+def root_update_(L, R, V):
+    """In-place rank-q update of a root / inverse-root pair (a6, URLT:69-119; wiski_root_update): on entry L L^T = A and
+    R^T L = I, on return L L^T = A + V V^T and R^T L = I.  L, R [m, r], V [m, q], all contiguous."""
+    assert L.dim() == 2 and R.shape == L.shape and V.dim() == 2 and V.shape[0] == L.shape[0]
+    assert L.is_contiguous() and R.is_contiguous()
+    V = V.contiguous()
+    m, r = L.shape
+    q = V.shape[1]
+    n = int(_hip.lib().wiski_root_update_workspace_elems(ctypes.c_int32(m), ctypes.c_int32(r), ctypes.c_int32(q)))
+    ws = torch.empty(n, dtype=L.dtype, device=L.device)
+    rc = _hip.fn("wiski_root_update", L.dtype)(ctypes.c_int32(m), ctypes.c_int32(r), ctypes.c_int32(q), _hip.dptr(L), ctypes.c_int32(r), _hip.dptr(R),
+                                               ctypes.c_int32(r), _hip.dptr(V), ctypes.c_int32(q), _hip.dptr(ws), ctypes.c_int64(n),
+                                               _hip.stream_ptr(L.device))
+    _hip.check(rc, "wiski_root_update")
+    return L, R
 
 
 def chol_logdet(L):

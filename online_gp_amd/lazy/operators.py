@@ -8,7 +8,7 @@ them per output.
 """
 import torch
 
-from .. import grid_ops
+from .. import grid_ops, settings
 from ..distributions import LazyCovariance
 
 
@@ -41,6 +41,15 @@ class _Operator(LazyCovariance):
         return self.evaluate().diagonal()
 
 
+class _RootHolder:
+    """``.root`` as gpytorch's RootLazyTensor exposes it (URLT:74-76)."""
+
+    def __init__(self, root):
+        from ..distributions import DenseLazyTensor
+
+        self.root = DenseLazyTensor(root)
+
+
 class StencilWtW(_Operator):
     """W^T D^-1 W in block-stencil form.  Native storage is the symmetric half: the
     (7^d + 1)/2 relative offsets >= the centre (A is symmetric: every stored entry
@@ -52,12 +61,45 @@ class StencilWtW(_Operator):
     tensor held by the reference's UpdatedRootLazyTensor
     (updated_root_lazy_tensor.py:42,58)."""
 
-    def __init__(self, grid, stencil):
+    def __init__(self, grid, stencil, root=None, inv_root=None):
         self.grid = grid
         self.stencil = stencil
         self.shape = torch.Size([grid.m, grid.m])
         self.dtype = stencil.dtype
         self.device = stencil.device
+        # the reference's own representation of this matrix (UpdatedRootLazyTensor: a root L and an inverse root
+        # R = L^-T, URLT:36-42), kept on small grids (m <= settings.max_cholesky_size) from the first time it is
+        # asked for and then carried through streaming updates by rank-q root updates (URLT:62-119)
+        self.root = root
+        self.inv_root = inv_root
+
+    # -- root API of UpdatedRootLazyTensor (URLT:121-133): Cholesky branch of gpytorch's root_decomposition
+    def _ensure_roots(self):
+        if self.root is not None and self.inv_root is not None:
+            return
+        if self.grid.m > settings.max_cholesky_size.value():
+            raise NotImplementedError("a dense root of W^T D^-1 W is only kept for grids of <= settings.max_cholesky_size nodes")
+        L = grid_ops.psd_safe_cholesky(self.evaluate().contiguous(), jitter=settings.cholesky_jitter.value())
+        eye = torch.eye(self.grid.m, dtype=self.dtype, device=self.device)
+        self.root = L
+        self.inv_root = grid_ops.trsm_(L, eye, trans=False).t().contiguous()      # R = L^-T
+
+    def root_decomposition(self, **kwargs):
+        self._ensure_roots()
+        return _RootHolder(self.root)
+
+    def root_inv_decomposition(self, **kwargs):
+        self._ensure_roots()
+        return _RootHolder(self.inv_root)
+
+    def update_roots_(self, V):
+        """A += V V^T has just been scattered into the stencil: carry (L, R) along (no-op while no root exists)."""
+        if self.root is None or self.inv_root is None:
+            return
+        if V.shape[1] > self.grid.m // 2:          # a batch this large: cheaper to re-factorise when next asked
+            self.root = self.inv_root = None
+            return
+        grid_ops.root_update_(self.root, self.inv_root, V)
 
     @classmethod
     def zeros(cls, grid, dtype, device):
@@ -76,10 +118,12 @@ class StencilWtW(_Operator):
         return full
 
     def clone(self):
-        return StencilWtW(self.grid, self.stencil.clone())
+        cp = lambda t: None if t is None else t.clone()
+        return StencilWtW(self.grid, self.stencil.clone(), cp(self.root), cp(self.inv_root))
 
     def to(self, device):
-        return StencilWtW(self.grid, self.stencil.to(device))
+        mv = lambda t: None if t is None else t.to(device)
+        return StencilWtW(self.grid, self.stencil.to(device), mv(self.root), mv(self.inv_root))
 
     def _matmul(self, rhs):  # rhs [m, k]
         V = rhs.t().contiguous()

@@ -5,9 +5,9 @@ online_gp/lazy/updated_root_lazy_tensor.py:9-159 (same constructor, functional
 ``evaluate``, ``_matmul``/``@``, ``expand``) on the dense MFMA kernels.
 
 Root update (URLT:69-119).  The reference forms p = R^T V, a full SVD p = U S V^T with
-an r x r U, and L <- L U S~, R <- R U S~^-1 (O(m r^2)).  Here the same Gram matrices
-are produced in O(m r q) with the thin factor U_q = p V_t S^-1 obtained from the q x q
-eigen-problem p^T p = V_t S^2 V_t^T (host, tiny):
+an r x r U, and L <- L U S~, R <- R U S~^-1 (O(m r^2)).  ``wiski_root_update`` (csrc/dense.hip)
+produces the same Gram matrices in O(m r q) with the thin factor U_q = p V_t S^-1 obtained from the
+q x q eigen-problem p^T p = V_t S^2 V_t^T (host Jacobi, tiny):
     L <- L + (L U_q) diag(sqrt(S^2+1) - 1) U_q^T,   R <- R + (R U_q) diag(1/sqrt(S^2+1) - 1) U_q^T
 so that L L^T = A + V V^T and R = L^-T exactly as in the reference (roots are unique
 only up to a right orthogonal factor; L differs from the reference's L U S~ by one).
@@ -76,23 +76,11 @@ class UpdatedRootLazyTensor(_Operator):
         return UpdatedRootLazyTensor(tensor, initial_is_root=False, root=root, inv_root=inv_root)
 
     def collect_vector(self, V):
+        """(new root, new inverse root) for A + V V^T (URLT:69-119), on the C ABI's ``wiski_root_update``."""
         self._ensure_roots()
-        L, R = self.root, self.inv_root
-        p = grid_ops.gemm(R, V, ta=True)                                   # p = R^T V  [r, q]   URLT:79
-        gram = grid_ops.gemm(p, p, ta=True).double().cpu()                 # q x q
-        s2, Vt = torch.linalg.eigh(gram)
-        keep = s2 > 1e-14 * float(s2.max().clamp_min(1e-300))
-        s2, Vt = s2[keep], Vt[:, keep]
-        if s2.numel() == 0:
-            return L.clone(), R.clone()
-        coef = (Vt / s2.sqrt()).to(self.device, self.dtype).contiguous()  # V_t S^-1
-        Uq = grid_ops.gemm(p, coef)                                        # [r, q'] orthonormal columns
-        sp = (s2 + 1.0).sqrt()
-        LU = grid_ops.gemm(L, Uq) * (sp - 1.0).to(self.device, self.dtype)            # (L U_q)(S~ - I)
-        RU = grid_ops.gemm(R, Uq) * (1.0 / sp - 1.0).to(self.device, self.dtype)      # (R U_q)(S~^-1 - I)
-        new_L = grid_ops.gemm(LU.contiguous(), Uq, tb=True, alpha=1.0, beta=1.0, C=L.clone())
-        new_R = grid_ops.gemm(RU.contiguous(), Uq, tb=True, alpha=1.0, beta=1.0, C=R.clone())
-        return new_L, new_R
+        L, R = self.root.clone(), self.inv_root.clone()
+        grid_ops.root_update_(L, R, V.contiguous())
+        return L, R
 
     def expand(self, *sizes):
         return self._expand_batch(torch.Size(sizes[0] if len(sizes) == 1 and not isinstance(sizes[0], int) else sizes)[:-2])

@@ -247,6 +247,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 carry = ms["R_ok"] = False
             grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], dst[o], half, cnt_o, stats[o], self._err,
                                        u=ms["U"][o] if carry else None, res=ms["R"][o] if carry else None)
+            if half_delta is None and getattr(ops[o], "root", None) is not None and n > 0:
+                # the reference's root pair, once somebody asked for it: L L^T follows A by a rank-n root update (URLT:62-119)
+                Wd = grid_ops.wt_columns(self._grid, X, self._err)                 # [n, m]
+                ops[o].update_roots_((Wd * wa.sqrt()[:, None]).t().contiguous())   # V = W^T diag(wa)^(1/2), BFN:163-168
             if cache is self._kernel_cache or init:
                 if unit:
                     self._wsum_host[o] += float(n)
@@ -482,8 +486,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             Ls, KLs, Qs, projs = [], [], [], []
             b = self._kernel_cache["interpolation_cache"]
             for o, (tcol, s2, _) in enumerate(self._hyper()):
-                A = _wtw_ops(self._kernel_cache["WtW"])[o].evaluate().contiguous()
-                L = grid_ops.psd_safe_cholesky(A, jitter=settings.cholesky_jitter.value())
+                # L of the reference's UpdatedRootLazyTensor: chol(A + jitter) when first asked for, afterwards carried
+                # through every streaming update by the rank-q root update (so it stops being triangular: BFN:343-366 only
+                # ever use L L^T = A, which holds)
+                L = _wtw_ops(self._kernel_cache["WtW"])[o].root_decomposition().root.evaluate()
                 KL = grid_ops.kron_toeplitz_mm(self._grid, tcol, L.t().contiguous(), 1.0 / s2).t().contiguous()     # Kt L
                 Q = grid_ops.gemm(L, KL, ta=True)
                 Q.diagonal().add_(1.0)                                                                                # add_jitter(1.0), :355

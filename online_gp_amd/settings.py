@@ -81,6 +81,15 @@ class skip_logdet_forward(_feature_flag):
     _state = False
 
 
+class float32_grid(_feature_flag):
+    """gpytorch builds the inducing grid in float32 and promotes it; the spec'd geometry here is float64.
+    On = reproduce the quirk: first grid point and spacing come from a float32 ``linspace(lo - delta, hi + delta, g)``.
+    The difference is ~1e-7 relative in g0 / h; tests/test_model_gpu.py shows the posterior moves by far less than the
+    parity tolerance either way.  Read when a GridSpec / kernel is constructed."""
+
+    _state = False
+
+
 class deferred_bounds_check(_feature_flag):
     """Query points outside the inducing grid: off (default) = the posterior call itself raises, as gpytorch's grid
     check does (one flag read per call: a publish kernel + a host spin behind the gather).  On = the device flag is

@@ -161,3 +161,88 @@ def test_rank_q_posterior_updates_match_a_fresh_factor(dtype, tol):
             for o, p in enumerate(m_._memo["prediction_cache"]["pred_cov"].ops):
                 fresh = ref._memo["prediction_cache"]["pred_cov"].ops[o]
                 assert isinstance(p, DenseInducingPosterior) and abs(float(p.logdet) - float(fresh.logdet)) < max(tol, 1e-6) * abs(float(fresh.logdet)) * 10
+
+
+def test_root_space_objects_match_the_dense_reference_b1():
+    """the reference-named root-space objects against the op-for-op dense restatement B1
+    (oracle/dense_reference.py), value by value.
+      * fresh model, A of full rank (no jitter, the Cholesky root is unique): Q = I + L^T Kt L, Kt L and L^T Kt b entry-wise;
+      * after streaming updates the model's (L, R) are carried by the rank-q root update (wiski_root_update, URLT:69-119)
+        like B1's SVD update; roots then differ by a right orthogonal factor, so: L L^T = A, R^T L = I, spec(Q), the
+        quadratic form proj^T Q^-1 proj of the MLL (BWM:27), and the posterior mean / covariance the reference algebra
+        gives from them (BFN:375-376, 399-403) against B1's."""
+    from oracle import dense_reference
+    from online_gp_amd import grid_ops
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(11)
+    d, g = 2, 6
+    gb = [[-1.1, 1.1]] * d
+    n0 = 400
+    X = rng.uniform(-1.1, 1.1, (n0 + 50, d)); y = np.sin(2 * X[:, 0]) * X[:, 1] + 0.1 * rng.standard_normal(n0 + 50)
+    nz = rng.uniform(0.5, 1.5, n0 + 50)
+    Xt, yt, nt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None], torch.as_tensor(nz, device=DEV)[:, None]
+    m = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], nt[:n0], grid_bounds=torch.tensor(gb, dtype=torch.float64), grid_size=g, learn_additional_noise=True)
+    m.eval()
+    s2 = float(m.likelihood.second_noise.detach())
+    ell = m.covar_module.base_kernel.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1)    # fp32 parameters: hand B1 the same values
+    osc = float(m.covar_module.base_kernel.outputscale.detach().double())
+    B1 = dense_reference.DenseWISKI(gb, g, lengthscale=ell, outputscale=osc, sigma2=s2)
+    B1.set_train_data(X[:n0], y[:n0], nz[:n0])
+    Kt, L1, KL1, Q1, Kb1, proj1, _ = B1._posterior_pieces()
+    assert np.linalg.matrix_rank(B1.WtW) == g ** d          # full rank: both sides take the plain Cholesky root
+    Q, KL, proj = (t.cpu().numpy() for t in (m.current_qmatrix, m.current_inducing_compression_matrix, m.root_space_projection))
+    assert np.abs(Q - Q1).max() < 1e-8 * np.abs(Q1).max()
+    assert np.abs(KL - KL1).max() < 1e-8 * np.abs(KL1).max()
+    assert np.abs(proj - proj1).max() < 1e-8 * np.abs(proj1).max()
+    wtw = m._kernel_cache["WtW"]
+    L0 = wtw.root_decomposition().root.evaluate().clone()
+    assert torch.allclose(L0, torch.tril(L0))
+    # streaming: q = 1, 4, 12 -- the root pair follows by rank-q updates on both sides (a batch of more than m / 2 points
+    # drops the pair and the next request re-factorises: q = 25 below)
+    lo = n0
+    for q in (1, 4, 12, 25):
+        sl = slice(lo, lo + q); lo += q
+        m.condition_on_observations(Xt[sl], yt[sl], nt[sl], inplace=True)
+        B1.condition_on_observations(X[sl], y[sl], nz[sl])
+        L = wtw.root_decomposition().root.evaluate()
+        R = wtw.root_inv_decomposition().root.evaluate()
+        assert torch.allclose(L, torch.tril(L)) == (q == 25)    # updated, not re-factorised
+        A = wtw.evaluate()
+        assert (L @ L.t() - A).abs().max() < 1e-10 * A.abs().max()
+        assert (torch.as_tensor(B1.WtW, device=DEV) - A).abs().max() < 1e-10 * A.abs().max()
+        assert (R.t() @ L - torch.eye(g ** d, device=DEV, dtype=L.dtype)).abs().max() < 1e-8
+        Kt, L1, KL1, Q1, Kb1, proj1, cq = B1._posterior_pieces()
+        Q, KL, proj = (t.cpu().numpy() for t in (m.current_qmatrix, m.current_inducing_compression_matrix, m.root_space_projection))
+        ev, ev1 = np.linalg.eigvalsh(0.5 * (Q + Q.T)), np.linalg.eigvalsh(0.5 * (Q1 + Q1.T))
+        assert np.abs(ev - ev1).max() < 1e-8 * ev1.max()
+        qf, qf1 = float(proj.T @ np.linalg.solve(Q, proj)), float(proj1.T @ np.linalg.solve(Q1, proj1))
+        assert abs(qf - qf1) < 1e-9 * abs(qf1)
+        Kb = m.Kuu_response[0].cpu().numpy().reshape(-1, 1)
+        mean_ref_alg = Kb - KL @ np.linalg.solve(Q, proj)                       # BFN:375-376 from the model's own pieces
+        assert np.abs(mean_ref_alg - B1.pred_mean_cache()).max() < 1e-8 * np.abs(B1.pred_mean_cache()).max()
+        cov_ref_alg = Kt - KL @ np.linalg.solve(Q, KL.T)                         # BFN:399-403
+        assert np.abs(cov_ref_alg - B1.pred_cov_cache()).max() < 1e-8 * np.abs(B1.pred_cov_cache()).max()
+        mu = m.prediction_cache["pred_mean"][0].cpu().numpy()
+        assert np.abs(mu - B1.pred_mean_cache()).max() < 1e-7 * np.abs(mu).max()
+    # the standalone operator: UpdatedRootLazyTensor.update against B1's SVD update on the same V
+    from online_gp_amd.lazy import UpdatedRootLazyTensor
+
+    A0 = torch.as_tensor(B1.WtW, device=DEV)
+    U = UpdatedRootLazyTensor(A0, initial_is_root=False)
+    V = torch.as_tensor(B1.wmat(X[lo:lo + 5]) / np.sqrt(nz[lo:lo + 5])[None, :], device=DEV)
+    U2 = U.update(V)
+    B1.condition_on_observations(X[lo:lo + 5], y[lo:lo + 5], nz[lo:lo + 5])
+    L2, R2 = U2.root_decomposition().root.evaluate(), U2.root_inv_decomposition().root.evaluate()
+    assert (U2.evaluate() - torch.as_tensor(B1.WtW, device=DEV)).abs().max() < 1e-10 * A0.abs().max()
+    assert (L2 @ L2.t() - U2.evaluate()).abs().max() < 1e-9 * A0.abs().max()
+    assert (R2.t() @ L2 - torch.eye(g ** d, device=DEV, dtype=L2.dtype)).abs().max() < 1e-8
+    LB, RB = torch.as_tensor(B1.root, device=DEV), torch.as_tensor(B1.inv_root, device=DEV)
+    assert (LB @ LB.t() - L2 @ L2.t()).abs().max() < 1e-8 * A0.abs().max()     # same Gram matrix as B1's L U S~
+    assert (RB @ RB.t() - R2 @ R2.t()).abs().max() < 1e-6 * (RB @ RB.t()).abs().max()
+    # fp32 root update, C ABI directly
+    Lf, Rf, Vf = L0.float().contiguous(), torch.linalg.inv(L0).t().float().contiguous(), V.float().contiguous()
+    Af = Lf @ Lf.t()
+    grid_ops.root_update_(Lf, Rf, Vf)
+    assert (Lf @ Lf.t() - (Af + Vf @ Vf.t())).abs().max() < 1e-4 * Af.abs().max()
+    assert (Rf.t() @ Lf - torch.eye(g ** d, device=DEV)).abs().max() < 1e-2

@@ -131,6 +131,31 @@ def test_out_of_bounds_raises_like_gpytorch():
         model(x[:2]).mean
 
 
+def test_float32_grid_quirk_does_not_move_the_posterior():
+    """gpytorch creates the grid in float32 and promotes it; the spec'd geometry is float64 (VERDICT r1
+    'Parity').  With the quirk switched on the grid moves by ~1e-7 relative and the posterior by far less than the
+    1e-4 parity tolerance, in the dense and in the PCG regime."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(9)
+    for d, g in ((2, 10), (3, 14)):
+        X = rng.uniform(-1, 1, (300, d)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(300)
+        Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+        res = []
+        for quirk in (False, True):
+            with settings.float32_grid(quirk):
+                m = FixedNoiseOnlineSKIGP(Xt[:200], yt[:200], None, grid_bounds=torch.tensor([[-1.1, 1.1]] * d, dtype=torch.float64), grid_size=g,
+                                          learn_additional_noise=True).eval()
+            m.condition_on_observations(Xt[200:], yt[200:], inplace=True)
+            mvn = m(Xt[:40])
+            res.append((mvn.mean.clone(), mvn.variance.clone(), m._grid.g0[0], m._grid.h[0]))
+        (m0, v0, g00, h0), (m1, v1, g01, h1) = res
+        assert g00 != g01 and abs(g00 - g01) < 5e-7 and abs(h0 - h1) < 5e-7 * h0 * 10
+        assert float((m0 - m1).abs().max()) < 1e-5 * float(m0.abs().max())
+        assert float((v0 - v1).abs().max()) < 1e-5 * float(v0.abs().max())
+
+
 @pytest.mark.parametrize("g", [8, 24])     # 8^2: dense factor; 24^3 > max_cholesky_size: PCG path (flag rides on the solver poll)
 def test_out_of_grid_points_leave_consistent_statistics(g):
     """Advisor finding r1: (a) a query outside the grid raises inside the posterior call, not at the next update;
