@@ -588,6 +588,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """a7, :258-285.  inplace: the statistics buffers are updated where they
         live (O(4^{2d}) atomics per point); otherwise they are cloned first and a
         sibling model sharing covar_module / likelihood is returned."""
+        if X.dim() > 2 or Y.dim() > 2:
+            # batch-expanded conditioning (what OSB.fantasize asks for, OSB:51-61): a batch of conditioned copies
+            if inplace:
+                raise RuntimeError("batched conditioning returns a batch of models and cannot be done in place")
+            from .fantasy import BatchedFantasyModel
+
+            return BatchedFantasyModel(self, X, Y, noise)
         if Y.dim() == 1:
             Y = Y[:, None]
         if noise is not None:
@@ -672,14 +679,18 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                                           "cg_iters": [0] * out, "ver": ver}
 
     def get_fantasy_model(self, inputs, targets, noise_term=None, **kwargs):
-        """Single-batch fantasy: condition a copy on (inputs, targets).  The
-        reference's batched version (:287-332) is broken at HEAD."""
+        """BFN:287-332.  inputs [*b, q, d], targets [*b, q] or [num_fantasies, *b, q]: a batch of conditioned copies
+        (``models/fantasy.py``: specified from the maths, the reference's cache expansion is broken at HEAD, SURVEY 0);
+        unbatched inputs [q, d] with targets [q] / [q, 1]: a plain functional ``condition_on_observations``."""
+        plain = inputs.dim() == 2 and (targets.dim() == 1 or (targets.dim() == 2 and tuple(targets.shape) == (inputs.shape[0], self.num_outputs)))
+        if not plain:
+            from .fantasy import BatchedFantasyModel
+
+            return BatchedFantasyModel(self, inputs, targets, noise_term)
         if targets.dim() == 1:
             targets = targets[:, None]
         if noise_term is None:
             noise_term = torch.ones_like(targets)
-        if inputs.dim() > 2 or targets.dim() > 2:
-            raise RuntimeError("Unsupported batch shapes: batched fantasies are not supported (the reference path is broken, SURVEY.md section 0)")
         return self.condition_on_observations(inputs, targets, noise_term, inplace=False)
 
     def set_train_data(self, train_inputs, train_targets, train_noise_term):

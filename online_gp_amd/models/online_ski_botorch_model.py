@@ -56,18 +56,25 @@ class OnlineSKIBotorchModel(FixedNoiseOnlineSKIGP):
         return super().get_fantasy_model(inputs, targets, noise)
 
     def fantasize(self, X, sampler, observation_noise=True, **kwargs):
+        """OSB:51-61: sample fantasy targets at X [*b, q, d] from the current posterior (``sampler(posterior)`` ->
+        [num_fantasies, *b, q, 1]) and condition on them; the noise of the fantasy points is the mean of the likelihood's
+        noise, as upstream.  Returns a batch of conditioned models (batch shape [num_fantasies, *b])."""
+        kwargs.pop("propagate_grads", None)
         post_X = self.posterior(X, observation_noise=observation_noise, **kwargs)
         Y_fantasized = sampler(post_X)
-        if Y_fantasized.dim() > 2:
-            raise RuntimeError("Unsupported batch shapes: batched fantasies are not supported "
-                               "(the reference path is broken at HEAD, SURVEY.md section 0)")
-        noise = self.likelihood.noise.mean().expand(Y_fantasized.shape)
+        noise = self.likelihood.noise.mean().detach().expand(Y_fantasized.shape[1:])
         return self.condition_on_observations(X=X, Y=Y_fantasized, noise=noise)
 
     def posterior(self, X, observation_noise=False, **kwargs):
         self.eval()
         X = X.to(self._dtype)
         mvn = self(X)
+        if observation_noise:          # sigma2 on the diagonal (the fixed per-point part is unknown at new inputs)
+            from ..distributions import MultivariateNormal
+
+            cov = mvn.covariance_matrix
+            eye = torch.eye(cov.shape[-1], dtype=cov.dtype, device=cov.device)
+            mvn = MultivariateNormal(mvn.mean, cov + float(self._sigma2(0)) * eye)
         if _GPyTorchPosterior is not None:  # pragma: no cover
             try:
                 import gpytorch
