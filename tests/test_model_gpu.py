@@ -350,6 +350,20 @@ def test_dirichlet_classifier_wrapper_banana_like():
     assert correct / 200 >= 0.75
     assert clf.gp.num_data == 400 and clf.gp.num_outputs == 2
     assert clf.predict(Xt[400:]).eq(yt[400:]).float().mean().item() >= 0.85
+    # the two regression outputs behind the argmax, against the data-space oracle on the Dirichlet-transformed problem
+    # (gp_dirichlet_classification.py:15-21): per-output targets log(alpha) - sigma2_i / 2 with fixed noise sigma2_i, no learned noise
+    from online_gp_amd.models.online_ski_classifier import dirichlet_transform
+
+    ty, _, s2i = dirichlet_transform(yt[:400], 1e-2)
+    k = clf.gp.covar_module.base_kernel
+    means = clf.gp(Xt[400:420]).mean.double().cpu().numpy()                       # [2, 20]
+    for o in range(2):
+        ell = k.base_kernel.lengthscale.detach().double()[o].cpu().numpy().reshape(-1) if k.base_kernel.lengthscale.dim() > 2 else \
+            k.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1)
+        osc = float(k.outputscale.detach().double().reshape(-1)[o if k.outputscale.numel() > 1 else 0])
+        O = dataspace.DataSpaceGP([[-1.0, 1.0]] * 2, 16, "rbf", ell, osc, 1.0).fit(X[:400], ty[:, o].double().cpu().numpy(), s2i[:, o].double().cpu().numpy())
+        mo, _ = O.predict(X[400:420])
+        assert np.abs(means[o] - mo).max() <= 1e-2 * np.abs(mo).max()
 
 
 def test_c2_full_stream_30pow4_fp64_parity():
