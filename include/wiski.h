@@ -225,6 +225,21 @@ int64_t wiski_root_update_workspace_elems(int32_t m, int32_t r, int32_t q);
 int wiski_root_update_f32(int32_t m, int32_t r, int32_t q, float* d_L, int32_t ldl, float* d_R, int32_t ldr, const float* d_V, int32_t ldv, float* d_ws, int64_t ws_elems, void* stream);
 int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* d_L, int32_t ldl, double* d_R, int32_t ldr, const double* d_V, int32_t ldv, double* d_ws, int64_t ws_elems, void* stream);
 
+/* (e) -- the one collective of the path: in-place RCCL all-reduce(SUM), grouped into one launch, of the
+ * statistics that are sums over data points: the half-stencil delta of W^T D^-1 W (n_half reals), W^T D^-1 y (n_b), the
+ * row-sum vector W^T D^-1 1 (n_cnt) and fp64 scalars ([y^T D^-1 y, log|D|] per output, point count, weight sums: n_scal
+ * doubles).  Any pointer may be NULL / count 0.  `comm` is an ncclComm_t owned by the caller (one rank per GPU); librccl
+ * is resolved with dlopen at the first call (WISKI_RCCL_LIB overrides its name), so the library has no link-time
+ * dependency on it.  wiski_comm_* are thin bootstrap helpers for hosts without their own RCCL setup: rank 0 creates
+ * wiski_comm_unique_id_bytes() bytes with wiski_comm_unique_id, ships them to the other ranks by any means, and every
+ * rank calls wiski_comm_init_rank.  The reference has no distributed code. */
+int wiski_comm_unique_id_bytes(void);
+int wiski_comm_unique_id(void* id_out);
+int wiski_comm_init_rank(const void* id_bytes, int32_t nranks, int32_t rank, void** comm_out);
+int wiski_comm_destroy(void* comm);
+int wiski_allreduce_stats_f32(void* comm, float* d_half, int64_t n_half, float* d_b, int64_t n_b, float* d_cnt, int64_t n_cnt, double* d_scal, int64_t n_scal, void* stream);
+int wiski_allreduce_stats_f64(void* comm, double* d_half, int64_t n_half, double* d_b, int64_t n_b, double* d_cnt, int64_t n_cnt, double* d_scal, int64_t n_scal, void* stream);
+
 /* Value of a device int32 flag after everything already queued on `stream`, without a stream
  * synchronisation (a one-thread publish kernel + a host spin on pinned memory, a few microseconds once the
  * queue has drained).  Used for the out-of-grid flag after a query gather, where the reference raises

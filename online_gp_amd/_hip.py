@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libwiski_hip.so")
-_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip"]
+_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip"]
 _HEADERS = ["wiski_common.h", "spmv_sym_dma.h", os.path.join("..", "..", "include", "wiski.h")]
 MAX_DIM = 4
 
@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
         if all(os.path.getmtime(d) <= os.path.getmtime(_SO) for d in deps if os.path.exists(d)):
             return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _SO] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _SO] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -30,6 +30,56 @@ def allreduce_sum_(tensors, group=None):
     return tensors
 
 
+class RcclCommunicator:
+    """An ncclComm_t created through the C ABI (``wiski_comm_*``, include/wiski.h) for the ``wiski_allreduce_stats``
+    collective: rank 0 draws the unique id, torch.distributed (any backend) ships its bytes to the other ranks, every rank
+    joins.  One rank per GPU (RCCL refuses two ranks on one device).  Without a process group: a 1-rank communicator."""
+
+    def __init__(self, group=None):
+        import ctypes
+
+        from . import _hip
+
+        lib = _hip.lib()
+        nb = int(lib.wiski_comm_unique_id_bytes())
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        buf = (ctypes.c_ubyte * nb)()
+        if rank == 0:
+            _hip.check(lib.wiski_comm_unique_id(buf), "wiski_comm_unique_id")
+        if world > 1:
+            t = torch.tensor(list(buf), dtype=torch.uint8)
+            backend = dist.get_backend(group)
+            if backend == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            buf = (ctypes.c_ubyte * nb)(*t.cpu().tolist())
+        comm = ctypes.c_void_p()
+        _hip.check(lib.wiski_comm_init_rank(buf, ctypes.c_int32(world), ctypes.c_int32(rank), ctypes.byref(comm)), "wiski_comm_init_rank")
+        self.handle, self.world, self.rank, self._lib = comm, world, rank, lib
+
+    def allreduce_stats_(self, halves, b, cnt, scal):
+        """In-place SUM of (list of half-stencil deltas, W^T D^-1 y, row sums, fp64 scalars) -- one grouped launch per output."""
+        import ctypes
+
+        from . import _hip
+
+        dev = b.device
+        for o, half in enumerate(halves):
+            first = o == 0
+            fn = _hip.fn("wiski_allreduce_stats", half.dtype)
+            rc = fn(self.handle, _hip.dptr(half), ctypes.c_int64(half.numel()),
+                    _hip.dptr(b) if first else None, ctypes.c_int64(b.numel() if first else 0),
+                    _hip.dptr(cnt) if (first and cnt is not None) else None, ctypes.c_int64(cnt.numel() if (first and cnt is not None) else 0),
+                    _hip.dptr(scal) if first else None, ctypes.c_int64(scal.numel() if first else 0), _hip.stream_ptr(dev))
+            _hip.check(rc, "wiski_allreduce_stats")
+
+    def close(self):
+        if self.handle:
+            self._lib.wiski_comm_destroy(self.handle)
+            self.handle = None
+
+
 class ShardedStatsUpdater:
     """Streams rank-local shards into a model whose statistics stay replicated.
 
@@ -37,7 +87,7 @@ class ShardedStatsUpdater:
     noise_all, inplace=True)`` on every rank, where *_all is the concatenation of
     all ranks' shards."""
 
-    def __init__(self, model, group=None, exchange="auto", equal_shards=False):
+    def __init__(self, model, group=None, exchange="auto", equal_shards=False, comm=None):
         """exchange: "stats" (all-reduce the statistics deltas), "points" (all-gather the shards, scatter them all
         on every rank) or "auto" (the cheaper of the two by a simple cost model).  The point exchange needs the same
         shard length on every rank; ``equal_shards=True`` promises that (no size check), otherwise the sizes are
@@ -48,6 +98,7 @@ class ShardedStatsUpdater:
         self.group = group
         self.exchange = exchange
         self.equal_shards = equal_shards
+        self.comm = comm            # RcclCommunicator: the statistics exchange goes through the C ABI's wiski_allreduce_stats
         self._delta = None
         self.last_exchange = None
 
@@ -111,13 +162,15 @@ class ShardedStatsUpdater:
         if Y.dim() == 1:
             Y = Y[:, None]
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world == 1:
+        if self.comm is not None:
+            world = self.comm.world
+        if world == 1 and self.comm is None:
             m.condition_on_observations(X, Y, noise, inplace=True)
             return
         if noise is not None:
             noise = m._canon_noise(noise, Y)
         q = X.reshape(-1, m._grid.d).shape[0]
-        if self._use_points(q, world, m._kernel_cache["_stats"].device):
+        if self.comm is None and self._use_points(q, world, m._kernel_cache["_stats"].device):
             self.last_exchange = "points"
             self._update_points(X, Y, noise, world)
             return
@@ -134,8 +187,15 @@ class ShardedStatsUpdater:
         else:
             wsum = (1.0 / noise.to(dev, torch.float64).clamp_min(1e-7)).sum(0)        # [out]
         count = torch.cat([torch.tensor([nloc], dtype=torch.float64, device=dev), wsum])
-        small = [delta["interpolation_cache"], delta["_stats"], count] + ([delta["_cnt"]] if "_cnt" in delta else [])
-        allreduce_sum_(small + list(halves), self.group)
+        if self.comm is not None:
+            scal = torch.cat([delta["_stats"].reshape(-1), count])
+            self.comm.allreduce_stats_(list(halves), delta["interpolation_cache"], delta.get("_cnt"), scal)
+            ns = delta["_stats"].numel()
+            delta["_stats"].copy_(scal[:ns].reshape(delta["_stats"].shape))
+            count = scal[ns:]
+        else:
+            small = [delta["interpolation_cache"], delta["_stats"], count] + ([delta["_cnt"]] if "_cnt" in delta else [])
+            allreduce_sum_(small + list(halves), self.group)
         c = m._kernel_cache
         c["interpolation_cache"].add_(delta["interpolation_cache"])
         c["_stats"].add_(delta["_stats"])

@@ -61,3 +61,89 @@ def test_sharded_updater_on_gpu_world2(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f"ok_{r}").read() == "1"
+
+
+def test_cabi_rccl_allreduce_stats_single_rank():
+    """`wiski_allreduce_stats` + `wiski_comm_*` (the C-ABI collective of SURVEY 8b): a 1-rank RCCL communicator (RCCL refuses two
+    ranks on one device, and the test boxes have one) drives the statistics-delta exchange of ShardedStatsUpdater; the result
+    must equal plain in-place conditioning.  Multi-rank correctness of the same code path is covered with gloo above."""
+    sys.path.insert(0, ROOT)
+    from online_gp_amd.distributed import RcclCommunicator, ShardedStatsUpdater
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    X = torch.as_tensor(rng.uniform(-1, 1, (40 + 2 * 512, 3)), device=dev, dtype=torch.float32)
+    y = torch.sin(2 * X[:, :1]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=torch.float32)
+    nz = torch.as_tensor(rng.uniform(0.5, 1.5, (X.shape[0], 1)), device=dev, dtype=torch.float32)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    ref = FixedNoiseOnlineSKIGP(X[:40], y[:40], nz[:40], grid_bounds=gb, grid_size=12, learn_additional_noise=True).eval()
+    model = FixedNoiseOnlineSKIGP(X[:40], y[:40], nz[:40], grid_bounds=gb, grid_size=12, learn_additional_noise=True).eval()
+    comm = RcclCommunicator()
+    assert comm.world == 1 and comm.handle
+    upd = ShardedStatsUpdater(model, exchange="stats", comm=comm)
+    for s in range(2):
+        sl = slice(40 + s * 512, 40 + (s + 1) * 512)
+        ref.condition_on_observations(X[sl], y[sl], nz[sl], inplace=True)
+        upd.update(X[sl], y[sl], nz[sl])
+        assert upd.last_exchange == "stats"
+    a, b = model._kernel_cache, ref._kernel_cache
+    sc = float(b["WtW"].stencil.abs().max())
+    assert (a["WtW"].stencil - b["WtW"].stencil).abs().max().item() < 1e-5 * sc
+    assert torch.allclose(a["interpolation_cache"], b["interpolation_cache"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(a["_stats"], b["_stats"], rtol=1e-7) and torch.allclose(a["_cnt"], b["_cnt"], rtol=1e-4, atol=1e-5)
+    assert model.num_data == ref.num_data and abs(model._wsum[0] - ref._wsum[0]) < 1e-3
+    assert torch.allclose(model(X[:16]).mean, ref(X[:16]).mean, rtol=1e-3, atol=1e-4)
+    comm.close()
+
+
+def _worker_c5(rank, world, port, tmpdir):
+    """BASELINE config 5's data-parallel leg on its geometry: d = 2, 30^2 grid, Matern-1/2, heteroscedastic noise, batch 6 per
+    step, points dealt round-robin to the ranks, exchange = all-reduce of the statistics (the north-star form); every rank's
+    replica must equal the data-space oracle on the whole stream."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import dataspace
+    from online_gp_amd.distributed import ShardedStatsUpdater
+    from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, ScaleKernel
+    from online_gp_amd.models import OnlineSKIBotorchModel
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    n0, q, steps = 10, 6, 20
+    X = rng.uniform(0, 1, (n0 + q * steps, 2)); y = np.sin(5 * X[:, 0]) * np.cos(4 * X[:, 1]) + 0.1 * rng.standard_normal(X.shape[0])
+    nz = rng.uniform(1e-6, 0.05, X.shape[0])
+    Xt, yt, nt = torch.as_tensor(X, device=dev), torch.as_tensor(y, device=dev)[:, None], torch.as_tensor(nz, device=dev)[:, None]
+    gb = torch.tensor([[0.0, 1.0]] * 2, dtype=torch.float64)
+    cov = GridInterpolationKernel(ScaleKernel(MaternKernel(nu=0.5, ard_num_dims=2)), grid_size=30, num_dims=2, grid_bounds=gb)
+    model = OnlineSKIBotorchModel(Xt[:n0], yt[:n0], nt[:n0], covar_module=cov, learn_additional_noise=True)
+    model.eval()
+    upd = ShardedStatsUpdater(model, exchange="stats")
+    for s in range(steps):
+        lo = n0 + s * q
+        mine = slice(lo + rank, lo + q, world)                      # round-robin shard of the batch (3 points per rank)
+        upd.update(Xt[mine], yt[mine], nt[mine])
+        if s % 5 == 4:
+            model.posterior(Xt[:4]).mean                            # posterior requests between synchronisation points
+    ok = upd.last_exchange == "stats" and model.num_data == n0 + q * steps
+    s2 = float(model._sigma2(0))
+    ell = model.covar_module.base_kernel.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1)
+    osc = float(model.covar_module.base_kernel.outputscale.detach().double())
+    O = dataspace.DataSpaceGP(gb.numpy(), 30, "matern12", ell, osc, s2).fit(X, y, nz)
+    Xq = rng.uniform(0, 1, (12, 2))                                  # same draw on both ranks
+    mo, vo = O.predict(Xq)
+    post = model.posterior(torch.as_tensor(Xq, device=dev))
+    ok = ok and np.abs(post.mean[:, 0].cpu().numpy() - mo).max() < 1e-4 * np.abs(mo).max()
+    ok = ok and np.abs(post.variance[:, 0].cpu().numpy() - vo).max() < 1e-4 * vo.max()
+    open(os.path.join(tmpdir, f"c5_{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_malaria_geometry_stats_allreduce_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_c5, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"c5_{r}").read() == "1"
