@@ -100,6 +100,7 @@ class ShardedStatsUpdater:
         self.equal_shards = equal_shards
         self.comm = comm            # RcclCommunicator: the statistics exchange goes through the C ABI's wiski_allreduce_stats
         self._delta = None
+        self._res_delta = None
         self.last_exchange = None
 
     def _use_points(self, q, world, dev):
@@ -177,9 +178,20 @@ class ShardedStatsUpdater:
         self.last_exchange = "stats"
         delta = self._delta_cache()
         halves = m._half_buffers()
-        m._absorb(delta, X, Y, noise, init=False, half_delta=halves)
-        if getattr(m, "_mean_state", None) is not None:
-            m._mean_state["R_ok"] = False            # the carried-over residual does not see the all-reduced increment
+        # the carried residual R = b - Z - A U stays valid across the exchange: every rank adds its shard's innovation
+        # W^T (wb y - wa (W U)) to a zeroed buffer that is all-reduced with the other deltas and added to R
+        ms = getattr(m, "_mean_state", None)
+        res_delta = None
+        if ms is not None and ms.get("R_ok", False):
+            if self._res_delta is None or self._res_delta.shape != ms["R"].shape:
+                self._res_delta = torch.zeros_like(ms["R"])
+            else:
+                self._res_delta.zero_()
+            res_delta = self._res_delta
+        carried = m._absorb(delta, X, Y, noise, init=False, half_delta=halves, res_delta=res_delta)
+        # every rank must make the same choice: carried is a function of replicated state (R_ok, settings) only
+        if ms is not None and not carried:
+            ms["R_ok"] = False
         dev = delta["_stats"].device
         nloc = float(X.reshape(-1, m._grid.d).shape[0])
         if noise is None:
@@ -189,14 +201,16 @@ class ShardedStatsUpdater:
         count = torch.cat([torch.tensor([nloc], dtype=torch.float64, device=dev), wsum])
         if self.comm is not None:
             scal = torch.cat([delta["_stats"].reshape(-1), count])
-            self.comm.allreduce_stats_(list(halves), delta["interpolation_cache"], delta.get("_cnt"), scal)
+            self.comm.allreduce_stats_(list(halves) + ([res_delta] if carried else []), delta["interpolation_cache"], delta.get("_cnt"), scal)
             ns = delta["_stats"].numel()
             delta["_stats"].copy_(scal[:ns].reshape(delta["_stats"].shape))
             count = scal[ns:]
         else:
             small = [delta["interpolation_cache"], delta["_stats"], count] + ([delta["_cnt"]] if "_cnt" in delta else [])
-            allreduce_sum_(small + list(halves), self.group)
+            allreduce_sum_(small + ([res_delta] if carried else []) + list(halves), self.group)
         c = m._kernel_cache
+        if carried:
+            ms["R"].add_(res_delta)
         c["interpolation_cache"].add_(delta["interpolation_cache"])
         c["_stats"].add_(delta["_stats"])
         if "_cnt" in delta and "_cnt" in c:

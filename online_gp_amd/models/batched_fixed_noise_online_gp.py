@@ -200,13 +200,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._half_delta = [torch.zeros((H, self._grid.m), dtype=self._dtype, device=self._device) for _ in range(self.num_outputs)]
         return self._half_delta
 
-    def _absorb(self, cache, X, Y, noise, init, half_delta=None):
+    def _absorb(self, cache, X, Y, noise, init, half_delta=None, res_delta=None):
         """_initialize_caches (:31-60) / _update_cache_dicts (:155-171) fused into
         one scatter launch per output; mutates `cache` in place.
 
         W^T D^-1 W accumulates straight into the symmetric half stencil (T(T+1)/2 atomics
         per point).  With `half_delta` given (data-parallel path) the increments go to those
-        buffers instead, for the caller to all-reduce and add."""
+        buffers instead, for the caller to all-reduce and add; `res_delta` ([out, m], zeroed) then receives this shard's
+        innovation W^T (wb y - wa (W U)) of the carried residual, to be all-reduced and added to R alongside."""
         X = X.reshape(-1, self._grid.d).to(self._device, self._dtype).contiguous()
         Y = Y.to(self._device, self._dtype)
         if Y.dim() == 1:
@@ -229,6 +230,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         mine = cache is self._kernel_cache
         carry = (mine and half_delta is None and not init and ms is not None and ms.get("R_ok", False)
                  and settings.residual_carry_over.on())
+        carry_delta = (half_delta is not None and res_delta is not None and not init and ms is not None and ms.get("R_ok", False)
+                       and settings.residual_carry_over.on())
         if mine and ms is not None and not carry:
             ms["R_ok"] = False
         if getattr(self, "_scratch_stats", None) is None:
@@ -245,8 +248,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             half = grid_ops.is_half_stencil(self._grid, dst[o])      # a handed-over cache may carry a full stencil
             if carry and not half:
                 carry = ms["R_ok"] = False
+            if carry_delta and not half:
+                carry_delta = False
             grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], dst[o], half, cnt_o, stats[o], self._err,
-                                       u=ms["U"][o] if carry else None, res=ms["R"][o] if carry else None)
+                                       u=ms["U"][o] if (carry or carry_delta) else None,
+                                       res=ms["R"][o] if carry else (res_delta[o] if carry_delta else None))
             if half_delta is None and getattr(ops[o], "root", None) is not None and n > 0:
                 # the reference's root pair, once somebody asked for it: L L^T follows A by a rank-n root update (URLT:62-119)
                 Wd = grid_ops.wt_columns(self._grid, X, self._err)                 # [n, m]
@@ -257,7 +263,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 else:
                     self._wsum_dev[o] += wa.sum(dtype=torch.float64)
                     self._wsum_dirty = True
+        return carry_delta
 
+    # (the return value of _absorb tells the data-parallel caller whether res_delta was filled)
     @property
     def _wsum(self):
         if self._wsum_dirty:

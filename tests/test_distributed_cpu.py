@@ -59,7 +59,7 @@ class StubModel:
             self._half = [torch.zeros((self.R + 1) // 2, self.m, dtype=torch.float64)]
         return self._half
 
-    def _absorb(self, cache, X, Y, noise, init, half_delta=None):
+    def _absorb(self, cache, X, Y, noise, init, half_delta=None, res_delta=None):
         B2 = self.cp.MatrixFreeWISKI(self.gb, self.g)
         B2.absorb(X.numpy(), Y[:, 0].numpy(), noise[:, 0].numpy(), init=init)
         cache["interpolation_cache"][0, :, 0] += torch.from_numpy(B2.b)
@@ -68,6 +68,12 @@ class StubModel:
         else:
             cache["WtW"].stencil += torch.from_numpy(B2.A[(self.R - 1) // 2:])
         cache["_stats"][0] += torch.from_numpy(B2.c_ld)
+        ms = getattr(self, "_mean_state", None)
+        if half_delta is not None and res_delta is not None and ms is not None and ms.get("R_ok", False):
+            # what the scatter kernel's (u, res) arguments do: res += W^T (wb y - wa (W U))  = delta b - (delta A) U
+            res_delta[0] += torch.from_numpy(B2.b - B2.stencil_mv(ms["U"].numpy())[0])
+            return True
+        return False
 
     def condition_on_observations(self, X, Y, noise, inplace=True):
         self._absorb(self._kernel_cache, X, Y, noise, init=False)
@@ -112,6 +118,32 @@ def _worker(rank, world, port, tmpdir):
                      model.num_data == 120 and (expect is None or upd.last_exchange == expect))
         if mode == "stats":
             ok = ok and model.dumped == 3 and abs(model._wsum_host[0] - float((1.0 / N).sum())) < 1e-9
+    # the carried residual R = b - Z - A U survives the statistics exchange: every rank's shard innovation is all-reduced with the deltas
+    model = StubModel(gb, g)
+    U = torch.from_numpy(np.random.default_rng(7).standard_normal((1, model.m)))      # same (U, Z) on both ranks
+    Zs = torch.from_numpy(np.random.default_rng(8).standard_normal((1, model.m)))
+    model._mean_state = {"U": U, "Z": Zs, "R": -Zs.clone(), "R_ok": True}            # b = 0, A = 0 at the start
+    upd = ShardedStatsUpdater(model, exchange="stats")
+    for s in range(2):
+        sl = slice(rank * 20, (rank + 1) * 20)
+        upd.update(X[s, sl], Y[s, sl], N[s, sl])
+    full = StubModel(gb, g)
+    for s in range(2):
+        full.condition_on_observations(X[s], Y[s], N[s])
+    B2 = full.cp.MatrixFreeWISKI(gb, g)
+    B2.A[(full.R - 1) // 2:] = full._kernel_cache["WtW"].stencil.numpy()
+    B2.A[:(full.R - 1) // 2] = 0
+    # A U from the half stencil: direct + transposed terms (dense, tiny grid)
+    idx = np.arange(full.m)
+    Ad = np.zeros((full.m, full.m))
+    offs = [(a - 3) * g + (b_ - 3) for a in range(7) for b_ in range(7)]
+    for o, f in enumerate(offs):
+        j = idx + f
+        ok_j = (j >= 0) & (j < full.m)
+        Ad[idx[ok_j], j[ok_j]] += B2.A[o][ok_j]
+    Ad = Ad + Ad.T - np.diag(np.diag(Ad))
+    want = full._kernel_cache["interpolation_cache"][0, :, 0].numpy() - Zs[0].numpy() - Ad @ U[0].numpy()
+    ok = ok and model._mean_state["R_ok"] and np.abs(model._mean_state["R"][0].numpy() - want).max() < 1e-10 * max(np.abs(want).max(), 1.0)
     # unequal shard lengths: the point exchange must fall back to the statistics exchange (same result)
     model = StubModel(gb, g)
     upd = ShardedStatsUpdater(model, exchange="points")
