@@ -800,6 +800,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 }
 
 #include "spmv_sym_dma.h"
+#include "spmm_sym_cols.h"
 
 // Which wide half-stencil kernel serves (G, k): the LDS-DMA pipelined one (d = 3, fp32, one right-hand side; 4 chunks)
 // or the LDS-window one (anything else with m % 4 == 0; up to 7 chunks).  WISKI_SYM_DMA=0 forces the latter,
@@ -821,9 +822,28 @@ static inline bool sym_use_dma(const GridDev<real>& G, int k) {
   }
   return g_sym_dma != 0 && G.d == 3 && k == 1 && (G.m % 4) == 0 && symdma_lds_bytes(G.g[2], g_sym_dma_nst) <= 64 * 1024;
 }
+// Many right-hand sides (k >= 32): the lanes-are-columns SpMM (spmm_sym_cols.h) reads A_h once per 64 columns and leaves
+// ONE finished vector per column in part[0] (no atomically accumulated partial).  WISKI_SPMM_COLS=0 disables it.
+static int g_spmm_cols = -1;
+static inline bool sym_use_cols(int k) {
+  if (g_spmm_cols < 0) {
+    const char* e = getenv("WISKI_SPMM_COLS");
+    g_spmm_cols = e ? atoi(e) : 1;
+  }
+  return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 350 us at k = 64 (670)
+}
+static inline int spmmc_kp(int k) { return (k + 15) / 16 * 16; }
 // number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
 template <typename real>
 static inline int sym_nch(const GridDev<real>& G, int k) { return sym_use_dma<real>(G, k) ? g_sym_dma_parts : sym_nch_lds(G.d); }
+// total number of partial vectors the consumers of launch_spmv4_sym have to sum, and whether the last one is the
+// atomically accumulated one (to be re-zeroed once consumed)
+template <typename real>
+static inline int sym_partials(const GridDev<real>& G, int k, int* zl) {
+  if (sym_use_cols(k)) { *zl = 0; return 1; }
+  *zl = 1;
+  return sym_nch<real>(G, k) + 1;
+}
 
 // One launch with optional per-dispatch timing: in profiling mode the start/stop events are attached to the
 // kernel's own dispatch packet (hipExtLaunchKernelGGL), so their difference is the kernel's execution time --
@@ -844,6 +864,22 @@ static inline void launch_timed(F kern, dim3 grd, dim3 blk, size_t sh, hipStream
 template <typename real>
 static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, real* part, const real* add, real beta, double* dots,
                             hipStream_t s) {
+  if (sym_use_cols(k)) {
+    // part[0] <- A V (column-major); the row-major copies of V and A V live behind it (the caller provides 8 k m reals)
+    const int m = G.m, kp = spmmc_kp(k);
+    const int64_t km = (int64_t)k * m;
+    real* Vt = part + km;
+    real* Ot = Vt + (int64_t)m * kp;
+    dim3 tg((unsigned)((m + 63) / 64), (unsigned)((kp + 63) / 64));
+    if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true>), tg, dim3(256), 0, s, m, k, kp, V, Vt, add, beta, dots);
+    else hipLaunchKernelGGL((k_transpose_cm_rm<real, false>), tg, dim3(256), 0, s, m, k, kp, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
+    dim3 grd((unsigned)((m + SPMMC_RT - 1) / SPMMC_RT), (unsigned)((kp + 63) / 64));
+    const int ng = sym_groups(G.d);
+    if (dots) launch_timed(k_spmm_sym_cols<real, true>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+    else launch_timed(k_spmm_sym_cols<real, false>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+    hipLaunchKernelGGL((k_transpose_rm_cm<real>), tg, dim3(256), 0, s, m, k, kp, (const real*)Ot, part);
+    return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+  }
   if constexpr (sizeof(real) == 4) {
     if (sym_use_dma<real>(G, k)) {
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
@@ -1498,8 +1534,8 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   const bool sym = a_sym != 0;
   // number of partial vectors the wide SpMV leaves behind; on the half stencil the last one is the
   // atomically accumulated transposed term: zero here, re-zeroed by every consumer (zl)
-  const int nch = wide ? (sym ? sym_nch<real>(G, k) + 1 : spmv_nch(G.d)) : 0;
-  const int zl = wide && sym ? 1 : 0;
+  int zl = 0;
+  const int nch = wide ? (sym ? sym_partials<real>(G, k, &zl) : spmv_nch(G.d)) : 0;
   auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) {
     return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
   };
@@ -1684,11 +1720,13 @@ static int spmv_sym_impl(const wiski_grid* grid, const real* d_A, const real* d_
   if (!d_A || !d_V || !d_out || k < 1 || d_out == d_V) return WISKI_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (G.m % 4 != 0) return launch_spmv_sym<real>(G, d_A, d_V, k, d_add, beta, d_out, nullptr, s);
-  const int nch = sym_nch<real>(G, k) + 1;
+  int zl = 0;
+  const int nch = sym_partials<real>(G, k, &zl);
   const int64_t km = (int64_t)k * G.m;
   real* part = nullptr;
-  if (hipMallocAsync((void**)&part, (size_t)nch * km * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;  // stream-ordered scratch
-  if (hipMemsetAsync(part + (int64_t)(nch - 1) * km, 0, (size_t)km * sizeof(real), s) != hipSuccess) rc = WISKI_E_LAUNCH;
+  const int64_t slots = zl ? nch : 8;           // the many-column SpMM keeps its row-major copies behind part[0]
+  if (hipMallocAsync((void**)&part, (size_t)slots * km * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;  // stream-ordered scratch
+  if (zl && hipMemsetAsync(part + (int64_t)(nch - 1) * km, 0, (size_t)km * sizeof(real), s) != hipSuccess) rc = WISKI_E_LAUNCH;
   if (rc == WISKI_OK) rc = launch_spmv4_sym<real>(G, d_A, d_V, k, part, nullptr, (real)0, nullptr, s);
   if (rc == WISKI_OK) {
     int64_t blocks = (km + 255) / 256;

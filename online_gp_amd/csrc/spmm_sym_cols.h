@@ -1,0 +1,208 @@
+// Symmetric half-stencil SpMM for many right-hand sides (k >= 8): A_h is read ONCE per 64 columns.
+// Included by solve.hip after spmv_sym_dma.h.
+//
+// The k = 1 kernels give a lane 4 rows and make a pass over A_h per 1 / 4 columns (16 passes for 64 predictive-variance
+// right-hand sides: 783 us, 20x above the product's own roofline).  Here a lane IS a column: one 64-lane wave owns RT = 16
+// consecutive rows x 64 columns, walks all (7^d + 1) / 2 stored stencil groups for them and writes finished output rows:
+//
+//   out[j, c] = sum_{o >= centre} a(o, j) v[j + off(o), c]  +  sum_{o > centre} a(o, j - off(o)) v[j - off(o), c]
+//
+//  * every stencil coefficient is wave-uniform, so A_h is fetched through the scalar unit (s_load, contiguous spans of
+//    7 RT resp. 7 (RT + 6) reals per group) and enters the FMAs as an SGPR operand -- no LDS, no lane shuffles;
+//  * both terms are written in pull form ("for my rows, who contributes"), so there are no atomics, no partial vectors and
+//    no transposed-term window; each A_h entry is read twice (by the tile it belongs to and by the tile it points into),
+//    the second time from L2 / Infinity Cache;
+//  * the right-hand sides are needed ROW-major, [m][kp] (256 B per row and 64 columns: one fully coalesced load per row);
+//    the 7 innermost offsets of RT rows share a window of RT + 6 rows (22 loads for 112 FMAs per direction);
+//  * V arrives column-major ([k][m], the layout of every other PCG kernel): k_transpose_cm_rm / k_transpose_rm_cm convert
+//    on the way in and out (64 x 64 tiles through LDS), the first one also forming beta * v . add per column (CG's p . pt).
+//
+// Works for any d (1..4) and any m; rows past m and columns past k are masked.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+constexpr int SPMMC_RT = 16;
+
+template <typename real, int n, int I0, typename V, typename F, int... T>
+__device__ __forceinline__ void spmmc_visit(const V& blk, F&& fn, std::integer_sequence<int, T...>) {
+  (fn(std::integral_constant<int, I0 + T>{}, blk[T]), ...);
+}
+
+// Visit N contiguous wave-uniform coefficients p[0..N) in 64-byte pieces: fn(integral_constant<idx>, p[idx]).
+// The vector type is only dword-aligned: hipcc turns each piece into one s_load_dwordx16 (x8 / x4 / ... for the tail).
+template <typename real, int N, int I0 = 0, typename F>
+__device__ __forceinline__ void spmmc_span(const real* __restrict__ p, F&& fn) {
+  constexpr int CH = 64 / (int)sizeof(real);
+  if constexpr (I0 < N) {
+    constexpr int n = (N - I0) >= CH ? CH : ((N - I0) >= CH / 2 ? CH / 2 : ((N - I0) >= CH / 4 ? CH / 4 : ((N - I0) >= 2 ? 2 : 1)));
+    if constexpr (n == 1) {
+      fn(std::integral_constant<int, I0>{}, p[I0]);
+    } else {
+      typedef real vec_t __attribute__((ext_vector_type(n), aligned(4)));
+      const vec_t blk = *reinterpret_cast<const vec_t*>(p + I0);
+      spmmc_visit<real, n, I0>(blk, fn, std::make_integer_sequence<int, n>{});
+    }
+    spmmc_span<real, N, I0 + n>(p, fn);
+  }
+}
+
+// column-major [k][m] -> row-major [m][kp] (kp = k rounded up to 64; padding columns are written as zeros).
+// DOT: dots[c] += beta * sum_i V[c][i] * add[c][i]  (slotted, see PcgScal).
+template <typename real, bool DOT>
+__global__ __launch_bounds__(256) void k_transpose_cm_rm(int m, int k, int kp, const real* __restrict__ V, real* __restrict__ Vt,
+                                                         const real* __restrict__ add, real beta, double* __restrict__ dots) {
+  __shared__ real tile[64][65];
+  const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  double part[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = c0 + ty + 4 * u, i = i0 + tx;
+    real v = (real)0;
+    part[u] = 0;
+    if (c < k && i < m) {
+      v = V[(int64_t)c * m + i];
+      if (DOT) part[u] = (double)v * (double)add[(int64_t)c * m + i];
+    }
+    tile[ty + 4 * u][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = i0 + ty + 4 * u, c = c0 + tx;
+    if (i < m && c < kp) Vt[(int64_t)i * kp + c] = tile[tx][ty + 4 * u];
+  }
+  if (DOT) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double tot = wave_reduce_sum<double>(part[u]);       // a wave holds one column (64 consecutive rows) per u
+      const int c = c0 + ty + 4 * u;
+      if (tx == 0 && c < k && tot != 0.0) pcg_dot_add(dots, c, (double)beta * tot);
+    }
+  }
+}
+
+// row-major [m][kp] -> column-major [k][m]
+template <typename real>
+__global__ __launch_bounds__(256) void k_transpose_rm_cm(int m, int k, int kp, const real* __restrict__ Ot, real* __restrict__ O) {
+  __shared__ real tile[64][65];
+  const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = i0 + ty + 4 * u, c = c0 + tx;
+    tile[ty + 4 * u][tx] = (i < m && c < kp) ? Ot[(int64_t)i * kp + c] : (real)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = c0 + ty + 4 * u, i = i0 + tx;
+    if (c < k && i < m) O[(int64_t)c * m + i] = tile[tx][ty + 4 * u];
+  }
+}
+
+// One wave = RT rows x 64 columns.  Vt, Ot row-major [m][kp].  DOT: dots[c] += sum_j Vt[j][c] * Ot[j][c].
+template <typename real, bool DOT>
+__global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ Vt, int k, int kp,
+                                                      int ng, real* __restrict__ Ot, double* __restrict__ dots) {
+  constexpr int RT = SPMMC_RT, WN = RT + 6;
+  const int m = G.m, d = G.d;
+  const int lane = threadIdx.x;
+  const int c = blockIdx.y * 64 + lane;            // this lane's column
+  const bool cok = c < kp;
+  const int j0 = blockIdx.x * RT;                  // first row of the tile (wave-uniform)
+  const real* __restrict__ vcol = Vt + (cok ? c : 0);
+  real acc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = (real)0;
+  const int cP = ng - 1;                           // prefix code of the centre: (7^(d-1) - 1) / 2
+
+  // one stencil group: CENTRE = the group of the diagonal (4 reals per row, digits 3..6; digit 3 is the diagonal and
+  // belongs to the direct term only), else 7 reals per row.  Compile-time strides let the coefficient loads of a row
+  // (and of neighbouring rows) merge into wide scalar loads.
+  // one stencil group: CENTRE = the group of the diagonal (4 reals per row, digits 3..6; digit 3 is the diagonal and
+  // belongs to the direct term only), else 7 reals per row.  The coefficients of a term form ONE contiguous span of A_h
+  // (RT x RS resp. (RT + 6) x RS reals); it is fetched in 64-byte pieces (s_load_dwordx16, dword-aligned) and every
+  // piece is consumed straight from its SGPRs.
+  auto group = [&](auto centre_tag, const real* __restrict__ Ag, int f) {
+    constexpr bool CENTRE = decltype(centre_tag)::value;
+    constexpr int RS = CENTRE ? 4 : 7;               // reals per row
+    constexpr int S0 = CENTRE ? 3 : 0;               // first stored digit
+    {  // ---- direct term: out[j0 + r] += a(s, j0 + r) * v[j0 + r + f + s - 3]
+      real win[WN];
+#pragma unroll
+      for (int e = 0; e < WN; ++e) {
+        int j = j0 + f - 3 + e;
+        j = j < 0 ? 0 : (j >= m ? m - 1 : j);        // clamped rows only ever meet coefficients that are exactly zero
+        win[e] = vcol[(int64_t)j * kp];
+      }
+      // ragged last tile: read the span of the last RT rows of the grid and shift the row index (rows >= m are not stored)
+      const int jb = j0 + RT <= m ? j0 : (m - RT > 0 ? m - RT : 0);
+      const int sh = j0 - jb;
+      const real* __restrict__ a = Ag + (int64_t)RS * jb;
+      if (sh == 0) {
+        spmmc_span<real, RT * RS>(a, [&](auto idx_tag, real coef) {
+          constexpr int idx = decltype(idx_tag)::value, r = idx / RS, s = S0 + idx % RS;
+          acc[r] += coef * win[r + s];
+        });
+      } else {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const int rr = r + sh < RT ? r + sh : RT - 1;
+#pragma unroll
+          for (int s = S0; s < 7; ++s) acc[r] += a[RS * rr + (s - S0)] * win[r + s];
+        }
+      }
+    }
+    {  // ---- transposed term: out[j] += a(s, i') * v[i'],  i' = j - f - (s - 3) = j0 - f - 3 + e,  r = e + s - 6
+      constexpr int T0 = CENTRE ? 4 : 0;
+      real src[WN];
+      const int ib = j0 - f - 3;
+#pragma unroll
+      for (int e = 0; e < WN; ++e) {
+        int i = ib + e;
+        i = i < 0 ? 0 : (i >= m ? m - 1 : i);
+        src[e] = vcol[(int64_t)i * kp];
+      }
+      const bool whole = ib >= 0 && ib + WN <= m;    // wave-uniform: the source rows all exist (always, away from the grid ends)
+      if (whole) {
+        spmmc_span<real, WN * RS>(Ag + (int64_t)RS * ib, [&](auto idx_tag, real coef) {
+          constexpr int idx = decltype(idx_tag)::value, e = idx / RS, s = S0 + idx % RS, r = e + s - 6;
+          if constexpr (s >= T0 && r >= 0 && r < RT) acc[r] += coef * src[e];
+        });
+      } else {
+#pragma unroll
+        for (int e = 0; e < WN; ++e) {
+          const int i = ib + e;
+          const bool inside = i >= 0 && i < m;
+          const real* __restrict__ a = Ag + (int64_t)RS * (inside ? i : 0);
+#pragma unroll
+          for (int s = T0; s < 7; ++s) {
+            const int r = e + s - 6;
+            if (r >= 0 && r < RT) acc[r] += (inside ? a[s - S0] : (real)0) * src[e];
+          }
+        }
+      }
+    }
+  };
+  group(std::true_type{}, A_h, 0);
+  for (int g = 1; g < ng; ++g) {
+    int f = 0, rem = cP + g;                         // flat offset of the group's centre digit (leading d-1 stencil digits)
+    for (int q = d - 2; q >= 0; --q) {
+      f += (rem % 7 - 3) * G.stride[q];
+      rem /= 7;
+    }
+    group(std::false_type{}, A_h + (int64_t)(7 * g - 3) * m, f);
+  }
+  double dot = 0;
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int j = j0 + r;
+    if (j < m && cok) {
+      Ot[(int64_t)j * kp + c] = acc[r];
+      if (DOT) dot += (double)vcol[(int64_t)j * kp] * (double)acc[r];
+    }
+  }
+  if (DOT && c < k) pcg_dot_add(dots, c, dot);
+}

@@ -285,6 +285,21 @@ class PredictiveCovariance(LazyCovariance):
         if want_full:
             full = torch.empty(self.shape, dtype=self.dtype, device=self.device)
         step = self.chunk if self.block is None else max(self.block, (self.chunk // self.block) * self.block)
+        tol_keep = getattr(self.post, "tol", None)
+        vt = settings.variance_cg_tolerance.value()
+        if vt is not None and not want_full and tol_keep is not None:
+            self.post.tol = max(float(vt), float(tol_keep))          # quadratic forms: second order in the residual
+        try:
+            self._solve_chunk_loop(n, step, grid, diag, full, want_full)
+        finally:
+            if tol_keep is not None:
+                self.post.tol = tol_keep
+        self._diag = diag * self.sigma2
+        if want_full:
+            full = full * self.sigma2
+            self._full = 0.5 * (full + full.transpose(-1, -2))
+
+    def _solve_chunk_loop(self, n, step, grid, diag, full, want_full):
         for s in range(0, n, step):
             e = min(s + step, n)
             xs = self.x[s:e]
@@ -301,10 +316,6 @@ class PredictiveCovariance(LazyCovariance):
                     G = G.reshape(nb, q, nb, q)
                     idx = torch.arange(nb, device=self.device)
                     full[s // q:e // q] = G[idx, :, idx, :]
-        self._diag = diag * self.sigma2
-        if want_full:
-            full = full * self.sigma2
-            self._full = 0.5 * (full + full.transpose(-1, -2))
 
     def diag(self):
         if self._diag is None:

@@ -111,6 +111,16 @@ class cg_tolerance(_value_context):
     _global_value = None
 
 
+class variance_cg_tolerance(_value_context):
+    """Relative-residual tolerance of the PCG solves behind predictive *variances* (diagonal requests only).  None = the
+    same as ``cg_tolerance``.  A variance is the quadratic form w^T M w = w^T u of the solve's own right-hand side, and CG's
+    error in that form is the squared energy norm of the error -- second order in the residual -- so a residual tolerance of
+    1e-2 already gives variances good to ~1e-4 (bench.py measures the deviation from a tight solve next to the latency).  Full
+    covariance requests keep ``cg_tolerance`` (bilinear forms of different vectors are first order)."""
+
+    _global_value = None
+
+
 class max_cg_iterations(_value_context):
     _global_value = 2000
 
