@@ -30,6 +30,44 @@ def allreduce_sum_(tensors, group=None):
     return tensors
 
 
+def sharded_posterior_moments(model, X, group=None, want_variance=True):
+    """Predictive mean and variance at X [n*, d] with the *solves* divided over the ranks (last sentence:
+    predictions shard over query points -- embarrassingly parallel).  The statistics are replicated, so every rank holds the
+    same posterior; rank r computes the variance right-hand sides of its contiguous slice of the queries (the expensive
+    part: one PCG column per query on large grids) and one all-gather assembles the full vectors on every rank.
+    Returns (mean [n*], variance [n*] or None).  Single-output models."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    n = X.shape[0]
+    per = (n + world - 1) // world
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        mean = model(X).mean if not want_variance else None                  # the mean is one gather: cheaper than any exchange
+        if want_variance:
+            mvn = model(X[lo:hi]) if hi > lo else None
+            part = torch.zeros(2, per, dtype=model._dtype, device=model._device)
+            if mvn is not None:
+                part[0, :hi - lo] = mvn.mean.reshape(-1)
+                part[1, :hi - lo] = mvn.variance.reshape(-1)
+    if was_training:
+        model.train()
+    if not want_variance:
+        return mean.reshape(-1), None
+    if world == 1:
+        return part[0, :n], part[1, :n]
+    parts = [torch.empty_like(part) for _ in range(world)]
+    if dist.get_backend(group) == "gloo" and part.is_cuda:
+        cpu_parts = [p_.cpu() for p_ in parts]
+        dist.all_gather(cpu_parts, part.cpu(), group=group)
+        parts = [p_.to(part.device) for p_ in cpu_parts]
+    else:
+        dist.all_gather(parts, part, group=group)
+    full = torch.cat(parts, dim=1)[:, :n]
+    return full[0], full[1]
+
+
 class RcclCommunicator:
     """An ncclComm_t created through the C ABI (``wiski_comm_*``, include/wiski.h) for the ``wiski_allreduce_stats``
     collective: rank 0 draws the unique id, torch.distributed (any backend) ships its bytes to the other ranks, every rank

@@ -51,6 +51,13 @@ def _worker(rank, world, port, tmpdir):
                      model.num_data == ref.num_data == 40 + 3 * 2048 and abs(model._wsum[0] - ref._wsum[0]) < 1e-6 and
                      upd.last_exchange == mode)
         ok = ok and torch.allclose(model(Xs).mean, ref(Xs).mean, rtol=1e-3, atol=1e-4)
+    # predictions shard over the query points: each rank solves the variance columns of its slice, one all-gather
+    from online_gp_amd.distributed import sharded_posterior_moments
+
+    Xq = X[100:137]                                                  # 37 queries: uneven split 19 + 18
+    mean_s, var_s = sharded_posterior_moments(model, Xq)
+    mvn = ref(Xq)
+    ok = ok and mean_s.shape == (37,) and torch.allclose(mean_s, mvn.mean, rtol=1e-3, atol=1e-4) and torch.allclose(var_s, mvn.variance, rtol=1e-2, atol=1e-6)
     open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
