@@ -211,8 +211,11 @@ def main():
             upd = ShardedStatsUpdater(model, equal_shards=True, exchange=exchange)   # every rank streams q points per step
 
             def step(xb, yb):
+                if world == 1:                             # evaluate -> absorb -> refresh behind one C-ABI call (wiski_stream_step)
+                    mean = model.stream_step(xb, yb)
+                    return mean, model._last_iters[0]
                 mean = model(xb).mean                      # 1. evaluate
-                upd.update(xb, yb)                         # 2. absorb (+ exchange between the ranks when N > 1)
+                upd.update(xb, yb)                         # 2. absorb + exchange between the ranks
                 pc = model.prediction_cache                # 3. refresh
                 return mean, pc["cg_iters"][0]
 

@@ -196,6 +196,29 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
 int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream);
 int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream);
 
+/* One streaming step in one call (single output, symmetric half stencil): the launches of wiski_gather (predictive mean of
+ * the incoming batch under the CURRENT posterior mean d_U, written to d_mean_out [q]; skipped when NULL),
+ * wiski_scatter_stats_cnt (absorb the q points into b / A_half / cnt / stats; with carry != 0 the residual d_R is kept
+ * equal to b - Z - A U) and wiski_pcg (refresh of (d_U, d_Z) for RHS = d_b, warm = 2 when carry != 0 else 1) are queued
+ * back to back on `stream` -- what BFN:204-210, BFN:258-273 and BFN:368-383 do in three Python calls.  d_wa / d_wb /
+ * d_noise [q]: the per-point weights 1/clamp(noise,1e-7), 1/noise and the noise itself (ones for unit noise).  The struct
+ * carries the model-resident pointers and solver parameters (meaning as in wiski_pcg); first_check / h_iters / h_relres /
+ * h_err as in wiski_pcg. */
+typedef struct wiski_stream_args_f32 {
+  float* d_A_half; float* d_b; float* d_cnt; double* d_stats; int32_t* d_err;     /* statistics + out-of-grid flag      */
+  float* d_U; float* d_Z; float* d_R;                                              /* posterior-mean state (in place)    */
+  const float* d_tcol; float kscale; const float* d_evec; const float* d_evec2; const float* d_eval; float shift;
+  double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
+} wiski_stream_args_f32;
+typedef struct wiski_stream_args_f64 {
+  double* d_A_half; double* d_b; double* d_cnt; double* d_stats; int32_t* d_err;
+  double* d_U; double* d_Z; double* d_R;
+  const double* d_tcol; double kscale; const double* d_evec; const double* d_evec2; const double* d_eval; double shift;
+  double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
+} wiski_stream_args_f64;
+int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* args, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream);
+int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* args, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream);
+
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky
  * solve `Q.inv_matmul` (BFN:375), a13 `pred_cov` (BFN:399-403), BWM:27 logdet.

@@ -1,0 +1,64 @@
+// One streaming step behind ONE C-ABI call: the launches of
+//   predictive mean of the incoming batch   wiski_gather        (BFN:206-210)
+//   absorb the batch                        wiski_scatter_stats_cnt (BFN:155-171 + URLT:58; carries the residual)
+//   warm-started refresh of the mean        wiski_pcg           (CG branch of BFN:368-383)
+// are queued back to back on the caller's stream without returning to the host language in between (the Python
+// front-end left the GPU idle for ~30 us between the gather and the scatter and ~40 us after the solver's last poll).
+// Pure host code: it only sequences the three entry points above.
+#include "wiski_common.h"
+
+template <typename real>
+struct StreamArgs;
+template <>
+struct StreamArgs<float> { using type = wiski_stream_args_f32; };
+template <>
+struct StreamArgs<double> { using type = wiski_stream_args_f64; };
+
+extern "C" {
+int wiski_gather_f32(const wiski_grid*, const float*, int64_t, const float*, int32_t, int32_t, float*, int32_t*, void*);
+int wiski_gather_f64(const wiski_grid*, const double*, int64_t, const double*, int32_t, int32_t, double*, int32_t*, void*);
+}
+
+static int gather1(const wiski_grid* g, const float* x, int64_t n, const float* V, float* out, int32_t* err, void* s) { return wiski_gather_f32(g, x, n, V, 1, 0, out, err, s); }
+static int gather1(const wiski_grid* g, const double* x, int64_t n, const double* V, double* out, int32_t* err, void* s) { return wiski_gather_f64(g, x, n, V, 1, 0, out, err, s); }
+static int scatter1(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* nz, int64_t n, float* b, float* A, float* cnt, const float* u, float* res, double* st, int32_t* err, void* s) {
+  return wiski_scatter_stats_cnt_f32(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
+}
+static int scatter1(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, double* b, double* A, double* cnt, const double* u, double* res, double* st, int32_t* err, void* s) {
+  return wiski_scatter_stats_cnt_f64(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
+}
+static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s) {
+  return wiski_pcg_f32(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol, a->max_iter,
+                       a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s);
+}
+static int pcg1(const wiski_grid* g, const wiski_stream_args_f64* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s) {
+  return wiski_pcg_f64(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol, a->max_iter,
+                       a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s);
+}
+
+template <typename real>
+static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<real>::type* a, const real* d_x, const real* d_y, const real* d_wa,
+                            const real* d_wb, const real* d_noise, int64_t q, real* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters,
+                            double* h_relres, int32_t* h_err, void* stream) {
+  if (!grid || !a || !d_x || !d_y || !d_wa || !d_wb || !d_noise || q < 0 || !a->d_A_half || !a->d_b || !a->d_U || !a->d_Z || !a->d_R) return WISKI_E_BADARG;
+  int rc = WISKI_OK;
+  if (q > 0) {
+    if (d_mean_out) {
+      rc = gather1(grid, d_x, q, a->d_U, d_mean_out, a->d_err, stream);
+      if (rc) return rc;
+    }
+    rc = scatter1(grid, d_x, d_y, d_wa, d_wb, d_noise, q, a->d_b, a->d_A_half, a->d_cnt, carry ? a->d_U : nullptr, carry ? a->d_R : nullptr, a->d_stats,
+                  a->d_err, stream);
+    if (rc) return rc;
+  }
+  return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream);
+}
+
+extern "C" {
+int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* a, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream) {
+  return stream_step_impl<float>(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, d_mean_out, carry, first_check, h_iters, h_relres, h_err, stream);
+}
+int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* a, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream) {
+  return stream_step_impl<double>(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, d_mean_out, carry, first_check, h_iters, h_relres, h_err, stream);
+}
+}

@@ -289,6 +289,56 @@ class PCGWorkspace:
         return self.buf, need
 
 
+class _StreamArgs32(ctypes.Structure):
+    _fields_ = [("d_A_half", ctypes.c_void_p), ("d_b", ctypes.c_void_p), ("d_cnt", ctypes.c_void_p), ("d_stats", ctypes.c_void_p),
+                ("d_err", ctypes.c_void_p), ("d_U", ctypes.c_void_p), ("d_Z", ctypes.c_void_p), ("d_R", ctypes.c_void_p),
+                ("d_tcol", ctypes.c_void_p), ("kscale", ctypes.c_float), ("d_evec", ctypes.c_void_p), ("d_evec2", ctypes.c_void_p),
+                ("d_eval", ctypes.c_void_p), ("shift", ctypes.c_float), ("tol", ctypes.c_double), ("max_iter", ctypes.c_int32),
+                ("check_every", ctypes.c_int32), ("d_work", ctypes.c_void_p), ("work_bytes", ctypes.c_int64)]
+
+
+class _StreamArgs64(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double if t is ctypes.c_float else t) for n, t in _StreamArgs32._fields_]
+
+
+class StreamStep:
+    """Prepared call of ``wiski_stream_step`` (include/wiski.h): the model-resident pointers are marshalled once, a step only
+    passes the batch.  Returns (iterations, relative residual, raw out-of-grid flag, converged)."""
+
+    def __init__(self, grid, dtype, device, A_half, b, cnt, stats, err, U, Z, R, tcol, workspace, max_iter):
+        self.grid, self.dtype, self.device = grid, dtype, device
+        self.keep = (A_half, b, cnt, stats, err, U, Z, R, tcol)             # the tensors behind the raw pointers
+        self.args = (_StreamArgs32 if dtype == torch.float32 else _StreamArgs64)()
+        a = self.args
+        a.d_A_half, a.d_b, a.d_cnt, a.d_stats, a.d_err = A_half.data_ptr(), b.data_ptr(), cnt.data_ptr(), stats.data_ptr(), err.data_ptr()
+        a.d_U, a.d_Z, a.d_R, a.d_tcol = U.data_ptr(), Z.data_ptr(), R.data_ptr(), tcol.data_ptr()
+        buf, need = workspace.get(grid, 1, max_iter, dtype, device)
+        self.keep += (buf,)
+        a.d_work, a.work_bytes, a.max_iter = buf.data_ptr(), need, max_iter
+        self.fn = _hip.fn("wiski_stream_step", dtype)
+        self.it, self.herr, self.rr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0)
+        self.eig_keep = None
+
+    def set_solver(self, kscale, eig, shift, tol, check_every):
+        a = self.args
+        evec, evals, evec2 = (tuple(eig) + (None,))[:3]
+        self.eig_keep = (evec, evals, evec2)
+        a.kscale, a.shift, a.tol, a.check_every = kscale, shift, tol, check_every
+        a.d_evec, a.d_eval = evec.data_ptr(), evals.data_ptr()
+        a.d_evec2 = evec2.data_ptr() if evec2 is not None else None
+
+    def __call__(self, x, y, wa, wb, noise, mean_out, carry, first_check):
+        q = x.shape[0]
+        rc = self.fn(self.grid.ref, ctypes.byref(self.args), _hip.dptr(x), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise),
+                     ctypes.c_int64(q), _hip.dptr(mean_out), ctypes.c_int32(int(carry)), ctypes.c_int32(int(first_check)), ctypes.byref(self.it),
+                     ctypes.byref(self.rr), ctypes.byref(self.herr), _hip.stream_ptr(self.device))
+        if rc == -4:
+            warnings.warn(f"wiski_pcg stopped at max_iter={self.args.max_iter} with relative residual {self.rr.value:.3e}", RuntimeWarning)
+        else:
+            _hip.check(rc, "wiski_stream_step")
+        return int(self.it.value), float(self.rr.value), int(self.herr.value), rc == 0
+
+
 def kron_eigen(grid, tcol, profiles=None):
     """Per-dim (generalized) eigen-decomposition of the d small symmetric-Toeplitz Kronecker
     factors (host side, fp64, O(d g^3) -- done when the hyper-parameters or the data-density

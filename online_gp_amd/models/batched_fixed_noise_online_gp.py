@@ -636,6 +636,87 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self._seed_rank_updated_cache(new_gp, old_pc, X, noise, Y)
         return new_gp
 
+    def stream_step(self, X, Y, want_mean=True):
+        """evaluate -> absorb -> refresh for one streamed batch (the reference driver's online step at batch granularity,
+        experiments/regression.py:48-54 with fixed hyper-parameters): predictive mean of X under the current posterior, then
+        ``condition_on_observations(X, Y, inplace=True)``, then the posterior mean refreshed.  Equivalent to
+        ``m = self(X).mean; self.condition_on_observations(X, Y, inplace=True); self.prediction_cache`` -- which is also the
+        fallback -- but on large single-output grids the three launches go through ONE C-ABI call (``wiski_stream_step``) with
+        the per-step host work reduced to bookkeeping.  Unit noise.  Returns the mean [n] (or None)."""
+        st = self._stream_fast_state(X, Y)
+        if st is None:
+            mean = None
+            if want_mean:
+                with settings.skip_posterior_variances(True):
+                    mean = self(X).mean
+            self.condition_on_observations(X, Y, None, inplace=True)
+            self.prediction_cache
+            return mean
+        step, ms, pst = st
+        q = X.shape[0]
+        if getattr(self, "_ones_cache", None) is None or self._ones_cache.shape[0] < q:
+            self._ones_cache = torch.ones(max(q, 4096), dtype=self._dtype, device=self._device)
+        ones = self._ones_cache[:q]
+        mean = torch.empty(q, dtype=self._dtype, device=self._device) if want_mean else None
+        # bookkeeping of _absorb / prediction_cache
+        self._wsum_host[0] += float(q)
+        self.num_data = self.num_data + q
+        self._refresh_count = getattr(self, "_refresh_count", 0) + 1
+        probe = getattr(self, "_probe_down", True) or self._refresh_count % 8 == 0
+        last = (getattr(self, "_last_iters", None) or [0])[0]
+        fc = max(1, last - (1 if probe else 0)) if last else 0
+        carry = ms.get("R_ok", False) and self._refresh_count % 16 != 0
+        step.args.shift = float(self._wsum[0]) / pst["norm"]
+        y1 = Y.reshape(-1)
+        it, rel, flag, conv = step(X, y1 if y1.is_contiguous() else y1.contiguous(), ones, ones, ones, mean, carry, fc)
+        if fc:
+            self._probe_down = it <= fc and fc > 1
+        self._last_iters = [it]
+        ms["R_ok"] = conv
+        pc = self._memo.get("prediction_cache")
+        if pc is not None:
+            pc["cg_iters"] = [it]
+        if flag:
+            ms["R_ok"] = False
+            self._raise_out_of_bounds(flag)
+        return mean
+
+    def _stream_fast_state(self, X, Y):
+        """(prepared StreamStep, mean state, preconditioner state) when the one-call streaming step applies, else None."""
+        if (self.num_outputs != 1 or self._use_dense() or settings.spectral_preconditioner.off() or settings.residual_carry_over.off()
+                or X.dim() != 2 or not X.is_cuda or X.dtype != self._dtype or not X.is_contiguous() or Y.dtype != self._dtype):
+            return None
+        ms = self._mean_state
+        pc = self._memo.get("prediction_cache")
+        ver = self._hyper_version()
+        if ms is None or pc is None or ms.get("ver") != ver or "pending_rank_update" in self._memo:
+            return None
+        op = _wtw_ops(self._kernel_cache["WtW"])[0]
+        if not op.is_half or op.root is not None or "_cnt" not in self._kernel_cache:
+            return None
+        pst = self._memo.get("precond", {}).get(0)
+        wsum_new = float(self._wsum[0]) + X.shape[0]
+        if pst is None or pst["ver"] != ver or wsum_new > 2.0 * pst["wsum"]:
+            return None                                   # the density profile is due for a look: generic path this step
+        its = (getattr(self, "_last_iters", None) or [0])[0]
+        if pst.get("it0") is None and its > 0:
+            pst["it0"] = its
+        if pst.get("it0") is not None and its >= pst["it0"] + 2 and wsum_new > 1.1 * pst["wsum"]:
+            return None
+        tol = _default_tol(self._dtype)
+        key = (ver, id(ms["U"]), id(pst["eig"]), tol, settings.cg_check_every.value(), settings.max_cg_iterations.value())
+        cached = self.__dict__.get("_stream_step_cache")
+        if cached is None or cached[0] != key:
+            tcol, s2, _ = self._hyper()[0]
+            c = self._kernel_cache
+            step = grid_ops.StreamStep(self._grid, self._dtype, self._device, op.stencil, c["interpolation_cache"][0, :, 0], c["_cnt"][0],
+                                       c["_stats"][0], self._err, ms["U"][0], ms["Z"][0], ms["R"][0], tcol, self._pcg_ws,
+                                       settings.max_cg_iterations.value())
+            step.set_solver(1.0 / s2, pst["eig"], 0.0, tol, 1)
+            cached = (key, step)
+            self.__dict__["_stream_step_cache"] = cached
+        return cached[1], ms, pst
+
     def _rank_update_source(self, q):
         """The cached dense posterior(s), if a rank-q Woodbury update of them is valid and cheaper than a fresh factor:
         dense regime, cache built for the current hyper-parameters, 0 < q <= m / 8, fewer than 64 stacked updates."""

@@ -481,3 +481,54 @@ def test_empty_batches_and_colliding_points(dtype):
     assert model.num_data == 200 + 777 + 8
     assert np.abs(mean - mo).max() <= RTOL[dtype] * np.abs(mo).max()
     assert np.abs(var - vo).max() <= RTOL[dtype] * np.abs(vo).max()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 1e-8)])
+def test_stream_step_one_call_equals_the_three_python_calls(dtype, tol):
+    """`stream_step` (one C-ABI call: wiski_stream_step = gather + scatter with residual carry + warm PCG) against
+    evaluate -> condition_on_observations(inplace) -> prediction_cache, over a stream long enough to hit the periodic residual
+    recomputation, and against the data-space oracle at the end; falls back to the generic path where the fast path does not
+    apply (dense grids, out-of-date preconditioner profile) and reports out-of-grid points from inside the call."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(12)
+    d, g, n0, q, steps = 3, 20, 400, 64, 40
+    X = rng.uniform(-1, 1, (n0 + q * steps, d)); y = np.sin(2 * X[:, 0]) * np.cos(X[:, 1]) + 0.3 * X[:, 2] + 0.1 * rng.standard_normal(X.shape[0])
+    Xt, yt = torch.as_tensor(X, device=DEV, dtype=dtype), torch.as_tensor(y, device=DEV, dtype=dtype)[:, None]
+    gb = torch.tensor([[-1.1, 1.1]] * d, dtype=torch.float64)
+    with settings.cg_tolerance(1e-5 if dtype == torch.float32 else 1e-11), torch.no_grad():
+        a = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        b = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        a.prediction_cache; b.prediction_cache
+        fast = 0
+        for s in range(steps):
+            sl = slice(n0 + s * q, n0 + (s + 1) * q)
+            fast += a._stream_fast_state(Xt[sl], yt[sl]) is not None
+            ma = a.stream_step(Xt[sl], yt[sl])
+            with settings.skip_posterior_variances(True):
+                mb = b(Xt[sl]).mean
+            b.condition_on_observations(Xt[sl], yt[sl], inplace=True)
+            b.prediction_cache
+            assert float((ma - mb).abs().max()) <= 10 * tol * float(mb.abs().max())
+        assert fast >= steps - 6                      # the one-call path carried (nearly) every step
+        assert a.num_data == b.num_data == n0 + q * steps and abs(a._wsum[0] - b._wsum[0]) < 1e-9
+        sa, sb = a._kernel_cache["WtW"].stencil, b._kernel_cache["WtW"].stencil
+        assert float((sa - sb).abs().max()) <= tol * float(sb.abs().max())
+        assert torch.allclose(a._kernel_cache["_stats"], b._kernel_cache["_stats"], rtol=1e-9)
+        mv = a(Xt[:32])
+        s2 = float(a.likelihood.second_noise.detach())
+        O = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, sigma2=s2).fit(X, y, np.ones(X.shape[0]))
+        mo, vo = O.predict(X[:32])
+        rt = RTOL[dtype]
+        assert np.abs(mv.mean.double().cpu().numpy() - mo).max() <= rt * np.abs(mo).max()
+        assert np.abs(mv.variance.double().cpu().numpy() - vo).max() <= rt * vo.max()
+        # an out-of-grid point inside the batch is reported by the same call; the model stays consistent
+        bad = Xt[:q].clone(); bad[5, 1] = 3.0
+        with pytest.raises(RuntimeError, match="out of bounds"):
+            a.stream_step(bad, yt[:q])
+        assert a.num_data == n0 + q * steps + q - 1
+        # dense regime: plain fallback
+        c = FixedNoiseOnlineSKIGP(Xt[:50, :2], yt[:50], None, grid_bounds=gb[:2], grid_size=8, learn_additional_noise=True).eval()
+        mc = c.stream_step(Xt[50:60, :2].contiguous(), yt[50:60])
+        assert mc.shape == (10,) and c.num_data == 60
