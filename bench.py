@@ -246,6 +246,8 @@ def main():
                         lib.wiski_prof_start(ctypes.c_int32(256))
                     _, it = step(Xs[t * q:(t + 1) * q], ys[t * q:(t + 1) * q])
                     iters.append(it)
+                    if k == K - 1 and world == 1:
+                        model._finish_pending()             # a block ends with its last refresh converged, inside the timed region
                     if sampled:
                         # step() returned from the solver's convergence poll, which is ordered after every SpMV of the step
                         tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
@@ -260,7 +262,8 @@ def main():
             dist.all_reduce(bt, op=dist.ReduceOp.MAX)
         return model, upd, bt.tolist(), iters, ms_sum, n_launch
 
-    with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), torch.no_grad():
+    with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), settings.deferred_refresh(True), \
+            torch.no_grad():
         # headline: the configured stream; N > 1: the exchange the cost model picks ("auto")
         model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=True)
         R = len(block_s)

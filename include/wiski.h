@@ -38,6 +38,7 @@ extern "C" {
 #define WISKI_E_LAUNCH (-2)   /* hip launch or runtime error               */
 #define WISKI_E_WORKSPACE (-3) /* workspace too small                      */
 #define WISKI_E_NOTCONV (-4)  /* wiski_pcg hit max_iter (result still written) */
+#define WISKI_PENDING 1       /* wiski_pcg_async / wiski_stream_step: the solve was started, its first poll is in flight */
 
 #define WISKI_MAX_DIM 4
 
@@ -196,6 +197,22 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
 int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream);
 int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream);
 
+/* Deferred convergence poll.  wiski_pcg_async_* = wiski_pcg_* plus a host-side handle (zero-initialised by the caller,
+ * released with wiski_pcg_async_free) and a mode: 0 = as wiski_pcg; 1 = START: queue the iterations up to the first poll
+ * (first_check), queue the poll, return WISKI_PENDING without waiting -- the host gets its time back while the GPU iterates;
+ * 2 = RESUME with the same arguments: wait for that poll (normally long over), finish with synchronous polls if it had not
+ * converged, fill h_iters / h_relres / h_err, return 0 / WISKI_E_NOTCONV.  Between START and RESUME nothing else may touch
+ * (d_U, d_Z, d_R, d_work) or the system (d_A, d_RHS); the handle owns its own poll buffer. */
+typedef struct wiski_pcg_async {
+  int32_t state;   /* 0 idle, 1 a started solve is waiting to be resumed */
+  int32_t it;      /* iterations queued so far */
+  int64_t seq;     /* sequence number of the poll in flight */
+  void* poll;      /* opaque: the handle's pinned poll buffer */
+} wiski_pcg_async;
+int wiski_pcg_async_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
+int wiski_pcg_async_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
+int wiski_pcg_async_free(wiski_pcg_async* handle);
+
 /* One streaming step in one call (single output, symmetric half stencil): the launches of wiski_gather (predictive mean of
  * the incoming batch under the CURRENT posterior mean d_U, written to d_mean_out [q]; skipped when NULL),
  * wiski_scatter_stats_cnt (absorb the q points into b / A_half / cnt / stats; with carry != 0 the residual d_R is kept
@@ -203,7 +220,11 @@ int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_
  * back to back on `stream` -- what BFN:204-210, BFN:258-273 and BFN:368-383 do in three Python calls.  d_wa / d_wb /
  * d_noise [q]: the per-point weights 1/clamp(noise,1e-7), 1/noise and the noise itself (ones for unit noise).  The struct
  * carries the model-resident pointers and solver parameters (meaning as in wiski_pcg); first_check / h_iters / h_relres /
- * h_err as in wiski_pcg. */
+ * h_err as in wiski_pcg.
+ * handle != NULL selects the deferred form: the call first RESUMEs the solve a previous call started (its iteration count,
+ * residual and out-of-grid flag land in h_iters / h_relres / h_err; h_resumed = 1), then queues gather + scatter for the new
+ * batch, then STARTs the new solve (defer != 0: returns WISKI_PENDING) or runs it to convergence (defer == 0).  q = 0 with
+ * defer = 0 just finishes a pending solve.  So the host-language work between two steps overlaps the GPU's CG iterations. */
 typedef struct wiski_stream_args_f32 {
   float* d_A_half; float* d_b; float* d_cnt; double* d_stats; int32_t* d_err;     /* statistics + out-of-grid flag      */
   float* d_U; float* d_Z; float* d_R;                                              /* posterior-mean state (in place)    */
@@ -216,8 +237,8 @@ typedef struct wiski_stream_args_f64 {
   const double* d_tcol; double kscale; const double* d_evec; const double* d_evec2; const double* d_eval; double shift;
   double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
 } wiski_stream_args_f64;
-int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* args, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream);
-int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* args, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream);
+int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* args, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
+int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* args, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

@@ -1506,11 +1506,19 @@ template <typename real>
 static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol, real kscale, const real* d_evec, const real* d_evec2, const real* d_eval,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
-                    const int32_t* d_err, int32_t* h_err, int32_t a_sym, real* d_R, void* stream) {
+                    const int32_t* d_err, int32_t* h_err, int32_t a_sym, real* d_R, void* stream, wiski_pcg_async* as = nullptr,
+                    int32_t amode = 0) {
+  // amode (with `as`): 0 = run to convergence; 1 = START: queue the iterations up to the first convergence poll, queue the
+  // poll and return WISKI_PENDING without waiting for it; 2 = RESUME a started solve (same arguments): wait for that poll
+  // (normally long over), finish with synchronous polls if it was not converged.  Nothing but the resume call may use
+  // (U, Z, R, workspace) in between.
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
   if (!d_A || !d_RHS || !d_U || !d_Z || !d_work || k < 1 || max_iter < 1) return WISKI_E_BADARG;
+  if (amode != 0 && !as) return WISKI_E_BADARG;
+  const bool resume = amode == 2;
+  if (resume && as->state != 1) return WISKI_E_BADARG;
   const bool spectral = d_evec != nullptr && d_eval != nullptr;
   if (!spectral && !d_tcol) return WISKI_E_BADARG;
   if (work_bytes < pcg_ws_bytes(G.m, k, max_iter, (int)sizeof(real))) return WISKI_E_WORKSPACE;
@@ -1542,7 +1550,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   auto spmv_narrow = [&](const real* v, const real* add, real beta, real* out, double* dots) {
     return sym ? launch_spmv_sym<real>(G, d_A, v, k, add, beta, out, dots, s) : launch_spmv<real>(G, d_A, v, k, add, beta, out, dots, s);
   };
-  {
+  if (!resume) {
     const int64_t nscal = PcgScal::doubles(k, max_iter), nvec = zl ? (int64_t)k * m : 0;
     int64_t zb = ((nscal > nvec ? nscal : nvec) + 255) / 256;
     if (zb > 1024) zb = 1024;
@@ -1556,7 +1564,9 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   if (vb < 1) vb = 1;
   dim3 vgrid((unsigned)vb, (unsigned)k);   // one 16-byte group per thread
 
-  if (warm == 2) {
+  if (resume) {
+    // the start call queued everything up to (and including) the poll of iteration as->it
+  } else if (warm == 2) {
     // r0 carried over by the caller in d_R (wiski_scatter_stats_cnt's d_res): no A u product
     if (!d_R) return WISKI_E_BADARG;
     if (wide) hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)nullptr, (real*)nullptr, 0, 0, 1, r, S);
@@ -1582,19 +1592,39 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   double err_seen = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return WISKI_E_LAUNCH;
-  std::lock_guard<std::mutex> poll_lock(g_poll_mu);
-  WiskiPoll& P = g_polls[dev];
+  // a deferred solve owns a poll buffer of its own (nobody else may publish into it between start and resume)
+  std::unique_lock<std::mutex> poll_lock(g_poll_mu, std::defer_lock);
+  WiskiPoll* Pp = nullptr;
+  if (as) {
+    if (!as->poll) as->poll = new WiskiPoll();
+    Pp = static_cast<WiskiPoll*>(as->poll);
+  } else {
+    poll_lock.lock();
+    Pp = &g_polls[dev];
+  }
+  WiskiPoll& P = *Pp;
   if (poll_reserve(P, k) != WISKI_OK) return WISKI_E_LAUNCH;
-  auto fetch = [&](int slot) -> int {
-    const long long seq = ++P.seq;
-    hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq);
-    if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
-    if (int prc = poll_wait(P, seq, s)) return prc;
+  auto collect = [&]() {
     for (int c = 0; c < k; ++c) {
       h_rn0[c] = P.h[1 + c];
       h_rn[c] = P.h[1 + k + c];
     }
     err_seen = P.h[1 + 2 * k];
+  };
+  bool deferred = false;      // START mode: the first poll has been queued but not waited for
+  auto fetch = [&](int slot) -> int {
+    const long long seq = ++P.seq;
+    hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq);
+    if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
+    if (amode == 1) {
+      as->state = 1;
+      as->it = slot;
+      as->seq = seq;
+      deferred = true;
+      return WISKI_OK;
+    }
+    if (int prc = poll_wait(P, seq, s)) return prc;
+    collect();
     return WISKI_OK;
   };
   auto converged = [&]() {
@@ -1605,6 +1635,15 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
 
   int it = 0;
   bool done = false;
+  if (resume) {
+    it = as->it;
+    as->state = 0;
+    if (int prc = poll_wait(P, as->seq, s)) return prc;
+    collect();
+    done = converged();
+    first_check = it;          // from here on: a poll after every check_every-th further iteration
+    amode = 0;
+  }
   if (first_check < 1) first_check = check_every;
   if (first_check > max_iter) first_check = max_iter;
   // host convergence polls: after `first_check` iterations, then every `check_every`
@@ -1636,6 +1675,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
         flush_update();
         rc = fetch(it);
         if (rc) return rc;
+        if (deferred) return WISKI_PENDING;
         done = converged();
       }
       continue;
@@ -1672,6 +1712,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (due(it)) {
       rc = fetch(it);
       if (rc) return rc;
+      if (deferred) return WISKI_PENDING;
       done = converged();
     }
   }
@@ -1763,6 +1804,23 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
   int64_t m = 1;
   for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
   return pcg_ws_bytes((int)m, k, max_iter, elem_size);
+}
+int wiski_pcg_async_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s, wiski_pcg_async* as, int32_t amode) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode);
+}
+int wiski_pcg_async_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* R, void* s, wiski_pcg_async* as, int32_t amode) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode);
+}
+int wiski_pcg_async_free(wiski_pcg_async* as) {
+  if (!as) return WISKI_E_BADARG;
+  if (as->poll) {
+    WiskiPoll* P = static_cast<WiskiPoll*>(as->poll);
+    if (P->h) (void)hipHostFree(P->h);
+    delete P;
+    as->poll = nullptr;
+  }
+  as->state = 0;
+  return WISKI_OK;
 }
 int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s) {
   return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s);

@@ -27,21 +27,36 @@ static int scatter1(const wiski_grid* g, const float* x, const float* y, const f
 static int scatter1(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, double* b, double* A, double* cnt, const double* u, double* res, double* st, int32_t* err, void* s) {
   return wiski_scatter_stats_cnt_f64(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
 }
-static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s) {
-  return wiski_pcg_f32(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol, a->max_iter,
-                       a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s);
+static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
+                wiski_pcg_async* as, int mode) {
+  return wiski_pcg_async_f32(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol,
+                             a->max_iter, a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s, as, mode);
 }
-static int pcg1(const wiski_grid* g, const wiski_stream_args_f64* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s) {
-  return wiski_pcg_f64(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol, a->max_iter,
-                       a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s);
+static int pcg1(const wiski_grid* g, const wiski_stream_args_f64* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
+                wiski_pcg_async* as, int mode) {
+  return wiski_pcg_async_f64(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol,
+                             a->max_iter, a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s, as, mode);
 }
 
 template <typename real>
 static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<real>::type* a, const real* d_x, const real* d_y, const real* d_wa,
                             const real* d_wb, const real* d_noise, int64_t q, real* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters,
-                            double* h_relres, int32_t* h_err, void* stream) {
-  if (!grid || !a || !d_x || !d_y || !d_wa || !d_wb || !d_noise || q < 0 || !a->d_A_half || !a->d_b || !a->d_U || !a->d_Z || !a->d_R) return WISKI_E_BADARG;
+                            double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* as, int32_t defer, int32_t* h_resumed) {
+  if (!grid || !a || q < 0 || !a->d_A_half || !a->d_b || !a->d_U || !a->d_Z || !a->d_R) return WISKI_E_BADARG;
+  if (q > 0 && (!d_x || !d_y || !d_wa || !d_wb || !d_noise)) return WISKI_E_BADARG;
   int rc = WISKI_OK;
+  if (h_resumed) *h_resumed = 0;
+  if (as && as->state == 1) {
+    // finish the solve the previous call started BEFORE anything reads U (the gather) or changes the system (the scatter)
+    rc = pcg1(grid, a, 2, first_check, h_iters, h_relres, h_err, stream, as, 2);
+    if (h_resumed) *h_resumed = 1;
+    if (rc != WISKI_OK && rc != WISKI_E_NOTCONV) return rc;
+    if (q == 0) return rc;
+    if (h_err && *h_err) return rc;          // out-of-grid points in the previous batch: let the caller deal with them first
+  } else if (q == 0 && as) {
+    return WISKI_OK;
+  }
+  const int resumed_rc = rc;
   if (q > 0) {
     if (d_mean_out) {
       rc = gather1(grid, d_x, q, a->d_U, d_mean_out, a->d_err, stream);
@@ -51,14 +66,21 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
                   a->d_err, stream);
     if (rc) return rc;
   }
-  return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream);
+  if (!as) return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream, nullptr, 0);
+  if (defer) {
+    int32_t it2 = 0, e2 = 0;
+    double r2 = 0;
+    rc = pcg1(grid, a, carry ? 2 : 1, first_check, &it2, &r2, &e2, stream, as, 1);      // outputs of THIS solve arrive with the next call
+    return rc == WISKI_PENDING ? (resumed_rc == WISKI_E_NOTCONV ? WISKI_E_NOTCONV : WISKI_PENDING) : rc;
+  }
+  return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream, as, 0);
 }
 
 extern "C" {
-int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* a, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream) {
-  return stream_step_impl<float>(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, d_mean_out, carry, first_check, h_iters, h_relres, h_err, stream);
+int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* a, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* as, int32_t defer, int32_t* h_resumed) {
+  return stream_step_impl<float>(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, d_mean_out, carry, first_check, h_iters, h_relres, h_err, stream, as, defer, h_resumed);
 }
-int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* a, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream) {
-  return stream_step_impl<double>(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, d_mean_out, carry, first_check, h_iters, h_relres, h_err, stream);
+int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* a, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* as, int32_t defer, int32_t* h_resumed) {
+  return stream_step_impl<double>(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, d_mean_out, carry, first_check, h_iters, h_relres, h_err, stream, as, defer, h_resumed);
 }
 }

@@ -301,6 +301,10 @@ class _StreamArgs64(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double if t is ctypes.c_float else t) for n, t in _StreamArgs32._fields_]
 
 
+class _PcgAsync(ctypes.Structure):
+    _fields_ = [("state", ctypes.c_int32), ("it", ctypes.c_int32), ("seq", ctypes.c_int64), ("poll", ctypes.c_void_p)]
+
+
 class StreamStep:
     """Prepared call of ``wiski_stream_step`` (include/wiski.h): the model-resident pointers are marshalled once, a step only
     passes the batch.  Returns (iterations, relative residual, raw out-of-grid flag, converged)."""
@@ -318,6 +322,19 @@ class StreamStep:
         self.fn = _hip.fn("wiski_stream_step", dtype)
         self.it, self.herr, self.rr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0)
         self.eig_keep = None
+        self.handle = _PcgAsync()              # deferred-poll state (include/wiski.h: wiski_pcg_async)
+        self.resumed = ctypes.c_int32(0)
+
+    @property
+    def pending(self):
+        return self.handle.state == 1
+
+    def __del__(self):
+        try:
+            if self.handle.poll:
+                _hip.lib().wiski_pcg_async_free(ctypes.byref(self.handle))
+        except Exception:  # noqa: BLE001
+            pass
 
     def set_solver(self, kscale, eig, shift, tol, check_every):
         a = self.args
@@ -327,16 +344,25 @@ class StreamStep:
         a.d_evec, a.d_eval = evec.data_ptr(), evals.data_ptr()
         a.d_evec2 = evec2.data_ptr() if evec2 is not None else None
 
-    def __call__(self, x, y, wa, wb, noise, mean_out, carry, first_check):
-        q = x.shape[0]
+    def __call__(self, x, y, wa, wb, noise, mean_out, carry, first_check, defer=False):
+        """Without deferral: (iterations, relres, out-of-grid flag, converged) of THIS step's solve.  With `defer` (or a pending
+        solve): the same four values describe the solve a previous call started (None when there was none) and the fifth
+        element says whether this step's solve is now pending."""
+        q = x.shape[0] if x is not None else 0
+        use_handle = defer or self.pending
+        self.herr.value = 0
         rc = self.fn(self.grid.ref, ctypes.byref(self.args), _hip.dptr(x), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise),
                      ctypes.c_int64(q), _hip.dptr(mean_out), ctypes.c_int32(int(carry)), ctypes.c_int32(int(first_check)), ctypes.byref(self.it),
-                     ctypes.byref(self.rr), ctypes.byref(self.herr), _hip.stream_ptr(self.device))
+                     ctypes.byref(self.rr), ctypes.byref(self.herr), _hip.stream_ptr(self.device),
+                     ctypes.byref(self.handle) if use_handle else None, ctypes.c_int32(int(defer)), ctypes.byref(self.resumed))
         if rc == -4:
             warnings.warn(f"wiski_pcg stopped at max_iter={self.args.max_iter} with relative residual {self.rr.value:.3e}", RuntimeWarning)
-        else:
+        elif rc != 1:
             _hip.check(rc, "wiski_stream_step")
-        return int(self.it.value), float(self.rr.value), int(self.herr.value), rc == 0
+        res = (int(self.it.value), float(self.rr.value), int(self.herr.value), rc != -4)
+        if not use_handle:
+            return res
+        return (res if self.resumed.value else None), self.pending
 
 
 def kron_eigen(grid, tcol, profiles=None):

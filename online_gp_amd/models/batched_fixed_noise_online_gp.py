@@ -208,6 +208,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         per point).  With `half_delta` given (data-parallel path) the increments go to those
         buffers instead, for the caller to all-reduce and add; `res_delta` ([out, m], zeroed) then receives this shard's
         innovation W^T (wb y - wa (W U)) of the carried residual, to be all-reduced and added to R alongside."""
+        self._finish_pending()
         X = X.reshape(-1, self._grid.d).to(self._device, self._dtype).contiguous()
         Y = Y.to(self._device, self._dtype)
         if Y.dim() == 1:
@@ -277,6 +278,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """Raise like gpytorch's grid check if any point seen so far was outside the
         grid (the kernels only set a device flag; this is the one host sync; the
         device part of the noise-weight sum rides on the same transfer)."""
+        self._finish_pending()
         if self._wsum_dirty:
             vals = torch.cat([self._err.double(), self._wsum_dev]).tolist()
             self._wsum_dev_host, self._wsum_dirty = vals[1:], False
@@ -410,6 +412,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """pred_mean = (Kt^-1 + A)^-1 W^T D^-1 y  [out, m, 1]   (:368-383), and the
         lazy pred_cov operator(s).  The mean solve is warm-started from the
         previous solution (U, Z) after every streaming update."""
+        self._finish_pending()
         self._apply_pending_rank_update()
         pc = self._memo.get("prediction_cache")
         if pc is not None:
@@ -645,6 +648,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         the per-step host work reduced to bookkeeping.  Unit noise.  Returns the mean [n] (or None)."""
         st = self._stream_fast_state(X, Y)
         if st is None:
+            self._finish_pending()
             mean = None
             if want_mean:
                 with settings.skip_posterior_variances(True):
@@ -668,18 +672,47 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         carry = ms.get("R_ok", False) and self._refresh_count % 16 != 0
         step.args.shift = float(self._wsum[0]) / pst["norm"]
         y1 = Y.reshape(-1)
-        it, rel, flag, conv = step(X, y1 if y1.is_contiguous() else y1.contiguous(), ones, ones, ones, mean, carry, fc)
+        y1 = y1 if y1.is_contiguous() else y1.contiguous()
+        if settings.deferred_refresh.on() or step.pending:
+            prev, pending = step(X, y1, ones, ones, ones, mean, carry, fc, defer=settings.deferred_refresh.on())
+            self._pending_step = step if pending else None
+            if prev is not None:
+                if prev[2]:                              # the PREVIOUS batch held out-of-grid points: this one was not queued at all
+                    self._wsum_host[0] -= float(q)
+                    self.num_data = self.num_data - q
+                    self._refresh_count -= 1
+                self._note_solve(ms, prev, getattr(self, "_pending_fc", 0))
+            self._pending_fc = fc
+            if not pending:                              # deferral switched off meanwhile: this call ran to convergence
+                self._note_solve(ms, (step.it.value, step.rr.value, step.herr.value, True), fc)
+            return mean
+        self._note_solve(ms, step(X, y1, ones, ones, ones, mean, carry, fc), fc)
+        return mean
+
+    def _note_solve(self, ms, res, fc):
+        """Host bookkeeping after a refresh: iteration history for the poll placement, residual validity, out-of-grid error."""
+        it, rel, flag, conv = res
         if fc:
             self._probe_down = it <= fc and fc > 1
         self._last_iters = [it]
-        ms["R_ok"] = conv
+        ms["R_ok"] = bool(conv)
         pc = self._memo.get("prediction_cache")
         if pc is not None:
             pc["cg_iters"] = [it]
         if flag:
             ms["R_ok"] = False
             self._raise_out_of_bounds(flag)
-        return mean
+
+    def _finish_pending(self):
+        """A deferred refresh (settings.deferred_refresh) is still in flight: wait for its poll, finish the solve if needed."""
+        step = self.__dict__.get("_pending_step")
+        if step is None:
+            return
+        self._pending_step = None
+        if step.pending:
+            prev, _ = step(None, None, None, None, None, None, 0, 0, defer=False)
+            if prev is not None and self._mean_state is not None:
+                self._note_solve(self._mean_state, prev, getattr(self, "_pending_fc", 0))
 
     def _stream_fast_state(self, X, Y):
         """(prepared StreamStep, mean state, preconditioner state) when the one-call streaming step applies, else None."""

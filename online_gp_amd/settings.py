@@ -81,6 +81,16 @@ class skip_logdet_forward(_feature_flag):
     _state = False
 
 
+class deferred_refresh(_feature_flag):
+    """``stream_step`` returns as soon as its launches are queued -- the first convergence poll of the warm-started solve is
+    left in flight and looked at by the NEXT call that needs the posterior (a following ``stream_step``, ``prediction_cache``,
+    ``posterior`` ...), which also finishes the solve should that poll say "not converged".  The host-side work between two
+    steps then overlaps the GPU's CG iterations.  Results are identical; the iteration count and the out-of-grid error of a
+    step surface one call later."""
+
+    _state = False
+
+
 class float32_grid(_feature_flag):
     """gpytorch builds the inducing grid in float32 and promotes it; the spec'd geometry here is float64.
     On = reproduce the quirk: first grid point and spacing come from a float32 ``linspace(lo - delta, hi + delta, g)``.

@@ -532,3 +532,47 @@ def test_stream_step_one_call_equals_the_three_python_calls(dtype, tol):
         c = FixedNoiseOnlineSKIGP(Xt[:50, :2], yt[:50], None, grid_bounds=gb[:2], grid_size=8, learn_additional_noise=True).eval()
         mc = c.stream_step(Xt[50:60, :2].contiguous(), yt[50:60])
         assert mc.shape == (10,) and c.num_data == 60
+
+
+def test_deferred_refresh_gives_the_same_stream_and_reports_one_call_later():
+    """settings.deferred_refresh: stream_step leaves the first convergence poll in flight (wiski_stream_step with a
+    wiski_pcg_async handle); the next consumer resumes it.  Same posterior as the synchronous stream, `prediction_cache` /
+    `posterior` finish a pending solve, an out-of-grid batch is reported by the following call and leaves the model
+    consistent."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(13)
+    d, g, n0, q, steps = 3, 20, 400, 128, 24
+    X = rng.uniform(-1, 1, (n0 + q * steps, d)); y = np.sin(2 * X[:, 0]) * np.cos(X[:, 1]) + 0.3 * X[:, 2] + 0.1 * rng.standard_normal(X.shape[0])
+    Xt, yt = torch.as_tensor(X, device=DEV, dtype=torch.float32), torch.as_tensor(y, device=DEV, dtype=torch.float32)[:, None]
+    gb = torch.tensor([[-1.1, 1.1]] * d, dtype=torch.float64)
+    with settings.cg_tolerance(1e-5), torch.no_grad():
+        a = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        b = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        a.prediction_cache; b.prediction_cache
+        pend = 0
+        for s in range(steps):
+            sl = slice(n0 + s * q, n0 + (s + 1) * q)
+            with settings.deferred_refresh(True):
+                ma = a.stream_step(Xt[sl], yt[sl])
+            pend += a.__dict__.get("_pending_step") is not None
+            mb = b.stream_step(Xt[sl], yt[sl])
+            assert float((ma - mb).abs().max()) <= 2e-3 * float(mb.abs().max())
+            if s % 7 == 3:
+                va = a(Xt[:8]).mean                      # a consumer in between: finishes the pending solve first
+                assert a.__dict__.get("_pending_step") is None
+                assert float((va - b(Xt[:8]).mean).abs().max()) <= 2e-3 * float(va.abs().max())
+        assert pend >= steps - 4
+        pa, pb = a.prediction_cache["pred_mean"], b.prediction_cache["pred_mean"]
+        assert float((pa - pb).abs().max()) <= 2e-3 * float(pb.abs().max())
+        assert a.num_data == b.num_data and torch.allclose(a._kernel_cache["_stats"], b._kernel_cache["_stats"], rtol=1e-9)
+        # out-of-grid batch: the error arrives with the next call, which is then not absorbed
+        bad = Xt[:q].clone(); bad[7, 0] = -5.0
+        n_before = a.num_data
+        with settings.deferred_refresh(True):
+            a.stream_step(bad, yt[:q])
+            with pytest.raises(RuntimeError, match="out of bounds"):
+                a.stream_step(Xt[q:2 * q], yt[q:2 * q])
+        assert a.num_data == n_before + q - 1
+        assert torch.isfinite(a(Xt[:8]).mean).all()
