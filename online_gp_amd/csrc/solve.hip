@@ -973,6 +973,46 @@ __global__ __launch_bounds__(256) void k_toeplitz_mode(const real* __restrict__ 
   }
 }
 
+// Innermost mode (post == 1, g <= 64): one 64-lane wave per grid line, lane = position in the line.  The line is loaded once
+// (coalesced) and the symmetric-Toeplitz product is a running pair of wavefront shifts:
+//   out_i = t_0 v_i + sum_{s >= 1} t_s (v_{i-s} + v_{i+s}),
+// v_{i-s} / v_{i+s} obtained from the previous step by one-lane shuffles (zeros shifted in at the line ends); the
+// coefficient t_s is wave-uniform.  g shuffles-up, g shuffles-down and 2 g VALU per line instead of g dependent L2 loads per
+// output.  DOT: dots[c] += sum_e w[c][e] * out[c][e].
+template <typename real, bool DOT>
+__global__ __launch_bounds__(256) void k_toeplitz_line_shfl(const real* __restrict__ tcol, int g, int m, const real* __restrict__ in, real scale,
+                                                            real* __restrict__ out, const real* __restrict__ wvec, double* __restrict__ dots) {
+  __shared__ double s_red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nlines = m / g;
+  const int c = blockIdx.y;
+  const int64_t cm = (int64_t)c * m;
+  double part = 0;
+  for (int line = blockIdx.x * 4 + wave; line < nlines; line += gridDim.x * 4) {
+    const int64_t e = cm + (int64_t)line * g + lane;
+    const bool live = lane < g;
+    const real v = live ? in[e] : (real)0;
+    real acc = tcol[0] * v;
+    real up = v, dn = v;                       // v_{i-s}, v_{i+s}
+    for (int sft = 1; sft < g; ++sft) {
+      up = __shfl_up(up, 1, 64);
+      dn = __shfl_down(dn, 1, 64);
+      if (lane == 0) up = (real)0;             // zeros enter at the line ends (lanes >= g hold zeros already)
+      if (lane == 63) dn = (real)0;
+      acc += tcol[sft] * (up + dn);
+    }
+    if (live) {
+      acc *= scale;
+      out[e] = acc;
+      if (DOT) part += (double)wvec[e] * (double)acc;
+    }
+  }
+  if (DOT) {
+    const double tot = block_reduce_sum(part, s_red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dots + c, tot);
+  }
+}
+
 // out = scale * Kuu V ; tmp is a k*m scratch; out must not alias V.
 template <typename real>
 static int launch_kron(const GridDev<real>& G, const real* tcol, const real* V, int k, real scale, real* tmp, real* out, const real* wvec,
@@ -988,7 +1028,16 @@ static int launch_kron(const GridDev<real>& G, const real* tcol, const real* V, 
     const bool last = q == G.d - 1;
     real* dst = ((G.d - 1 - q) % 2 == 0) ? out : tmp;
     const real sc = last ? scale : (real)1;
-    if (last && dots)
+    const int gq = G.g[q], post = G.stride[q];
+    // innermost mode: wavefront shuffles along the line; the strided modes keep the one-thread-per-output kernel (its g reads per
+    // output are coalesced along the fast index and L2-resident; an LDS-tiled thread-per-line variant measured 2x slower)
+    if (post == 1 && gq <= 64) {
+      int blocks = (G.m / gq + 3) / 4;
+      if (blocks > 2048) blocks = 2048;
+      dim3 lg((unsigned)blocks, (unsigned)k);
+      if (last && dots) hipLaunchKernelGGL((k_toeplitz_line_shfl<real, true>), lg, dim3(256), 0, s, tcol + toff, gq, G.m, src, sc, dst, wvec, dots);
+      else hipLaunchKernelGGL((k_toeplitz_line_shfl<real, false>), lg, dim3(256), 0, s, tcol + toff, gq, G.m, src, sc, dst, wvec, dots);
+    } else if (last && dots)
       hipLaunchKernelGGL((k_toeplitz_mode<real, true>), grd, dim3(256), 0, s, tcol + toff, G.g[q], G.stride[q], G.m, src, sc, dst, wvec, dots);
     else
       hipLaunchKernelGGL((k_toeplitz_mode<real, false>), grd, dim3(256), 0, s, tcol + toff, G.g[q], G.stride[q], G.m, src, sc, dst, wvec, dots);
