@@ -115,24 +115,46 @@ template <typename real, int LPR>
 __global__ __launch_bounds__(256) void k_gather_ell(const int32_t* __restrict__ idx, const real* __restrict__ val, int64_t n,
                                                     const real* __restrict__ v, real* __restrict__ out) {
   constexpr int RPB = 256 / LPR;  // rows per block pass
+  constexpr int U = 4;            // rows in flight per lane group: all idx / val loads of a pass are issued before the first gather
   const int sub = threadIdx.x % LPR;
   const int rloc = threadIdx.x / LPR;
-  for (int64_t row = (int64_t)blockIdx.x * RPB + rloc; row < n; row += (int64_t)gridDim.x * RPB) {
-    const int64_t base = (row * LPR + sub) * 4;
-    int4 id = *reinterpret_cast<const int4*>(idx + base);
-    real a0, a1, a2, a3;
-    if constexpr (sizeof(real) == 4) {
-      float4 vv = *reinterpret_cast<const float4*>(val + base);
-      a0 = vv.x; a1 = vv.y; a2 = vv.z; a3 = vv.w;
-    } else {
-      double2 v0 = *reinterpret_cast<const double2*>(val + base);
-      double2 v1 = *reinterpret_cast<const double2*>(val + base + 2);
-      a0 = v0.x; a1 = v0.y; a2 = v1.x; a3 = v1.y;
-    }
-    real acc = a0 * v[id.x] + a1 * v[id.y] + a2 * v[id.z] + a3 * v[id.w];
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  typedef real vec4u __attribute__((ext_vector_type(4), aligned(4)));
+  for (int64_t row0 = (int64_t)blockIdx.x * RPB + rloc; row0 < n; row0 += U * stride) {
+    int4 id[U];
+    real a[U][4];
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (sub == 0) out[row] = acc;
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = row0 + u * stride;
+      const int64_t base = ((row < n ? row : row0) * LPR + sub) * 4;
+      typedef int nt_i4 __attribute__((ext_vector_type(4)));
+      typedef real nt_r4 __attribute__((ext_vector_type(4)));
+      // idx / val are read exactly once: non-temporal, so the stream does not push v out of L2
+      const nt_i4 qi = __builtin_nontemporal_load(reinterpret_cast<const nt_i4*>(idx + base));
+      const nt_r4 qv = __builtin_nontemporal_load(reinterpret_cast<const nt_r4*>(val + base));
+      id[u] = make_int4(qi[0], qi[1], qi[2], qi[3]);
+      a[u][0] = qv[0]; a[u][1] = qv[1]; a[u][2] = qv[2]; a[u][3] = qv[3];
+    }
+    real acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // the 4 taps of a lane are the innermost digits of one tap prefix: 4 CONSECUTIVE grid indices except in the one-hot
+      // boundary cells, so v is fetched with one (dword-aligned) 16-byte load instead of four gathers
+      const int4 q = id[u];
+      if (q.y == q.x + 1 && q.z == q.x + 2 && q.w == q.x + 3) {
+        const vec4u g4 = *reinterpret_cast<const vec4u*>(v + q.x);
+        acc[u] = a[u][0] * g4[0] + a[u][1] * g4[1] + a[u][2] * g4[2] + a[u][3] * g4[3];
+      } else {
+        acc[u] = a[u][0] * v[q.x] + a[u][1] * v[q.y] + a[u][2] * v[q.z] + a[u][3] * v[q.w];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, 64);
+      const int64_t row = row0 + u * stride;
+      if (sub == 0 && row < n) out[row] = acc[u];
+    }
   }
 }
 

@@ -101,5 +101,15 @@ int main() {
       });
     }
   }
+  // a read that does not fit the 256 MB Infinity Cache: the practical HBM ceiling (what k_gather_ell's 541 MB stream can hope for)
+  for (int blocks : {2048, 4096, 8192}) {
+    const size_t n16 = ((size_t)541 << 20) / 16;
+    std::vector<float> t;
+    for (int r = 0; r < 20; ++r) hipExtLaunchKernelGGL(k_read16, dim3(blocks), dim3(256), 0, 0, ev[2 * r], ev[2 * r + 1], 0, (const float4*)big, n16, sink);
+    hipDeviceSynchronize();
+    for (int r = 3; r < 20; ++r) { float ms; hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]); t.push_back(ms * 1e3f); }
+    const double us = med(t);
+    printf("plain 16 B loads of 541 MiB, %d x 256 threads : median %7.2f us -> %5.2f TB/s\n", blocks, us, n16 * 16 / us / 1e6);
+  }
   return 0;
 }
