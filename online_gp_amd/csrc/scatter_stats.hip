@@ -11,6 +11,38 @@
 // Tap values are exchanged through LDS (broadcast reads, conflict-free).
 // This is the full offset-major form A_st[o][i] (all 7^d offsets, T^2 atomics per point); the model itself
 // keeps the symmetric half (k_scatter_stats_sym below: T(T+1)/2 atomics, ~5x faster).
+// stats[0] += sum wb y^2, stats[1] += sum log(noise) over the points inside the grid.  Atomics of many blocks on one address
+// serialise at the memory side (~12 ns each): with one pair per block the 1 024 blocks of a q = 4 096 absorb spent 25 us of
+// their 87 us queueing on these two doubles.  So a few designated blocks sweep the points once more (x, y, wb, noise: 24 B per
+// point) and issue one pair each.
+template <typename real, int D>
+__device__ __forceinline__ void scatter_stats_pass(const GridDev<real>& G, const real* __restrict__ x, const real* __restrict__ y,
+                                                   const real* __restrict__ wb, const real* __restrict__ noise, int64_t n,
+                                                   double* __restrict__ stats, double* s_red) {
+  int64_t want = n / 512;
+  want = want < 1 ? 1 : (want > 64 ? 64 : want);
+  const int ns = (int64_t)gridDim.x < want ? (int)gridDim.x : (int)want;
+  if ((int)blockIdx.x >= ns) return;                       // block-uniform
+  double c_acc = 0, ld_acc = 0;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)ns * blockDim.x) {
+    real xp[D], w[D][4];
+    int j0[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) xp[q] = x[p * D + q];
+    if (point_stencil<real, D>(G, xp, j0, w)) {
+      const double yp = (double)y[p];
+      c_acc += yp * yp * (double)wb[p];
+      ld_acc += log((double)noise[p]);
+    }
+  }
+  const double c_tot = block_reduce_sum(c_acc, s_red);
+  const double ld_tot = block_reduce_sum(ld_acc, s_red);
+  if (threadIdx.x == 0 && (c_tot != 0 || ld_tot != 0)) {
+    unsafeAtomicAdd(stats + 0, c_tot);
+    unsafeAtomicAdd(stats + 1, ld_tot);
+  }
+}
+
 template <typename real, int D>
 __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const real* __restrict__ x, const real* __restrict__ y,
                                                        const real* __restrict__ wa, const real* __restrict__ wb,
@@ -29,7 +61,6 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
 #pragma unroll
   for (int q = 0; q < D; ++q) R *= 7;
   const int center = (R - 1) / 2;
-  double c_acc = 0, ld_acc = 0;
   bool bad = false;
 
   for (int64_t base = (int64_t)blockIdx.x * PPB; base < n; base += (int64_t)gridDim.x * PPB) {
@@ -52,10 +83,6 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
       yp = y[p];
       wap = wa[p];
       wbp = wb[p];
-      if (sub == 0 && inside) {
-        c_acc += (double)yp * (double)yp * (double)wbp;
-        ld_acc += log((double)noise[p]);
-      }
     } else {
 #pragma unroll
       for (int q = 0; q < D; ++q) {
@@ -112,12 +139,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats(GridDev<real> G, const re
     }
     __syncthreads();
   }
-  double c_tot = block_reduce_sum(c_acc, s_red);
-  double ld_tot = block_reduce_sum(ld_acc, s_red);
-  if (threadIdx.x == 0 && (c_tot != 0 || ld_tot != 0)) {
-    unsafeAtomicAdd(stats + 0, c_tot);
-    unsafeAtomicAdd(stats + 1, ld_tot);
-  }
+  scatter_stats_pass<real, D>(G, x, y, wb, noise, n, stats, s_red);
   if (bad) atomicOr(err, 1);
 }
 
@@ -171,7 +193,6 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
       __syncthreads();
     }
   }
-  double c_acc = 0, ld_acc = 0;
   bool bad = false;
   const int64_t m = G.m;
   for (int64_t base = (int64_t)blockIdx.x * 4; base < n; base += (int64_t)gridDim.x * 4) {
@@ -194,10 +215,6 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
       yp = y[p];
       wap = wa[p];
       wbp = wb[p];
-      if (lane == 0 && inside) {
-        c_acc += (double)yp * (double)yp * (double)wbp;
-        ld_acc += log((double)noise[p]);
-      }
     } else {
 #pragma unroll
       for (int q = 0; q < D; ++q) {
@@ -268,12 +285,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
     }
     __syncthreads();
   }
-  double c_tot = block_reduce_sum(c_acc, s_red);
-  double ld_tot = block_reduce_sum(ld_acc, s_red);
-  if (threadIdx.x == 0 && (c_tot != 0 || ld_tot != 0)) {
-    unsafeAtomicAdd(stats + 0, c_tot);
-    unsafeAtomicAdd(stats + 1, ld_tot);
-  }
+  scatter_stats_pass<real, D>(G, x, y, wb, noise, n, stats, s_red);
   if (bad) atomicOr(err, 1);
 }
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ void spmmc_span(const real* __restrict__ p, F&& fn) {
       fn(std::integral_constant<int, I0>{}, p[I0]);
     } else {
       typedef real vec_t __attribute__((ext_vector_type(n), aligned(4)));
-      const vec_t blk = *reinterpret_cast<const vec_t*>(p + I0);
+      typedef real nvec_t __attribute__((ext_vector_type(n)));
+      const nvec_t blk = *reinterpret_cast<const vec_t*>(p + I0);   // under-aligned load, naturally aligned value
       spmmc_visit<real, n, I0>(blk, fn, std::make_integer_sequence<int, n>{});
     }
     spmmc_span<real, N, I0 + n>(p, fn);
