@@ -383,7 +383,7 @@ def main():
         # the reference's timed step at full fidelity (experiments/regression.py:48-54, OSR:56-146): evaluate = predictive
         # mean AND variance (rmse, nll) of the incoming batch, update = one Adam step on the Woodbury MLL + condition
         X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
-        Xr, yr = synth_stream(4096, d, 31337, dev, dtype, args.stream)
+        Xr, yr = synth_stream(8192, d, 31337, dev, dtype, args.stream)
         with settings.cg_tolerance(tol), settings.variance_cg_tolerance(3e-3):
             reg = OnlineSKIRegression(Identity(d), X0, y0, 1e-3, args.grid, 1.0)
             for qs, nst in ((1, 6), (64, 4), (1024, 3)):
@@ -400,6 +400,7 @@ def main():
             gp = reg.gp
             with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():
                 for qs in (1, 64):
+                    # the three model calls of the reference surface, one after the other
                     torch.cuda.synchronize(); tq = time.perf_counter()
                     for i in range(10):
                         xq, yq = Xr[2048 + i * qs:2048 + (i + 1) * qs], yr[2048 + i * qs:2048 + (i + 1) * qs]
@@ -407,7 +408,17 @@ def main():
                         gp.condition_on_observations(xq, yq, inplace=True)
                         gp.prediction_cache
                     torch.cuda.synchronize()
-                    extra[f"step_ms_q{qs}"] = (time.perf_counter() - tq) / 10 * 1e3
+                    extra[f"step_ms_q{qs}_three_calls"] = (time.perf_counter() - tq) / 10 * 1e3
+                    # the same step behind ONE C-ABI call with the deferred poll (what the headline loop uses)
+                    with settings.deferred_refresh(True):
+                        for rep in range(2):                                  # rep 0 warms the path
+                            torch.cuda.synchronize(); tq = time.perf_counter()
+                            for i in range(40):
+                                lo = 2048 + 640 + (rep * 40 + i) * qs
+                                gp.stream_step(Xr[lo:lo + qs], yr[lo:lo + qs])
+                            gp._finish_pending()
+                            torch.cuda.synchronize()
+                        extra[f"step_ms_q{qs}"] = (time.perf_counter() - tq) / 40 * 1e3
                 # large-batch throughput (SURVEY.md 8d lists q = 16384): the same full step, 6 steps of fresh points
                 qL = 16384
                 XL, yL = synth_stream(7 * qL, d, 5000, dev, dtype, args.stream)

@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 // or the LDS-window one (anything else with m % 4 == 0; up to 7 chunks).  WISKI_SYM_DMA=0 forces the latter,
 // WISKI_SYM_DMA_NST sets the ring depth (2 or 3) and WISKI_SYM_DMA_PARTS the work split (4..7): A/B hooks for
 // tools/spmv_probe.py.
-static int g_sym_dma = -1, g_sym_dma_nst = 0, g_sym_dma_parts = 6;
+static int g_sym_dma = -1, g_sym_dma_nst = 0, g_sym_dma_parts = 4;
 template <typename real>
 static inline bool sym_use_dma(const GridDev<real>& G, int k) {
   if constexpr (sizeof(real) != 4) return false;
@@ -817,8 +817,8 @@ static inline bool sym_use_dma(const GridDev<real>& G, int k) {
     g_sym_dma_nst = n ? atoi(n) : 2;
     if (g_sym_dma_nst != 2 && g_sym_dma_nst != 3) g_sym_dma_nst = 2;
     const char* pp = getenv("WISKI_SYM_DMA_PARTS");
-    g_sym_dma_parts = pp ? atoi(pp) : 6;
-    if (g_sym_dma_parts < 4 || g_sym_dma_parts > 7) g_sym_dma_parts = 6;
+    g_sym_dma_parts = pp ? atoi(pp) : 4;
+    if (g_sym_dma_parts < 4 || g_sym_dma_parts > 7) g_sym_dma_parts = 4;
   }
   return g_sym_dma != 0 && G.d == 3 && k == 1 && (G.m % 4) == 0 && symdma_lds_bytes(G.g[2], g_sym_dma_nst) <= 64 * 1024;
 }

@@ -6,10 +6,11 @@
 //
 //  * One 64-lane wave per workgroup owns 256 consecutive rows and one *part* of the half stencil: a run of
 //    groups (= values of the leading two stencil digits) that share the dim-0 offset d0 = 0..3.  nparts = 4
-//    takes whole d0 chunks (7, 7, 7 and 4 groups, the centre group with 4 reals per row first); nparts = 6
-//    (default) splits two of the 7-group chunks into 4 + 3, nparts = 7 all three.  Heavy parts come first in
-//    dispatch order and the light ones refill the slots the early finishers free.  Every part writes its own
-//    direct partial vector (+ one atomically accumulated transposed vector), so nparts + 1 partials in all.
+//    (default) takes whole d0 chunks (7, 7, 7 and 4 groups, the centre group with 4 reals per row first): 1 956 waves,
+//    all resident at once (8 per CU), the two chunks dispatched last at raised wave priority so that every chunk
+//    finishes together.  nparts = 5..7 split 7-group chunks into 4 + 3 (a second dispatch round refills the slots the
+//    early finishers free).  Every part writes its own direct partial vector (+ one atomically accumulated transposed
+//    vector), so nparts + 1 partials in all.
 //  * Every operand enters through `global_load_lds` (LDS-DMA, no VGPR destination): the 7 KB A_h tile of a
 //    group (256 rows x 7 reals, one contiguous span: 7 x 1 KiB wave instructions) goes into an NST-deep ring
 //    of LDS stages and the next tile is issued as soon as the current one has been copied to registers, so
@@ -22,13 +23,14 @@
 //    odd plane stride, so the lanes' 4-row groups update it conflict-free at any shift), is never moved, and
 //    is flushed once at the end with coalesced fire-and-forget atomics.
 //
-// Measured at 50^3 (MI355X, per-dispatch timestamps, tools/spmv_probe.py; A_h = 86 MB re-read every launch, i.e.
-// served by the 256 MB Infinity Cache): 20.0 us (nparts 6; 20.5 / 21.4 with 7 / 4; a 3-deep ring leaves 6 waves per CU
-// and is slower, 22.8) against 21.9 us for k_stencil_spmv4_sym.  Where the rest goes (tools/ubench/stream_ubench.hip,
-// WISKI_DMA_ABLATE builds, tools/dma_timing.py): an empty kernel already measures 4.0 us by the same clock; the same
-// DMA ring with nothing but the tile read-back moves the 84 MB in 12.0 us; this kernel without any arithmetic 16.7 us
-// (window copies, zeroing and read-back of the transposed window, unequal parts); the FMAs and v-window reads add 1.7,
-// the LDS window updates 1.4, the flush atomics 0.3.  Wave priorities (late parts first) help nparts = 4 (20.0) only.
+// Measured at 50^3 (MI355X, tools/spmv_probe.py; A_h = 86 MB re-read every launch, i.e. served by the 256 MB Infinity
+// Cache): 18.4..18.7 us back to back, 20.2 us per dispatch inside bench.py (k_stencil_spmv4_sym: 21.9).  History: plain
+// DMA loads, nparts 6: 20.0 (20.5 / 21.4 with 7 / 4 parts; a 3-deep ring leaves 6 waves per CU: 22.8); "sc0 nt" on the
+// A_h tiles: 19.8 (nparts 6), 19.2 (nparts 4); + wave priority for the late chunks: 18.4..18.7.  Where the rest goes
+// (tools/ubench/stream_ubench.hip, WISKI_DMA_ABLATE builds, tools/dma_timing.py): an empty kernel already measures
+// 4.0 us by the same clock; the bare DMA ring moves the 84 MB in 12.0 us (10.8 with sc0 nt); the wave timeline of this
+// kernel spans 15.1 us: 1.5 us until the first tile lands, ~8 us at 8.5..9.7 TB/s, a 3 us tail in which the chunks run
+// out (the 4-tile chunk ends at 8.5 us, the others at 11.6..13.2 median) and ~1.7 us of last-tile FMAs + window flush.
 //
 // Requires d == 3, m % 4 == 0.  part holds (nparts + 1) * m reals: part[y] = direct term of part y (plain stores),
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
@@ -37,6 +39,19 @@
 __device__ __forceinline__ void glds_b128(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+// the A_h stream: read once per launch, so "sc0 nt" (stream through the XCD's L2 without keeping the line; the bare ring of
+// tools/ubench/stream_ubench.hip moves 86 MB in 10.8 us with it against 12.1 us plain; nt / sc1 / sc0 sc1 alone: no change)
+__device__ __forceinline__ void glds_b128_stream(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+#ifdef WISKI_DMA_PLAIN_STREAM
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#else
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 nt\n\ts_mov_b32 m0, %0"
+#endif
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
@@ -114,6 +129,10 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
     else if (y == 3) { d0 = 0; p1lo = 3; ntile = 4; }
     else { d0 = y - 3; p1lo = 4; ntile = 3; }
   }
+  // All waves of a 4-part launch are resident at once (1 956 <= 8 per CU) and the CU arbitrates oldest-first: the chunks
+  // dispatched last (y = 2: 7 tiles, y = 3: 4 tiles) get their first DMA issued 2.5 us after the others and finish last.
+  // Raising their priority evens the finish times (19.3 -> 18.4..18.7 us; graded maps 0-1-2-3 / 0-1-2-0: no better).
+  if (nparts == 4 && blockIdx.y >= 2) __builtin_amdgcn_s_setprio(3);
   const int iw0 = blockIdx.x * 256;
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int e = 4 * (64 * j + lane);
-      glds_b128(src + (e < lim ? e : 0), dst + 1024u * j);
+      glds_b128_stream(src + (e < lim ? e : 0), dst + 1024u * j);
     }
   };
 

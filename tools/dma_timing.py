@@ -29,7 +29,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 lib = _hip.lib()
 nrb = (grid.m + 255) // 256
-NP = int(os.environ.get("WISKI_SYM_DMA_PARTS", "6"))
+NP = int(os.environ.get("WISKI_SYM_DMA_PARTS", "4"))
 nw = nrb * NP
 buf = (ctypes.c_longlong * (nw * 16))()
 assert lib.wiski_dma_dbg(buf, ctypes.c_int(nw * 16)) == 0

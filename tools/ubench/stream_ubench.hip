@@ -30,6 +30,46 @@ __device__ __forceinline__ void glds_b128(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+template <int MOD>
+__device__ __forceinline__ void glds_b128_mod(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  if (MOD == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else if (MOD == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else if (MOD == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int MOD>
+__global__ __launch_bounds__(64) void k_dma_ring_mod(const float* __restrict__ a, int ntile, size_t tile_stride, int nrb, float* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* st = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x;
+  const unsigned sa = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)st);
+  const int rb = blockIdx.x % nrb, part = blockIdx.x / nrb;
+  const float* base = a + (size_t)part * ntile * tile_stride + (size_t)rb * 1792;
+  auto issue = [&](int t) {
+    const float* src = base + (size_t)t * tile_stride;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) glds_b128_mod<MOD>(src + 4 * (64 * j + lane), sa + (unsigned)((t & 1) * 7168 + 1024 * j));
+  };
+  issue(0);
+  if (ntile > 1) issue(1);
+  float s = 0.f;
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* q = st + (t & 1) * 1792 + 28 * lane;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const float4 v = *reinterpret_cast<const float4*>(q + 4 * j); s += v.x + v.y + v.z + v.w; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t + 2 < ntile) issue(t + 2);
+  }
+  if (s == 1234.5f) sink[0] = s;
+}
+
 // one wave per block; each wave streams `ntile` 7 KiB tiles through a 2-deep LDS ring and reads them back (b128)
 __global__ __launch_bounds__(64) void k_dma_ring(const float* __restrict__ a, int ntile, size_t tile_stride, int nrb, float* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,6 +141,10 @@ int main() {
       });
     }
   }
+  // cache-policy modifiers on the LDS-DMA loads (2934 waves x 4 tiles)
+#define MODRUN(M, NAME) run("LDS-DMA ring 2934 x 4, " NAME, false, [&](hipEvent_t s, hipEvent_t e) { \
+    hipExtLaunchKernelGGL((k_dma_ring_mod<M>), dim3(489 * 6), dim3(64), 19968, 0, s, e, 0, (const float*)a, 4, (size_t)(7 * m), 489, sink); });
+  MODRUN(1, "nt") MODRUN(2, "sc1") MODRUN(3, "sc0 sc1") MODRUN(4, "sc0 nt")
   // a read that does not fit the 256 MB Infinity Cache: the practical HBM ceiling (what k_gather_ell's 541 MB stream can hope for)
   for (int blocks : {2048, 4096, 8192}) {
     const size_t n16 = ((size_t)541 << 20) / 16;
