@@ -830,7 +830,7 @@ static inline bool sym_use_cols(int k) {
     const char* e = getenv("WISKI_SPMM_COLS");
     g_spmm_cols = e ? atoi(e) : 1;
   }
-  return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 350 us at k = 64 (670)
+  return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 277 us at k = 64 (670)
 }
 static inline int spmmc_kp(int k) { return (k + 15) / 16 * 16; }
 // number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
@@ -873,7 +873,10 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     dim3 tg((unsigned)((m + 63) / 64), (unsigned)((kp + 63) / 64));
     if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true>), tg, dim3(256), 0, s, m, k, kp, V, Vt, add, beta, dots);
     else hipLaunchKernelGGL((k_transpose_cm_rm<real, false>), tg, dim3(256), 0, s, m, k, kp, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
-    dim3 grd((unsigned)((m + SPMMC_RT - 1) / SPMMC_RT), (unsigned)((kp + 63) / 64));
+    // grid.x is padded to a multiple of 8: workgroup b runs on XCD b % 8 and takes tile (b % 8) * (grid.x / 8) + b / 8, so
+    // each XCD sweeps ONE contiguous eighth of the rows and its L2 holds the v windows of neighbouring tiles
+    const int ntile = (m + SPMMC_RT - 1) / SPMMC_RT;
+    dim3 grd((unsigned)((ntile + 7) / 8 * 8), (unsigned)((kp + 63) / 64));
     const int ng = sym_groups(G.d);
     if (dots) launch_timed(k_spmm_sym_cols<real, true>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
     else launch_timed(k_spmm_sym_cols<real, false>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);

@@ -17,6 +17,17 @@
 //  * V arrives column-major ([k][m], the layout of every other PCG kernel): k_transpose_cm_rm / k_transpose_rm_cm convert
 //    on the way in and out (64 x 64 tiles through LDS), the first one also forming beta * v . add per column (CG's p . pt).
 //
+//  * workgroup b runs on XCD b % 8: tiles are dealt so that every XCD sweeps one contiguous eighth of the rows and the v
+//    windows of neighbouring tiles meet in ITS L2 (round-robin dealing made each XCD stream all of V: 350 -> 277 us).
+//
+// Measured at 50^3, 64 columns (tools/spmv_probe.py --k 64, both transposes included): 277 us = 29 % of the vector-FMA
+// peak (2.74 G lane-FMAs = 70 us).  Insensitive to the tile height (RT = 8 / 12 / 16: 291 / 276 / 277 us at 7 / 6 / 5
+// waves per SIMD; 25 / 32: 309 / 413 us, fewer waves than slots), i.e. neither occupancy nor the 67 L1 row loads per output
+// row bound it; the suspect is the scalar path (204 MB of A_h, every s_load a scalar-cache miss).  A line-tiled variant
+// (a wave = 2..4 grid lines x 17..25 rows, window loads shared between the lines: 35 / 22 loads per row) was built and
+// measured at 519 / 721 us -- 2 500 / 1 250 waves cannot hide their own load latency -- and removed.  What is left to do
+// is the workgroup-tiled form: v windows shared through LDS by the waves of a block, A_h spans by LDS-DMA.
+//
 // Works for any d (1..4) and any m; rows past m and columns past k are masked.
 #pragma once
 #include <type_traits>
@@ -31,21 +42,45 @@ __device__ __forceinline__ void spmmc_visit(const V& blk, F&& fn, std::integer_s
 
 // Visit N contiguous wave-uniform coefficients p[0..N) in 64-byte pieces: fn(integral_constant<idx>, p[idx]).
 // The vector type is only dword-aligned: hipcc turns each piece into one s_load_dwordx16 (x8 / x4 / ... for the tail).
-template <typename real, int N, int I0 = 0, typename F>
-__device__ __forceinline__ void spmmc_span(const real* __restrict__ p, F&& fn) {
-  constexpr int CH = 64 / (int)sizeof(real);
-  if constexpr (I0 < N) {
-    constexpr int n = (N - I0) >= CH ? CH : ((N - I0) >= CH / 2 ? CH / 2 : ((N - I0) >= CH / 4 ? CH / 4 : ((N - I0) >= 2 ? 2 : 1)));
+// Software-pipelined by hand, one piece ahead: piece i + 1 is requested before the FMAs of piece i and a scheduling
+// barrier closes every stage -- left alone, the scheduler hoists ALL loads of a span to its top (a 217-real span wants
+// 217 live SGPRs: 500..3000 SGPR spills and one wave per SIMD in k_spmm_sym_lines).
+template <typename real, int N, int I0>
+struct spmmc_piece {
+  static constexpr int CH = 64 / (int)sizeof(real);
+  static constexpr int n = (N - I0) >= CH ? CH : ((N - I0) >= CH / 2 ? CH / 2 : ((N - I0) >= CH / 4 ? CH / 4 : ((N - I0) >= 2 ? 2 : 1)));
+  typedef real vec_t __attribute__((ext_vector_type(n > 1 ? n : 2), aligned(4)));
+  typedef real nvec_t __attribute__((ext_vector_type(n > 1 ? n : 2)));
+  static __device__ __forceinline__ nvec_t load(const real* __restrict__ p) {
     if constexpr (n == 1) {
-      fn(std::integral_constant<int, I0>{}, p[I0]);
+      nvec_t v;
+      v[0] = p[I0];
+      v[1] = (real)0;
+      return v;
     } else {
-      typedef real vec_t __attribute__((ext_vector_type(n), aligned(4)));
-      typedef real nvec_t __attribute__((ext_vector_type(n)));
-      const nvec_t blk = *reinterpret_cast<const vec_t*>(p + I0);   // under-aligned load, naturally aligned value
-      spmmc_visit<real, n, I0>(blk, fn, std::make_integer_sequence<int, n>{});
+      return *reinterpret_cast<const vec_t*>(p + I0);   // under-aligned load, naturally aligned value
     }
-    spmmc_span<real, N, I0 + n>(p, fn);
   }
+};
+template <typename real, int N, int I0, bool PIPE, typename F, typename V>
+__device__ __forceinline__ void spmmc_stage(const real* __restrict__ p, F&& fn, const V cur) {
+  using P = spmmc_piece<real, N, I0>;
+  constexpr int I1 = I0 + P::n;
+  if constexpr (I1 < N) {
+    const auto nxt = spmmc_piece<real, N, I1>::load(p);
+    spmmc_visit<real, P::n, I0>(cur, fn, std::make_integer_sequence<int, P::n>{});
+    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+    spmmc_stage<real, N, I1, PIPE>(p, fn, nxt);
+  } else {
+    spmmc_visit<real, P::n, I0>(cur, fn, std::make_integer_sequence<int, P::n>{});
+    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// PIPE = false leaves the order of loads and FMAs to the scheduler (it hoists the loads of a span as far as SGPRs allow)
+template <typename real, int N, bool PIPE = false, typename F>
+__device__ __forceinline__ void spmmc_span(const real* __restrict__ p, F&& fn) {
+  if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+  spmmc_stage<real, N, 0, PIPE>(p, fn, spmmc_piece<real, N, 0>::load(p));
 }
 
 // column-major [k][m] -> row-major [m][kp] (kp = k rounded up to 64; padding columns are written as zeros).
@@ -112,7 +147,13 @@ __global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const rea
   const int lane = threadIdx.x;
   const int c = blockIdx.y * 64 + lane;            // this lane's column
   const bool cok = c < kp;
-  const int j0 = blockIdx.x * RT;                  // first row of the tile (wave-uniform)
+#ifdef WISKI_SPMMC_NOREMAP
+  const int tile = blockIdx.x;
+#else
+  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous row ranges (see the launch)
+#endif
+  const int j0 = tile * RT;                        // first row of the tile (wave-uniform)
+  if (j0 >= m) return;
   const real* __restrict__ vcol = Vt + (cok ? c : 0);
   real acc[RT];
 #pragma unroll
