@@ -830,7 +830,7 @@ static inline bool sym_use_cols(int k) {
     const char* e = getenv("WISKI_SPMM_COLS");
     g_spmm_cols = e ? atoi(e) : 1;
   }
-  return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 277 us at k = 64 (670)
+  return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 240 us at k = 64 (670)
 }
 static inline int spmmc_kp(int k) { return (k + 15) / 16 * 16; }
 // number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
@@ -878,8 +878,13 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     const int ntile = (m + SPMMC_RT - 1) / SPMMC_RT;
     dim3 grd((unsigned)((ntile + 7) / 8 * 8), (unsigned)((kp + 63) / 64));
     const int ng = sym_groups(G.d);
-    if (dots) launch_timed(k_spmm_sym_cols<real, true>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
-    else launch_timed(k_spmm_sym_cols<real, false>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+    if (kp == 64) {
+      if (dots) launch_timed(k_spmm_sym_cols<real, true, 64>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+      else launch_timed(k_spmm_sym_cols<real, false, 64>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+    } else {
+      if (dots) launch_timed(k_spmm_sym_cols<real, true, 0>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+      else launch_timed(k_spmm_sym_cols<real, false, 0>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+    }
     hipLaunchKernelGGL((k_transpose_rm_cm<real>), tg, dim3(256), 0, s, m, k, kp, (const real*)Ot, part);
     return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
   }

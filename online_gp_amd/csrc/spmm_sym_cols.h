@@ -18,9 +18,9 @@
 //    on the way in and out (64 x 64 tiles through LDS), the first one also forming beta * v . add per column (CG's p . pt).
 //
 //  * workgroup b runs on XCD b % 8: tiles are dealt so that every XCD sweeps one contiguous eighth of the rows and the v
-//    windows of neighbouring tiles meet in ITS L2 (round-robin dealing made each XCD stream all of V: 350 -> 277 us).
+//    windows of neighbouring tiles meet in ITS L2 (round-robin dealing made each XCD stream all of V: 350 -> 277 us; with the constant row stride below: 240 us).
 //
-// Measured at 50^3, 64 columns (tools/spmv_probe.py --k 64, both transposes included): 277 us = 29 % of the vector-FMA
+// Measured at 50^3, 64 columns (tools/spmv_probe.py --k 64, both transposes included): 240 us = 29 % of the vector-FMA
 // peak (2.74 G lane-FMAs = 70 us).  Insensitive to the tile height (RT = 8 / 12 / 16: 291 / 276 / 277 us at 7 / 6 / 5
 // waves per SIMD; 25 / 32: 309 / 413 us, fewer waves than slots), i.e. neither occupancy nor the 67 L1 row loads per output
 // row bound it; the suspect is the scalar path (204 MB of A_h, every s_load a scalar-cache miss).  A line-tiled variant
@@ -139,10 +139,18 @@ __global__ __launch_bounds__(256) void k_transpose_rm_cm(int m, int k, int kp, c
 }
 
 // One wave = RT rows x 64 columns.  Vt, Ot row-major [m][kp].  DOT: dots[c] += sum_j Vt[j][c] * Ot[j][c].
-template <typename real, bool DOT>
-__global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ Vt, int k, int kp,
+// KP: row stride of Vt / Ot known at compile time (64: the common case) or 0 (read kp).  With a constant stride the rows of
+// a window that lies inside the grid are base + e * KP: immediate offsets instead of ~9 scalar instructions per row load
+// (clamp, 64-bit multiply, add) -- PMC counters showed 2.4 scalar-ALU instructions per vector one and the one scalar ALU
+// of a CU as the bound of the launch (104.6 M SALU instructions = 170 us) rather than the loads or the FMAs: 277 -> 240 us.
+// The rest of the scalar work is hipcc pairing the FMAs into v_pk_fma_f32 (2 s_mov + 0.5 v_mov per pair to build aligned
+// operand pairs); -fno-slp-vectorize gives 212 us but changes nothing end to end (variance of 64 queries 2.53 vs 2.52 ms),
+// plain v_fmac through inline asm is slower (256 us: the scheduler no longer sees through it); neither is used.
+template <typename real, bool DOT, int KP>
+__global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ Vt, int k, int kp_rt,
                                                       int ng, real* __restrict__ Ot, double* __restrict__ dots) {
   constexpr int RT = SPMMC_RT, WN = RT + 6;
+  const int kp = KP ? KP : kp_rt;
   const int m = G.m, d = G.d;
   const int lane = threadIdx.x;
   const int c = blockIdx.y * 64 + lane;            // this lane's column
@@ -173,11 +181,18 @@ __global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const rea
     constexpr int S0 = CENTRE ? 3 : 0;               // first stored digit
     {  // ---- direct term: out[j0 + r] += a(s, j0 + r) * v[j0 + r + f + s - 3]
       real win[WN];
+      const int wb = j0 + f - 3;
+      if (wb >= 0 && wb + WN <= m) {                 // wave-uniform: the whole window exists (always, away from the grid ends)
+        const real* __restrict__ wp = vcol + (int64_t)wb * kp;
 #pragma unroll
-      for (int e = 0; e < WN; ++e) {
-        int j = j0 + f - 3 + e;
-        j = j < 0 ? 0 : (j >= m ? m - 1 : j);        // clamped rows only ever meet coefficients that are exactly zero
-        win[e] = vcol[(int64_t)j * kp];
+        for (int e = 0; e < WN; ++e) win[e] = wp[(int64_t)e * kp];
+      } else {
+#pragma unroll
+        for (int e = 0; e < WN; ++e) {
+          int j = wb + e;
+          j = j < 0 ? 0 : (j >= m ? m - 1 : j);      // clamped rows only ever meet coefficients that are exactly zero
+          win[e] = vcol[(int64_t)j * kp];
+        }
       }
       // ragged last tile: read the span of the last RT rows of the grid and shift the row index (rows >= m are not stored)
       const int jb = j0 + RT <= m ? j0 : (m - RT > 0 ? m - RT : 0);
@@ -201,13 +216,19 @@ __global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const rea
       constexpr int T0 = CENTRE ? 4 : 0;
       real src[WN];
       const int ib = j0 - f - 3;
-#pragma unroll
-      for (int e = 0; e < WN; ++e) {
-        int i = ib + e;
-        i = i < 0 ? 0 : (i >= m ? m - 1 : i);
-        src[e] = vcol[(int64_t)i * kp];
-      }
       const bool whole = ib >= 0 && ib + WN <= m;    // wave-uniform: the source rows all exist (always, away from the grid ends)
+      if (whole) {
+        const real* __restrict__ sp = vcol + (int64_t)ib * kp;
+#pragma unroll
+        for (int e = 0; e < WN; ++e) src[e] = sp[(int64_t)e * kp];
+      } else {
+#pragma unroll
+        for (int e = 0; e < WN; ++e) {
+          int i = ib + e;
+          i = i < 0 ? 0 : (i >= m ? m - 1 : i);
+          src[e] = vcol[(int64_t)i * kp];
+        }
+      }
       if (whole) {
         spmmc_span<real, WN * RS>(Ag + (int64_t)RS * ib, [&](auto idx_tag, real coef) {
           constexpr int idx = decltype(idx_tag)::value, e = idx / RS, s = S0 + idx % RS, r = e + s - 6;
@@ -238,12 +259,22 @@ __global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const rea
     group(std::false_type{}, A_h + (int64_t)(7 * g - 3) * m, f);
   }
   double dot = 0;
+  if (j0 + RT <= m) {
+    real* __restrict__ op = Ot + (int64_t)j0 * kp + (cok ? c : 0);
+    const real* __restrict__ vp = vcol + (int64_t)j0 * kp;
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    const int j = j0 + r;
-    if (j < m && cok) {
-      Ot[(int64_t)j * kp + c] = acc[r];
-      if (DOT) dot += (double)vcol[(int64_t)j * kp] * (double)acc[r];
+    for (int r = 0; r < RT; ++r) {
+      if (cok) op[(int64_t)r * kp] = acc[r];
+      if (DOT) dot += (double)vp[(int64_t)r * kp] * (double)acc[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const int j = j0 + r;
+      if (j < m && cok) {
+        Ot[(int64_t)j * kp + c] = acc[r];
+        if (DOT) dot += (double)vcol[(int64_t)j * kp] * (double)acc[r];
+      }
     }
   }
   if (DOT && c < k) pcg_dot_add(dots, c, dot);
