@@ -1,6 +1,8 @@
 #!/bin/bash
-python tools/q1_probe.py 1 400 2>&1 | grep "q ="
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $GRAFT_REPO_ROOT/tools/q1_probe.py 1 100 > /tmp/b.log 2>&1
-f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
-python $GRAFT_REPO_ROOT/tools/step_timeline.py $f 2
+python bench.py --no-cpu-baseline --blocks 10 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['value'], d['ms_per_step']); print({k: v for k, v in d['extra'].items() if '1e-2' in k or 'mean_max' in k or 'cg_iters' in k})
+    elif 'Error' in l or 'Traceback' in l or 'line' in l: print(l)
+"
