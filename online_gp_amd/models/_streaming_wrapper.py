@@ -13,7 +13,6 @@ prediction.  The protocol, from SURVEY.md 8(b) / 3.1:
                    rebuilt from the current features after every step.
 """
 import math
-import warnings
 
 import torch
 
@@ -61,7 +60,6 @@ class StreamingSKIWrapper(torch.nn.Module):
         self.mll = BatchedWoodburyMarginalLogLikelihood(gp.likelihood, gp)
         self._make_optimizers(lr, lr)
         self._replay = _ReplayBuffer(init_x)
-        self._warned_no_stem_grad = False
 
     # ------------------------------------------------------------------ hooks
     def _encode(self, targets):
@@ -179,15 +177,7 @@ class StreamingSKIWrapper(torch.nn.Module):
         return records
 
     def _feature_loss(self, feats, labels):
-        """A scalar whose gradient w.r.t. `feats` is d(-MLL)/d features (joint stem + GP training).  Written out
-        for the dense regime (mlls/feature_gradient.py); beyond it the stem keeps its weights -- said once, loudly."""
-        if self.gp._use_dense():
-            gp_targets, noise = self._encode(labels)
-            return mll_feature_surrogate(self.gp, feats, gp_targets.to(feats.dtype), None if noise is None else noise.to(feats.dtype))
-        if not self._warned_no_stem_grad:
-            warnings.warn(
-                f"fit(): the inducing grid has {self.gp._grid.m} nodes (> settings.max_cholesky_size); the MLL gradient with respect "
-                "to the stem features is only implemented in the dense regime, so the stem parameters are NOT trained by fit() here "
-                "(update() still trains them through the streaming partial MLL).", RuntimeWarning)
-            self._warned_no_stem_grad = True
-        return feats.sum() * 0.0
+        """A scalar whose gradient w.r.t. `feats` is d(-MLL)/d features (joint stem + GP training, OSR:80-112): exact in the
+        dense regime, with a Hutchinson estimate of the log-determinant part beyond it (mlls/feature_gradient.py)."""
+        gp_targets, noise = self._encode(labels)
+        return mll_feature_surrogate(self.gp, feats, gp_targets.to(feats.dtype), None if noise is None else noise.to(feats.dtype))

@@ -245,6 +245,52 @@ def test_mll_feature_gradient_matches_finite_differences_and_fit_trains_the_stem
     assert rec[-1]["train_loss"] < rec[0]["train_loss"]
 
 
+def test_mll_feature_gradient_matrix_free_regime():
+    """Beyond max_cholesky_size the trace part of d(-MLL)/d features is a Hutchinson estimate over probe solves
+    (mlls/feature_gradient.py).  With the identity as probes (weight 1) the estimate is exact: it must equal the
+    dense-regime gradient / central differences of the exact MLL up to the CG tolerance; with Rademacher probes it must
+    agree statistically; and fit() on a grid past the dense regime now moves the stem."""
+    from online_gp_amd import settings
+    from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood, mll_feature_surrogate
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP, LinearStem, OnlineSKIRegression
+
+    rng = np.random.default_rng(6)
+    n, d = 40, 3
+    X = torch.as_tensor(rng.uniform(-0.9, 0.9, (n, d)), device=DEV)
+    Y = torch.as_tensor(np.sin(2 * X[:, :1].cpu().numpy()) + 0.1 * rng.standard_normal((n, 1)), device=DEV)
+    N = torch.as_tensor(rng.uniform(0.5, 1.5, (n, 1)), device=DEV)
+    gb = torch.tensor([[-1.1, 1.1]] * d)
+
+    def build(Xq):
+        return FixedNoiseOnlineSKIGP(Xq, Y, N, grid_bounds=gb, grid_size=6, learn_additional_noise=True).double()
+
+    # dense-regime gradient (checked against central differences by the test above)
+    Xd = X.clone().requires_grad_(True)
+    mll_feature_surrogate(build(X), Xd, Y, N).backward()
+    g_dense = Xd.grad.clone()
+    with settings.max_cholesky_size(10), settings.cg_tolerance(1e-10):
+        m = build(X)
+        assert not m._use_dense()
+        Xg = X.clone().requires_grad_(True)
+        mll_feature_surrogate(m, Xg, Y, N, probes=torch.eye(m._grid.m, device=DEV, dtype=torch.float64), probe_weight=1.0).backward()
+        assert (Xg.grad - g_dense).abs().max() < 1e-6 * g_dense.abs().max()
+        from online_gp_amd.mlls.batched_woodbury_marginal_log_likelihood import num_trace_samples
+
+        Xr = X.clone().requires_grad_(True)
+        with num_trace_samples(4000):
+            mll_feature_surrogate(build(X), Xr, Y, N).backward()
+        assert (Xr.grad - g_dense).norm() < 0.1 * g_dense.norm()
+        # fit(): a stem on a grid past the dense regime receives gradients and moves
+        torch.manual_seed(0)
+        Xh = torch.randn(96, 5, device=DEV, dtype=torch.float32)
+        yh = torch.tanh(Xh[:, :1] - 0.5 * Xh[:, 1:2]) + 0.05 * torch.randn(96, 1, device=DEV)
+        model = OnlineSKIRegression(LinearStem(5, 2), Xh, yh, 5e-2, 8, 1.0)
+        assert not model.gp._use_dense()
+        w0 = [p.detach().clone() for p in model.stem.parameters()]
+        model.fit(Xh, yh, 5)
+        assert any((p.detach() - q).abs().max() > 1e-4 for p, q in zip(model.stem.parameters(), w0))
+
+
 def test_mll_adds_registered_priors_before_dividing_by_n():
     """BWM:48-51: res += sum_priors log p(theta); res /= n.  The reference's BO kernel (Matern-5/2, Gamma priors, Interval
     constraints, experiments/bayesopt/bayesopt.py:69-77): value = prior-free MLL at the same hyper-parameters + log-priors / n,
