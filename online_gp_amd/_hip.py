@@ -97,17 +97,23 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 def stream_ptr(device=None):
     """The caller's current HIP stream on `device` (a torch.device, index or None = current device)."""
+    cur = torch.cuda.current_device()
+    if device is None:
+        idx = cur
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = torch.device(device).index
+        if idx is None:
+            idx = cur
+    if idx != cur:
+        # the library launches on the CURRENT HIP device; a stream of another device would make every launch fail (or hang a
+        # convergence poll).  Fail loudly instead of guarding silently: the caller owns the device selection.
+        raise RuntimeError(f"online_gp_amd: tensors live on cuda:{idx} but the current device is cuda:{cur}; "
+                           f"call torch.cuda.set_device({idx}) (or use `with torch.cuda.device({idx}):`) around the model calls")
     if _raw_stream is not None:                      # ~0.3 us instead of ~3 us through torch.cuda.current_stream
-        if device is None:
-            idx = torch.cuda.current_device()
-        elif isinstance(device, int):
-            idx = device
-        else:
-            idx = torch.device(device).index
-            if idx is None:
-                idx = torch.cuda.current_device()
         return ctypes.c_void_p(_raw_stream(idx))
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
 _fn_cache = {}

@@ -875,15 +875,15 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     else hipLaunchKernelGGL((k_transpose_cm_rm<real, false>), tg, dim3(256), 0, s, m, k, kp, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
     // grid.x is padded to a multiple of 8: workgroup b runs on XCD b % 8 and takes tile (b % 8) * (grid.x / 8) + b / 8, so
     // each XCD sweeps ONE contiguous eighth of the rows and its L2 holds the v windows of neighbouring tiles
-    const int ntile = (m + SPMMC_RT - 1) / SPMMC_RT;
-    dim3 grd((unsigned)((ntile + 7) / 8 * 8), (unsigned)((kp + 63) / 64));
+    const int ntile = (m + SPMMC_RT - 1) / SPMMC_RT, nblk = (ntile + 3) / 4;    // 4 tiles (waves) per block
+    dim3 grd((unsigned)((nblk + 7) / 8 * 8), (unsigned)((kp + 63) / 64));
     const int ng = sym_groups(G.d);
     if (kp == 64) {
-      if (dots) launch_timed(k_spmm_sym_cols<real, true, 64>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
-      else launch_timed(k_spmm_sym_cols<real, false, 64>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+      if (dots) launch_timed(k_spmm_sym_cols<real, true, 64>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+      else launch_timed(k_spmm_sym_cols<real, false, 64>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
     } else {
-      if (dots) launch_timed(k_spmm_sym_cols<real, true, 0>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
-      else launch_timed(k_spmm_sym_cols<real, false, 0>, grd, dim3(64), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+      if (dots) launch_timed(k_spmm_sym_cols<real, true, 0>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
+      else launch_timed(k_spmm_sym_cols<real, false, 0>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
     }
     hipLaunchKernelGGL((k_transpose_rm_cm<real>), tg, dim3(256), 0, s, m, k, kp, (const real*)Ot, part);
     return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
@@ -1614,12 +1614,18 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     hipLaunchKernelGGL((k_pcg_zero<real>), dim3((unsigned)zb), dim3(256), 0, s, S.base, nscal, part + (int64_t)(nch > 0 ? nch - 1 : 0) * k * m, nvec);
   }
   const double tol2 = tol * tol;
+  // Blocks per column of the vector kernels (grid-stride loops).  Every block ends with one fp64 atomic per norm on the
+  // column's scalar, the scalars of 16 columns share a 128-byte line, and same-line atomics serialise at the memory side
+  // (~12 ns each): 489 blocks x 64 columns made k_pcg_init 138 us on a 32 MB sweep.  m / 4096 blocks, 32..256.
+  int bcap = m / 4096;
+  bcap = bcap < 32 ? 32 : (bcap > 256 ? 256 : bcap);
   int eb = (m + 255) / 256;
-  if (eb > 1024) eb = 1024;
+  if (eb > bcap) eb = bcap;
   dim3 egrid((unsigned)eb, (unsigned)k);
   int vb = (m / 4 + 255) / 256;
   if (vb < 1) vb = 1;
-  dim3 vgrid((unsigned)vb, (unsigned)k);   // one 16-byte group per thread
+  if (vb > bcap) vb = bcap;
+  dim3 vgrid((unsigned)vb, (unsigned)k);   // 16-byte groups, grid-stride
 
   if (resume) {
     // the start call queued everything up to (and including) the poll of iteration as->it

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_transpose_rm_cm(int m, int k, int kp, c
   }
 }
 
-// One wave = RT rows x 64 columns.  Vt, Ot row-major [m][kp].  DOT: dots[c] += sum_j Vt[j][c] * Ot[j][c].
+// One wave = RT rows x 64 columns, four waves per block.  Vt, Ot row-major [m][kp].  DOT: dots[c] += sum_j Vt[j][c] * Ot[j][c].
 // KP: row stride of Vt / Ot known at compile time (64: the common case) or 0 (read kp).  With a constant stride the rows of
 // a window that lies inside the grid are base + e * KP: immediate offsets instead of ~9 scalar instructions per row load
 // (clamp, 64-bit multiply, add) -- PMC counters showed 2.4 scalar-ALU instructions per vector one and the one scalar ALU
@@ -147,21 +147,22 @@ __global__ __launch_bounds__(256) void k_transpose_rm_cm(int m, int k, int kp, c
 // operand pairs); -fno-slp-vectorize gives 212 us but changes nothing end to end (variance of 64 queries 2.53 vs 2.52 ms),
 // plain v_fmac through inline asm is slower (256 us: the scheduler no longer sees through it); neither is used.
 template <typename real, bool DOT, int KP>
-__global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ Vt, int k, int kp_rt,
+__global__ __launch_bounds__(256) void k_spmm_sym_cols(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ Vt, int k, int kp_rt,
                                                       int ng, real* __restrict__ Ot, double* __restrict__ dots) {
   constexpr int RT = SPMMC_RT, WN = RT + 6;
   const int kp = KP ? KP : kp_rt;
   const int m = G.m, d = G.d;
-  const int lane = threadIdx.x;
+  // a block = 4 independent waves on 4 consecutive tiles; they only meet at the end, to add their p . Ap partials into ONE
+  // atomic per column and block instead of one per wave (7 813 x 64 cache-line atomics per launch).  Inside a 64-column
+  // solve the kernel takes 304 us against 240 us back to back in the probe either way: the solver's ten 32 MB vectors push
+  // A_h out of the 256 MB Infinity Cache between products, the probe's single V does not
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the tile index, and with it every coefficient load, scalar
   const int c = blockIdx.y * 64 + lane;            // this lane's column
   const bool cok = c < kp;
-#ifdef WISKI_SPMMC_NOREMAP
-  const int tile = blockIdx.x;
-#else
-  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous row ranges (see the launch)
-#endif
-  const int j0 = tile * RT;                        // first row of the tile (wave-uniform)
-  if (j0 >= m) return;
+  const int tile = 4 * ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) + wv;   // XCD-contiguous row ranges (see the launch)
+  const bool active = tile * RT < m;               // padding waves recompute tile 0 and discard it (they must reach the barrier)
+  const int j0 = active ? tile * RT : 0;           // first row of the tile (wave-uniform)
   const real* __restrict__ vcol = Vt + (cok ? c : 0);
   real acc[RT];
 #pragma unroll
@@ -264,18 +265,23 @@ __global__ __launch_bounds__(64) void k_spmm_sym_cols(GridDev<real> G, const rea
     const real* __restrict__ vp = vcol + (int64_t)j0 * kp;
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      if (cok) op[(int64_t)r * kp] = acc[r];
+      if (cok && active) op[(int64_t)r * kp] = acc[r];
       if (DOT) dot += (double)vp[(int64_t)r * kp] * (double)acc[r];
     }
   } else {
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       const int j = j0 + r;
-      if (j < m && cok) {
+      if (j < m && cok && active) {
         Ot[(int64_t)j * kp + c] = acc[r];
         if (DOT) dot += (double)vcol[(int64_t)j * kp] * (double)acc[r];
       }
     }
   }
-  if (DOT && c < k) pcg_dot_add(dots, c, dot);
+  if constexpr (DOT) {
+    __shared__ double s_dot[4][64];
+    s_dot[wv][lane] = active ? dot : 0.0;
+    __syncthreads();
+    if (wv == 0 && c < k) pcg_dot_add(dots, c, s_dot[0][lane] + s_dot[1][lane] + s_dot[2][lane] + s_dot[3][lane]);
+  }
 }
