@@ -421,6 +421,18 @@ def main():
                     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
                 extra[f"reference_step_ms_q{qs}"] = float(np.median(ts[1:])) * 1e3
                 extra[f"reference_step_updates_per_s_q{qs}"] = qs / float(np.median(ts[1:]))
+            # the same step under the reference's own solver setting (config/regression.yaml:24-27: cg_tolerance 1e-2 for every solve)
+            with settings.cg_tolerance(1e-2):
+                for qs, nst in ((1, 6), (64, 4), (1024, 3)):
+                    ts = []
+                    for i in range(nst):
+                        lo = 4096 + i * qs
+                        xb, yb = Xr[lo:lo + qs], yr[lo:lo + qs]
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        reg.evaluate(xb, yb)
+                        reg.update(xb, yb)
+                        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                    extra[f"reference_step_ms_q{qs}_at_cg_tolerance_1e-2"] = float(np.median(ts[1:])) * 1e3
             # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
             gp = reg.gp
             with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():

@@ -1619,6 +1619,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   // (~12 ns each): 489 blocks x 64 columns made k_pcg_init 138 us on a 32 MB sweep.  m / 4096 blocks, 32..256.
   int bcap = m / 4096;
   bcap = bcap < 32 ? 32 : (bcap > 256 ? 256 : bcap);
+  if (k < 16 && bcap < 1024 / k) bcap = 1024 / k;     // few columns: the sweep wants the parallelism more than the atomics cost
   int eb = (m + 255) / 256;
   if (eb > bcap) eb = bcap;
   dim3 egrid((unsigned)eb, (unsigned)k);
@@ -1831,7 +1832,13 @@ static int spmv_sym_impl(const wiski_grid* grid, const real* d_A, const real* d_
   const int64_t slots = zl ? nch : 8;           // the many-column SpMM keeps its row-major copies behind part[0]
   if (hipMallocAsync((void**)&part, (size_t)slots * km * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;  // stream-ordered scratch
   if (zl && hipMemsetAsync(part + (int64_t)(nch - 1) * km, 0, (size_t)km * sizeof(real), s) != hipSuccess) rc = WISKI_E_LAUNCH;
+#ifdef WISKI_PROBE_DOTS     /* timing builds: exercise the DOT variant of the kernels from tools/spmv_probe.py */
+  static double* probe_dots = nullptr;
+  if (!probe_dots) { (void)hipMalloc((void**)&probe_dots, sizeof(double) * 2 * 64 * PCG_DOT_COL); (void)hipMemset(probe_dots, 0, sizeof(double) * 2 * 64 * PCG_DOT_COL); }
+  if (rc == WISKI_OK) rc = launch_spmv4_sym<real>(G, d_A, d_V, k, part, d_V, (real)1, k <= 64 ? probe_dots : nullptr, s);
+#else
   if (rc == WISKI_OK) rc = launch_spmv4_sym<real>(G, d_A, d_V, k, part, nullptr, (real)0, nullptr, s);
+#endif
   if (rc == WISKI_OK) {
     int64_t blocks = (km + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   long long dma_ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   DMA_STAMP(0);
-  // ---- prologue: own rows of v, the chunk's v window, the first NST tiles; zero the transposed window
+  // ---- prologue: the first tile (the A_h stream is the critical path: its first request goes out before anything else),
+  // own rows of v, the chunk's v window, the other NST - 1 tiles; zero the transposed window
+  issue_tile(0);
   glds_b128(V + (live ? i4 : 0), xo_a);
   // v window, linear image: element c of the LDS array is v[jal + c], jal = (iw0 + wb - 3) rounded down to a
   // multiple of 4, so every lane copies one aligned 16-byte group (groups lie wholly inside or outside [0, m))
@@ -184,13 +186,13 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   }
   DMA_STAMP(13);
 #pragma unroll
-  for (int t = 0; t < NST; ++t)
+  for (int t = 1; t < NST; ++t)
     if (t < ntile) issue_tile(t);
   DMA_STAMP(14);
   for (int e = lane; e < WP; e += 64) tw[e] = 0.f;
-  // everything older than the tiles has landed once at most NST tiles are outstanding
+  // tile 0 and the windows have landed once at most the NST - 1 younger tiles are outstanding
   DMA_STAMP(1);
-  wait_vm_tiles(NST < ntile ? NST : ntile);
+  wait_vm_tiles(NST - 1 < ntile - 1 ? NST - 1 : ntile - 1);
   DMA_STAMP(2);
   float xo[4];
   {

@@ -122,11 +122,36 @@ __device__ __forceinline__ bool point_stencil(const GridDev<real>& G, const real
 __device__ __forceinline__ void atomic_add_real(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_real(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// Sum over the 64 lanes of a wave; every lane receives the total.  Data-parallel primitives (DPP) instead of __shfl_down:
+// a shuffle is a ds_bpermute on gfx9 (two for a double), i.e. a dependent trip through the LDS crossbar per step -- ~0.5 us
+// at the very end of a kernel whose waves all finish together (the p . Ap epilogue of the SpMV: 19.2 vs 17.2 us).
+// row_shr 1 / 2 / 4 / 8 build the 16-lane row totals in lane 15 of each row, row_bcast15 / row_bcast31 carry them to lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float wave_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double wave_dpp_add(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+  return v + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v = wave_dpp_add<0x111, 0xf>(v);   // row_shr:1
+  v = wave_dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = wave_dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = wave_dpp_add<0x118, 0xf>(v);   // row_shr:8
+  v = wave_dpp_add<0x142, 0xa>(v);   // row_bcast15 into rows 1, 3
+  v = wave_dpp_add<0x143, 0xc>(v);   // row_bcast31 into rows 2, 3
+  if constexpr (sizeof(T) == 8) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(T, ((long long)hi << 32) | (long long)(unsigned)lo);
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  }
 }
 
 // Block-wide sum of a double; result valid in thread 0. `sm` needs >= 16 doubles.

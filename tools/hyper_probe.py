@@ -8,7 +8,7 @@ from online_gp_amd.models import Identity, OnlineSKIRegression
 dev, dt = torch.device("cuda:0"), torch.float32
 X0, y0 = bench.synth_stream(21743, 3, 0, dev, dt, "uniform")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-with settings.cg_tolerance(1e-4), settings.variance_cg_tolerance(3e-3):
+with settings.cg_tolerance(float(os.environ.get("CGTOL", "1e-4"))), settings.variance_cg_tolerance(3e-3):
     reg = OnlineSKIRegression(Identity(3), X0, y0, 1e-3, 50, 1.0)
     for _ in range(3): reg._hyper_step()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -11,7 +11,7 @@ X0, y0 = bench.synth_stream(21743, 3, 0, dev, dt, "uniform")
 Xr, yr = bench.synth_stream(8192, 3, 31337, dev, dt, "uniform")
 def T(fn):
     torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return (time.perf_counter() - t) * 1e3, r
-with settings.cg_tolerance(1e-4), settings.variance_cg_tolerance(3e-3):
+with settings.cg_tolerance(float(os.environ.get("CGTOL", "1e-4"))), settings.variance_cg_tolerance(3e-3):
     reg = OnlineSKIRegression(Identity(3), X0, y0, 1e-3, 50, 1.0)
     for qs in (1, 64, 1024):
         for i in range(4):
