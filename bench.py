@@ -448,14 +448,17 @@ def main():
                     extra[f"step_ms_q{qs}_three_calls"] = (time.perf_counter() - tq) / 10 * 1e3
                     # the same step behind ONE C-ABI call with the deferred poll (what the headline loop uses)
                     with settings.deferred_refresh(True):
-                        for rep in range(2):                                  # rep 0 warms the path
-                            torch.cuda.synchronize(); tq = time.perf_counter()
-                            for i in range(40):
-                                lo = 2048 + 640 + (rep * 40 + i) * qs
+                        tb = []
+                        for rep in range(8):                                  # rep 0 warms the path; median of 7 blocks of 10 steps
+                            torch.cuda.synchronize(); tq = time.perf_counter()  # (a preconditioner-profile refresh lands in a block now and then)
+                            for i in range(10):
+                                lo = 2048 + 640 + (rep * 10 + i) * qs
                                 gp.stream_step(Xr[lo:lo + qs], yr[lo:lo + qs])
                             gp._finish_pending()
                             torch.cuda.synchronize()
-                        extra[f"step_ms_q{qs}"] = (time.perf_counter() - tq) / 40 * 1e3
+                            tb.append((time.perf_counter() - tq) / 10 * 1e3)
+                        extra[f"step_ms_q{qs}"] = float(np.median(tb[1:]))
+                        extra[f"step_ms_q{qs}_max_block"] = float(max(tb[1:]))
                 # large-batch throughput (SURVEY.md 8d lists q = 16384): the same full step, 6 steps of fresh points
                 qL = 16384
                 XL, yL = synth_stream(7 * qL, d, 5000, dev, dtype, args.stream)

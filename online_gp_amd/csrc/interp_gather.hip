@@ -107,6 +107,36 @@ __global__ __launch_bounds__(256) void k_gather(GridDev<real> G, const real* __r
   }
 }
 
+// Small batches on 3-D grids (the predictive mean of a streamed batch: q = 4 096 points are only 64 waves for the kernel
+// above, each walking its 64 taps alone -- 10 us, latency-bound): 16 lanes per point, lane = (c0, c1) tap prefix with its four
+// consecutive innermost taps in one 16-byte load; the 16-lane groups are DPP rows, so the tap sums meet in lane 15 of the row.
+template <typename real>
+__global__ __launch_bounds__(256) void k_gather_coop3(GridDev<real> G, const real* __restrict__ x, int64_t n, const real* __restrict__ V,
+                                                      int k, real* __restrict__ out, int32_t* __restrict__ err) {
+  const int sub = threadIdx.x & 15;
+  const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = p < n;
+  const int64_t pp = live ? p : 0;
+  int j0[3];
+  real w[3][4], xp[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) xp[q] = x[pp * 3 + q];
+  if (!point_stencil<real, 3>(G, xp, j0, w) && live && sub == 0) atomicOr(err, 1);
+  const int c0 = sub >> 2, c1 = sub & 3;
+  const real w01 = (c0 == 0 ? w[0][0] : c0 == 1 ? w[0][1] : c0 == 2 ? w[0][2] : w[0][3]) * (c1 == 0 ? w[1][0] : c1 == 1 ? w[1][1] : c1 == 2 ? w[1][2] : w[1][3]);
+  const int64_t flat = (int64_t)(j0[0] + c0) * G.stride[0] + (int64_t)(j0[1] + c1) * G.stride[1] + j0[2];
+  typedef real vec4u __attribute__((ext_vector_type(4), aligned(4)));
+  for (int c = 0; c < k; ++c) {
+    const vec4u r = *reinterpret_cast<const vec4u*>(V + (int64_t)c * G.m + flat);
+    real s = w01 * (w[2][0] * r[0] + w[2][1] * r[1] + w[2][2] * r[2] + w[2][3] * r[3]);
+    s = wave_dpp_add<0x111, 0xf>(s);
+    s = wave_dpp_add<0x112, 0xf>(s);
+    s = wave_dpp_add<0x114, 0xf>(s);
+    s = wave_dpp_add<0x118, 0xf>(s);
+    if (sub == 15 && live) out[p * k + c] = s;
+  }
+}
+
 // ------------------------------------------------------------ ELL gather ---
 // Rows of (idx, val) are streamed from HBM with 16-byte-per-lane loads:
 // LPR = T/4 lanes cooperate on one row (4 taps each), then an xor-shuffle
@@ -319,6 +349,11 @@ static int gather_impl(const wiski_grid* grid, const real* d_x, int64_t n, const
   if (n == 0) return WISKI_OK;
   if (!d_x || !d_V || !d_out || !d_err || k < 1) return WISKI_E_BADARG;
   if (diag && k != n) return WISKI_E_BADARG;
+  if (G.d == 3 && !diag && k <= 4 && n <= 65536 && G.g[2] >= 4) {
+    hipLaunchKernelGGL((k_gather_coop3<real>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, k, d_out, d_err);
+    WISKI_LAUNCH_CHECK();
+    return WISKI_OK;
+  }
   dim3 grd((unsigned)((n + 255) / 256));
 #define CALL(DD) hipLaunchKernelGGL((k_gather<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, k, diag, d_out, d_err)
   WISKI_DISPATCH_D(G.d, CALL)

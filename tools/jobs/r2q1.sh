@@ -3,6 +3,6 @@ python bench.py --no-cpu-baseline --blocks 10 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print(d['value'], d['ms_per_step']); print({k: v for k, v in d['extra'].items() if '1e-2' in k or 'mean_max' in k or 'cg_iters' in k})
+        d = json.loads(l); print(d['value'], d['ms_per_step']); print({k: v for k, v in d['extra'].items() if 'step_ms' in k})
     elif 'Error' in l or 'Traceback' in l or 'line' in l: print(l)
 "
