@@ -343,12 +343,21 @@ def main():
             ones = torch.ones(q, device=dev, dtype=dtype)
             errf = grid_ops.new_err_flag(dev)
             grid_ops.scatter_stats_sym(grid, Xe[:q], ye[:q, 0].contiguous(), ones, ones, ones, bvec, half, st, errf)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(8):
-                grid_ops.scatter_stats_sym(grid, Xe[(i + 4) * q:(i + 5) * q], ye[(i + 4) * q:(i + 5) * q, 0].contiguous(), ones, ones, ones, bvec, half, st, errf)
-            e1.record(); torch.cuda.synchronize()
-            sc_us = e0.elapsed_time(e1) / 8 * 1e3
+            def event_us(launch, n, reps=5):
+                """median over `reps` event brackets of n launches each (us per launch).  Single brackets are not robust: every
+                20-30 s something stalls the device for ~80 ms (seen as one 10 ms 'launch' in a bracket of 8) on these boxes."""
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ts = []
+                for _ in range(reps):
+                    e0.record()
+                    for i in range(n):
+                        launch(i)
+                    e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / n * 1e3)
+                return float(np.median(ts))
+
+            ycols = [ye[(i + 4) * q:(i + 5) * q, 0].contiguous() for i in range(8)]
+            sc_us = event_us(lambda i: grid_ops.scatter_stats_sym(grid, Xe[(i + 4) * q:(i + 5) * q], ycols[i], ones, ones, ones, bvec, half, st, errf), 8)
             es = 4 if dtype == torch.float32 else 8
             T = grid.T
             sc_bytes = ((d + 2) + 2 * T + T * (T + 1)) * es       # SURVEY 8(d): read (d + 2 out) s, RMW 2 T s (W^T y), RMW T (T + 1) s (symmetric WtW)
@@ -358,27 +367,19 @@ def main():
             idx, val = grid_ops.interp(grid, Xq, errf)
             mu = model.prediction_cache["pred_mean"][0, :, 0].contiguous()
             grid_ops.gather_ell(idx, val, mu)
-            e0.record()
-            for i in range(10):
-                grid_ops.gather_ell(idx, val, mu)
-            e1.record(); torch.cuda.synchronize()
-            ell_us = e0.elapsed_time(e1) / 10 * 1e3
+            ell_us = event_us(lambda i: grid_ops.gather_ell(idx, val, mu), 6)
             ell_bytes = nq * (T * (4 + es) + es)
-            e0.record()
-            for i in range(10):
-                grid_ops.gather(grid, Xq, mu, errf)
-            e1.record(); torch.cuda.synchronize()
-            fused_us = e0.elapsed_time(e1) / 10 * 1e3
+            fused_us = event_us(lambda i: grid_ops.gather(grid, Xq, mu, errf), 6)
             roofline_secondary = [
                 {"kernel": "k_scatter_stats_sym (statistics scatter of q points; memory-side atomics)", "bound": "hbm",
                  "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                  "avg_launch_us": sc_us, "algorithmic_bytes_per_point": sc_bytes, "points_per_s": q / (sc_us * 1e-6),
-                 "lane_atomics_per_s": q * (T * (T + 1) // 2 + 2 * T) / (sc_us * 1e-6), "timing": "torch.cuda.Event bracket around 8 launches"},
+                 "lane_atomics_per_s": q * (T * (T + 1) // 2 + 2 * T) / (sc_us * 1e-6), "timing": "median of 5 torch.cuda.Event brackets of 8 launches"},
                 {"kernel": "k_gather_ell (predictive interpolated MVM from stored idx/val, 2^20 query rows)", "bound": "hbm",
                  "achieved": ell_bytes / (ell_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ell_bytes / (ell_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                  "avg_launch_us": ell_us, "algorithmic_bytes_per_row": T * (4 + es) + es,
                  "fused_form_rows_per_s": nq / (fused_us * 1e-6), "note": "the product path uses the fused form (weights recomputed from x, 16 B/row)",
-                 "timing": "torch.cuda.Event bracket around 10 launches"},
+                 "timing": "median of 5 torch.cuda.Event brackets of 6 launches"},
             ]
         else:
             roofline_secondary = None
@@ -388,15 +389,21 @@ def main():
         with settings.cg_tolerance(tol), torch.no_grad():
             Xv, _ = synth_stream(128, d, 99, dev, dtype, args.stream)
             model(Xv[64:128]).variance                 # warm the 64-column PCG workspace (first call allocates ~0.8 GB)
-            torch.cuda.synchronize(); tv = time.perf_counter()
-            v_same = model(Xv[:64]).variance
-            torch.cuda.synchronize(); tv = time.perf_counter() - tv
+            tvs = []
+            for rep in range(3):                       # median of 3: a single 2-4 ms measurement can swallow a device stall
+                torch.cuda.synchronize(); tv = time.perf_counter()
+                v_same = model(Xv[:64]).variance
+                torch.cuda.synchronize(); tvs.append(time.perf_counter() - tv)
+            tv = float(np.median(tvs))
             # quadratic forms converge with the square of the residual: variance solves stopped at 3e-3 (settings.variance_cg_tolerance)
             with settings.variance_cg_tolerance(3e-3):
                 model(Xv[64:128]).variance
-                torch.cuda.synchronize(); tq = time.perf_counter()
-                v_loose = model(Xv[:64]).variance
-                torch.cuda.synchronize(); tq = time.perf_counter() - tq
+                tqs = []
+                for rep in range(3):
+                    torch.cuda.synchronize(); tq = time.perf_counter()
+                    v_loose = model(Xv[:64]).variance
+                    torch.cuda.synchronize(); tqs.append(time.perf_counter() - tq)
+                tq = float(np.median(tqs))
             with settings.cg_tolerance(1e-7):
                 v_tight = model(Xv[:64]).variance
         extra["variance_ms_per_64_queries"] = tv * 1e3
@@ -462,14 +469,14 @@ def main():
                 # large-batch throughput (SURVEY.md 8d lists q = 16384): the same full step, 6 steps of fresh points
                 qL = 16384
                 XL, yL = synth_stream(7 * qL, d, 5000, dev, dtype, args.stream)
+                tLs = []
                 for i in range(7):
-                    if i == 1:
-                        torch.cuda.synchronize(); tL = time.perf_counter()
+                    torch.cuda.synchronize(); tL = time.perf_counter()
                     gp(XL[i * qL:(i + 1) * qL]).mean
                     gp.condition_on_observations(XL[i * qL:(i + 1) * qL], yL[i * qL:(i + 1) * qL], inplace=True)
                     gp.prediction_cache
-                torch.cuda.synchronize()
-                extra["updates_per_s_q16384"] = 6 * qL / (time.perf_counter() - tL)
+                    torch.cuda.synchronize(); tLs.append(time.perf_counter() - tL)
+                extra["updates_per_s_q16384"] = qL / float(np.median(tLs[1:]))
             del reg, gp
             torch.cuda.empty_cache()
         extra["dense_regime"] = dense_reference_timings(dev)
