@@ -33,6 +33,7 @@ OpenMP port of the same step on all host cores, rank 0, N=1 only).
 """
 import argparse
 import ctypes
+import gc
 import json
 import math
 import os
@@ -156,6 +157,10 @@ def main():
     ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
 
+    # the cyclic garbage collector of the host interpreter pauses for ~80 ms now and then (a full collection over torch's and
+    # numpy's object graph): it showed up as one 10 ms "launch" in an event bracket and as 9 ms blocks of ten 0.15 ms steps.
+    # Collections happen between the legs instead (gc.collect() calls below), never inside a timed region.
+    gc.disable()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,6 +204,7 @@ def main():
         then as many timed K-step blocks as fit into a 3droad-sized stream (N_STREAM points over all ranks); passes are
         repeated on fresh points until `blocks` blocks have been timed (blocks <= 0: enough for ~0.3 s).
         Returns (model, updater, per-block seconds [MAX over ranks], CG iterations per step, SpMV event ms, SpMV launches)."""
+        gc.collect()
         per_pass = max(1, ((N_STREAM - args.n_init) // (q * world) - Wm) // K)
         X0, y0 = synth_stream(args.n_init, d, seed0, dev, dtype, kind)        # identical init on every rank
         block_s, iters = [], []
@@ -329,6 +335,7 @@ def main():
             del means
             torch.cuda.empty_cache()
 
+            gc.collect()
             # absorb-only rate and the scatter kernel by itself (torch events on the launch stream)
             Xe, ye = synth_stream(12 * q, d, 4242, dev, dtype, args.stream)
             torch.cuda.synchronize(); ta = time.perf_counter()
@@ -412,6 +419,7 @@ def main():
                                                     "variance_cg_tolerance_3e-3": float(((v_loose - v_tight).abs() / v_tight).max())}
         del model
         torch.cuda.empty_cache()
+        gc.collect()
         # the reference's timed step at full fidelity (experiments/regression.py:48-54, OSR:56-146): evaluate = predictive
         # mean AND variance (rmse, nll) of the incoming batch, update = one Adam step on the Woodbury MLL + condition
         X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
@@ -440,6 +448,7 @@ def main():
                         reg.update(xb, yb)
                         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
                     extra[f"reference_step_ms_q{qs}_at_cg_tolerance_1e-2"] = float(np.median(ts[1:])) * 1e3
+            gc.collect()
             # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
             gp = reg.gp
             with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():
