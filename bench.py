@@ -158,10 +158,16 @@ def main():
     ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
 
-    # the cyclic garbage collector of the host interpreter pauses for ~80 ms now and then (a full collection over torch's and
-    # numpy's object graph): it showed up as one 10 ms "launch" in an event bracket and as 9 ms blocks of ten 0.15 ms steps.
-    # Collections happen between the legs instead (gc.collect() calls below), never inside a timed region.
-    gc.disable()
+    # The host interpreter's cyclic garbage collector pauses for ~80 ms when it runs a FULL collection over torch's and numpy's
+    # object graph (seen as one 10 ms "launch" in an event bracket and as 9 ms blocks of ten 0.15 ms steps).  Switching it off is
+    # worse: the per-step temporaries that sit in reference cycles then pile up and the caching allocator has to hipMalloc in
+    # the middle of a block (also ~80 ms).  So: collect + freeze the long-lived heap at every leg boundary (gc_settle), which
+    # leaves the collector only the young objects of the leg to look at.
+    def gc_settle():
+        gc.unfreeze()
+        gc.collect()
+        gc.freeze()
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,7 +211,6 @@ def main():
         then as many timed K-step blocks as fit into a 3droad-sized stream (N_STREAM points over all ranks); passes are
         repeated on fresh points until `blocks` blocks have been timed (blocks <= 0: enough for ~0.3 s).
         Returns (model, updater, per-block seconds [MAX over ranks], CG iterations per step, SpMV event ms, SpMV launches)."""
-        gc.collect()
         per_pass = max(1, ((N_STREAM - args.n_init) // (q * world) - Wm) // K)
         X0, y0 = synth_stream(args.n_init, d, seed0, dev, dtype, kind)        # identical init on every rank
         block_s, iters = [], []
@@ -213,6 +218,8 @@ def main():
         R, p = blocks, 0
         model = upd = None
         while R <= 0 or len(block_s) < R:
+            model = upd = None
+            gc_settle()                                    # the previous pass's model (reference cycles) goes before the new one allocates
             model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
             model.eval()
             upd = ShardedStatsUpdater(model, equal_shards=True, exchange=exchange)   # every rank streams q points per step
@@ -227,6 +234,7 @@ def main():
                 return mean, pc["cg_iters"][0]
 
             model.prediction_cache                         # cold solve on the init data (not timed)
+            gc_settle()
             nb = per_pass if R <= 0 else min(per_pass, R - len(block_s))
             Xs, ys = synth_stream((Wm + per_pass * K) * q, d, seed0 + 1000 + 97 * p + rank, dev, dtype, kind)
             lib.wiski_prof_start(ctypes.c_int32(256))      # creates the event pool outside the timed region
@@ -336,7 +344,7 @@ def main():
             del means
             torch.cuda.empty_cache()
 
-            gc.collect()
+            gc_settle()
             # absorb-only rate and the scatter kernel by itself (torch events on the launch stream)
             Xe, ye = synth_stream(12 * q, d, 4242, dev, dtype, args.stream)
             torch.cuda.synchronize(); ta = time.perf_counter()
@@ -420,7 +428,7 @@ def main():
                                                     "variance_cg_tolerance_3e-3": float(((v_loose - v_tight).abs() / v_tight).max())}
         del model
         torch.cuda.empty_cache()
-        gc.collect()
+        gc_settle()
         # the reference's timed step at full fidelity (experiments/regression.py:48-54, OSR:56-146): evaluate = predictive
         # mean AND variance (rmse, nll) of the incoming batch, update = one Adam step on the Woodbury MLL + condition
         X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
@@ -449,7 +457,7 @@ def main():
                         reg.update(xb, yb)
                         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
                     extra[f"reference_step_ms_q{qs}_at_cg_tolerance_1e-2"] = float(np.median(ts[1:])) * 1e3
-            gc.collect()
+            gc_settle()
             # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
             gp = reg.gp
             with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():
