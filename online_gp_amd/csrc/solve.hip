@@ -1486,7 +1486,9 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int m, int it, double tol2
 template <typename real, int VEC>
 __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2, const real* __restrict__ p, const real* __restrict__ pt,
                                                       const real* __restrict__ hp, real* __restrict__ part, int nch, int zl,
-                                                      real* __restrict__ u, real* __restrict__ z, real* __restrict__ r, PcgScal S) {
+                                                      real* __restrict__ u, real* __restrict__ z, real* __restrict__ r, PcgScal S,
+                                                      double* __restrict__ poll = nullptr, const int32_t* __restrict__ err = nullptr,
+                                                      long long seq = 0) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   double alpha = 0;
@@ -1549,6 +1551,32 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
   }
   acc = block_reduce_sum(acc, s_red);
   if (threadIdx.x == 0) unsafeAtomicAdd(S.rn(it + 1) + c, acc);
+  if (poll != nullptr) {
+    // Convergence poll folded into the update (one launch less per poll): the block that draws the last ticket knows every
+    // block's ||r||^2 contribution has been performed at the memory side (each block fences between its contribution and
+    // its ticket) and publishes what k_pcg_publish would, reading the norms around L2.
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned t = atomicAdd(S.ticket(), 1u);
+      s_last = t == gridDim.x * gridDim.y - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+      const int k = S.k;
+      for (int c2 = threadIdx.x; c2 < k; c2 += blockDim.x) {
+        poll[1 + c2] = __hip_atomic_load(S.rn0() + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        poll[1 + k + c2] = __hip_atomic_load(S.rn(it + 1) + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (threadIdx.x == 0) {
+        poll[1 + 2 * k] = err ? (double)*err : 0.0;
+        __hip_atomic_store(S.ticket(), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next poll of this solve
+      }
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<long long*>(poll), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -1676,9 +1704,13 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     err_seen = P.h[1 + 2 * k];
   };
   bool deferred = false;      // START mode: the first poll has been queued but not waited for
-  auto fetch = [&](int slot) -> int {
-    const long long seq = ++P.seq;
-    hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq);
+  // after_publish: the poll with sequence number `seq` (iteration slot `slot`) has been queued
+  auto fetch = [&](int slot, long long queued_seq = 0) -> int {
+    long long seq = queued_seq;
+    if (!seq) {
+      seq = ++P.seq;
+      hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq);
+    }
     if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
     if (amode == 1) {
       as->state = 1;
@@ -1714,12 +1746,16 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   auto due = [&](int i) { return i == max_iter || i == first_check || (i > first_check && (i - first_check) % check_every == 0); };
   const bool fused_cg = spectral && wide && spectral_fused_ok<real>(G);
   bool pending = false;   // fused path: update_x of iteration it-1 not applied yet
-  auto flush_update = [&]() {
+  // publish: fold the convergence poll of iteration `it` into this update; returns its sequence number (0: nothing launched)
+  auto flush_update = [&](bool publish = false) -> long long {
+    long long seq = 0;
     if (pending) {
+      if (publish) seq = ++P.seq;
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it - 1, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S);
+                         part, nch, zl, d_U, d_Z, r, S, publish ? P.d : (double*)nullptr, d_err, seq);
       pending = false;
     }
+    return seq;
   };
   while (!done && it < max_iter) {
     if (fused_cg) {
@@ -1736,8 +1772,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       pending = true;
       ++it;
       if (due(it)) {
-        flush_update();
-        rc = fetch(it);
+        rc = fetch(it, flush_update(true));
         if (rc) return rc;
         if (deferred) return WISKI_PENDING;
         done = converged();
@@ -1766,15 +1801,17 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (wide) rc = spmv_wide(p, pt, (real)1, S.php(it));
     else rc = spmv_narrow(p, pt, (real)1, hp, S.php(it));
     if (rc) return rc;
+    const bool pub = due(it + 1);
+    const long long useq = pub ? ++P.seq : 0;
     if (wide)
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S);
+                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq);
     else
       hipLaunchKernelGGL((k_pcg_update_x<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S);
+                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq);
     ++it;
     if (due(it)) {
-      rc = fetch(it);
+      rc = fetch(it, useq);
       if (rc) return rc;
       if (deferred) return WISKI_PENDING;
       done = converged();

@@ -211,7 +211,9 @@ struct PcgScal {
     for (int j = 0; j < PCG_DOT_SLOTS; ++j) t += q[j * PCG_DOT_STRIDE];
     return t;
   }
-  static int64_t scalars(int k, int max_iter) { return (int64_t)k * (1 + 2 * (int64_t)(max_iter + 2)); }
+  // + 1: the ticket counter of the publishing vector update (k_pcg_update_x), zeroed with the scalars
+  static int64_t scalars(int k, int max_iter) { return (int64_t)k * (1 + 2 * (int64_t)(max_iter + 2)) + 1; }
+  __host__ __device__ unsigned* ticket() const { return reinterpret_cast<unsigned*>(ring) - 2; }   // the last scalar before the ring
   static int64_t doubles(int k, int max_iter) { return scalars(k, max_iter) + 2 * (int64_t)k * PCG_DOT_COL; }
 };
 
