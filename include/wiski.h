@@ -208,10 +208,20 @@ typedef struct wiski_pcg_async {
   int32_t it;      /* iterations queued so far */
   int64_t seq;     /* sequence number of the poll in flight */
   void* poll;      /* opaque: the handle's pinned poll buffer */
+  int32_t prezeroed; /* set by wiski_stream_step when an earlier kernel of the step has zeroed the solve's scalar block and
+                        accumulated partial vector (wiski_gather_zero): the next START / run skips its own zero launch */
+  int32_t reserved;
 } wiski_pcg_async;
 int wiski_pcg_async_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
 int wiski_pcg_async_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
 int wiski_pcg_async_free(wiski_pcg_async* handle);
+/* Support of wiski_stream_step: the two device regions (pointer, bytes) a solve with these parameters zeroes before its first
+ * kernel, and a predictive-mean gather (k <= 4 columns, as wiski_gather with diag = 0) whose kernel zeroes them on the way when
+ * it can (*zeroed = 1; d = 3 and n <= 65536) -- one launch less per streaming step. */
+int wiski_pcg_zero_regions_f32(const wiski_grid* grid, int32_t k, int32_t max_iter, void* d_work, int32_t a_sym, void** p1, int64_t* n1_bytes, void** p2, int64_t* n2_bytes);
+int wiski_pcg_zero_regions_f64(const wiski_grid* grid, int32_t k, int32_t max_iter, void* d_work, int32_t a_sym, void** p1, int64_t* n1_bytes, void** p2, int64_t* n2_bytes);
+int wiski_gather_zero_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, float* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
+int wiski_gather_zero_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, double* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 
 /* One streaming step in one call (single output, symmetric half stencil): the launches of wiski_gather (predictive mean of
  * the incoming batch under the CURRENT posterior mean d_U, written to d_mean_out [q]; skipped when NULL),

@@ -112,7 +112,13 @@ __global__ __launch_bounds__(256) void k_gather(GridDev<real> G, const real* __r
 // consecutive innermost taps in one 16-byte load; the 16-lane groups are DPP rows, so the tap sums meet in lane 15 of the row.
 template <typename real>
 __global__ __launch_bounds__(256) void k_gather_coop3(GridDev<real> G, const real* __restrict__ x, int64_t n, const real* __restrict__ V,
-                                                      int k, real* __restrict__ out, int32_t* __restrict__ err) {
+                                                      int k, real* __restrict__ out, int32_t* __restrict__ err,
+                                                      uint32_t* __restrict__ z1 = nullptr, int64_t n1 = 0, uint32_t* __restrict__ z2 = nullptr,
+                                                      int64_t n2 = 0) {
+  // optional: zero two word arrays on the way (wiski_gather_zero: the scalar block and the accumulated partial vector of the
+  // solve that follows in the same streaming step -- saves that solve's own zero launch)
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1; e += (int64_t)gridDim.x * blockDim.x) z1[e] = 0u;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) z2[e] = 0u;
   const int sub = threadIdx.x & 15;
   const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool live = p < n;
@@ -363,6 +369,24 @@ static int gather_impl(const wiski_grid* grid, const real* d_x, int64_t n, const
 }
 
 template <typename real>
+static int gather_zero_impl(const wiski_grid* grid, const real* d_x, int64_t n, const real* d_V, int32_t k, real* d_out, int32_t* d_err, void* z1,
+                            int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream) {
+  if (zeroed) *zeroed = 0;
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  const bool coop = G.d == 3 && k >= 1 && k <= 4 && n >= 1 && n <= 65536 && G.g[2] >= 4 && zeroed && (n1_bytes % 4) == 0 && (n2_bytes % 4) == 0 &&
+                    (n1_bytes == 0 || z1) && (n2_bytes == 0 || z2);
+  if (!coop) return gather_impl<real>(grid, d_x, n, d_V, k, 0, d_out, d_err, stream);
+  if (!d_x || !d_V || !d_out || !d_err) return WISKI_E_BADARG;
+  hipLaunchKernelGGL((k_gather_coop3<real>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, k, d_out, d_err,
+                     (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4);
+  WISKI_LAUNCH_CHECK();
+  *zeroed = 1;
+  return WISKI_OK;
+}
+
+template <typename real>
 static int gather_ell_impl(const int32_t* d_idx, const real* d_val, int64_t n, int32_t T, const real* d_v, real* d_out, void* stream) {
   if (n == 0) return WISKI_OK;
   if (!d_idx || !d_val || !d_v || !d_out) return WISKI_E_BADARG;
@@ -403,6 +427,8 @@ extern "C" {
 int wiski_version(void) { return WISKI_VERSION; }
 int wiski_interp_f32(const wiski_grid* g, const float* x, int64_t n, int32_t* idx, float* val, int32_t* err, void* s) { return interp_impl<float>(g, x, n, idx, val, err, s); }
 int wiski_interp_f64(const wiski_grid* g, const double* x, int64_t n, int32_t* idx, double* val, int32_t* err, void* s) { return interp_impl<double>(g, x, n, idx, val, err, s); }
+int wiski_gather_zero_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t k, float* out, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, int32_t* zeroed, void* s) { return gather_zero_impl<float>(g, x, n, V, k, out, err, z1, n1, z2, n2, zeroed, s); }
+int wiski_gather_zero_f64(const wiski_grid* g, const double* x, int64_t n, const double* V, int32_t k, double* out, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, int32_t* zeroed, void* s) { return gather_zero_impl<double>(g, x, n, V, k, out, err, z1, n1, z2, n2, zeroed, s); }
 int wiski_gather_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t k, int32_t diag, float* out, int32_t* err, void* s) { return gather_impl<float>(g, x, n, V, k, diag, out, err, s); }
 int wiski_gather_f64(const wiski_grid* g, const double* x, int64_t n, const double* V, int32_t k, int32_t diag, double* out, int32_t* err, void* s) { return gather_impl<double>(g, x, n, V, k, diag, out, err, s); }
 int wiski_gather_grad_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t diag, float* out, void* s) { return gather_grad_impl<float>(g, x, n, V, diag, out, s); }

@@ -1639,7 +1639,9 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   auto spmv_narrow = [&](const real* v, const real* add, real beta, real* out, double* dots) {
     return sym ? launch_spmv_sym<real>(G, d_A, v, k, add, beta, out, dots, s) : launch_spmv<real>(G, d_A, v, k, add, beta, out, dots, s);
   };
-  if (!resume) {
+  if (!resume && as && as->prezeroed) {
+    as->prezeroed = 0;      // wiski_stream_step had the step's first kernel zero both regions (wiski_pcg_zero_regions)
+  } else if (!resume) {
     const int64_t nscal = PcgScal::doubles(k, max_iter), nvec = zl ? (int64_t)k * m : 0;
     int64_t zb = ((nscal > nvec ? nscal : nvec) + 255) / 256;
     if (zb > 1024) zb = 1024;
@@ -1899,7 +1901,32 @@ static int kron_impl(const wiski_grid* grid, const real* d_tcol, const real* d_V
   return launch_kron<real>(G, d_tcol, d_V, k, scale, d_tmp, d_out, nullptr, nullptr, (hipStream_t)stream);
 }
 
+// The two regions a solve zeroes before its first kernel (scalars + dot-slot ring; the atomically accumulated partial
+// vector of the half-stencil SpMV), for a caller that has an earlier kernel do it: same layout arithmetic as pcg_impl.
+template <typename real>
+static int pcg_zero_regions_impl(const wiski_grid* grid, int32_t k, int32_t max_iter, void* d_work, int32_t a_sym, void** p1, int64_t* n1, void** p2,
+                                 int64_t* n2) {
+  GridDev<real> G;
+  int rc = make_grid_dev<real>(grid, &G);
+  if (rc) return rc;
+  if (!d_work || !p1 || !n1 || !p2 || !n2 || k < 1 || max_iter < 1) return WISKI_E_BADARG;
+  const int m = G.m;
+  const int64_t vec = align_up((int64_t)k * m * sizeof(real), 256);
+  char* w = (char*)d_work;
+  real* part = (real*)(w + 6 * vec);
+  int zl = 0;
+  const bool wide = (m % 4) == 0;
+  const int nch = wide ? (a_sym ? sym_partials<real>(G, k, &zl) : spmv_nch(G.d)) : 0;
+  *p1 = w + 20 * vec;
+  *n1 = PcgScal::doubles(k, max_iter) * (int64_t)sizeof(double);
+  *p2 = part + (int64_t)(nch > 0 ? nch - 1 : 0) * k * m;
+  *n2 = zl ? (int64_t)k * m * (int64_t)sizeof(real) : 0;
+  return WISKI_OK;
+}
+
 extern "C" {
+int wiski_pcg_zero_regions_f32(const wiski_grid* g, int32_t k, int32_t max_iter, void* work, int32_t a_sym, void** p1, int64_t* n1, void** p2, int64_t* n2) { return pcg_zero_regions_impl<float>(g, k, max_iter, work, a_sym, p1, n1, p2, n2); }
+int wiski_pcg_zero_regions_f64(const wiski_grid* g, int32_t k, int32_t max_iter, void* work, int32_t a_sym, void** p1, int64_t* n1, void** p2, int64_t* n2) { return pcg_zero_regions_impl<double>(g, k, max_iter, work, a_sym, p1, n1, p2, n2); }
 int wiski_stencil_spmv_f32(const wiski_grid* g, const float* A, const float* V, int32_t k, const float* add, float beta, float* out, void* s) { return spmv_impl<float>(g, A, V, k, add, beta, out, s); }
 int wiski_stencil_spmv_f64(const wiski_grid* g, const double* A, const double* V, int32_t k, const double* add, double beta, double* out, void* s) { return spmv_impl<double>(g, A, V, k, add, beta, out, s); }
 int wiski_stencil_spmv_sym_f32(const wiski_grid* g, const float* A, const float* V, int32_t k, const float* add, float beta, float* out, void* s) { return spmv_sym_impl<float>(g, A, V, k, add, beta, out, s); }

@@ -21,6 +21,21 @@ int wiski_gather_f64(const wiski_grid*, const double*, int64_t, const double*, i
 
 static int gather1(const wiski_grid* g, const float* x, int64_t n, const float* V, float* out, int32_t* err, void* s) { return wiski_gather_f32(g, x, n, V, 1, 0, out, err, s); }
 static int gather1(const wiski_grid* g, const double* x, int64_t n, const double* V, double* out, int32_t* err, void* s) { return wiski_gather_f64(g, x, n, V, 1, 0, out, err, s); }
+// the gather of the batch mean also zeroes what the solve of this step would zero in a launch of its own
+static int gather1z(const wiski_grid* g, const wiski_stream_args_f32* a, const float* x, int64_t n, float* out, int32_t* zeroed, void* s) {
+  void *p1, *p2;
+  int64_t n1, n2;
+  int rc = wiski_pcg_zero_regions_f32(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2);
+  if (rc) return rc;
+  return wiski_gather_zero_f32(g, x, n, a->d_U, 1, out, a->d_err, p1, n1, p2, n2, zeroed, s);
+}
+static int gather1z(const wiski_grid* g, const wiski_stream_args_f64* a, const double* x, int64_t n, double* out, int32_t* zeroed, void* s) {
+  void *p1, *p2;
+  int64_t n1, n2;
+  int rc = wiski_pcg_zero_regions_f64(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2);
+  if (rc) return rc;
+  return wiski_gather_zero_f64(g, x, n, a->d_U, 1, out, a->d_err, p1, n1, p2, n2, zeroed, s);
+}
 static int scatter1(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* nz, int64_t n, float* b, float* A, float* cnt, const float* u, float* res, double* st, int32_t* err, void* s) {
   return wiski_scatter_stats_cnt_f32(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
 }
@@ -59,12 +74,17 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
   const int resumed_rc = rc;
   if (q > 0) {
     if (d_mean_out) {
-      rc = gather1(grid, d_x, q, a->d_U, d_mean_out, a->d_err, stream);
+      int32_t zeroed = 0;
+      rc = as ? gather1z(grid, a, d_x, q, d_mean_out, &zeroed, stream) : gather1(grid, d_x, q, a->d_U, d_mean_out, a->d_err, stream);
       if (rc) return rc;
+      if (as) as->prezeroed = zeroed;      // nothing touches the solve's workspace between this kernel and the solve below
     }
     rc = scatter1(grid, d_x, d_y, d_wa, d_wb, d_noise, q, a->d_b, a->d_A_half, a->d_cnt, carry ? a->d_U : nullptr, carry ? a->d_R : nullptr, a->d_stats,
                   a->d_err, stream);
-    if (rc) return rc;
+    if (rc) {
+      if (as) as->prezeroed = 0;
+      return rc;
+    }
   }
   if (!as) return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream, nullptr, 0);
   if (defer) {
