@@ -1662,8 +1662,12 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   if (vb > bcap) vb = bcap;
   dim3 vgrid((unsigned)vb, (unsigned)k);   // 16-byte groups, grid-stride
 
+  // fp32 fused path with a carried residual: the norms are formed by the first forward transform of r (apply = 2 below)
+  const bool init_in_fwd = !resume && warm == 2 && sizeof(real) == 4 && spectral && wide && spectral_fused_ok<real>(G);
   if (resume) {
     // the start call queued everything up to (and including) the poll of iteration as->it
+  } else if (warm == 2 && init_in_fwd) {
+    if (!d_R) return WISKI_E_BADARG;
   } else if (warm == 2) {
     // r0 carried over by the caller in d_R (wiski_scatter_stats_cnt's d_res): no A u product
     if (!d_R) return WISKI_E_BADARG;
@@ -1769,8 +1773,9 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       // fp64: the update is its own launch (5 per iteration)
       constexpr bool fuse_upd = sizeof(real) == 4;
       if (!fuse_upd) flush_update();
+      const bool init_now = init_in_fwd && it == 0;
       rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, part, nch, zl,
-                                          d_U, d_Z, S, s);
+                                          d_U, d_Z, S, s, init_now ? d_RHS : (const real*)nullptr);
       pending = false;
       if (rc) return rc;
       rc = spmv_wide(p, pt, (real)1, S.php(it));

@@ -602,12 +602,12 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
   tV.issue(V0, g0, g0);
   float4 tin[2];
   float al = 0.f;
-  if (MODE == 2 && apply) {
+  if (MODE == 2 && apply == 1) {
     const double den = S.php_sum(it - 1, cc);
     if (blockIdx.x == 0) pcg_dot_clear(S.php(it), cc, 1, S.k);   // ring entry the SpMV of this iteration accumulates into
     if (pcg_active(S, it - 1, cc, tol2) && den > 0) al = (float)(S.rho(it - 1)[cc] / den);
   }
-  float rn_part = 0.f;
+  float rn_part = 0.f, rhs_part = 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int b = (t >> 3) + 32 * q, q4 = (t & 7) * 4;
@@ -615,7 +615,14 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
     const int64_t e = (int64_t)cc * m + (ok ? (int64_t)b * Sf + s0 + q4 : 0);
     tin[q] = *reinterpret_cast<const float4*>(src + e);
     if (!ok) tin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 2 && apply && ok) {
+    if (MODE == 2 && apply == 2 && ok) {
+      // iteration 0 of a solve whose residual was carried over: this sweep over r also forms ||r||^2 and ||rhs||^2
+      // (k_pcg_init's job; `p` carries the right-hand side here) -- one launch less per streaming step
+      const float4 f4 = *reinterpret_cast<const float4*>(p + e), rv = tin[q];
+      rhs_part += f4.x * f4.x + f4.y * f4.y + f4.z * f4.z + f4.w * f4.w;
+      rn_part += rv.x * rv.x + rv.y * rv.y + rv.z * rv.z + rv.w * rv.w;
+    }
+    if (MODE == 2 && apply == 1 && ok) {
       const int64_t km = (int64_t)S.k * m;
       const float4 pv = *reinterpret_cast<const float4*>(p + e), ptv = *reinterpret_cast<const float4*>(pt + e);
       float4 uv = *reinterpret_cast<const float4*>(u + e), zv = *reinterpret_cast<const float4*>(z + e);
@@ -642,6 +649,10 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
   if (MODE == 2 && apply) {                                  // block-uniform
     const double tot = block_reduce_sum((double)rn_part, s_red);
     if (t == 0) unsafeAtomicAdd(S.rn(it) + cc, tot);
+    if (apply == 2) {
+      const double tot0 = block_reduce_sum((double)rhs_part, s_red);
+      if (t == 0) unsafeAtomicAdd(S.rn0() + cc, tot0);
+    }
   }
   tV.commit(sF, transposed ? SPEC_LDN : SPEC_LDT);
 #pragma unroll
@@ -943,7 +954,7 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 template <typename real>
 int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
                              int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
-                             real* z, PcgScal S, hipStream_t s) {
+                             real* z, PcgScal S, hipStream_t s, const real* rhs0) {
   const int g0 = G.g[0], g1 = G.g[1];
   if (!evec2) evec2 = evec;
   const real* V0 = evec;
@@ -953,9 +964,13 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
   const real* Z1 = evec2 + g0 * g0;
   const real* Z2 = Z1 + g1 * g1;
   if constexpr (sizeof(real) == 4) {
-    if (int rc = launch_mode0_fwd_upd(G, V0, r, w0, k, it, apply, tol2, p, pt, part, nch, zl, u, z, S, s)) return rc;
+    // rhs0 (iteration 0 of a solve with a carried residual): the forward sweep also forms ||r||^2 and ||rhs||^2; the kernel's
+    // `p` argument -- not read at it = 0 -- carries the right-hand side for THIS launch only (the backward kernel below writes p)
+    if (rhs0 && apply) return WISKI_E_BADARG;
+    if (int rc = launch_mode0_fwd_upd(G, V0, r, w0, k, it, rhs0 ? 2 : apply, tol2, rhs0 ? const_cast<float*>(rhs0) : p, pt, part, nch, zl, u, z, S, s))
+      return rc;
   } else {
-    if (apply) return WISKI_E_BADARG;
+    if (apply || rhs0) return WISKI_E_BADARG;
     if (int rc = launch_mode0<real, false>(G, V0, V0, 0, 0, (const real*)r, w0, k, (const real*)nullptr, 0, (double*)nullptr, s)) return rc;
   }
   if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, S.rho(it), s)) return rc;
@@ -964,10 +979,11 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
 template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, float*, int, float*,
-                                             float*, int, int, double, float*, float*, float*, int, int, float*, float*, PcgScal, hipStream_t);
+                                             float*, int, int, double, float*, float*, float*, int, int, float*, float*, PcgScal, hipStream_t,
+                                             const float*);
 template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, double*, int,
                                               double*, double*, int, int, double, double*, double*, double*, int, int, double*, double*, PcgScal,
-                                              hipStream_t);
+                                              hipStream_t, const double*);
 template bool spectral_fused_ok<double>(const GridDev<double>&);
 template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int, float*,
                                           float*, float*, double*, hipStream_t);
