@@ -228,10 +228,10 @@ def main():
                 if world == 1:                             # evaluate -> absorb -> refresh behind one C-ABI call (wiski_stream_step)
                     mean = model.stream_step(xb, yb)
                     return mean, model._last_iters[0]
-                mean = model(xb).mean                      # 1. evaluate
-                upd.update(xb, yb)                         # 2. absorb + exchange between the ranks
-                pc = model.prediction_cache                # 3. refresh
-                return mean, pc["cg_iters"][0]
+                # N > 1: evaluate -> exchange between the ranks -> absorb -> refresh; with the point exchange the gathered batch
+                # goes through the same one-call step, with the statistics all-reduce through the three generic calls
+                mean = upd.stream_step(xb, yb)
+                return mean, (getattr(model, "_last_iters", None) or [0])[0]
 
             model.prediction_cache                         # cold solve on the init data (not timed)
             gc_settle()
@@ -261,7 +261,7 @@ def main():
                         lib.wiski_prof_start(ctypes.c_int32(256))
                     _, it = step(Xs[t * q:(t + 1) * q], ys[t * q:(t + 1) * q])
                     iters.append(it)
-                    if k == K - 1 and world == 1:
+                    if k == K - 1:
                         model._finish_pending()             # a block ends with its last refresh converged, inside the timed region
                     if sampled:
                         # step() returned from the solver's convergence poll, which is ordered after every SpMV of the step

@@ -176,6 +176,40 @@ class ShardedStatsUpdater:
         Na = allp[:, d + out:].contiguous() if noise is not None else None
         m.condition_on_observations(Xa, Ya, Na, inplace=True)
 
+    def stream_step(self, X, Y, want_mean=True):
+        """evaluate -> exchange -> absorb -> refresh for this rank's shard of a streamed batch (unit noise), the data-parallel face
+        of ``FixedNoiseOnlineSKIGP.stream_step``.  With the point exchange the all-gathered batch goes through the model's
+        one-call step (``wiski_stream_step``, deferred poll) and the rank keeps its slice of the predictive means; with the
+        statistics all-reduce the three generic calls run (the exchange sits between the absorb and the refresh).
+        Returns the predictive mean of X under the posterior before the update ([q]) or None."""
+        m = self.model
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1 and self.comm is None:
+            return m.stream_step(X, Y, want_mean)
+        if Y.dim() == 1:
+            Y = Y[:, None]
+        d = m._grid.d
+        q = X.reshape(-1, d).shape[0]
+        if self.comm is None and m.num_outputs == 1 and self._use_points(q, world, m._device):
+            self.last_exchange = "points"
+            packed = torch.cat([X.reshape(-1, d).to(m._device, m._dtype), Y.to(m._device, m._dtype)], dim=1).contiguous()
+            parts = [torch.empty_like(packed) for _ in range(world)]
+            dist.all_gather(parts, packed, group=self.group)
+            allp = torch.cat(parts, dim=0)
+            mean = m.stream_step(allp[:, :d].contiguous(), allp[:, d:d + 1].contiguous(), want_mean)
+            r = dist.get_rank(self.group)
+            return mean.reshape(-1)[r * q:(r + 1) * q] if mean is not None else None
+        from . import settings
+
+        m._finish_pending()
+        mean = None
+        if want_mean:
+            with settings.skip_posterior_variances(True):
+                mean = m(X).mean
+        self.update(X, Y)
+        m.prediction_cache
+        return mean
+
     def _delta_cache(self):
         """Zeroed delta copies of (b, stats); the W^T W delta lives in the model's symmetric
         half-stencil delta buffers (half the bytes of a full stencil on the wire)."""

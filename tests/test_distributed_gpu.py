@@ -63,6 +63,54 @@ def _worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
+def _worker_stream_step(rank, world, port, tmpdir):
+    """ShardedStatsUpdater.stream_step (point exchange -> the model's one-call step on the gathered batch, deferred poll) on a
+    grid past the dense regime: every rank's replica equals plain conditioning on the concatenated shards, and the returned
+    means are the rank's slice of the pre-update predictive means."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from online_gp_amd import settings
+    from online_gp_amd.distributed import ShardedStatsUpdater
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    q, steps = 256, 6
+    X = torch.as_tensor(rng.uniform(-1, 1, (500 + steps * world * q, 3)), device=dev, dtype=torch.float32)
+    y = torch.sin(2 * X[:, :1]) * torch.cos(X[:, 1:2]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=torch.float32)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    ok = True
+    with settings.cg_tolerance(1e-6), settings.skip_posterior_variances(True), settings.deferred_refresh(True), settings.deferred_bounds_check(True), torch.no_grad():
+        ref = FixedNoiseOnlineSKIGP(X[:500], y[:500], torch.ones_like(y[:500]), grid_bounds=gb, grid_size=16, learn_additional_noise=True).eval()
+        model = FixedNoiseOnlineSKIGP(X[:500], y[:500], torch.ones_like(y[:500]), grid_bounds=gb, grid_size=16, learn_additional_noise=True).eval()
+        ref.prediction_cache; model.prediction_cache
+        upd = ShardedStatsUpdater(model, equal_shards=True, exchange="points")
+        for s in range(steps):
+            lo = 500 + s * world * q
+            mine = slice(lo + rank * q, lo + (rank + 1) * q)
+            want = ref(X[mine]).mean                               # predictive mean before the update
+            got = upd.stream_step(X[mine], y[mine])
+            ok = ok and got.shape == (q,) and torch.allclose(got, want, rtol=1e-3, atol=2e-4)
+            ref.condition_on_observations(X[lo:lo + world * q], y[lo:lo + world * q], inplace=True)
+            ref.prediction_cache
+        model._finish_pending()
+        ok = ok and upd.last_exchange == "points" and model.num_data == ref.num_data == 500 + steps * world * q
+        Xs = X[:64]
+        ok = ok and torch.allclose(model(Xs).mean, ref(Xs).mean, rtol=1e-3, atol=2e-4)
+    open(os.path.join(tmpdir, f"ss_{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_stream_step_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_stream_step, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"ss_{r}").read() == "1"
+
+
 def test_sharded_updater_on_gpu_world2(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
