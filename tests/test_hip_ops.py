@@ -81,6 +81,54 @@ def test_gather_and_ell(d, g, tdt, ndt, tol):
     assert int(err.item()) == 0
 
 
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 37, 5000])
+def test_gather_zero_and_pcg_zero_regions(tdt, n):
+    """wiski_gather_zero (the streaming step's batch-mean gather that also zeroes the following solve's scalar block and
+    accumulated partial vector) and wiski_pcg_zero_regions, straight through the C ABI: same means as wiski_gather for k = 1..3
+    columns, both regions zeroed and nothing around them touched, `zeroed` reported; 2-D grids fall back to the plain gather."""
+    import ctypes
+
+    from online_gp_amd import _hip, grid_ops
+
+    rng = np.random.default_rng(11)
+    for d, g in ((3, 12), (2, 16)):
+        grid = grid_ops.GridSpec([[-1.1, 1.1]] * d, g)
+        X = torch.as_tensor(rng.uniform(-1, 1, (n, d)), device="cuda", dtype=tdt)
+        err = grid_ops.new_err_flag("cuda")
+        for k in (1, 3):
+            V = torch.as_tensor(rng.standard_normal((k, grid.m)), device="cuda", dtype=tdt)
+            ref = grid_ops.gather(grid, X, V, err)
+            work, _ = grid_ops.PCGWorkspace().get(grid, 1, 50, tdt, torch.device("cuda", torch.cuda.current_device()))
+            work.fill_(1)
+            p1, p2 = ctypes.c_void_p(), ctypes.c_void_p()
+            n1, n2 = ctypes.c_int64(), ctypes.c_int64()
+            rc = _hip.fn("wiski_pcg_zero_regions", tdt)(grid.ref, ctypes.c_int32(1), ctypes.c_int32(50), _hip.dptr(work), ctypes.c_int32(1),
+                                                      ctypes.byref(p1), ctypes.byref(n1), ctypes.byref(p2), ctypes.byref(n2))
+            assert rc == 0 and n1.value > 0 and n1.value % 8 == 0
+            base = work.data_ptr()
+            o1, o2 = p1.value - base, p2.value - base
+            nbytes = work.numel() * work.element_size()
+            assert 0 <= o2 and o2 + n2.value <= o1 and o1 + n1.value <= nbytes
+            out = torch.empty((n, k), device="cuda", dtype=tdt)
+            zeroed = ctypes.c_int32(-1)
+            rc = _hip.fn("wiski_gather_zero", tdt)(grid.ref, _hip.dptr(X), ctypes.c_int64(n), _hip.dptr(V), ctypes.c_int32(k), _hip.dptr(out),
+                                                 _hip.dptr(err), p1, n1, p2, n2, ctypes.byref(zeroed), _hip.stream_ptr(X.device))
+            assert rc == 0
+            assert torch.allclose(out, ref, rtol=1e-5 if tdt == torch.float32 else 1e-12, atol=1e-6 if tdt == torch.float32 else 1e-13)
+            raw = work.view(torch.uint8).reshape(-1)
+            assert zeroed.value == (1 if d == 3 else 0)
+            if zeroed.value:
+                assert int(raw[o1:o1 + n1.value].max()) == 0 and (n2.value == 0 or int(raw[o2:o2 + n2.value].max()) == 0)
+                keep = torch.ones(nbytes, dtype=torch.bool, device="cuda")
+                keep[o1:o1 + n1.value] = False
+                keep[o2:o2 + n2.value] = False
+                assert bool((raw[keep] != 0).all())
+            else:
+                assert bool((raw != 0).all())
+        assert int(err.item()) == 0
+
+
 @pytest.mark.parametrize("d,g", CASES)
 @pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
 def test_scatter_stats(d, g, tdt, ndt, tol):
