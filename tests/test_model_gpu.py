@@ -301,7 +301,8 @@ def test_c3_scale_properties_50cubed_fp32():
     assert np.abs(var - vo).max() <= 1e-2 * np.abs(vo).max()
 
 
-def test_c3_full_stream_checkpoints_vs_cpu_port():
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+def test_c3_full_stream_checkpoints_vs_cpu_port(kind):
     """BASELINE metric config at FULL size: the whole 3droad-sized synthetic stream (434 874 points, d = 3, 50^3 grid, fp32,
     q = 4096 per step through the one-call streaming step with the deferred poll) against the matrix-free CPU port of the same
     algorithm in fp64 (oracle/baseline.py, OpenMP), predictive means at 4096 fixed test points at three checkpoints: after
@@ -313,8 +314,8 @@ def test_c3_full_stream_checkpoints_vs_cpu_port():
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
 
     N, n0, q = 434874, 21743, 4096
-    Xc, yc = bench.synth_stream(N, 3, 0, torch.device("cpu"), torch.float64, "uniform")
-    Xt, _ = bench.synth_stream(4096, 3, 99, torch.device("cpu"), torch.float64, "uniform")
+    Xc, yc = bench.synth_stream(N, 3, 0, torch.device("cpu"), torch.float64, kind)     # "clustered": the road-like variant of SURVEY 8d
+    Xt, _ = bench.synth_stream(4096, 3, 99, torch.device("cpu"), torch.float64, kind)
     Xg, yg = Xc.to(DEV, torch.float32), yc.to(DEV, torch.float32)
     Xtg = Xt.to(DEV, torch.float32)
     marks = [n0, n0 + ((N // 4 - n0) // q) * q, N]
@@ -343,7 +344,7 @@ def test_c3_full_stream_checkpoints_vs_cpu_port():
         B.refresh(1e-9)
         want = B.predict_mean(Xt.numpy()).astype(np.float64)
         dev = np.abs(g - want).max() / np.abs(want).max()
-        print(f"checkpoint {mark:6d} points: max |mean - cpu| / max |cpu| = {dev:.2e}")
+        print(f"{kind} checkpoint {mark:6d} points: max |mean - cpu| / max |cpu| = {dev:.2e}")
         assert dev <= 1e-2
         assert dev <= 2e-4        # what fp32 statistics + a 1e-5 solve actually give (about 1e-5)
 
