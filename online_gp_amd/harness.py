@@ -33,6 +33,18 @@ def write_csv(rows, path):
             w.writerow(r)
 
 
+def settle_interpreter_heap():
+    """Collect, then freeze the interpreter's long-lived object graph (torch + numpy: ~10^6 objects).  A streaming loop of
+    0.1 - 0.3 ms steps otherwise meets a FULL cyclic-GC pass every few hundred steps, and that pass costs ~80 ms
+    (tools/stall_probe.py) -- several hundred steps' worth.  After the freeze the collector only scans objects created since.
+    Call once after the models are built; harmless to call again (it unfreezes, collects and re-freezes)."""
+    import gc
+
+    gc.unfreeze()
+    gc.collect()
+    gc.freeze()
+
+
 def _sync(t):
     if torch.is_tensor(t) and t.is_cuda:
         torch.cuda.synchronize(t.device)
@@ -47,6 +59,7 @@ def online_regression(online_model, train_x, train_y, test_x, test_y, batch_size
     is appended.  Returns the rows of the reference's `online_metrics` table."""
     rows = []
     on_rmse = on_nll = b_rmse_sum = b_nll_sum = 0.0
+    settle_interpreter_heap()
     n = train_x.shape[-2]
     steps = n // batch_size if max_steps is None else min(max_steps, n // batch_size)
     for t in range(steps):
