@@ -72,12 +72,38 @@ def synth_stream(n, d, seed, device, dtype, kind="uniform"):
     return X.to(device, dtype), y.to(device, dtype)[:, None]
 
 
-def cpu_baseline(args, tol, budget_s=20.0, max_steps=24):
+def usable_cpus():
+    """CPUs this process may really use: logical CPUs capped by the scheduler affinity and the cgroup CPU quota (cgroup v2
+    cpu.max = "<quota> <period>").  The GPU test boxes show 256 logical CPUs under a quota of 16: thread pools sized for 256
+    get the whole container throttled for tens of milliseconds at a time, and the OpenMP baseline runs 5x slower on 128
+    threads than on 16."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(args, tol, budget_s=20.0, max_steps=64):
     """The same step (predictive mean of the batch -> absorb -> warm-started refresh; same grid, q, init, dtype,
     tolerance) by the OpenMP port on all host cores: oracle/baseline.py.  Bounded sample: steps until `budget_s`."""
     from oracle import baseline, spec
 
     baseline.build()
+    baseline.set_num_threads(usable_cpus())         # 16 on the test boxes, not the 256 logical CPUs they show
     ndt = np.float32 if args.dtype == "f32" else np.float64
     q = args.batch
     Xt, yt = synth_stream(args.n_init, args.dim, 0, "cpu", torch.float64, args.stream)
@@ -98,7 +124,8 @@ def cpu_baseline(args, tol, budget_s=20.0, max_steps=24):
     dt = time.perf_counter() - t0
     return {"value": steps * q / dt, "unit": "updates/s", "cores": baseline.num_threads(), "kind": "port",
             "sample": f"{steps} steps of q={q} after the {args.n_init}-point init (same grid / dtype / tolerance / warm starts as the GPU leg), "
-                      f"OpenMP C port on {baseline.num_threads()} threads of {os.cpu_count()} logical CPUs, Kt-preconditioned CG "
+                      f"OpenMP C port on {baseline.num_threads()} threads (= the CPUs the container's quota allows; {os.cpu_count()} logical CPUs are "
+                      f"visible, and 128 threads run 5x slower under that quota), Kt-preconditioned CG "
                       f"({np.mean(iters):.0f} iterations per step; the GPU library's density-profile preconditioner is not ported), {dt:.1f} s"}
 
 
@@ -163,6 +190,7 @@ def main():
     # worse: the per-step temporaries that sit in reference cycles then pile up and the caching allocator has to hipMalloc in
     # the middle of a block (also ~80 ms).  So: collect + freeze the long-lived heap at every leg boundary (gc_settle), which
     # leaves the collector only the young objects of the leg to look at.
+    torch.set_num_threads(usable_cpus())            # host-side tensor work (stream generation) must not over-subscribe the CPU quota
     def gc_settle():
         gc.unfreeze()
         gc.collect()

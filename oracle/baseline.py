@@ -37,6 +37,11 @@ def num_threads():
     return int(lib().wb_num_threads())
 
 
+def set_num_threads(n):
+    lib().wb_set_num_threads(ctypes.c_int(int(n)))
+    return num_threads()
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 

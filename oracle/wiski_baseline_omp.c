@@ -28,6 +28,16 @@ int wb_num_threads(void) {
 #endif
 }
 
+/* threads of the parallel regions that follow (the caller picks the CPUs it is actually allowed to use: a container's CPU
+ * quota can be far below the logical CPU count, and over-subscribing it gets the whole process throttled) */
+void wb_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SUFFIX)

@@ -15,6 +15,8 @@ with settings.skip_posterior_variances(True), settings.cg_tolerance(1e-4), setti
     for p in range(6):
         model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=50, learn_additional_noise=True).eval()
         model.prediction_cache
+        if os.environ.get("FREEZE"):
+            gc.unfreeze(); gc.collect(); gc.freeze()
         Xr, yr = bench.synth_stream(q * 100, 3, 7 + p, dev, dt, "uniform")
         ts = []
         for i in range(100):
