@@ -555,6 +555,19 @@ def main():
                     break
             except Exception:  # noqa: BLE001
                 pass
+        # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (dispatch timestamps: they
+        # exclude the ~1 us of packet processing that the start / stop events above include) -- read back, labelled with its source
+        rp_us, rp_src = None, None
+        try:
+            import csv
+
+            with open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")) as fh:
+                for row in csv.DictReader(fh):
+                    if args.grid == 50 and d == 3 and args.dtype == "f32" and row["Name"].replace("void ", "").startswith(kname):
+                        rp_us, rp_src = float(row["AverageNs"]) / 1e3, "profiles/r02_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)"
+                        break
+        except Exception:  # noqa: BLE001
+            pass
         par = "single"
         if world > 1:
             par = f"dp{world} (" + ("shard all-gather + replicated scatter: divides no work, every rank scatters all N q points and solves"
@@ -578,6 +591,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches": spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
+                         "rocprofv3_avg_launch_us": rp_us, "rocprofv3_frac": (spmv_bytes / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
+                         "rocprofv3_source": rp_src,
                          "timing": "start/stop HIP events attached to each SpMV dispatch (hipExtLaunchKernel) on its launch stream, every 4th timed step",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
