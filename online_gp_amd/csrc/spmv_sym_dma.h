@@ -32,6 +32,12 @@
 // kernel spans 15.1 us: 1.5 us until the first tile lands, ~8 us at 8.5..9.7 TB/s, a 3 us tail in which the chunks run
 // out (the 4-tile chunk ends at 8.5 us, the others at 11.6..13.2 median) and ~1.7 us of last-tile FMAs + window flush.
 //
+// A register-staged sibling (tiles in flight wait in VGPRs -- plain coalesced 16-byte loads, fully unrolled, the compiler's own
+// vmcnt bookkeeping -- and one 7 KB LDS stage only re-tiles the landed tile) was built to put MORE tiles in flight per wave:
+// 19.8 / 20.6 / 21.6 us with 2 / 3 / 4 tiles in flight against 18.3 us here.  More outstanding requests make it slower, not
+// faster: at 8.6..9.7 TB/s the mid-phase of this kernel is already at what the fabric delivers for this pattern; the remaining
+// time is start-up, tail and epilogue.
+//
 // Requires d == 3, m % 4 == 0.  part holds (nparts + 1) * m reals: part[y] = direct term of part y (plain stores),
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
 #pragma once
