@@ -220,6 +220,12 @@ int wiski_pcg_async_free(wiski_pcg_async* handle);
  * it can (*zeroed = 1; d = 3 and n <= 65536) -- one launch less per streaming step. */
 int wiski_pcg_zero_regions_f32(const wiski_grid* grid, int32_t k, int32_t max_iter, void* d_work, int32_t a_sym, void** p1, int64_t* n1_bytes, void** p2, int64_t* n2_bytes);
 int wiski_pcg_zero_regions_f64(const wiski_grid* grid, int32_t k, int32_t max_iter, void* d_work, int32_t a_sym, void** p1, int64_t* n1_bytes, void** p2, int64_t* n2_bytes);
+/* The absorb of a streaming step: wiski_scatter_stats_cnt (half-stencil form) that also (i) writes the predictive mean of every
+ * point under the CURRENT posterior mean d_u into d_mean_out [n] (the w_p . u it forms for the residual carry anyway -- BFN:206-210
+ * without a gather launch; d_res may be NULL when only the mean is wanted), and (ii) zeroes the two regions of
+ * wiski_pcg_zero_regions on the way (n*_bytes = 0: none). */
+int wiski_scatter_stats_step_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, float* d_cnt, const float* d_u, float* d_res, float* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, void* stream);
+int wiski_scatter_stats_step_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_cnt, const double* d_u, double* d_res, double* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, void* stream);
 int wiski_gather_zero_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, float* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 int wiski_gather_zero_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, double* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 

@@ -160,7 +160,13 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
                                                            const real* __restrict__ wa, const real* __restrict__ wb,
                                                            const real* __restrict__ noise, int64_t n, real* __restrict__ b,
                                                            real* __restrict__ A, double* __restrict__ stats, int32_t* __restrict__ err,
-                                                           real* __restrict__ cnt, const real* __restrict__ u, real* __restrict__ res) {
+                                                           real* __restrict__ cnt, const real* __restrict__ u, real* __restrict__ res,
+                                                           real* __restrict__ mean_out = nullptr, uint32_t* __restrict__ z1 = nullptr,
+                                                           int64_t n1 = 0, uint32_t* __restrict__ z2 = nullptr, int64_t n2 = 0) {
+  // optional (wiski_scatter_stats_step): zero two word arrays on the way -- the scalar block and the accumulated partial
+  // vector of the solve that follows in the same streaming step
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1; e += (int64_t)gridDim.x * blockDim.x) z1[e] = 0u;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) z2[e] = 0u;
   constexpr int T = 1 << (2 * D);
   constexpr int TP = T / 4;                      // tap prefixes (leading d-1 digits)
   constexpr int NPAIR = TP * (TP + 1) / 2;       // prefix pairs with code(pb) >= code(pa)
@@ -249,18 +255,21 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
     }
     // residual carry-over (optional): res += W^T (wb y - wa (W u)) keeps res = b - z - A u exact under the
     // increment (b, A) += (W^T wb y, W^T wa W), so the next warm-started solve needs no A u product
+    // w_p . u is also the predictive mean of the point under the posterior BEFORE this update (u = the current posterior mean
+    // on the grid): mean_out makes the separate gather launch of a streaming step unnecessary
     real innov = yp * wbp;
     if (u) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) wu += __shfl_xor(wu, off, 64);
       innov -= wap * wu;
+      if (mean_out && lane == 0 && valid) mean_out[p] = wu;
     }
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
       if (valid && val_t[t] != (real)0) {
         atomic_add_real(b + flat_t[t], val_t[t] * yp * wbp);
         if (cnt) atomic_add_real(cnt + flat_t[t], val_t[t] * wap);     // row sums of the increment (preconditioner density model)
-        if (u) atomic_add_real(res + flat_t[t], val_t[t] * innov);
+        if (res) atomic_add_real(res + flat_t[t], val_t[t] * innov);
       }
     }
     __syncthreads();
@@ -339,13 +348,16 @@ static int expand_impl(const wiski_grid* grid, real* d_half, real* d_full, void*
 template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
                         int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
-                        real* d_cnt = nullptr, const real* d_u = nullptr, real* d_res = nullptr) {
+                        real* d_cnt = nullptr, const real* d_u = nullptr, real* d_res = nullptr, real* d_mean_out = nullptr,
+                        void* z1 = nullptr, int64_t n1_bytes = 0, void* z2 = nullptr, int64_t n2_bytes = 0) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
   if (n == 0) return WISKI_OK;
   if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
-  if ((d_u != nullptr) != (d_res != nullptr) || (d_u && !half)) return WISKI_E_BADARG;   // residual carry-over: half-stencil form only
+  if (d_mean_out == nullptr && (d_u != nullptr) != (d_res != nullptr)) return WISKI_E_BADARG;
+  if ((d_res && !d_u) || (d_mean_out && !d_u) || (d_u && !half)) return WISKI_E_BADARG;  // residual carry-over / mean: half-stencil form only
+  if ((n1_bytes | n2_bytes) & 3 || (n1_bytes && !z1) || (n2_bytes && !z2) || ((n1_bytes || n2_bytes) && !half)) return WISKI_E_BADARG;
   const int grp = half ? 64 : (G.T < 64 ? G.T : 64);
   const int64_t ppb = 256 / grp;
   int64_t blocks = (n + ppb - 1) / ppb;
@@ -353,7 +365,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   dim3 grd((unsigned)blocks);
 #define CALL(DD)                                                                                                                              \
   do {                                                                                                                                        \
-    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res); \
+    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4); \
     else hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
   } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
@@ -380,6 +392,12 @@ int wiski_scatter_stats_cnt_f32(const wiski_grid* g, const float* x, const float
 }
 int wiski_scatter_stats_cnt_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A, int32_t half, double* cnt, const double* u, double* res, double* stats, int32_t* err, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A, stats, err, s, half != 0, cnt, u, res);
+}
+int wiski_scatter_stats_step_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, float* cnt, const float* u, float* res, float* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2);
+}
+int wiski_scatter_stats_step_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2);
 }
 int wiski_stencil_expand_add_f32(const wiski_grid* g, float* half, float* full, void* s) { return expand_impl<float>(g, half, full, s); }
 int wiski_stencil_expand_add_f64(const wiski_grid* g, double* half, double* full, void* s) { return expand_impl<double>(g, half, full, s); }

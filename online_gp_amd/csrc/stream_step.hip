@@ -42,6 +42,21 @@ static int scatter1(const wiski_grid* g, const float* x, const float* y, const f
 static int scatter1(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, double* b, double* A, double* cnt, const double* u, double* res, double* st, int32_t* err, void* s) {
   return wiski_scatter_stats_cnt_f64(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
 }
+// absorb + predictive mean of the batch (+ the zeroing the following solve would do in a launch of its own) in ONE kernel
+static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f32* a, const float* x, const float* y, const float* wa, const float* wb, const float* nz, int64_t n, int carry, float* mean_out, int zero, void* s) {
+  void *p1 = nullptr, *p2 = nullptr;
+  int64_t n1 = 0, n2 = 0;
+  if (zero)
+    if (int rc = wiski_pcg_zero_regions_f32(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
+  return wiski_scatter_stats_step_f32(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, s);
+}
+static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f64* a, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, int carry, double* mean_out, int zero, void* s) {
+  void *p1 = nullptr, *p2 = nullptr;
+  int64_t n1 = 0, n2 = 0;
+  if (zero)
+    if (int rc = wiski_pcg_zero_regions_f64(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
+  return wiski_scatter_stats_step_f64(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, s);
+}
 static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
                 wiski_pcg_async* as, int mode) {
   return wiski_pcg_async_f32(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol,
@@ -74,16 +89,15 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
   const int resumed_rc = rc;
   if (q > 0) {
     if (d_mean_out) {
-      int32_t zeroed = 0;
-      rc = as ? gather1z(grid, a, d_x, q, d_mean_out, &zeroed, stream) : gather1(grid, d_x, q, a->d_U, d_mean_out, a->d_err, stream);
+      // the absorb kernel forms w_p . U for the residual carry anyway: it is the predictive mean of the batch, so there is no
+      // gather launch; with a handle the same kernel also zeroes what the solve below would zero in a launch of its own
+      rc = scatter_step1(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, carry, d_mean_out, as ? 1 : 0, stream);
       if (rc) return rc;
-      if (as) as->prezeroed = zeroed;      // nothing touches the solve's workspace between this kernel and the solve below
-    }
-    rc = scatter1(grid, d_x, d_y, d_wa, d_wb, d_noise, q, a->d_b, a->d_A_half, a->d_cnt, carry ? a->d_U : nullptr, carry ? a->d_R : nullptr, a->d_stats,
-                  a->d_err, stream);
-    if (rc) {
-      if (as) as->prezeroed = 0;
-      return rc;
+      if (as) as->prezeroed = 1;           // nothing touches the solve's workspace between this kernel and the solve below
+    } else {
+      rc = scatter1(grid, d_x, d_y, d_wa, d_wb, d_noise, q, a->d_b, a->d_A_half, a->d_cnt, carry ? a->d_U : nullptr, carry ? a->d_R : nullptr, a->d_stats,
+                    a->d_err, stream);
+      if (rc) return rc;
     }
   }
   if (!as) return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream, nullptr, 0);

@@ -129,6 +129,69 @@ def test_gather_zero_and_pcg_zero_regions(tdt, n):
         assert int(err.item()) == 0
 
 
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d,g,n", [(3, 12, 1), (3, 12, 700), (2, 16, 333), (4, 6, 50)])
+def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
+    """wiski_scatter_stats_step (the absorb of a streaming step) through the C ABI: the same (b, A_half, cnt, res, stats) as
+    wiski_scatter_stats_cnt with the residual carry, mean_out = W u as wiski_gather gives it, both regions of
+    wiski_pcg_zero_regions zeroed and nothing else in the workspace touched; res = NULL leaves the residual alone."""
+    import ctypes
+
+    from online_gp_amd import _hip, grid_ops
+
+    rng = np.random.default_rng(5)
+    grid = grid_ops.GridSpec([[-1.1, 1.1]] * d, g)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    mk = lambda a: torch.as_tensor(a, device="cuda", dtype=tdt)
+    X, y = mk(rng.uniform(-1, 1, (n, d))), mk(rng.standard_normal(n))
+    noise = mk(rng.uniform(0.5, 2.0, n))
+    wa, wb = 1.0 / noise, 1.0 / noise
+    u = mk(rng.standard_normal(grid.m))
+    H = (grid.R + 1) // 2
+    err = grid_ops.new_err_flag("cuda")
+    ref = dict(b=torch.zeros(grid.m, device="cuda", dtype=tdt), A=torch.zeros((H, grid.m), device="cuda", dtype=tdt),
+               cnt=torch.zeros(grid.m, device="cuda", dtype=tdt), res=torch.zeros(grid.m, device="cuda", dtype=tdt),
+               stats=torch.zeros(2, device="cuda", dtype=torch.float64))
+    grid_ops.scatter_stats_cnt(grid, X, y, wa, wb, noise, ref["b"], ref["A"], True, ref["cnt"], ref["stats"], err, u=u, res=ref["res"])
+    mean_ref = grid_ops.gather(grid, X, u[None], err)[:, 0]
+    rtol, atol = (2e-5, 2e-5) if tdt == torch.float32 else (1e-12, 1e-12)
+    for with_res in (True, False):
+        got = {k: torch.zeros_like(v) for k, v in ref.items()}
+        work, _ = grid_ops.PCGWorkspace().get(grid, 1, 50, tdt, dev)
+        work.fill_(1)
+        p1, p2 = ctypes.c_void_p(), ctypes.c_void_p()
+        n1, n2 = ctypes.c_int64(), ctypes.c_int64()
+        rc = _hip.fn("wiski_pcg_zero_regions", tdt)(grid.ref, ctypes.c_int32(1), ctypes.c_int32(50), _hip.dptr(work), ctypes.c_int32(1),
+                                                  ctypes.byref(p1), ctypes.byref(n1), ctypes.byref(p2), ctypes.byref(n2))
+        assert rc == 0
+        mean = torch.full((n,), float("nan"), device="cuda", dtype=tdt)
+        rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
+                                                    _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), _hip.dptr(u),
+                                                    _hip.dptr(got["res"]) if with_res else None, _hip.dptr(mean), _hip.dptr(got["stats"]),
+                                                    _hip.dptr(err), p1, n1, p2, n2, _hip.stream_ptr(dev))
+        assert rc == 0
+        assert torch.allclose(mean, mean_ref, rtol=rtol, atol=atol)
+        for k in ("b", "A", "cnt", "stats"):
+            assert torch.allclose(got[k], ref[k], rtol=rtol, atol=atol), k
+        if with_res:
+            assert torch.allclose(got["res"], ref["res"], rtol=rtol * 10, atol=atol * 10)
+        else:
+            assert float(got["res"].abs().max()) == 0.0
+        raw = work.view(torch.uint8).reshape(-1)
+        o1, o2 = p1.value - work.data_ptr(), p2.value - work.data_ptr()
+        assert int(raw[o1:o1 + n1.value].max()) == 0 and (n2.value == 0 or int(raw[o2:o2 + n2.value].max()) == 0)
+        keep = torch.ones(raw.numel(), dtype=torch.bool, device="cuda")
+        keep[o1:o1 + n1.value] = False
+        keep[o2:o2 + n2.value] = False
+        assert bool((raw[keep] != 0).all())
+    assert int(err.item()) == 0
+    # the mean needs u; the residual carry needs u
+    rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
+                                                _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), None, None, _hip.dptr(mean),
+                                                _hip.dptr(got["stats"]), _hip.dptr(err), None, ctypes.c_int64(0), None, ctypes.c_int64(0), _hip.stream_ptr(dev))
+    assert rc != 0
+
+
 @pytest.mark.parametrize("d,g", CASES)
 @pytest.mark.parametrize("tdt,ndt,tol", DTYPES)
 def test_scatter_stats(d, g, tdt, ndt, tol):
