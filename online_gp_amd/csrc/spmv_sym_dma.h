@@ -38,6 +38,10 @@
 // faster: at 8.6..9.7 TB/s the mid-phase of this kernel is already at what the fabric delivers for this pattern; the remaining
 // time is start-up, tail and epilogue.
 //
+// Flushing the transposed window progressively (after tile t everything below (t + 1) * S1 is final: one ~4-granule atomic
+// instruction per tile in the loop, 17 instead of 36 granules left for the epilogue) shortens the epilogue (0.92 -> 0.58 us per
+// wave) but the atomics in the loop slow the stream (1 300 -> 1 050..1 170 tiles/us): 19.15 us against 18.45 us back to back.
+//
 // Requires d == 3, m % 4 == 0.  part holds (nparts + 1) * m reals: part[y] = direct term of part y (plain stores),
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
 #pragma once
