@@ -559,6 +559,154 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const 
   SPEC_STAMP(5);
 }
 
+// ------------------------------------- slab, fp32 on the matrix cores, many columns ---
+// k_spec_slab_mfma for multi-column solves (predictive variances, probe solves).  There a block per (slab, half, column)
+// is 2 g0 k blocks of 115 KB LDS -- one per CU at a time, each a serial chain of [5 matrix loads, 4 products, 4 barriers]
+// (8.6 us; 215 us for 64 columns at 50^3, the forward half computed twice).  Here a block owns slab i0 for a strided set of
+// columns: the four eigenvector images are loaded ONCE, the forward products P2, P3 run once per column and both output halves
+// are formed from the C3 fragment kept in registers (6 products per column instead of 8), and the next column's slab is
+// fetched into registers while the current one is in the matrix cores.
+//   LDS: bufA, bufB, sV1, sV2 (stride LDT), sB1, sB2 per half (stride LDN): 115 KB, 150 KB with a generalized eigenbasis.
+template <int KS, int VW>
+__global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
+                                                           const float* __restrict__ Z1, const float* __restrict__ Z2,
+                                                           const float* __restrict__ evals, float kscale, float shift,
+                                                           const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double s_red[16];
+  __shared__ float sE[128];                       // eigenvalues of dims 1 | 2, zero padded to 64 each
+  float* bufA = reinterpret_cast<float*>(smem);   // [64][80]: X, later scaled C3 (stride LDN)
+  float* bufB = bufA + 64 * SPEC_LDT;             // [64][80]: C2 (stride LDN), later C5 (stride LDT)
+  float* sV1 = bufB + 64 * SPEC_LDT;              // [b][x], stride LDT
+  float* sV2 = sV1 + 64 * SPEC_LDT;               // [b][y], stride LDT
+  float* sB1[2], *sB2[2];                         // backward images of half 0 (t: Z when generalized) and half 1 (y: V)
+  sB1[1] = sV2 + 64 * SPEC_LDT;                   // bV1[x][b], stride LDN
+  sB2[1] = sB1[1] + 64 * SPEC_LDN;                // bV2[y][b], stride LDN
+  const bool alt = Z1 != V1 || Z2 != V2;          // grid-uniform
+  sB1[0] = alt ? sB2[1] + 64 * SPEC_LDN : sB1[1];
+  sB2[0] = alt ? sB1[0] + 64 * SPEC_LDN : sB2[1];
+  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2], m = G.m;
+  const int i0 = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  int c = blockIdx.y;
+  if (c >= k) return;
+  SpecTile<VW> tX;
+  {
+    SpecTile<VW> tV1, tV2, tB1, tB2;
+    tX.issue(src + (int64_t)c * m + (int64_t)i0 * g1 * g2, g1, g2);
+    tV1.issue(V1, g1, g1);
+    tV2.issue(V2, g2, g2);
+    tB1.issue(V1, g1, g1);
+    tB2.issue(V2, g2, g2);
+    if (t < 128) {
+      const int q = t & 63;
+      float ev = 0.f;
+      if (t < 64 ? q < g1 : q < g2) ev = evals[t < 64 ? g0 + q : g0 + g1 + q];
+      sE[t] = ev;
+    }
+    tX.commit(bufA, SPEC_LDT);
+    tV1.commit(sV1, SPEC_LDT);
+    tV2.commit(sV2, SPEC_LDT);
+    tB1.commit(sB1[1], SPEC_LDN);
+    tB2.commit(sB2[1], SPEC_LDN);
+    if (alt) {
+      tB1.issue(Z1, g1, g1);
+      tB2.issue(Z2, g2, g2);
+      tB1.commit(sB1[0], SPEC_LDN);
+      tB2.commit(sB2[0], SPEC_LDN);
+    }
+  }
+  const float l0 = kscale * evals[i0];
+  __syncthreads();
+  spec_f32x4 acc[2][2];
+  const int l15 = lane & 15, l4 = lane >> 4;
+  auto store_tiles = [&](float* __restrict__ out, int ld) {       // C fragments -> out[row][col], row-major with stride ld
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(wr * 32 + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
+  };
+  // spectral factors of this thread's 16 C3 entries: the same for every column
+  float f1v[2][2][4], f2v[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const float e2 = sE[64 + wc * 32 + cc * 16 + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float lam = l0 * sE[wr * 32 + a * 16 + l4 * 4 + r] * e2;
+        const float f1 = __frcp_rn(1.f + shift * lam);
+        f1v[a][cc][r] = f1;
+        f2v[a][cc][r] = lam * f1;
+      }
+    }
+  for (; c < k; c += gridDim.y) {
+    const int cn = c + gridDim.y;
+    const bool more = cn < k;                     // block-uniform
+    if (more) tX.issue(src + (int64_t)cn * m + (int64_t)i0 * g1 * g2, g1, g2);
+    // P2: A = V1^T (sV1 [b][x]), B = X (bufA [b][y])  -> C2 natural (bufB, stride LDN)
+    spec_mfma_product<false, false, KS>(sV1, bufA, wr, wc, lane, acc);
+    store_tiles(bufB, SPEC_LDN);
+    __syncthreads();
+    // P3: A = C2 (bufB natural), B = V2 (sV2 [b][y]) -> C3, kept in registers for both halves
+    spec_mfma_product<true, false, KS>(bufB, sV2, wr, wc, lane, acc);
+    spec_f32x4 c3[2][2];
+    float rho_lane = 0.f;   // 16 terms per lane in fp32, the cross-lane / cross-block sum in fp64
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[a][cc][r];
+          c3[a][cc][r] = v;
+          rho_lane += f2v[a][cc][r] * v * v;      // r^T P r in the eigenbasis (padding: lam = 0)
+          acc[a][cc][r] = v * f1v[a][cc][r];
+        }
+    store_tiles(bufA, SPEC_LDN);                  // bufA (X) was last read by P2, a barrier ago
+    if (rho != nullptr) {
+      const double tot = block_reduce_sum((double)rho_lane, s_red);
+      if (t == 0) unsafeAtomicAdd(rho + c, tot);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // P5: A = scaled C3 (bufA natural), B = bV2^T (sB2 [y][b]) -> C5 [b = i1'][y = i2] (bufB, stride LDT)
+      spec_mfma_product<true, true, KS>(bufA, sB2[h], wr, wc, lane, acc);
+      store_tiles(bufB, SPEC_LDT);
+      __syncthreads();
+      // bufA is free now: half 0 -> the y-half's scaled C3; half 1 -> the next column's slab
+      if (h == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][cc][r] = c3[a][cc][r] * f2v[a][cc][r];
+        store_tiles(bufA, SPEC_LDN);
+      } else if (more) {
+        tX.commit(bufA, SPEC_LDT);
+      }
+      // P6: A = bV1 (sB1 natural), B = C5 (bufB [b][y]) -> global
+      spec_mfma_product<true, false, KS>(sB1[h], bufB, wr, wc, lane, acc);
+      float* __restrict__ os = dst + ((int64_t)h * k + c) * m + (int64_t)i0 * g1 * g2;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int x = wr * 32 + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
+            if (x < g1 && y < g2) os[x * g2 + y] = acc[a][cc][r];
+          }
+      __syncthreads();                            // bufB (C5) read by P6; bufA written above
+    }
+  }
+}
+
 // ----------------------------------------------- mode 0, fp32 on the matrix cores ---
 // dst[c][x, s] = sum_b A[x][b] src[c][b, s] for a tile of 32 fibres s, A = V0^T (forward) or V0 (backward):
 // one 64 x 32 x (4 KS) product per block, the 4 waves own 32 x 16 output sub-tiles (2 MFMA tiles each).
@@ -786,6 +934,16 @@ static int launch_mode0_bwd_updp(const GridDev<real>& G, const real* X0, const r
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+static int spec_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 constexpr size_t SPEC_SLAB_MFMA_LDS = (size_t)(4 * 64 * SPEC_LDT + 2 * 64 * SPEC_LDN) * sizeof(float);
 
 // slab launch: fp32 on the matrix cores, fp64 on the register-tile kernel
@@ -813,6 +971,40 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
     if (even) SLAB_MFMA2(KS, 2);   \
     else SLAB_MFMA2(KS, 1);        \
   } while (0)
+    // three or more columns: blocks that own a slab for a strided set of columns (about one block per CU)
+    if (k >= 3 && getenv("WISKI_SLAB_MC_OFF") == nullptr) {
+      const bool alt = Z1 != V1 || Z2 != V2;
+      const size_t lds = SPEC_SLAB_MFMA_LDS + (alt ? (size_t)2 * 64 * SPEC_LDN * sizeof(float) : 0);
+      int nb = spec_cu_count() / g0;
+      nb = nb < 1 ? 1 : (nb > k ? k : nb);
+      // even out the columns per block: the fewest blocks that keep the longest chain
+      const int per = (k + nb - 1) / nb;
+      nb = (k + per - 1) / per;
+#define SLAB_MC2(KS, VW)                                                                                                                          \
+  do {                                                                                                                                            \
+    static size_t lds_set = 0;                                                                                                                    \
+    if (lds > lds_set) {                                                                                                                          \
+      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma_mc<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
+        return WISKI_E_LAUNCH;                                                                                                                    \
+      lds_set = lds;                                                                                                                              \
+    }                                                                                                                                             \
+    hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW>), dim3((unsigned)g0, (unsigned)nb), dim3(256), lds, s, G, V1, V2, Z1, Z2, evals, kscale,     \
+                       shift, src, dst, k, rho);                                                                                                  \
+  } while (0)
+#define SLAB_MC(KS)              \
+  do {                           \
+    if (even) SLAB_MC2(KS, 2);   \
+    else SLAB_MC2(KS, 1);        \
+  } while (0)
+      if (gm <= 16) SLAB_MC(4);
+      else if (gm <= 32) SLAB_MC(8);
+      else if (gm <= 48) SLAB_MC(12);
+      else if (gm <= 52) SLAB_MC(13);
+      else SLAB_MC(16);
+#undef SLAB_MC
+#undef SLAB_MC2
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
     if (gm <= 16) SLAB_MFMA(4);          // inner dimension padded to 16 / 32 / 48 / 52 / 64
     else if (gm <= 32) SLAB_MFMA(8);
     else if (gm <= 48) SLAB_MFMA(12);

@@ -350,6 +350,35 @@ def test_fused_spectral_pcg_on_anisotropic_grids(gs, tdt, ndt, tol):
         assert np.abs(U.double().cpu().numpy() - Uref).max() < tol * np.abs(Uref).max()
 
 
+@pytest.mark.parametrize("k", [3, 7, 12])
+@pytest.mark.parametrize("gs", [(9, 8, 12), (20, 17, 12), (12, 50, 6), (8, 8, 53), (50, 20, 20)])
+def test_fused_spectral_pcg_many_columns(gs, k):
+    """fp32 solves with >= 3 right-hand sides take the multi-column slab kernel of the preconditioner (k_spec_slab_mfma_mc: a
+    block owns a slab for a strided set of columns, both output halves from one forward transform): columns per block 1 and > 1
+    (g0 = 50 leaves 5 column groups), plain and generalized eigenbasis, against the oracle solve column by column."""
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(17)
+    gb = [[-1.1, 1.1]] * 3
+    grid = grid_ops.GridSpec(gb, list(gs))
+    n = 400
+    X = rng.uniform(-1.0, 1.0, (n, 3)); y = rng.standard_normal(n); noise = rng.uniform(0.5, 2.0, n)
+    B2 = cport.MatrixFreeWISKI(gb, list(gs), sigma2=0.5, dtype=np.float64)
+    B2.absorb(X, y, noise, init=True)
+    RHS = np.concatenate([B2.b[None], rng.standard_normal((k - 1, grid.m))])
+    Uref, _, _ = B2.solve(RHS, tol=1e-13)
+    tdt = torch.float32
+    A = grid_ops.half_stencil_from_offset_major(grid, _t(B2.A, tdt)[(grid.R - 1) // 2:].contiguous())
+    tc = _t(B2.tcol, tdt)
+    prof = [np.clip(0.3 + np.cos(np.linspace(0.0, 2.5, gq)) ** 2, 1e-2, None) for gq in grid.g]
+    for kw in (dict(eigen=grid_ops.kron_eigen(grid, tc), shift=n / grid.m),
+               dict(eigen=grid_ops.kron_eigen(grid, tc, profiles=prof), shift=n / grid.m)):
+        U, Z, it, res = grid_ops.pcg(grid, A, tc, 1.0 / B2.sigma2, _t(RHS, tdt), tol=1e-6, max_iter=500, check_every=5, **kw)
+        assert max(res) < 1e-6 * 1.01, (it, res)
+        err = np.abs(U.double().cpu().numpy() - Uref).max(axis=1) / np.abs(Uref).max(axis=1)
+        assert err.max() < 2e-3, err
+
+
 @pytest.mark.parametrize("gs", [(6, 10, 14), (8, 5, 9), (4, 4, 4), (20, 24, 50), (5, 7, 64)])
 def test_half_stencil_spmv_dma_kernel_on_3d_grids(gs):
     """fp32, d = 3, one right-hand side takes the LDS-DMA pipelined kernel (csrc/spmv_sym_dma.h): ragged
