@@ -865,11 +865,11 @@ template <typename real>
 static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, real* part, const real* add, real beta, double* dots,
                             hipStream_t s) {
   if (sym_use_cols(k)) {
-    // part[0] <- A V (column-major); the row-major copies of V and A V live behind it (the caller provides 8 k m reals)
+    // part[0] <- A V (column-major, written by the product itself); the row-major copy of V lives behind it
     const int m = G.m, kp = spmmc_kp(k);
     const int64_t km = (int64_t)k * m;
     real* Vt = part + km;
-    real* Ot = Vt + (int64_t)m * kp;
+    real* Ot = part;
     dim3 tg((unsigned)((m + 63) / 64), (unsigned)((kp + 63) / 64));
     if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true>), tg, dim3(256), 0, s, m, k, kp, V, Vt, add, beta, dots);
     else hipLaunchKernelGGL((k_transpose_cm_rm<real, false>), tg, dim3(256), 0, s, m, k, kp, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
@@ -885,7 +885,6 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       if (dots) launch_timed(k_spmm_sym_cols<real, true, 0>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
       else launch_timed(k_spmm_sym_cols<real, false, 0>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
     }
-    hipLaunchKernelGGL((k_transpose_rm_cm<real>), tg, dim3(256), 0, s, m, k, kp, (const real*)Ot, part);
     return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
   }
   if constexpr (sizeof(real) == 4) {

@@ -14,8 +14,9 @@
 //    the second time from L2 / Infinity Cache;
 //  * the right-hand sides are needed ROW-major, [m][kp] (256 B per row and 64 columns: one fully coalesced load per row);
 //    the 7 innermost offsets of RT rows share a window of RT + 6 rows (22 loads for 112 FMAs per direction);
-//  * V arrives column-major ([k][m], the layout of every other PCG kernel): k_transpose_cm_rm / k_transpose_rm_cm convert
-//    on the way in and out (64 x 64 tiles through LDS), the first one also forming beta * v . add per column (CG's p . pt).
+//  * V arrives column-major ([k][m], the layout of every other PCG kernel): k_transpose_cm_rm converts on the way in
+//    (64 x 64 tiles through LDS), also forming beta * v . add per column (CG's p . pt); the product is written column-major
+//    straight from the accumulators (a lane owns RT consecutive rows of its column).
 //
 //  * workgroup b runs on XCD b % 8: tiles are dealt so that every XCD sweeps one contiguous eighth of the rows and the v
 //    windows of neighbouring tiles meet in ITS L2 (round-robin dealing made each XCD stream all of V: 350 -> 277 us; with the constant row stride below: 240 us).
@@ -119,26 +120,8 @@ __global__ __launch_bounds__(256) void k_transpose_cm_rm(int m, int k, int kp, c
   }
 }
 
-// row-major [m][kp] -> column-major [k][m]
-template <typename real>
-__global__ __launch_bounds__(256) void k_transpose_rm_cm(int m, int k, int kp, const real* __restrict__ Ot, real* __restrict__ O) {
-  __shared__ real tile[64][65];
-  const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int i = i0 + ty + 4 * u, c = c0 + tx;
-    tile[ty + 4 * u][tx] = (i < m && c < kp) ? Ot[(int64_t)i * kp + c] : (real)0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int c = c0 + ty + 4 * u, i = i0 + tx;
-    if (c < k && i < m) O[(int64_t)c * m + i] = tile[tx][ty + 4 * u];
-  }
-}
-
-// One wave = RT rows x 64 columns, four waves per block.  Vt, Ot row-major [m][kp].  DOT: dots[c] += sum_j Vt[j][c] * Ot[j][c].
+// One wave = RT rows x 64 columns, four waves per block.  Vt row-major [m][kp], Ot column-major [k][m].
+// DOT: dots[c] += sum_j Vt[j][c] * Ot[c][j].
 // KP: row stride of Vt / Ot known at compile time (64: the common case) or 0 (read kp).  With a constant stride the rows of
 // a window that lies inside the grid are base + e * KP: immediate offsets instead of ~9 scalar instructions per row load
 // (clamp, 64-bit multiply, add) -- PMC counters showed 2.4 scalar-ALU instructions per vector one and the one scalar ALU
@@ -149,7 +132,11 @@ __global__ __launch_bounds__(256) void k_transpose_rm_cm(int m, int k, int kp, c
 template <typename real, bool DOT, int KP>
 __global__ __launch_bounds__(256) void k_spmm_sym_cols(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ Vt, int k, int kp_rt,
                                                       int ng, real* __restrict__ Ot, double* __restrict__ dots) {
+  // Ot: the product COLUMN-major [k][m] -- what the solver's vector kernels read.  A lane owns RT consecutive rows of its
+  // column, i.e. 64 contiguous bytes: four 16-byte stores per lane and tile (64 lines per wave instruction, 32 MB per
+  // launch) instead of a row-major image plus a 13 us transpose launch that reads and rewrites it.
   constexpr int RT = SPMMC_RT, WN = RT + 6;
+  static_assert(SPMMC_RT % 4 == 0, "column-major stores are 16-byte groups of rows");
   const int kp = KP ? KP : kp_rt;
   const int m = G.m, d = G.d;
   // a block = 4 independent waves on 4 consecutive tiles; they only meet at the end, to add their p . Ap partials into ONE
@@ -260,22 +247,22 @@ __global__ __launch_bounds__(256) void k_spmm_sym_cols(GridDev<real> G, const re
     group(std::false_type{}, A_h + (int64_t)(7 * g - 3) * m, f);
   }
   double dot = 0;
+  const bool cw = c < k && active;                  // this lane writes (padding columns and padding waves do not)
   if (j0 + RT <= m) {
-    real* __restrict__ op = Ot + (int64_t)j0 * kp + (cok ? c : 0);
+    real* __restrict__ op = Ot + (int64_t)(c < k ? c : 0) * m + j0;      // j0 and m are multiples of 4: 16-byte aligned
     const real* __restrict__ vp = vcol + (int64_t)j0 * kp;
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      if (cok && active) op[(int64_t)r * kp] = acc[r];
+    for (int r = 0; r < RT; r += 4)
+      if (cw) store4<real>(op + r, acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
       if (DOT) dot += (double)vp[(int64_t)r * kp] * (double)acc[r];
-    }
   } else {
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       const int j = j0 + r;
-      if (j < m && cok && active) {
-        Ot[(int64_t)j * kp + c] = acc[r];
-        if (DOT) dot += (double)vcol[(int64_t)j * kp] * (double)acc[r];
-      }
+      if (j < m && cw) Ot[(int64_t)c * m + j] = acc[r];
+      if (DOT && j < m && cok && active) dot += (double)vcol[(int64_t)j * kp] * (double)acc[r];
     }
   }
   if constexpr (DOT) {
