@@ -210,11 +210,17 @@ typedef struct wiski_pcg_async {
   void* poll;      /* opaque: the handle's pinned poll buffer */
   int32_t prezeroed; /* set by wiski_stream_step when an earlier kernel of the step has zeroed the solve's scalar block and
                         accumulated partial vector (wiski_gather_zero): the next START / run skips its own zero launch */
-  int32_t reserved;
+  int32_t guard_ok;  /* set by RESUME: 1 when the poll it waited for found every column converged and no error flag, i.e. when a
+                        kernel guarded by that poll (wiski_pcg_async_guard) has run */
 } wiski_pcg_async;
 int wiski_pcg_async_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
 int wiski_pcg_async_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
 int wiski_pcg_async_free(wiski_pcg_async* handle);
+/* Speculation across the poll of a started solve (state == 1): *d_guard is a device int64 that the poll's publishing block sets
+ * to +*expect when it finds the solve converged and the error flag clear -- exactly when RESUME will report convergence from
+ * that poll -- and to -*expect otherwise.  A kernel queued behind the solve that reads it can run or skip itself without the
+ * host having seen the poll (wiski_scatter_stats_step); RESUME then tells through handle->guard_ok which of the two happened. */
+int wiski_pcg_async_guard(const wiski_pcg_async* handle, const void** d_guard, int64_t* expect);
 /* Support of wiski_stream_step: the two device regions (pointer, bytes) a solve with these parameters zeroes before its first
  * kernel, and a predictive-mean gather (k <= 4 columns, as wiski_gather with diag = 0) whose kernel zeroes them on the way when
  * it can (*zeroed = 1; d = 3 and n <= 65536) -- one launch less per streaming step. */
@@ -223,9 +229,11 @@ int wiski_pcg_zero_regions_f64(const wiski_grid* grid, int32_t k, int32_t max_it
 /* The absorb of a streaming step: wiski_scatter_stats_cnt (half-stencil form) that also (i) writes the predictive mean of every
  * point under the CURRENT posterior mean d_u into d_mean_out [n] (the w_p . u it forms for the residual carry anyway -- BFN:206-210
  * without a gather launch; d_res may be NULL when only the mean is wanted), and (ii) zeroes the two regions of
- * wiski_pcg_zero_regions on the way (n*_bytes = 0: none). */
-int wiski_scatter_stats_step_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, float* d_cnt, const float* d_u, float* d_res, float* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, void* stream);
-int wiski_scatter_stats_step_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_cnt, const double* d_u, double* d_res, double* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, void* stream);
+ * wiski_pcg_zero_regions on the way (n*_bytes = 0: none).  d_guard != NULL: the whole kernel (absorb, mean, zeroing) runs only
+ * if *d_guard == guard_expect when it starts and is a no-op otherwise (wiski_pcg_async_guard: the absorb of the next batch is
+ * queued behind a solve whose convergence poll the host has not read yet). */
+int wiski_scatter_stats_step_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, float* d_cnt, const float* d_u, float* d_res, float* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, const void* d_guard, int64_t guard_expect, void* stream);
+int wiski_scatter_stats_step_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_cnt, const double* d_u, double* d_res, double* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, const void* d_guard, int64_t guard_expect, void* stream);
 int wiski_gather_zero_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, float* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 int wiski_gather_zero_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, double* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 

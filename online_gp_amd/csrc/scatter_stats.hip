@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
                                                            real* __restrict__ A, double* __restrict__ stats, int32_t* __restrict__ err,
                                                            real* __restrict__ cnt, const real* __restrict__ u, real* __restrict__ res,
                                                            real* __restrict__ mean_out = nullptr, uint32_t* __restrict__ z1 = nullptr,
-                                                           int64_t n1 = 0, uint32_t* __restrict__ z2 = nullptr, int64_t n2 = 0) {
+                                                           int64_t n1 = 0, uint32_t* __restrict__ z2 = nullptr, int64_t n2 = 0,
+                                                           const long long* __restrict__ guard = nullptr, long long guard_expect = 0) {
+  // speculative launch behind a solve whose convergence poll the host has not read yet (wiski_pcg_async_guard): the poll's
+  // publishing block decides on the device whether this absorb happens
+  if (guard && *guard != guard_expect) return;
   // optional (wiski_scatter_stats_step): zero two word arrays on the way -- the scalar block and the accumulated partial
   // vector of the solve that follows in the same streaming step
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1; e += (int64_t)gridDim.x * blockDim.x) z1[e] = 0u;
@@ -349,7 +353,8 @@ template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
                         int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
                         real* d_cnt = nullptr, const real* d_u = nullptr, real* d_res = nullptr, real* d_mean_out = nullptr,
-                        void* z1 = nullptr, int64_t n1_bytes = 0, void* z2 = nullptr, int64_t n2_bytes = 0) {
+                        void* z1 = nullptr, int64_t n1_bytes = 0, void* z2 = nullptr, int64_t n2_bytes = 0, const void* d_guard = nullptr,
+                        int64_t guard_expect = 0) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -357,6 +362,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
   if (d_mean_out == nullptr && (d_u != nullptr) != (d_res != nullptr)) return WISKI_E_BADARG;
   if ((d_res && !d_u) || (d_mean_out && !d_u) || (d_u && !half)) return WISKI_E_BADARG;  // residual carry-over / mean: half-stencil form only
+  if (d_guard && !half) return WISKI_E_BADARG;
   if ((n1_bytes | n2_bytes) & 3 || (n1_bytes && !z1) || (n2_bytes && !z2) || ((n1_bytes || n2_bytes) && !half)) return WISKI_E_BADARG;
   const int grp = half ? 64 : (G.T < 64 ? G.T : 64);
   const int64_t ppb = 256 / grp;
@@ -365,7 +371,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   dim3 grd((unsigned)blocks);
 #define CALL(DD)                                                                                                                              \
   do {                                                                                                                                        \
-    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4); \
+    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4, (const long long*)d_guard, (long long)guard_expect); \
     else hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
   } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
@@ -393,11 +399,11 @@ int wiski_scatter_stats_cnt_f32(const wiski_grid* g, const float* x, const float
 int wiski_scatter_stats_cnt_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A, int32_t half, double* cnt, const double* u, double* res, double* stats, int32_t* err, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A, stats, err, s, half != 0, cnt, u, res);
 }
-int wiski_scatter_stats_step_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, float* cnt, const float* u, float* res, float* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, void* s) {
-  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2);
+int wiski_scatter_stats_step_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, float* cnt, const float* u, float* res, float* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect);
 }
-int wiski_scatter_stats_step_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, void* s) {
-  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2);
+int wiski_scatter_stats_step_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect);
 }
 int wiski_stencil_expand_add_f32(const wiski_grid* g, float* half, float* full, void* s) { return expand_impl<float>(g, half, full, s); }
 int wiski_stencil_expand_add_f64(const wiski_grid* g, double* half, double* full, void* s) { return expand_impl<double>(g, half, full, s); }

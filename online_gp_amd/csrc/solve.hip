@@ -1293,8 +1293,10 @@ static int spectral_mm_impl(const wiski_grid* grid, const real* d_evec, const re
 // coherent buffer and then releases a sequence number; the host spins on it.  A poll costs a few
 // microseconds instead of the ~80 us of hipMemcpyAsync + hipStreamSynchronize + relaunch bubble.
 struct WiskiPoll {
-  double* h = nullptr;       // host view:   [0] = sequence (as int64), [1..k] = rn0, [k+1..2k] = rn, [2k+1] = err flag
+  double* h = nullptr;       // host view:   [0] = sequence (as int64), [1..k] = rn0, [k+1..2k] = rn, [2k+1] = err flag, [2k+2] = guard
   double* d = nullptr;       // device view of the same pinned allocation
+  long long* g = nullptr;    // device memory: +seq when the poll `seq` found every column converged and no error flag, else -seq --
+                             // the guard of a speculatively queued absorb (wiski_scatter_stats_step); mirrored in h[2k+2]
   int cap = 0;
   long long seq = 0;
 };
@@ -1307,18 +1309,43 @@ static int poll_reserve(WiskiPoll& P, int k) {
   if (P.cap >= k) return WISKI_OK;
   if (P.h) (void)hipHostFree(P.h);
   const int cap = k < 64 ? 64 : k;
-  if (hipHostMalloc((void**)&P.h, (size_t)(2 * cap + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) !=
+  if (hipHostMalloc((void**)&P.h, (size_t)(2 * cap + 3) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) !=
       hipSuccess)
     return WISKI_E_LAUNCH;
   if (hipHostGetDevicePointer((void**)&P.d, P.h, 0) != hipSuccess) return WISKI_E_LAUNCH;
+  if (!P.g) {
+    if (hipMalloc((void**)&P.g, sizeof(long long)) != hipSuccess) return WISKI_E_LAUNCH;
+    if (hipMemset(P.g, 0, sizeof(long long)) != hipSuccess) return WISKI_E_LAUNCH;
+  }
   P.h[0] = 0;
   P.cap = cap;
   return WISKI_OK;
 }
 
 // spin until the device has released sequence number `seq` into the poll buffer (20 s fallback: stream sync)
+#ifdef WISKI_STEP_TIMING   // host time spent waiting for polls (tools/spec_probe.py): is a streaming loop GPU- or host-bound?
+static double g_poll_wait_us = 0;
+static long long g_poll_waits = 0, g_poll_waits_immediate = 0;
+extern "C" void wiski_debug_poll_wait(double* us, long long* n, long long* immediate) {
+  *us = g_poll_wait_us; *n = g_poll_waits; *immediate = g_poll_waits_immediate;
+  g_poll_wait_us = 0; g_poll_waits = 0; g_poll_waits_immediate = 0;
+}
+struct PollWaitTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  bool immediate;
+  explicit PollWaitTimer(bool imm) : immediate(imm) {}
+  ~PollWaitTimer() {
+    g_poll_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    ++g_poll_waits;
+    if (immediate) ++g_poll_waits_immediate;
+  }
+};
+#endif
 static int poll_wait(WiskiPoll& P, long long seq, hipStream_t s) {
   volatile long long* flag = reinterpret_cast<volatile long long*>(P.h);
+#ifdef WISKI_STEP_TIMING
+  PollWaitTimer pwt(__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+#endif
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;
   while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
@@ -1355,13 +1382,24 @@ extern "C" int wiski_read_flag(const int32_t* d_flag, int32_t* h_value, void* st
   return WISKI_OK;
 }
 
-__global__ void k_pcg_publish(PcgScal S, int slot, double* __restrict__ poll, const int32_t* __restrict__ err, long long seq) {
+__global__ void k_pcg_publish(PcgScal S, int slot, double* __restrict__ poll, const int32_t* __restrict__ err, long long seq, double tol2,
+                              long long* __restrict__ guard) {
   const int k = S.k;
+  int ok = 1;
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
-    poll[1 + c] = S.rn0()[c];
-    poll[1 + k + c] = S.rn(slot)[c];
+    const double r0 = S.rn0()[c], r1 = S.rn(slot)[c];
+    poll[1 + c] = r0;
+    poll[1 + k + c] = r1;
+    if (r0 > 0 && r1 > tol2 * r0) ok = 0;        // the host's convergence test, on the same doubles
   }
-  if (threadIdx.x == 0) poll[1 + 2 * k] = err ? (double)*err : 0.0;
+  ok = __syncthreads_and(ok);
+  if (threadIdx.x == 0) {
+    const double e = err ? (double)*err : 0.0;
+    const long long gv = (ok && e == 0.0) ? seq : -seq;
+    poll[1 + 2 * k] = e;
+    poll[2 + 2 * k] = (double)gv;
+    if (guard) *guard = gv;
+  }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<long long*>(poll), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1487,7 +1525,7 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
                                                       const real* __restrict__ hp, real* __restrict__ part, int nch, int zl,
                                                       real* __restrict__ u, real* __restrict__ z, real* __restrict__ r, PcgScal S,
                                                       double* __restrict__ poll = nullptr, const int32_t* __restrict__ err = nullptr,
-                                                      long long seq = 0) {
+                                                      long long seq = 0, long long* __restrict__ guard = nullptr) {
   __shared__ double s_red[16];
   const int c = blockIdx.y;
   double alpha = 0;
@@ -1567,12 +1605,23 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
     __syncthreads();
     if (s_last) {
       const int k = S.k;
+      int ok = 1;
       for (int c2 = threadIdx.x; c2 < k; c2 += blockDim.x) {
-        poll[1 + c2] = __hip_atomic_load(S.rn0() + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        poll[1 + k + c2] = __hip_atomic_load(S.rn(it + 1) + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double r0 = __hip_atomic_load(S.rn0() + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double r1 = __hip_atomic_load(S.rn(it + 1) + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        poll[1 + c2] = r0;
+        poll[1 + k + c2] = r1;
+        if (r0 > 0 && r1 > tol2 * r0) ok = 0;    // the host's convergence test, on the same doubles
       }
+      ok = __syncthreads_and(ok);                // s_last is block-uniform: every thread of the block is here
       if (threadIdx.x == 0) {
-        poll[1 + 2 * k] = err ? (double)*err : 0.0;
+        // the guard of a speculatively queued absorb (wiski_scatter_stats_step): +seq iff the host will find this poll
+        // converged and error-free
+        const double e = err ? (double)*err : 0.0;
+        const long long gv = (ok && e == 0.0) ? seq : -seq;
+        poll[1 + 2 * k] = e;
+        poll[2 + 2 * k] = (double)gv;
+        if (guard) *guard = gv;
         __hip_atomic_store(S.ticket(), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next poll of this solve
       }
       __threadfence_system();
@@ -1718,7 +1767,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     long long seq = queued_seq;
     if (!seq) {
       seq = ++P.seq;
-      hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq);
+      hipLaunchKernelGGL(k_pcg_publish, dim3(1), dim3(64), 0, s, S, slot, P.d, d_err, seq, tol2, P.g);
     }
     if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
     if (amode == 1) {
@@ -1745,6 +1794,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     as->state = 0;
     if (int prc = poll_wait(P, as->seq, s)) return prc;
     collect();
+    as->guard_ok = (long long)P.h[2 + 2 * k] == as->seq ? 1 : 0;   // did an absorb guarded by this poll run? (wiski_pcg_async_guard)
     done = converged();
     first_check = it;          // from here on: a poll after every check_every-th further iteration
     amode = 0;
@@ -1761,7 +1811,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (pending) {
       if (publish) seq = ++P.seq;
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it - 1, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S, publish ? P.d : (double*)nullptr, d_err, seq);
+                         part, nch, zl, d_U, d_Z, r, S, publish ? P.d : (double*)nullptr, d_err, seq, P.g);
       pending = false;
     }
     return seq;
@@ -1815,10 +1865,10 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     const long long useq = pub ? ++P.seq : 0;
     if (wide)
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq);
+                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq, P.g);
     else
       hipLaunchKernelGGL((k_pcg_update_x<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq);
+                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq, P.g);
     ++it;
     if (due(it)) {
       rc = fetch(it, useq);
@@ -1958,10 +2008,19 @@ int wiski_pcg_async_free(wiski_pcg_async* as) {
   if (as->poll) {
     WiskiPoll* P = static_cast<WiskiPoll*>(as->poll);
     if (P->h) (void)hipHostFree(P->h);
+    if (P->g) (void)hipFree(P->g);
     delete P;
     as->poll = nullptr;
   }
   as->state = 0;
+  return WISKI_OK;
+}
+int wiski_pcg_async_guard(const wiski_pcg_async* as, const void** d_guard, int64_t* expect) {
+  if (!as || !d_guard || !expect || as->state != 1 || !as->poll) return WISKI_E_BADARG;
+  const WiskiPoll* P = static_cast<const WiskiPoll*>(as->poll);
+  if (!P->g) return WISKI_E_BADARG;
+  *d_guard = P->g;
+  *expect = as->seq;
   return WISKI_OK;
 }
 int wiski_pcg_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s) {

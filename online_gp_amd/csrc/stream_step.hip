@@ -1,10 +1,12 @@
 // One streaming step behind ONE C-ABI call: the launches of
-//   predictive mean of the incoming batch   wiski_gather        (BFN:206-210)
-//   absorb the batch                        wiski_scatter_stats_cnt (BFN:155-171 + URLT:58; carries the residual)
-//   warm-started refresh of the mean        wiski_pcg           (CG branch of BFN:368-383)
+//   predictive mean of the incoming batch + absorb   wiski_scatter_stats_step (BFN:206-210, BFN:155-171 + URLT:58; carries the residual)
+//   warm-started refresh of the mean                 wiski_pcg                (CG branch of BFN:368-383)
 // are queued back to back on the caller's stream without returning to the host language in between (the Python
 // front-end left the GPU idle for ~30 us between the gather and the scatter and ~40 us after the solver's last poll).
-// Pure host code: it only sequences the three entry points above.
+// With a deferred solve pending, the absorb of the NEXT batch is queued before the host has read that solve's convergence
+// poll, guarded on the device by the poll's own verdict (wiski_pcg_async_guard): the GPU goes from the last iteration
+// straight into the absorb instead of idling through the host's poll round trip (~20 us of a 220 us step).
+// Pure host code: it only sequences the entry points above.
 #include "wiski_common.h"
 
 template <typename real>
@@ -14,28 +16,6 @@ struct StreamArgs<float> { using type = wiski_stream_args_f32; };
 template <>
 struct StreamArgs<double> { using type = wiski_stream_args_f64; };
 
-extern "C" {
-int wiski_gather_f32(const wiski_grid*, const float*, int64_t, const float*, int32_t, int32_t, float*, int32_t*, void*);
-int wiski_gather_f64(const wiski_grid*, const double*, int64_t, const double*, int32_t, int32_t, double*, int32_t*, void*);
-}
-
-static int gather1(const wiski_grid* g, const float* x, int64_t n, const float* V, float* out, int32_t* err, void* s) { return wiski_gather_f32(g, x, n, V, 1, 0, out, err, s); }
-static int gather1(const wiski_grid* g, const double* x, int64_t n, const double* V, double* out, int32_t* err, void* s) { return wiski_gather_f64(g, x, n, V, 1, 0, out, err, s); }
-// the gather of the batch mean also zeroes what the solve of this step would zero in a launch of its own
-static int gather1z(const wiski_grid* g, const wiski_stream_args_f32* a, const float* x, int64_t n, float* out, int32_t* zeroed, void* s) {
-  void *p1, *p2;
-  int64_t n1, n2;
-  int rc = wiski_pcg_zero_regions_f32(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2);
-  if (rc) return rc;
-  return wiski_gather_zero_f32(g, x, n, a->d_U, 1, out, a->d_err, p1, n1, p2, n2, zeroed, s);
-}
-static int gather1z(const wiski_grid* g, const wiski_stream_args_f64* a, const double* x, int64_t n, double* out, int32_t* zeroed, void* s) {
-  void *p1, *p2;
-  int64_t n1, n2;
-  int rc = wiski_pcg_zero_regions_f64(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2);
-  if (rc) return rc;
-  return wiski_gather_zero_f64(g, x, n, a->d_U, 1, out, a->d_err, p1, n1, p2, n2, zeroed, s);
-}
 static int scatter1(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* nz, int64_t n, float* b, float* A, float* cnt, const float* u, float* res, double* st, int32_t* err, void* s) {
   return wiski_scatter_stats_cnt_f32(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
 }
@@ -43,19 +23,19 @@ static int scatter1(const wiski_grid* g, const double* x, const double* y, const
   return wiski_scatter_stats_cnt_f64(g, x, y, wa, wb, nz, n, b, A, 1, cnt, u, res, st, err, s);
 }
 // absorb + predictive mean of the batch (+ the zeroing the following solve would do in a launch of its own) in ONE kernel
-static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f32* a, const float* x, const float* y, const float* wa, const float* wb, const float* nz, int64_t n, int carry, float* mean_out, int zero, void* s) {
+static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f32* a, const float* x, const float* y, const float* wa, const float* wb, const float* nz, int64_t n, int carry, float* mean_out, int zero, const void* guard, int64_t expect, void* s) {
   void *p1 = nullptr, *p2 = nullptr;
   int64_t n1 = 0, n2 = 0;
   if (zero)
     if (int rc = wiski_pcg_zero_regions_f32(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
-  return wiski_scatter_stats_step_f32(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, s);
+  return wiski_scatter_stats_step_f32(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, s);
 }
-static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f64* a, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, int carry, double* mean_out, int zero, void* s) {
+static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f64* a, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, int carry, double* mean_out, int zero, const void* guard, int64_t expect, void* s) {
   void *p1 = nullptr, *p2 = nullptr;
   int64_t n1 = 0, n2 = 0;
   if (zero)
     if (int rc = wiski_pcg_zero_regions_f64(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
-  return wiski_scatter_stats_step_f64(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, s);
+  return wiski_scatter_stats_step_f64(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, s);
 }
 static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
                 wiski_pcg_async* as, int mode) {
@@ -76,22 +56,40 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
   if (q > 0 && (!d_x || !d_y || !d_wa || !d_wb || !d_noise)) return WISKI_E_BADARG;
   int rc = WISKI_OK;
   if (h_resumed) *h_resumed = 0;
+  bool absorbed = false;                     // the speculative absorb below has run
   if (as && as->state == 1) {
-    // finish the solve the previous call started BEFORE anything reads U (the gather) or changes the system (the scatter)
+    // A solve the previous call started is pending.  It has to finish BEFORE anything reads U (the batch mean) or changes the
+    // system (the absorb) -- but the host need not have SEEN it finish: queue this batch's absorb now, guarded on the device
+    // by the verdict of the pending poll (it runs iff that poll finds the solve converged and the error flag clear, which
+    // is exactly when RESUME below queues nothing more), and only then wait for the poll.  The absorb then executes while
+    // the host reads the poll and queues the next solve.
+    bool spec = false;
+    if (q > 0 && d_mean_out && getenv("WISKI_NO_SPECULATION") == nullptr) {
+      const void* guard = nullptr;
+      int64_t expect = 0;
+      if (wiski_pcg_async_guard(as, &guard, &expect) == WISKI_OK) {
+        rc = scatter_step1(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, carry, d_mean_out, 1, guard, expect, stream);
+        if (rc) return rc;
+        spec = true;
+      }
+    }
     rc = pcg1(grid, a, 2, first_check, h_iters, h_relres, h_err, stream, as, 2);
     if (h_resumed) *h_resumed = 1;
     if (rc != WISKI_OK && rc != WISKI_E_NOTCONV) return rc;
+    absorbed = spec && as->guard_ok;          // else the guarded kernel was a no-op (and RESUME may have queued more iterations)
     if (q == 0) return rc;
-    if (h_err && *h_err) return rc;          // out-of-grid points in the previous batch: let the caller deal with them first
+    if (!absorbed && h_err && *h_err) return rc;   // out-of-grid points in the previous batch: let the caller deal with them first
   } else if (q == 0 && as) {
     return WISKI_OK;
   }
   const int resumed_rc = rc;
-  if (q > 0) {
+  if (absorbed) {
+    as->prezeroed = 1;
+  } else if (q > 0) {
     if (d_mean_out) {
       // the absorb kernel forms w_p . U for the residual carry anyway: it is the predictive mean of the batch, so there is no
       // gather launch; with a handle the same kernel also zeroes what the solve below would zero in a launch of its own
-      rc = scatter_step1(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, carry, d_mean_out, as ? 1 : 0, stream);
+      rc = scatter_step1(grid, a, d_x, d_y, d_wa, d_wb, d_noise, q, carry, d_mean_out, as ? 1 : 0, nullptr, 0, stream);
       if (rc) return rc;
       if (as) as->prezeroed = 1;           // nothing touches the solve's workspace between this kernel and the solve below
     } else {

@@ -303,7 +303,7 @@ class _StreamArgs64(ctypes.Structure):
 
 class _PcgAsync(ctypes.Structure):
     _fields_ = [("state", ctypes.c_int32), ("it", ctypes.c_int32), ("seq", ctypes.c_int64), ("poll", ctypes.c_void_p),
-                ("prezeroed", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("prezeroed", ctypes.c_int32), ("guard_ok", ctypes.c_int32)]
 
 
 class StreamStep:

@@ -168,7 +168,7 @@ def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
         rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
                                                     _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), _hip.dptr(u),
                                                     _hip.dptr(got["res"]) if with_res else None, _hip.dptr(mean), _hip.dptr(got["stats"]),
-                                                    _hip.dptr(err), p1, n1, p2, n2, _hip.stream_ptr(dev))
+                                                    _hip.dptr(err), p1, n1, p2, n2, None, ctypes.c_int64(0), _hip.stream_ptr(dev))
         assert rc == 0
         assert torch.allclose(mean, mean_ref, rtol=rtol, atol=atol)
         for k in ("b", "A", "cnt", "stats"):
@@ -188,8 +188,28 @@ def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
     # the mean needs u; the residual carry needs u
     rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
                                                 _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), None, None, _hip.dptr(mean),
-                                                _hip.dptr(got["stats"]), _hip.dptr(err), None, ctypes.c_int64(0), None, ctypes.c_int64(0), _hip.stream_ptr(dev))
+                                                _hip.dptr(got["stats"]), _hip.dptr(err), None, ctypes.c_int64(0), None, ctypes.c_int64(0), None,
+                                                ctypes.c_int64(0), _hip.stream_ptr(dev))
     assert rc != 0
+    # guarded launch (speculation behind a pending solve, wiski_pcg_async_guard): a no-op unless the device word holds the expected value
+    guard = torch.tensor([-7], device="cuda", dtype=torch.int64)
+    for val, runs in ((-7, False), (7, True)):
+        guard.fill_(val)
+        got = {k: torch.zeros_like(v) for k, v in ref.items()}
+        work.fill_(1)
+        mean = torch.full((n,), float("nan"), device="cuda", dtype=tdt)
+        rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
+                                                    _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), _hip.dptr(u), _hip.dptr(got["res"]),
+                                                    _hip.dptr(mean), _hip.dptr(got["stats"]), _hip.dptr(err), p1, n1, p2, n2, _hip.dptr(guard),
+                                                    ctypes.c_int64(7), _hip.stream_ptr(dev))
+        assert rc == 0
+        raw = work.view(torch.uint8).reshape(-1)
+        if runs:
+            assert torch.allclose(mean, mean_ref, rtol=rtol, atol=atol) and torch.allclose(got["A"], ref["A"], rtol=rtol, atol=atol)
+            assert int(raw[o1:o1 + n1.value].max()) == 0
+        else:
+            assert bool(torch.isnan(mean).all()) and all(float(v.abs().max()) == 0.0 for v in got.values())
+            assert bool((raw != 0).all())
 
 
 @pytest.mark.parametrize("d,g", CASES)
