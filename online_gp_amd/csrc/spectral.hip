@@ -390,45 +390,49 @@ __global__ __launch_bounds__(256) void k_spec_slab(GridDev<real> G, const real* 
 using spec_f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int SPEC_LDT = 80, SPEC_LDN = 68;
 
-template <bool A_NAT, bool B_NAT, int KS>
+// RT = 16-row tiles per wave: 2 (a 32 x 32 quadrant, 4 waves per product) or 1 (a 16 x 32 strip, 8 waves; acc[1] unused)
+template <bool A_NAT, bool B_NAT, int KS, int RT = 2>
 __device__ __forceinline__ void spec_mfma_product(const float* __restrict__ pa, const float* __restrict__ pb, int wr, int wc, int lane,
                                                   spec_f32x4 acc[2][2]) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.f;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const float* qa = A_NAT ? pa + (wr * 32 + l15) * SPEC_LDN + l4 : pa + l4 * SPEC_LDT + wr * 32 + l15;
+  const float* qa = A_NAT ? pa + (wr * 16 * RT + l15) * SPEC_LDN + l4 : pa + l4 * SPEC_LDT + wr * 16 * RT + l15;
   const float* qb = B_NAT ? pb + (wc * 32 + l15) * SPEC_LDN + l4 : pb + l4 * SPEC_LDT + wc * 32 + l15;
   constexpr int SA = A_NAT ? 1 : SPEC_LDT, TA = A_NAT ? 16 * SPEC_LDN : 16;   // step per k, step per 16-row tile
   constexpr int SB = B_NAT ? 1 : SPEC_LDT, TB = B_NAT ? 16 * SPEC_LDN : 16;
   // KS = (padded inner dimension) / 4 is a compile-time constant (the zero padding makes a larger KS exact):
   // every operand word is read up front (4 KS registers), so the LDS latency is paid once and the 4 KS MFMAs
   // issue back to back.  (A run-time trip count turned this into one branch + s_waitcnt lgkmcnt(0) per step.)
-  float af[KS][2], bf[KS][2];
+  float af[KS][RT], bf[KS][2];
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    af[i][0] = qa[4 * i * SA]; af[i][1] = qa[4 * i * SA + TA];
+    af[i][0] = qa[4 * i * SA];
+    if constexpr (RT == 2) af[i][1] = qa[4 * i * SA + TA];
     bf[i][0] = qb[4 * i * SB]; bf[i][1] = qb[4 * i * SB + TB];
   }
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
     acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[i][0], acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[i][1], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i][0], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i][1], acc[1][1], 0, 0, 0);
+    if constexpr (RT == 2) {
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[i][1], acc[1][1], 0, 0, 0);
+    }
   }
 }
 
 // rows x cols compact row-major matrix -> LDS image [64][ld] with exact-zero padding, no integer division and
 // no separate zero fill: thread (r, c) mapping, 64 / VW threads per padded row, VW-wide loads and LDS stores
 // (VW = 2 needs even `cols`: rows are then 8-byte aligned).  issue() only loads, commit() only stores.
-template <int VW>
+template <int VW, int NT = 256>
 struct SpecTile {
   static constexpr int TPR = 64 / VW;          // threads per row
-  static constexpr int RPP = 256 / TPR;        // rows per pass
+  static constexpr int RPP = NT / TPR;         // rows per pass
   static constexpr int NP = 64 / RPP;          // passes
   float v[NP][VW];
   __device__ __forceinline__ void issue(const float* __restrict__ M, int rows, int cols) {
@@ -459,8 +463,9 @@ struct SpecTile {
   }
 };
 
-template <int KS, int VW>
-__global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
+// NW = 4: the waves own 32 x 32 quadrants; NW = 8: 16 x 32 strips (half the MFMA chain per wave, two waves per SIMD)
+template <int KS, int VW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
                                                         const float* __restrict__ Z1, const float* __restrict__ Z2,
                                                         const float* __restrict__ evals, float kscale, float shift,
                                                         const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho) {
@@ -475,10 +480,11 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const 
   float* sB2 = sB1 + 64 * SPEC_LDN;               // bV2[y][b], stride LDN
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2], m = G.m;
   const int i0 = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
+  constexpr int RT = NW == 4 ? 2 : 1;         // 16-row tiles per wave
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
   const bool alt = (h == 0) && (Z1 != V1 || Z2 != V2);   // block-uniform
   SPEC_STAMP(0);
-  SpecTile<VW> tX, tV1, tV2, tB1, tB2;
+  SpecTile<VW, 64 * NW> tX, tV1, tV2, tB1, tB2;
   tX.issue(src + (int64_t)c * m + (int64_t)i0 * g1 * g2, g1, g2);
   tV1.issue(V1, g1, g1);
   tV2.issue(V2, g2, g2);
@@ -504,28 +510,28 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const 
   const int l15 = lane & 15, l4 = lane >> 4;
   auto store_tiles = [&](float* __restrict__ out, int ld) {       // C fragments -> out[row][col], row-major with stride ld
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(wr * 32 + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
+        for (int r = 0; r < 4; ++r) out[(wr * 16 * RT + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
   };
   // P2: A = V1^T (sV1 [b][x]), B = X (bufA [b][y])  -> C2 natural (bufB, stride LDN)
-  spec_mfma_product<false, false, KS>(sV1, bufA, wr, wc, lane, acc);
+  spec_mfma_product<false, false, KS, RT>(sV1, bufA, wr, wc, lane, acc);
   store_tiles(bufB, SPEC_LDN);
   __syncthreads();
   SPEC_STAMP(2);
   // P3: A = C2 (bufB natural), B = V2 (sV2 [b][y]) -> scaled C3 natural (bufA, stride LDN)
-  spec_mfma_product<true, false, KS>(bufB, sV2, wr, wc, lane, acc);
+  spec_mfma_product<true, false, KS, RT>(bufB, sV2, wr, wc, lane, acc);
   float rho_lane = 0.f;   // 16 terms per lane in fp32, the cross-lane / cross-block sum in fp64
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const float e2 = sE[64 + wc * 32 + cc * 16 + l15];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float lam = l0 * sE[wr * 32 + a * 16 + l4 * 4 + r] * e2;
+        const float lam = l0 * sE[wr * 16 * RT + a * 16 + l4 * 4 + r] * e2;
         const float f1 = __frcp_rn(1.f + shift * lam);
         const float v = acc[a][cc][r];
         rho_lane += (lam * f1) * v * v;   // r^T P r in the eigenbasis (padding: lam = 0)
@@ -540,20 +546,20 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma(GridDev<float> G, const 
   __syncthreads();
   SPEC_STAMP(3);
   // P5: A = C3 (bufA natural), B = bV2^T (sB2 [y][b]) -> C5 [b = i1'][y = i2] (bufB, stride LDT)
-  spec_mfma_product<true, true, KS>(bufA, sB2, wr, wc, lane, acc);
+  spec_mfma_product<true, true, KS, RT>(bufA, sB2, wr, wc, lane, acc);
   store_tiles(bufB, SPEC_LDT);
   __syncthreads();
   SPEC_STAMP(4);
   // P6: A = bV1 (sB1 natural), B = C5 (bufB [b][y]) -> global
-  spec_mfma_product<true, false, KS>(sB1, bufB, wr, wc, lane, acc);
+  spec_mfma_product<true, false, KS, RT>(sB1, bufB, wr, wc, lane, acc);
   float* __restrict__ os = dst + ((int64_t)h * k + c) * m + (int64_t)i0 * g1 * g2;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int x = wr * 32 + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
+        const int x = wr * 16 * RT + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
         if (x < g1 && y < g2) os[x * g2 + y] = acc[a][cc][r];
       }
   SPEC_STAMP(5);
@@ -954,17 +960,28 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
   if constexpr (sizeof(real) == 4) {
     const int gm = g1 > g2 ? g1 : g2;
     const bool even = g1 % 2 == 0 && g2 % 2 == 0;      // 8-byte loads need 8-byte aligned rows
+    static int slab_waves = 0;                         // waves per block of the one- / two-column kernel (WISKI_SLAB_WAVES = 4 | 8)
+    if (slab_waves == 0) {
+      const char* e = getenv("WISKI_SLAB_WAVES");
+      slab_waves = (e && atoi(e) == 4) ? 4 : 8;
+    }
 #define SLAB_MFMA2(KS, VW)                                                                                                                     \
   do {                                                                                                                                         \
     static bool lds_set = false;   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                      \
     if (!lds_set) {                                                                                                                            \
-      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPEC_SLAB_MFMA_LDS) !=   \
-          hipSuccess)                                                                                                                          \
+      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma<KS, VW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,                            \
+                              (int)SPEC_SLAB_MFMA_LDS) != hipSuccess ||                                                                        \
+          hipFuncSetAttribute((const void*)k_spec_slab_mfma<KS, VW, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,                            \
+                              (int)SPEC_SLAB_MFMA_LDS) != hipSuccess)                                                                          \
         return WISKI_E_LAUNCH;                                                                                                                 \
       lds_set = true;                                                                                                                          \
     }                                                                                                                                          \
-    hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1, Z2,    \
-                       evals, kscale, shift, src, dst, k, rho);                                                                                \
+    if (slab_waves == 8)                                                                                                                       \
+      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 8>), dim3((unsigned)g0, 2, (unsigned)k), dim3(512), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1,   \
+                         Z2, evals, kscale, shift, src, dst, k, rho);                                                                          \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 4>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1,   \
+                         Z2, evals, kscale, shift, src, dst, k, rho);                                                                          \
   } while (0)
 #define SLAB_MFMA(KS)              \
   do {                             \
