@@ -320,6 +320,9 @@ int wiski_read_flag(const int32_t* d_flag, int32_t* h_value, void* stream);
  * synchronise the stream before calling it. */
 int wiski_prof_start(int32_t max_launches);
 int wiski_prof_stop(double* total_ms, int64_t* launches);
+/* between start and stop: switch the event attachment off / on again without touching what has been recorded (sample some
+ * steps of a pipelined loop, read all events once the loop has drained) */
+int wiski_prof_enable(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,11 @@ extern "C" int wiski_prof_start(int max_launches) {
   return WISKI_OK;
 }
 
+extern "C" int wiski_prof_enable(int32_t on) {
+  g_prof.on = on != 0;
+  return WISKI_OK;
+}
+
 // Stops recording; the caller must have synchronised the stream(s).
 extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
   g_prof.on = false;
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 // or the LDS-window one (anything else with m % 4 == 0; up to 7 chunks).  WISKI_SYM_DMA=0 forces the latter,
 // WISKI_SYM_DMA_NST sets the ring depth (2 or 3) and WISKI_SYM_DMA_PARTS the work split (4..7): A/B hooks for
 // tools/spmv_probe.py.
-static int g_sym_dma = -1, g_sym_dma_nst = 0, g_sym_dma_parts = 4;
+static int g_sym_dma = -1, g_sym_dma_nst = 0, g_sym_dma_parts = 4, g_sym_dma_delay = 0;
 template <typename real>
 static inline bool sym_use_dma(const GridDev<real>& G, int k) {
   if constexpr (sizeof(real) != 4) return false;
@@ -819,6 +824,9 @@ static inline bool sym_use_dma(const GridDev<real>& G, int k) {
     const char* pp = getenv("WISKI_SYM_DMA_PARTS");
     g_sym_dma_parts = pp ? atoi(pp) : 4;
     if (g_sym_dma_parts < 4 || g_sym_dma_parts > 7) g_sym_dma_parts = 4;
+    const char* dl = getenv("WISKI_SYM_DMA_DELAY");     // late start of the light chunk, units of 0.43 us at 50^3 (scaled with m)
+    g_sym_dma_delay = dl ? atoi(dl) : 12;               // swept 0..28 at 50^3: 18.40..18.56 us at 0, 18.03..18.20 at 12, 20.4 at 24
+    if (g_sym_dma_delay < 0 || g_sym_dma_delay > 64) g_sym_dma_delay = 12;
   }
   return g_sym_dma != 0 && G.d == 3 && k == 1 && (G.m % 4) == 0 && symdma_lds_bytes(G.g[2], g_sym_dma_nst) <= 64 * 1024;
 }
@@ -892,6 +900,8 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
       const size_t sh = symdma_lds_bytes(G.g[2], g_sym_dma_nst);
       dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)g_sym_dma_parts);
+      // the light chunk joins when the heavy ones are ~3 / 7 through their stream: proportional to the stream's length
+      const int delay = (int)((int64_t)g_sym_dma_delay * G.m / 125000);
 #define SYMDMA(NST, DOT)                                                                                                          \
   do {                                                                                                                            \
     static size_t lds_set = 0;                                                                                                    \
@@ -900,7 +910,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         return WISKI_E_LAUNCH;                                                                                                    \
       lds_set = sh;                                                                                                               \
     }                                                                                                                             \
-    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots);                       \
+    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay); \
   } while (0)
       if (g_sym_dma_nst == 3) {
         if (dots) SYMDMA(3, true); else SYMDMA(3, false);

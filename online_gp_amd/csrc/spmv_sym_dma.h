@@ -113,7 +113,7 @@ static inline size_t symdma_lds_bytes(int g2, int nst) {
 template <int NST, bool DOT>
 __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const float* __restrict__ A_h, const float* __restrict__ V, int W4, int WP,
                                                      int nparts, float* __restrict__ part, const float* __restrict__ add, float beta,
-                                                     double* __restrict__ dots) {
+                                                     double* __restrict__ dots, int delay) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int m = G.m, S0 = G.stride[0], S1 = G.stride[1];
@@ -143,6 +143,11 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   // dispatched last (y = 2: 7 tiles, y = 3: 4 tiles) get their first DMA issued 2.5 us after the others and finish last.
   // Raising their priority evens the finish times (19.3 -> 18.4..18.7 us; graded maps 0-1-2-3 / 0-1-2-0: no better).
   if (nparts == 4 && blockIdx.y >= 2) __builtin_amdgcn_s_setprio(3);
+  // The 4-tile chunk (d0 = 0) carries half the bytes of the others: started with them it is gone after 8.7 us and the 7-tile
+  // chunks stream on alone, then everybody's epilogue is exposed.  Started `delay` x 0.43 us late it joins when the others
+  // are about three tiles in (50^3: delay = 12, 18.5 -> 18.1 us back to back; 6..8 and 14..20 are no better than 0, 24+ worse).
+  if (nparts == 4 && blockIdx.y == 3)
+    for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(16);
   const int iw0 = blockIdx.x * 256;
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;

@@ -452,11 +452,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 carried = False
             # warm refreshes poll convergence first where the previous one converged (streaming steps are
             # alike), every 8th one an iteration earlier, and then after every iteration
-            fc = 0
+            fc, probe = 0, False
             if warm and getattr(self, "_last_iters", None):
                 self._refresh_count = getattr(self, "_refresh_count", 0) + 1
-                probe = getattr(self, "_probe_down", True) or self._refresh_count % 8 == 0
-                fc = max(1, self._last_iters[o] - (1 if probe else 0))
+                fc, probe = self._first_poll(self._last_iters[o])
                 post.check_every = 1
             # warm = 2: R was kept equal to b - Z - A U by the scatter launches since the last solve (recomputed
             # from scratch every 16th refresh so that fp rounding of the recursion cannot accumulate)
@@ -464,7 +463,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 carried = False
             post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=2 if carried else warm, first_check=fc, inplace=True, R=Ro)
             if fc:
-                self._probe_down = post.last_iters <= fc and fc > 1      # keep probing while it keeps paying off
+                self._note_poll(post.last_iters, fc, probe)
+            self._last_rel = None                    # this path does not keep the converged residual: timer-paced probes only
             iters.append(post.last_iters)
             posts.append(post)
             if post.last_err:            # out-of-grid flag delivered with the convergence poll (no extra sync)
@@ -666,9 +666,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self._wsum_host[0] += float(q)
         self.num_data = self.num_data + q
         self._refresh_count = getattr(self, "_refresh_count", 0) + 1
-        probe = getattr(self, "_probe_down", True) or self._refresh_count % 8 == 0
         last = (getattr(self, "_last_iters", None) or [0])[0]
-        fc = max(1, last - (1 if probe else 0)) if last else 0
+        fc, probe = self._first_poll(last)
         carry = ms.get("R_ok", False) and self._refresh_count % 16 != 0
         step.args.shift = float(self._wsum[0]) / pst["norm"]
         y1 = Y.reshape(-1)
@@ -681,20 +680,57 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                     self._wsum_host[0] -= float(q)
                     self.num_data = self.num_data - q
                     self._refresh_count -= 1
-                self._note_solve(ms, prev, getattr(self, "_pending_fc", 0))
-            self._pending_fc = fc
+                self._note_solve(ms, prev, *getattr(self, "_pending_fc", (0, False)))
+            self._pending_fc = (fc, probe)
             if not pending:                              # deferral switched off meanwhile: this call ran to convergence
-                self._note_solve(ms, (step.it.value, step.rr.value, step.herr.value, True), fc)
+                self._note_solve(ms, (step.it.value, step.rr.value, step.herr.value, True), fc, probe)
             return mean
-        self._note_solve(ms, step(X, y1, ones, ones, ones, mean, carry, fc), fc)
+        self._note_solve(ms, step(X, y1, ones, ones, ones, mean, carry, fc), fc, probe)
         return mean
 
-    def _note_solve(self, ms, res, fc):
+    def _first_poll(self, last):
+        """Where a warm refresh polls convergence first: (iteration count, is this a probe?).  Streaming steps are alike (at
+        50^3 the uniform bench stream needs 3 iterations for its first ~40 steps and 2 ever after; the clustered one 6, now and
+        then 5), so the first poll goes where the previous refresh converged.  A *probe* polls one iteration earlier to notice
+        that the stream got easier; one that fails costs a stand-alone vector update + poll and a host round trip (~14 us of a
+        ~215 us step), one that is not made when it would have succeeded costs an iteration (41 us) per step.  So: probe
+        every 4th refresh while the last converged residual says one iteration less might do (it is below tol / 5; the
+        contraction per iteration is ~0.08 here: the residual after 3 iterations falls from 8e-5 to 7e-6 before 2 suffice),
+        otherwise after 8, 16, 32 refreshes; a probe that succeeds is repeated at once.  (Probing every other refresh, as
+        before: 50 % failed polls, 0.221 ms per step against 0.216 with this placement, tools/policy_probe.py.)"""
+        if not last:
+            return 0, False
+        wait = getattr(self, "_probe_wait", 0)
+        rel = getattr(self, "_last_rel", None)
+        tol = settings.cg_tolerance.value() or (1e-7 if self._dtype == torch.float32 else 1e-11)
+        informed = rel is not None and rel < 0.2 * tol
+        if informed:
+            wait = min(wait, 4)
+        probe = wait <= 0 and last > 1
+        self._probe_informed = informed
+        # with deferred refreshes the verdict of this probe arrives one step late: no second probe before it is known, unless
+        # the probes before it succeeded (walking down from the cold solve's count, one iteration per refresh)
+        self._probe_wait = (0 if getattr(self, "_probe_streak", True) else 1) if probe else wait - 1
+        return max(1, last - (1 if probe else 0)), probe
+
+    def _note_poll(self, it, fc, probe):
+        if probe:
+            self._probe_streak = it <= fc
+            if it <= fc:
+                self._probe_gap, self._probe_wait = 0, 0
+            elif getattr(self, "_probe_informed", False):
+                self._probe_wait = 4
+            else:
+                self._probe_gap = min(32, max(8, 2 * getattr(self, "_probe_gap", 0)))
+                self._probe_wait = self._probe_gap
+
+    def _note_solve(self, ms, res, fc, probe=False):
         """Host bookkeeping after a refresh: iteration history for the poll placement, residual validity, out-of-grid error."""
         it, rel, flag, conv = res
         if fc:
-            self._probe_down = it <= fc and fc > 1
+            self._note_poll(it, fc, probe)
         self._last_iters = [it]
+        self._last_rel = rel
         ms["R_ok"] = bool(conv)
         pc = self._memo.get("prediction_cache")
         if pc is not None:
@@ -712,7 +748,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if step.pending:
             prev, _ = step(None, None, None, None, None, None, 0, 0, defer=False)
             if prev is not None and self._mean_state is not None:
-                self._note_solve(self._mean_state, prev, getattr(self, "_pending_fc", 0))
+                self._note_solve(self._mean_state, prev, *getattr(self, "_pending_fc", (0, False)))
 
     def _stream_fast_state(self, X, Y):
         """(prepared StreamStep, mean state, preconditioner state) when the one-call streaming step applies, else None."""
