@@ -475,6 +475,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         # do not carry it into the next refresh as if it were
         self._mean_state = None if self._use_dense() else {"U": U, "Z": Z, "R": R, "R_ok": converged, "ver": ver}
         self._last_iters = list(iters)
+        self._poll_hint = 0 if ms is not None else 2      # after a cold solve: see _first_poll
         pc = {"pred_mean": U[..., None], "pred_cov": posts[0] if out == 1 else BatchOperator(posts), "cg_iters": iters, "ver": ver}
         self._memo["prediction_cache"] = pc
         return pc
@@ -694,30 +695,43 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         then 5), so the first poll goes where the previous refresh converged.  A *probe* polls one iteration earlier to notice
         that the stream got easier; one that fails costs a stand-alone vector update + poll and a host round trip (~14 us of a
         ~215 us step), one that is not made when it would have succeeded costs an iteration (41 us) per step.  So: probe
-        every 4th refresh while the last converged residual says one iteration less might do (it is below tol / 5; the
+        every 4th refresh while the last converged residual says one iteration less might do (it is below tol / 10; the
         contraction per iteration is ~0.08 here: the residual after 3 iterations falls from 8e-5 to 7e-6 before 2 suffice),
-        otherwise after 8, 16, 32 refreshes; a probe that succeeds is repeated at once.  (Probing every other refresh, as
-        before: 50 % failed polls, 0.221 ms per step against 0.216 with this placement, tools/policy_probe.py.)"""
+        otherwise after 8, 16, 32 refreshes.  (Probing every other refresh, as before: 50 % failed polls, 0.221 ms per step
+        against 0.216 with this placement, tools/policy_probe.py.)"""
         if not last:
             return 0, False
+        hint = getattr(self, "_poll_hint", 0)
+        if hint:
+            # the previous solve was a cold one: its count (8 at 50^3) says nothing about a warm, residual-carrying refresh
+            # (3 there).  Poll early and then after every iteration -- a few extra polls instead of walking down from the
+            # cold count one wasted iteration per refresh.
+            return min(last, hint), False
+        pend = getattr(self, "_probe_pending", 0)
+        if pend:
+            # deferred refreshes: the verdict of the probe queued by the previous step is not in yet (and `last` is older
+            # still).  Poll where the probe did: if it fails this costs one more cheap poll, if it succeeds an iteration less.
+            self._probe_pending = 0
+            return pend, False
         wait = getattr(self, "_probe_wait", 0)
         rel = getattr(self, "_last_rel", None)
         tol = settings.cg_tolerance.value() or (1e-7 if self._dtype == torch.float32 else 1e-11)
-        informed = rel is not None and rel < 0.2 * tol
+        informed = rel is not None and rel < 0.1 * tol
         if informed:
             wait = min(wait, 4)
         probe = wait <= 0 and last > 1
         self._probe_informed = informed
-        # with deferred refreshes the verdict of this probe arrives one step late: no second probe before it is known, unless
-        # the probes before it succeeded (walking down from the cold solve's count, one iteration per refresh)
-        self._probe_wait = (0 if getattr(self, "_probe_streak", True) else 1) if probe else wait - 1
-        return max(1, last - (1 if probe else 0)), probe
+        self._probe_wait = wait - 1
+        fc = max(1, last - (1 if probe else 0))
+        if probe:
+            self._probe_pending = fc
+        return fc, probe
 
     def _note_poll(self, it, fc, probe):
         if probe:
-            self._probe_streak = it <= fc
+            self._probe_pending = 0
             if it <= fc:
-                self._probe_gap, self._probe_wait = 0, 0
+                self._probe_gap, self._probe_wait = 0, 8        # cut to 4 by _first_poll if the new residual invites it
             elif getattr(self, "_probe_informed", False):
                 self._probe_wait = 4
             else:
@@ -731,6 +745,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._note_poll(it, fc, probe)
         self._last_iters = [it]
         self._last_rel = rel
+        self._poll_hint = 0
         ms["R_ok"] = bool(conv)
         pc = self._memo.get("prediction_cache")
         if pc is not None:
