@@ -573,8 +573,8 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
 // are formed from the C3 fragment kept in registers (6 products per column instead of 8), and the next column's slab is
 // fetched into registers while the current one is in the matrix cores.
 //   LDS: bufA, bufB, sV1, sV2 (stride LDT), sB1, sB2 per half (stride LDN): 115 KB, 150 KB with a generalized eigenbasis.
-template <int KS, int VW>
-__global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
+template <int KS, int VW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
                                                            const float* __restrict__ Z1, const float* __restrict__ Z2,
                                                            const float* __restrict__ evals, float kscale, float shift,
                                                            const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho) {
@@ -593,12 +593,13 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, con
   sB2[0] = alt ? sB1[0] + 64 * SPEC_LDN : sB2[1];
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2], m = G.m;
   const int i0 = blockIdx.x;
+  constexpr int RT = NW == 4 ? 2 : 1;         // 16-row tiles per wave (NW = 8: 16 x 32 strips, as k_spec_slab_mfma)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
   int c = blockIdx.y;
   if (c >= k) return;
-  SpecTile<VW> tX;
+  SpecTile<VW, 64 * NW> tX;
   {
-    SpecTile<VW> tV1, tV2, tB1, tB2;
+    SpecTile<VW, 64 * NW> tV1, tV2, tB1, tB2;
     tX.issue(src + (int64_t)c * m + (int64_t)i0 * g1 * g2, g1, g2);
     tV1.issue(V1, g1, g1);
     tV2.issue(V2, g2, g2);
@@ -628,22 +629,22 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, con
   const int l15 = lane & 15, l4 = lane >> 4;
   auto store_tiles = [&](float* __restrict__ out, int ld) {       // C fragments -> out[row][col], row-major with stride ld
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(wr * 32 + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
+        for (int r = 0; r < 4; ++r) out[(wr * 16 * RT + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
   };
   // spectral factors of this thread's 16 C3 entries: the same for every column
   float f1v[2][2][4], f2v[2][2][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const float e2 = sE[64 + wc * 32 + cc * 16 + l15];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float lam = l0 * sE[wr * 32 + a * 16 + l4 * 4 + r] * e2;
+        const float lam = l0 * sE[wr * 16 * RT + a * 16 + l4 * 4 + r] * e2;
         const float f1 = __frcp_rn(1.f + shift * lam);
         f1v[a][cc][r] = f1;
         f2v[a][cc][r] = lam * f1;
@@ -654,15 +655,15 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, con
     const bool more = cn < k;                     // block-uniform
     if (more) tX.issue(src + (int64_t)cn * m + (int64_t)i0 * g1 * g2, g1, g2);
     // P2: A = V1^T (sV1 [b][x]), B = X (bufA [b][y])  -> C2 natural (bufB, stride LDN)
-    spec_mfma_product<false, false, KS>(sV1, bufA, wr, wc, lane, acc);
+    spec_mfma_product<false, false, KS, RT>(sV1, bufA, wr, wc, lane, acc);
     store_tiles(bufB, SPEC_LDN);
     __syncthreads();
     // P3: A = C2 (bufB natural), B = V2 (sV2 [b][y]) -> C3, kept in registers for both halves
-    spec_mfma_product<true, false, KS>(bufB, sV2, wr, wc, lane, acc);
+    spec_mfma_product<true, false, KS, RT>(bufB, sV2, wr, wc, lane, acc);
     spec_f32x4 c3[2][2];
     float rho_lane = 0.f;   // 16 terms per lane in fp32, the cross-lane / cross-block sum in fp64
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
@@ -681,13 +682,13 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, con
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       // P5: A = scaled C3 (bufA natural), B = bV2^T (sB2 [y][b]) -> C5 [b = i1'][y = i2] (bufB, stride LDT)
-      spec_mfma_product<true, true, KS>(bufA, sB2[h], wr, wc, lane, acc);
+      spec_mfma_product<true, true, KS, RT>(bufA, sB2[h], wr, wc, lane, acc);
       store_tiles(bufB, SPEC_LDT);
       __syncthreads();
       // bufA is free now: half 0 -> the y-half's scaled C3; half 1 -> the next column's slab
       if (h == 0) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RT; ++a)
 #pragma unroll
           for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
@@ -697,15 +698,15 @@ __global__ __launch_bounds__(256) void k_spec_slab_mfma_mc(GridDev<float> G, con
         tX.commit(bufA, SPEC_LDT);
       }
       // P6: A = bV1 (sB1 natural), B = C5 (bufB [b][y]) -> global
-      spec_mfma_product<true, false, KS>(sB1[h], bufB, wr, wc, lane, acc);
+      spec_mfma_product<true, false, KS, RT>(sB1[h], bufB, wr, wc, lane, acc);
       float* __restrict__ os = dst + ((int64_t)h * k + c) * m + (int64_t)i0 * g1 * g2;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int x = wr * 32 + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
+            const int x = wr * 16 * RT + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
             if (x < g1 && y < g2) os[x * g2 + y] = acc[a][cc][r];
           }
       __syncthreads();                            // bufB (C5) read by P6; bufA written above
@@ -960,11 +961,6 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
   if constexpr (sizeof(real) == 4) {
     const int gm = g1 > g2 ? g1 : g2;
     const bool even = g1 % 2 == 0 && g2 % 2 == 0;      // 8-byte loads need 8-byte aligned rows
-    static int slab_waves = 0;                         // waves per block of the one- / two-column kernel (WISKI_SLAB_WAVES = 4 | 8)
-    if (slab_waves == 0) {
-      const char* e = getenv("WISKI_SLAB_WAVES");
-      slab_waves = (e && atoi(e) == 4) ? 4 : 8;
-    }
 #define SLAB_MFMA2(KS, VW)                                                                                                                     \
   do {                                                                                                                                         \
     static bool lds_set = false;   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                      \
@@ -988,6 +984,11 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
     if (even) SLAB_MFMA2(KS, 2);   \
     else SLAB_MFMA2(KS, 1);        \
   } while (0)
+    static int slab_waves = 0;                         // waves per block of the slab kernels (WISKI_SLAB_WAVES = 4 | 8)
+    if (slab_waves == 0) {
+      const char* e = getenv("WISKI_SLAB_WAVES");
+      slab_waves = (e && atoi(e) == 4) ? 4 : 8;
+    }
     // three or more columns: blocks that own a slab for a strided set of columns (about one block per CU)
     if (k >= 3 && getenv("WISKI_SLAB_MC_OFF") == nullptr) {
       const bool alt = Z1 != V1 || Z2 != V2;
@@ -1001,12 +1002,17 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
   do {                                                                                                                                            \
     static size_t lds_set = 0;                                                                                                                    \
     if (lds > lds_set) {                                                                                                                          \
-      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma_mc<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
+      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma_mc<KS, VW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+          hipFuncSetAttribute((const void*)k_spec_slab_mfma_mc<KS, VW, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
         return WISKI_E_LAUNCH;                                                                                                                    \
       lds_set = lds;                                                                                                                              \
     }                                                                                                                                             \
-    hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW>), dim3((unsigned)g0, (unsigned)nb), dim3(256), lds, s, G, V1, V2, Z1, Z2, evals, kscale,     \
-                       shift, src, dst, k, rho);                                                                                                  \
+    if (slab_waves == 8)                                                                                                                          \
+      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 8>), dim3((unsigned)g0, (unsigned)nb), dim3(512), lds, s, G, V1, V2, Z1, Z2, evals, kscale, \
+                         shift, src, dst, k, rho);                                                                                                \
+    else                                                                                                                                          \
+      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 4>), dim3((unsigned)g0, (unsigned)nb), dim3(256), lds, s, G, V1, V2, Z1, Z2, evals, kscale, \
+                         shift, src, dst, k, rho);                                                                                                \
   } while (0)
 #define SLAB_MC(KS)              \
   do {                           \
