@@ -237,18 +237,21 @@ int wiski_scatter_stats_step_f64(const wiski_grid* grid, const double* d_x, cons
 int wiski_gather_zero_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_V, int32_t k, float* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 int wiski_gather_zero_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t k, double* d_out, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, int32_t* zeroed, void* stream);
 
-/* One streaming step in one call (single output, symmetric half stencil): the launches of wiski_gather (predictive mean of
- * the incoming batch under the CURRENT posterior mean d_U, written to d_mean_out [q]; skipped when NULL),
- * wiski_scatter_stats_cnt (absorb the q points into b / A_half / cnt / stats; with carry != 0 the residual d_R is kept
- * equal to b - Z - A U) and wiski_pcg (refresh of (d_U, d_Z) for RHS = d_b, warm = 2 when carry != 0 else 1) are queued
+/* One streaming step in one call (single output, symmetric half stencil): the predictive mean of the incoming batch under
+ * the CURRENT posterior mean d_U (written to d_mean_out [q]; skipped when NULL) and the absorb of the q points into b /
+ * A_half / cnt / stats (with carry != 0 the residual d_R is kept equal to b - Z - A U) -- one kernel,
+ * wiski_scatter_stats_step -- and wiski_pcg (refresh of (d_U, d_Z) for RHS = d_b, warm = 2 when carry != 0 else 1) are queued
  * back to back on `stream` -- what BFN:204-210, BFN:258-273 and BFN:368-383 do in three Python calls.  d_wa / d_wb /
  * d_noise [q]: the per-point weights 1/clamp(noise,1e-7), 1/noise and the noise itself (ones for unit noise).  The struct
  * carries the model-resident pointers and solver parameters (meaning as in wiski_pcg); first_check / h_iters / h_relres /
  * h_err as in wiski_pcg.
  * handle != NULL selects the deferred form: the call first RESUMEs the solve a previous call started (its iteration count,
- * residual and out-of-grid flag land in h_iters / h_relres / h_err; h_resumed = 1), then queues gather + scatter for the new
+ * residual and out-of-grid flag land in h_iters / h_relres / h_err; h_resumed = 1), then queues the absorb of the new
  * batch, then STARTs the new solve (defer != 0: returns WISKI_PENDING) or runs it to convergence (defer == 0).  q = 0 with
- * defer = 0 just finishes a pending solve.  So the host-language work between two steps overlaps the GPU's CG iterations. */
+ * defer = 0 just finishes a pending solve.  So the host-language work between two steps overlaps the GPU's CG iterations.
+ * (With a mean requested the absorb is in fact queued BEFORE the RESUME, guarded on the device by the verdict of the pending
+ * poll -- wiski_pcg_async_guard -- and queued again unguarded only if that verdict was "not converged" or "error flag set";
+ * the results are those of the order described above.) */
 typedef struct wiski_stream_args_f32 {
   float* d_A_half; float* d_b; float* d_cnt; double* d_stats; int32_t* d_err;     /* statistics + out-of-grid flag      */
   float* d_U; float* d_Z; float* d_R;                                              /* posterior-mean state (in place)    */
