@@ -624,3 +624,44 @@ def test_deferred_refresh_gives_the_same_stream_and_reports_one_call_later():
                 a.stream_step(Xt[q:2 * q], yt[q:2 * q])
         assert a.num_data == n_before + q - 1
         assert torch.isfinite(a(Xt[:8]).mean).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float64, 1e-7)])
+def test_deferred_stream_of_random_batch_sizes_matches_a_rebuilt_model(dtype, tol):
+    """60 deferred streaming steps of random size 1..3000 (speculative absorb ahead of the pending poll, guard hits and
+    misses, poll placement with probes, periodic residual recomputation) against the batch means of a synchronous twin and,
+    at the end, a model built from scratch on all the data: same statistics, same posterior mean."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(29)
+    d, g, n0 = 3, 24, 600
+    sizes = [int(rng.choice([1, 2, 5, 17, 64, 300, 1000, 3000])) for _ in range(60)]
+    n = n0 + sum(sizes)
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + 0.5 * X[:, 2] ** 2 + 0.1 * rng.standard_normal(n)
+    Xt, yt = torch.as_tensor(X, device=DEV, dtype=dtype), torch.as_tensor(y, device=DEV, dtype=dtype)[:, None]
+    gb = torch.tensor([[-1.1, 1.1]] * d, dtype=torch.float64)
+    cg = 1e-5 if dtype == torch.float32 else 1e-10
+    with settings.cg_tolerance(cg), settings.skip_posterior_variances(True), torch.no_grad():
+        a = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        b = FixedNoiseOnlineSKIGP(Xt[:n0], yt[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        a.prediction_cache; b.prediction_cache
+        lo, fast = n0, 0
+        for q in sizes:
+            sl = slice(lo, lo + q)
+            with settings.deferred_refresh(True):
+                ma = a.stream_step(Xt[sl], yt[sl])
+            fast += a.__dict__.get("_pending_step") is not None
+            mb = b(Xt[sl]).mean
+            b.condition_on_observations(Xt[sl], yt[sl], None, inplace=True)
+            b.prediction_cache
+            assert float((ma.reshape(-1) - mb.reshape(-1)).abs().max()) <= tol * max(float(mb.abs().max()), 1.0), q
+            lo += q
+        assert fast >= 50                                 # the one-call deferred path really ran
+        c = FixedNoiseOnlineSKIGP(Xt, yt, None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        pa, pc = a.prediction_cache["pred_mean"], c.prediction_cache["pred_mean"]
+        assert a.num_data == c.num_data == n
+        assert float((pa - pc).abs().max()) <= tol * float(pc.abs().max())
+        sa, sc = a._kernel_cache["_stats"], c._kernel_cache["_stats"]
+        assert torch.allclose(sa, sc, rtol=1e-5 if dtype == torch.float32 else 1e-11)
