@@ -725,6 +725,9 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G,
 //           With 256 threads a thread updates 2 x 4 elements: all 2 x 13 vector loads of a thread are independent and
 //           in flight together (the 128-thread register-tile predecessor serialised 4 such rounds and lost to a
 //           separate update launch; this one saves that launch).
+// (Several consecutive columns per block -- the 10 KB factor image loaded once per block instead of once per 6.4 KB tile --
+// were tried for the 64-column solves: 8 columns per block make the forward / backward kernels 131 / 104 us instead of
+// 94 / 79 us; the many small blocks are what keeps enough loads in flight.)
 template <int KS, int VW, int MODE>
 __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const float* __restrict__ Va, const float* __restrict__ Vb, int split,
                                                          int transposed, const float* __restrict__ src, float* __restrict__ dst,
