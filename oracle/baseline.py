@@ -47,7 +47,8 @@ def _p(a):
 
 
 class StreamingBaseline:
-    """Single-output matrix-free WISKI state; full 7^d block stencil, Kt-preconditioned CG with warm starts."""
+    """Single-output matrix-free WISKI state; full 7^d block stencil, warm-started CG preconditioned by Kt (refresh) or by the
+    separable density-profile model of the GPU library (refresh_profile)."""
 
     def __init__(self, grid_bounds, grid_size, kind="rbf", lengthscale=spec.SOFTPLUS0, outputscale=spec.SOFTPLUS0, sigma2=1.0,
                  dtype=np.float32):
@@ -66,6 +67,7 @@ class StreamingBaseline:
         self.z = np.zeros(self.m, self.dt)
         self.solved = False
         self.num_data = 0
+        self.wsum = 0.0
 
     def _fn(self, name):
         f = getattr(lib(), name + self.sfx)
@@ -82,12 +84,48 @@ class StreamingBaseline:
         if rc:
             raise RuntimeError("Received data that was out of bounds for the specified grid.")
         self.num_data += n
+        self.wsum += float(np.sum(1.0 / noise.astype(np.float64)))
 
     def refresh(self, tol, max_iter=5000):
         """u = (Kt^-1 + A)^-1 b, warm-started from the previous (u, z); returns (iterations, relative residual)."""
         res = ctypes.c_double(0)
         it = self._fn("wb_pcg")(_p(self.A), _p(self.tcol), self.d, _p(self.g), ctypes.c_long(self.m), self.creal(1.0 / self.sigma2),
                                 _p(self.b), int(self.solved), ctypes.c_double(tol), max_iter, _p(self.u), _p(self.z), ctypes.byref(res))
+        self.solved = True
+        return it, float(res.value)
+
+    def _profile_basis(self):
+        """Generalized eigenbasis of the density-profile preconditioner, re-solved when the data volume has
+        doubled: t_q = per-dim marginal of the row sums of A, normalised to max 1 and clipped at 1e-2;
+        K_q = X_q D_q X_q^T with X_q^T diag(t_q) X_q = I, Z_q = diag(t_q) X_q; shift a = (sum_p 1/noise_p) / prod_q sum(t_q)."""
+        wsum = float(self.wsum)
+        st = getattr(self, "_basis", None)
+        if st is None or wsum > 2.0 * st["wsum"]:
+            cnt = self.A.sum(axis=0, dtype=np.float64).reshape(tuple(int(v) for v in self.g))
+            X, Z, D, norm, off = [], [], [], 1.0, 0
+            tc = self.tcol.astype(np.float64)
+            for q, gq in enumerate(int(v) for v in self.g):
+                marg = cnt.sum(axis=tuple(r for r in range(self.d) if r != q)) if self.d > 1 else cnt
+                t = np.clip(marg / marg.max(), 1e-2, None)
+                norm *= float(t.sum())
+                c = tc[off:off + gq]
+                K = c[np.abs(np.arange(gq)[:, None] - np.arange(gq)[None, :])]
+                rt = np.sqrt(t)
+                w, U = np.linalg.eigh(rt[:, None] * K * rt[None, :])
+                X.append((U / rt[:, None]).reshape(-1)); Z.append((U * rt[:, None]).reshape(-1)); D.append(np.clip(w, 0.0, None))
+                off += gq
+            st = {"wsum": wsum, "norm": norm, "X": np.concatenate(X).astype(self.dt), "Z": np.concatenate(Z).astype(self.dt),
+                  "D": np.concatenate(D).astype(self.dt)}
+            self._basis = st
+        return st, wsum / st["norm"]
+
+    def refresh_profile(self, tol, max_iter=5000):
+        """As refresh(), with the separable density-profile preconditioner the GPU library uses (wb_pcg_profile)."""
+        st, shift = self._profile_basis()
+        res = ctypes.c_double(0)
+        it = self._fn("wb_pcg_profile")(_p(self.A), self.d, _p(self.g), ctypes.c_long(self.m), self.creal(1.0 / self.sigma2), _p(st["X"]), _p(st["Z"]),
+                                        _p(st["D"]), self.creal(shift), _p(self.b), int(self.solved), ctypes.c_double(tol), max_iter, _p(self.u),
+                                        _p(self.z), ctypes.byref(res))
         self.solved = True
         return it, float(res.value)
 

@@ -7,9 +7,11 @@
  *   absorb   (BFN:31-60,155-171 + URLT:58)   points in parallel, `omp atomic` adds into b and the block stencil
  *   A . v    (URLT:47-48)                    rows in parallel, stencil offsets streamed in order (full 7^d stencil)
  *   Kt . v   (BFN:334-348)                   Kronecker-Toeplitz mode products, lines in parallel
- *   refresh  (CG branch of BFN:368-383)      Kt-preconditioned CG on (Kt^-1 + A) u = b, warm-started from the
- *                                            previous (u, z = Kt^-1 u); the product path's density-profile
- *                                            preconditioner is NOT ported (that is the GPU library's own solver work)
+ *   refresh  (CG branch of BFN:368-383)      preconditioned CG on (Kt^-1 + A) u = b, warm-started from the previous
+ *                                            (u, z = Kt^-1 u): wb_pcg with Kt as the preconditioner, wb_pcg_profile with the
+ *                                            separable density-profile preconditioner of the GPU library (DESIGN.md 3.3;
+ *                                            its small generalized eigenproblems are solved by numpy in baseline.py) --
+ *                                            the one bench.py times, so that both legs run the same algorithm
  *   predict  (BFN:206-210)                   fused gather, queries in parallel
  * Checked against the scalar oracle in tests/test_oracle.py.  Never imported by online_gp_amd.
  */

@@ -229,3 +229,107 @@ int FN(wb_pcg)(const REAL *A_st, const REAL *tcol, int d, const int *g, long m, 
   free(off); free(r); free(y); free(p); free(pt); free(hp); free(tmp);
   return it;
 }
+
+/* out = (kron_q M_q) v (trans = 0) or (kron_q M_q^T) v (trans = 1); M_q dense g_q x g_q row-major, concatenated in `mats`;
+ * tmp holds 2 m reals.  Same line-parallel loop as wb_kron with a dense factor in place of the Toeplitz one. */
+static void FN(wb_modes)(const REAL *mats, int trans, int d, const int *g, long m, const REAL *v, REAL *tmp, REAL *out) {
+  const REAL *cur = v;
+  long post = m;
+  const REAL *M = mats;
+  for (int q = 0; q < d; ++q) {
+    const int gq = g[q];
+    post /= gq;
+    const long pre = m / (post * gq);
+    REAL *dst0 = (q == d - 1) ? out : (tmp + (q & 1) * m);
+    const long po = post;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (long pp = 0; pp < pre; ++pp)
+      for (int i = 0; i < gq; ++i) {
+        REAL *dst = dst0 + (pp * gq + i) * po;
+        for (long s = 0; s < po; ++s) dst[s] = 0;
+        for (int j = 0; j < gq; ++j) {
+          const REAL t = trans ? M[(long)j * gq + i] : M[(long)i * gq + j];
+          const REAL *src = cur + (pp * gq + j) * po;
+#pragma omp simd
+          for (long s = 0; s < po; ++s) dst[s] += t * src[s];
+        }
+      }
+    cur = dst0;
+    M += (long)gq * gq;
+  }
+}
+
+/* The same warm-started CG as wb_pcg with the separable density-profile preconditioner of DESIGN.md 3.3,
+ *   P = (Kt^-1 + a kron_q diag(t_q))^-1 = X f2(D) X^T,   Kt^-1 P = Z f1(D) X^T,
+ * from the d generalized eigenproblems K_q = X_q D_q X_q^T, X_q^T diag(t_q) X_q = I, Z_q = diag(t_q) X_q (host, numpy):
+ *   f1 = 1 / (1 + a lam), f2 = lam f1, lam = kscale prod_q D_q[i_q].
+ * X, Zm: concatenated g_q x g_q row-major factors; evals: concatenated D_q; shift = a. */
+int FN(wb_pcg_profile)(const REAL *A_st, int d, const int *g, long m, REAL kscale, const REAL *X, const REAL *Zm, const REAL *evals, REAL shift,
+                       const REAL *rhs, int warm, double tol, int max_iter, REAL *u, REAL *z, double *rel_res_out) {
+  long R = 1;
+  for (int q = 0; q < d; ++q) R *= 7;
+  long *off = (long *)malloc(sizeof(long) * R);
+  FN(wb_offsets)(d, g, off);
+  REAL *r = (REAL *)malloc(sizeof(REAL) * m), *y = (REAL *)malloc(sizeof(REAL) * m), *t = (REAL *)malloc(sizeof(REAL) * m);
+  REAL *p = (REAL *)malloc(sizeof(REAL) * m), *pt = (REAL *)malloc(sizeof(REAL) * m), *hp = (REAL *)malloc(sizeof(REAL) * m);
+  REAL *c1 = (REAL *)malloc(sizeof(REAL) * m), *c2 = (REAL *)malloc(sizeof(REAL) * m), *tmp = (REAL *)malloc(sizeof(REAL) * 2 * m);
+  REAL *f1 = (REAL *)malloc(sizeof(REAL) * m), *f2 = (REAL *)malloc(sizeof(REAL) * m);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < m; ++i) {
+    long rem = i;
+    double lam = (double)kscale;
+    long eo = 0;
+    for (int q = 0; q < d; ++q) eo += g[q];
+    for (int q = d - 1; q >= 0; --q) {
+      eo -= g[q];
+      lam *= (double)evals[eo + rem % g[q]];
+      rem /= g[q];
+    }
+    const double a1 = 1.0 / (1.0 + (double)shift * lam);
+    f1[i] = (REAL)a1;
+    f2[i] = (REAL)(lam * a1);
+  }
+  double rn0 = 0, rn = 0;
+  if (!warm) {
+    memset(u, 0, sizeof(REAL) * m);
+    memset(z, 0, sizeof(REAL) * m);
+  }
+  if (warm) FN(wb_spmv)(A_st, off, R, m, u, z, hp);   /* hp = z + A u */
+#pragma omp parallel for reduction(+ : rn0, rn) schedule(static)
+  for (long i = 0; i < m; ++i) {
+    r[i] = warm ? rhs[i] - hp[i] : rhs[i];
+    p[i] = 0; pt[i] = 0;
+    rn0 += (double)rhs[i] * rhs[i];
+    rn += (double)r[i] * r[i];
+  }
+  double rho_old = 1;
+  int it = 0;
+  if (rn0 > 0 && sqrt(rn / rn0) >= tol)
+    for (; it < max_iter;) {
+      FN(wb_modes)(X, 1, d, g, m, r, tmp, c1);          /* eigen-coefficients of r */
+#pragma omp parallel for schedule(static)
+      for (long i = 0; i < m; ++i) { const REAL c = c1[i]; c1[i] = f1[i] * c; c2[i] = f2[i] * c; }
+      FN(wb_modes)(X, 0, d, g, m, c2, tmp, y);          /* y = P r */
+      FN(wb_modes)(Zm, 0, d, g, m, c1, tmp, t);         /* t = Kt^-1 y */
+      double rho = 0;
+#pragma omp parallel for reduction(+ : rho) schedule(static)
+      for (long i = 0; i < m; ++i) rho += (double)r[i] * y[i];
+      const REAL beta = it == 0 ? (REAL)0 : (REAL)(rho / rho_old);
+#pragma omp parallel for schedule(static)
+      for (long i = 0; i < m; ++i) { p[i] = y[i] + beta * p[i]; pt[i] = t[i] + beta * pt[i]; }
+      FN(wb_spmv)(A_st, off, R, m, p, pt, hp);
+      double php = 0;
+#pragma omp parallel for reduction(+ : php) schedule(static)
+      for (long i = 0; i < m; ++i) php += (double)p[i] * hp[i];
+      const REAL alpha = (REAL)(rho / php);
+      rn = 0;
+#pragma omp parallel for reduction(+ : rn) schedule(static)
+      for (long i = 0; i < m; ++i) { u[i] += alpha * p[i]; z[i] += alpha * pt[i]; r[i] -= alpha * hp[i]; rn += (double)r[i] * r[i]; }
+      rho_old = rho;
+      ++it;
+      if (sqrt(rn / rn0) < tol) break;
+    }
+  if (rel_res_out) *rel_res_out = rn0 > 0 ? sqrt(rn / rn0) : 0;
+  free(off); free(r); free(y); free(t); free(p); free(pt); free(hp); free(c1); free(c2); free(tmp); free(f1); free(f2);
+  return it;
+}

@@ -142,8 +142,15 @@ def test_openmp_baseline_matches_scalar_oracle():
         for lo in (0, 200, 400):                    # three streaming steps, warm starts on the second and third
             B.absorb(X[lo:lo + 200], y[lo:lo + 200], nz[lo:lo + 200])
             C.absorb(X[lo:lo + 200], y[lo:lo + 200], nz[lo:lo + 200], init=(lo == 0))
-            it, res = B.refresh(1e-10 if dt == np.float64 else 1e-6)
+            # second step: the density-profile preconditioned solve bench.py times (wb_pcg_profile), else the Kt-preconditioned one
+            it, res = (B.refresh_profile if lo == 200 else B.refresh)(1e-10 if dt == np.float64 else 1e-6)
             assert res < (1e-9 if dt == np.float64 else 1e-5) and it > 0
+            if lo == 200:                           # same system, fewer iterations than the Kt-preconditioned solve
+                Bk = baseline.StreamingBaseline(gb, 10, sigma2=0.7, dtype=dt)
+                Bk.absorb(X[:400], y[:400], nz[:400])
+                itk, _ = Bk.refresh(1e-10 if dt == np.float64 else 1e-6)
+                assert it < itk
+                assert np.abs(Bk.u.astype(np.float64) - B.u.astype(np.float64)).max() < (1e-7 if dt == np.float64 else 5e-4) * np.abs(Bk.u).max()
         assert np.abs(B.A.astype(np.float64) - C.A).max() < tol * np.abs(C.A).max()
         assert np.abs(B.b.astype(np.float64) - C.b).max() < tol * np.abs(C.b).max()
         assert np.allclose(B.c_ld, C.c_ld, rtol=1e-10 if dt == np.float64 else 1e-6)
