@@ -5,6 +5,8 @@
 // The reference densifies W^T (m x q) and adds a dense m x m outer product per
 // update; here each streamed point touches exactly its 4^d x 4^d stencil block.
 #include "wiski_common.h"
+#include <atomic>
+#include <cstdlib>
 
 // GRP = min(T, 64) lanes cooperate on one point (lane <-> tap a); each lane
 // walks all taps b and issues fire-and-forget L2 atomics on A_st[o(a,b)][idx_a].
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
   if (bad) atomicOr(err, 1);
 }
 
+#include "scatter_owner.h"
+
 // Unpacks the row-interleaved half stencil into a full offset-major stencil full[o][i] = A[i, i + off(o)]
 // (diagnostics, tests, and models handed a full-stencil cache):
 //   full[c + oh][i] += h(oh, i);  full[c - oh][i + off(oh)] += h(oh, i) (oh > 0);  h(oh, i) = 0.
@@ -349,16 +353,73 @@ static int expand_impl(const wiski_grid* grid, real* d_half, real* d_full, void*
   return WISKI_OK;
 }
 
+// batches at least this large take the owner-computes absorb when the caller provides its workspace (WISKI_OWNER_MIN_POINTS;
+// 0 disables): its cost is a sweep over the touched part of A_h, that of the atomic form 19 ns per point
+static int64_t owner_min_points() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("WISKI_OWNER_MIN_POINTS");
+    // 50^3: 69 vs 79 us at 4096 uniform points (clustered: 80 vs 80), 255 vs 585 us at 32768.  At 4096 the streaming step gains
+    // only 2 % (0.209 -> 0.205 ms): the rows written through the XCDs' L2s leave A_h less Infinity-Cache resident than memory-side
+    // atomics do, and the SpMVs of the following solve slow down from 20.0 to 21.0 us -- so the default starts above that size
+    v = e ? atoll(e) : 8192;
+    if (v <= 0) v = (int64_t)1 << 62;
+  }
+  return v;
+}
+
 template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
                         int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
                         real* d_cnt = nullptr, const real* d_u = nullptr, real* d_res = nullptr, real* d_mean_out = nullptr,
                         void* z1 = nullptr, int64_t n1_bytes = 0, void* z2 = nullptr, int64_t n2_bytes = 0, const void* d_guard = nullptr,
-                        int64_t guard_expect = 0) {
+                        int64_t guard_expect = 0, void* d_bin = nullptr, int64_t bin_bytes = 0) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
   if (n == 0) return WISKI_OK;
+  // large batches on a d = 3 half stencil with a binning workspace: the owner-computes form (scatter_owner.h)
+  if (half && G.d == 3 && d_bin && d_cnt && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
+      n >= owner_min_points() && bin_bytes >= owner_work_bytes<real>(grid, n)) {
+    static std::atomic<unsigned> epoch_src{0};
+    const unsigned epoch = ++epoch_src == 0 ? ++epoch_src : epoch_src.load();      // never 0 (a zero-initialised head is "empty")
+    const int64_t ncell = (int64_t)(G.g[0] - 3) * (G.g[1] - 3) * (G.g[2] - 3);
+    char* w = static_cast<char*>(d_bin);
+    unsigned long long* head = reinterpret_cast<unsigned long long*>(w);
+    int32_t* next = reinterpret_cast<int32_t*>(w + (ncell * 8 + 255) / 256 * 256);
+    real* rec = reinterpret_cast<real*>(w + (ncell * 8 + 255) / 256 * 256 + (n * 4 + 255) / 256 * 256);
+    int64_t nb = (n + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL((k_bin_points<real>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_stats, d_err,
+                       d_u, d_res != nullptr ? 1 : 0, d_mean_out, head, next, rec, epoch, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4,
+                       (const long long*)d_guard, (long long)guard_expect, getenv("WISKI_OWNER_ABLATE") ? atoi(getenv("WISKI_OWNER_ABLATE")) : 0);
+    static int owner_nt = 0;                         // threads per owner block (WISKI_OWNER_THREADS = 256 | 512)
+    if (owner_nt == 0) {
+      const char* e = getenv("WISKI_OWNER_THREADS");
+      owner_nt = e ? atoi(e) : 256;                  // measured at 50^3, 4096 points: 69 us with 256, 88 us with 512
+      if (owner_nt != 128 && owner_nt != 512) owner_nt = 256;
+    }
+    const size_t lds = ((size_t)G.g[2] * (172 + 3) + 512) * sizeof(real);      // accumulators + one scratch word per thread
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+      if (hipFuncSetAttribute((const void*)k_owner_lines<real, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_owner_lines<real, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_owner_lines<real, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return WISKI_E_LAUNCH;
+      lds_set = lds;
+    }
+    const int abl = getenv("WISKI_OWNER_ABLATE") ? atoi(getenv("WISKI_OWNER_ABLATE")) : 0;
+    if (owner_nt == 512)
+      hipLaunchKernelGGL((k_owner_lines<real, 512>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(512), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
+                         (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
+    else if (owner_nt == 128)
+      hipLaunchKernelGGL((k_owner_lines<real, 128>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(128), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
+                         (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
+    else
+      hipLaunchKernelGGL((k_owner_lines<real, 256>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(256), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
+                         (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
+    return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+  }
   if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
   if (d_mean_out == nullptr && (d_u != nullptr) != (d_res != nullptr)) return WISKI_E_BADARG;
   if ((d_res && !d_u) || (d_mean_out && !d_u) || (d_u && !half)) return WISKI_E_BADARG;  // residual carry-over / mean: half-stencil form only
@@ -399,11 +460,15 @@ int wiski_scatter_stats_cnt_f32(const wiski_grid* g, const float* x, const float
 int wiski_scatter_stats_cnt_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A, int32_t half, double* cnt, const double* u, double* res, double* stats, int32_t* err, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A, stats, err, s, half != 0, cnt, u, res);
 }
-int wiski_scatter_stats_step_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, float* cnt, const float* u, float* res, float* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* s) {
-  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect);
+int wiski_scatter_stats_step_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, float* cnt, const float* u, float* res, float* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* bin, int64_t bin_bytes, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect, bin, bin_bytes);
 }
-int wiski_scatter_stats_step_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* s) {
-  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect);
+int wiski_scatter_stats_step_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* bin, int64_t bin_bytes, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect, bin, bin_bytes);
+}
+int64_t wiski_scatter_bin_bytes(const wiski_grid* g, int64_t n, int32_t elem_size) {
+  if (!g || g->d != 3 || n < 0 || (elem_size != 4 && elem_size != 8)) return -1;
+  return elem_size == 4 ? owner_work_bytes<float>(g, n) : owner_work_bytes<double>(g, n);
 }
 int wiski_stencil_expand_add_f32(const wiski_grid* g, float* half, float* full, void* s) { return expand_impl<float>(g, half, full, s); }
 int wiski_stencil_expand_add_f64(const wiski_grid* g, double* half, double* full, void* s) { return expand_impl<double>(g, half, full, s); }

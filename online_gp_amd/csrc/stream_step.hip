@@ -28,14 +28,14 @@ static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f32* a, co
   int64_t n1 = 0, n2 = 0;
   if (zero)
     if (int rc = wiski_pcg_zero_regions_f32(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
-  return wiski_scatter_stats_step_f32(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, s);
+  return wiski_scatter_stats_step_f32(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, a->d_bin, a->bin_bytes, s);
 }
 static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f64* a, const double* x, const double* y, const double* wa, const double* wb, const double* nz, int64_t n, int carry, double* mean_out, int zero, const void* guard, int64_t expect, void* s) {
   void *p1 = nullptr, *p2 = nullptr;
   int64_t n1 = 0, n2 = 0;
   if (zero)
     if (int rc = wiski_pcg_zero_regions_f64(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
-  return wiski_scatter_stats_step_f64(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, s);
+  return wiski_scatter_stats_step_f64(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, a->d_bin, a->bin_bytes, s);
 }
 static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
                 wiski_pcg_async* as, int mode) {

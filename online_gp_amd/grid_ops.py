@@ -294,7 +294,8 @@ class _StreamArgs32(ctypes.Structure):
                 ("d_err", ctypes.c_void_p), ("d_U", ctypes.c_void_p), ("d_Z", ctypes.c_void_p), ("d_R", ctypes.c_void_p),
                 ("d_tcol", ctypes.c_void_p), ("kscale", ctypes.c_float), ("d_evec", ctypes.c_void_p), ("d_evec2", ctypes.c_void_p),
                 ("d_eval", ctypes.c_void_p), ("shift", ctypes.c_float), ("tol", ctypes.c_double), ("max_iter", ctypes.c_int32),
-                ("check_every", ctypes.c_int32), ("d_work", ctypes.c_void_p), ("work_bytes", ctypes.c_int64)]
+                ("check_every", ctypes.c_int32), ("d_work", ctypes.c_void_p), ("work_bytes", ctypes.c_int64),
+                ("d_bin", ctypes.c_void_p), ("bin_bytes", ctypes.c_int64)]
 
 
 class _StreamArgs64(ctypes.Structure):
@@ -320,6 +321,7 @@ class StreamStep:
         buf, need = workspace.get(grid, 1, max_iter, dtype, device)
         self.keep += (buf,)
         a.d_work, a.work_bytes, a.max_iter = buf.data_ptr(), need, max_iter
+        self.bin_buf = None                    # binning workspace of the owner-computes absorb: grown on demand, zeroed once
         self.fn = _hip.fn("wiski_stream_step", dtype)
         self.it, self.herr, self.rr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0)
         self.eig_keep = None
@@ -350,6 +352,13 @@ class StreamStep:
         solve): the same four values describe the solve a previous call started (None when there was none) and the fifth
         element says whether this step's solve is now pending."""
         q = x.shape[0] if x is not None else 0
+        if q >= 4096 and self.grid.d == 3 and (self.bin_buf is None or self.bin_q < q):
+            f = _hip.lib().wiski_scatter_bin_bytes
+            f.restype = ctypes.c_int64
+            need = int(f(self.grid.ref, ctypes.c_int64(q), ctypes.c_int32(4 if self.dtype == torch.float32 else 8)))
+            if need > 0:
+                self.bin_buf, self.bin_q = torch.zeros(need, dtype=torch.uint8, device=self.device), q
+                self.args.d_bin, self.args.bin_bytes = self.bin_buf.data_ptr(), need
         use_handle = defer or self.pending
         self.herr.value = 0
         rc = self.fn(self.grid.ref, ctypes.byref(self.args), _hip.dptr(x), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise),

@@ -168,7 +168,7 @@ def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
         rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
                                                     _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), _hip.dptr(u),
                                                     _hip.dptr(got["res"]) if with_res else None, _hip.dptr(mean), _hip.dptr(got["stats"]),
-                                                    _hip.dptr(err), p1, n1, p2, n2, None, ctypes.c_int64(0), _hip.stream_ptr(dev))
+                                                    _hip.dptr(err), p1, n1, p2, n2, None, ctypes.c_int64(0), None, ctypes.c_int64(0), _hip.stream_ptr(dev))
         assert rc == 0
         assert torch.allclose(mean, mean_ref, rtol=rtol, atol=atol)
         for k in ("b", "A", "cnt", "stats"):
@@ -189,7 +189,7 @@ def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
     rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
                                                 _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), None, None, _hip.dptr(mean),
                                                 _hip.dptr(got["stats"]), _hip.dptr(err), None, ctypes.c_int64(0), None, ctypes.c_int64(0), None,
-                                                ctypes.c_int64(0), _hip.stream_ptr(dev))
+                                                ctypes.c_int64(0), None, ctypes.c_int64(0), _hip.stream_ptr(dev))
     assert rc != 0
     # guarded launch (speculation behind a pending solve, wiski_pcg_async_guard): a no-op unless the device word holds the expected value
     guard = torch.tensor([-7], device="cuda", dtype=torch.int64)
@@ -201,7 +201,7 @@ def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
         rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
                                                     _hip.dptr(got["b"]), _hip.dptr(got["A"]), _hip.dptr(got["cnt"]), _hip.dptr(u), _hip.dptr(got["res"]),
                                                     _hip.dptr(mean), _hip.dptr(got["stats"]), _hip.dptr(err), p1, n1, p2, n2, _hip.dptr(guard),
-                                                    ctypes.c_int64(7), _hip.stream_ptr(dev))
+                                                    ctypes.c_int64(7), None, ctypes.c_int64(0), _hip.stream_ptr(dev))
         assert rc == 0
         raw = work.view(torch.uint8).reshape(-1)
         if runs:
@@ -210,6 +210,65 @@ def test_scatter_stats_step_emits_mean_and_zeroes(tdt, d, g, n):
         else:
             assert bool(torch.isnan(mean).all()) and all(float(v.abs().max()) == 0.0 for v in got.values())
             assert bool((raw != 0).all())
+
+
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("gs,n", [((12, 12, 12), 9000), ((20, 9, 33), 8192), ((50, 50, 50), 10000), ((8, 64, 8), 12000)])
+def test_owner_computes_absorb_equals_the_atomic_form(tdt, gs, n):
+    """wiski_scatter_stats_step with a binning workspace (batches >= 8192 points, d = 3): points binned by cell, one block per
+    grid line adds every contribution to its rows without memory-side atomics.  Same (b, A_half, cnt, res, stats), mean and
+    zeroing as the atomic form up to the order of the additions -- dense cells (long lists), anisotropic grids, the clamped
+    boundary cells, points outside the grid (flagged, skipped), and a guarded no-op."""
+    import ctypes
+
+    from online_gp_amd import _hip, grid_ops
+
+    rng = np.random.default_rng(31)
+    grid = grid_ops.GridSpec([[-1.1, 1.1]] * 3, list(gs))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    mk = lambda a: torch.as_tensor(a, device="cuda", dtype=tdt)
+    Xn = rng.uniform(-1.0999, 1.0999, (n, 3))                   # out to the box edge: clamped boundary stencils
+    Xn[: n // 3] = 0.15 * rng.standard_normal((n // 3, 3))      # a dense clump: many points per cell
+    Xn = np.clip(Xn, -1.0999, 1.0999)
+    Xn[5] = [3.0, 0.0, 0.0]                                      # outside the grid
+    X, y = mk(Xn), mk(rng.standard_normal(n))
+    noise = mk(rng.uniform(0.5, 2.0, n))
+    wa, wb = 1.0 / noise, 1.0 / noise
+    u = mk(rng.standard_normal(grid.m))
+    H = (grid.R + 1) // 2
+    f = _hip.lib().wiski_scatter_bin_bytes
+    f.restype = ctypes.c_int64
+    nbytes = int(f(grid.ref, ctypes.c_int64(n), ctypes.c_int32(4 if tdt == torch.float32 else 8)))
+    assert nbytes > 0
+    binw = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+
+    def run(use_bin, guard=None, expect=0):
+        out = dict(b=torch.zeros(grid.m, device="cuda", dtype=tdt), A=torch.zeros((H, grid.m), device="cuda", dtype=tdt),
+                   cnt=torch.zeros(grid.m, device="cuda", dtype=tdt), res=torch.zeros(grid.m, device="cuda", dtype=tdt),
+                   stats=torch.zeros(2, device="cuda", dtype=torch.float64), mean=torch.full((n,), float("nan"), device="cuda", dtype=tdt),
+                   err=grid_ops.new_err_flag("cuda"))
+        rc = _hip.fn("wiski_scatter_stats_step", tdt)(grid.ref, _hip.dptr(X), _hip.dptr(y), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
+                                                    _hip.dptr(out["b"]), _hip.dptr(out["A"]), _hip.dptr(out["cnt"]), _hip.dptr(u), _hip.dptr(out["res"]),
+                                                    _hip.dptr(out["mean"]), _hip.dptr(out["stats"]), _hip.dptr(out["err"]), None, ctypes.c_int64(0), None,
+                                                    ctypes.c_int64(0), _hip.dptr(guard), ctypes.c_int64(expect), _hip.dptr(binw) if use_bin else None,
+                                                    ctypes.c_int64(nbytes if use_bin else 0), _hip.stream_ptr(dev))
+        assert rc == 0
+        return out
+
+    ref = run(False)
+    for rep in range(2):                                         # twice: the cell heads of the first call are stale, not reset
+        got = run(True)
+        assert int(got["err"].item()) == int(ref["err"].item()) == 3          # one point dropped (2) | any outside (1)
+        rtol = 3e-5 if tdt == torch.float32 else 1e-12
+        for k in ("b", "A", "cnt", "res"):
+            scale = float(ref[k].abs().max())
+            assert float((got[k] - ref[k]).abs().max()) <= rtol * scale, (k, rep)
+        ok = torch.ones(n, dtype=torch.bool, device="cuda"); ok[5] = False
+        assert torch.allclose(got["mean"][ok], ref["mean"][ok], rtol=rtol, atol=rtol)
+        assert torch.allclose(got["stats"], ref["stats"], rtol=1e-12)
+    guard = torch.tensor([-9], device="cuda", dtype=torch.int64)
+    noop = run(True, guard, 9)
+    assert all(float(noop[k].abs().max()) == 0.0 for k in ("b", "A", "cnt", "res", "stats")) and bool(torch.isnan(noop["mean"]).all())
 
 
 @pytest.mark.parametrize("d,g", CASES)
