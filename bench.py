@@ -335,7 +335,7 @@ def main():
         med = float(np.median(block_s))
         sec, dropped = block_seconds(block_s)
         extra = {"blocks": R, "blocks_dropped": dropped, "block_ms_first_median_last_min": [block_s[0] * 1e3, med * 1e3, block_s[-1] * 1e3, min(block_s) * 1e3],
-                 "updates_per_s_median_block": world * K * q / med,
+                 "updates_per_s_median_block": world * K * q / med, "updates_per_s_all_blocks": world * K * q * R / float(np.sum(block_s)),
                  "timed_region_s": float(np.sum(block_s)), "cg_iters_per_step_mean": float(np.mean(iters)),
                  "stream_points_per_pass": int(model.num_data), "note": "each pass re-starts from the init data and streams at most a 3droad-sized "
                  "stream (434 874 points) of fresh synthetic points"}
