@@ -48,8 +48,7 @@ __global__ __launch_bounds__(256) void k_bin_points(GridDev<real> G, const real*
                                                     double* __restrict__ stats, int32_t* __restrict__ err, const real* __restrict__ u, int carry,
                                                     real* __restrict__ mean_out, unsigned long long* __restrict__ head, int32_t* __restrict__ next,
                                                     real* __restrict__ rec, unsigned epoch, uint32_t* __restrict__ z1, int64_t n1,
-                                                    uint32_t* __restrict__ z2, int64_t n2, const long long* __restrict__ guard, long long guard_expect,
-                                                    int abl) {
+                                                    uint32_t* __restrict__ z2, int64_t n2, const long long* __restrict__ guard, long long guard_expect) {
   if (guard && *guard != guard_expect) return;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1; e += (int64_t)gridDim.x * blockDim.x) z1[e] = 0u;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) z2[e] = 0u;
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256) void k_bin_points(GridDev<real> G, const real*
     const real wc_ = c == 0 ? w[2][0] : c == 1 ? w[2][1] : c == 2 ? w[2][2] : w[2][3];
     const real v = wa_ * wb_ * wc_;
     const int64_t flat = (int64_t)(j0[0] + a) * G.stride[0] + (int64_t)(j0[1] + b) * G.stride[1] + (j0[2] + c);
-    real wu = (u && v != (real)0 && !(abl & 16)) ? v * u[flat] : (real)0;
+    real wu = (u && v != (real)0) ? v * u[flat] : (real)0;
     if (u) wu = wave_reduce_sum<real>(wu);     // every lane holds the total
     {
       real wl = (real)0;
@@ -102,11 +101,11 @@ __global__ __launch_bounds__(256) void k_bin_points(GridDev<real> G, const real*
       if (mean_out) mean_out[p] = wu;
       const int64_t cell = ((int64_t)j0[0] * nc1 + j0[1]) * nc2 + j0[2];
       const unsigned long long tag = ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)p;
-      const unsigned long long old = (abl & 4) ? 0ull : atomicExch(head + cell, tag);
+      const unsigned long long old = atomicExch(head + cell, tag);
       next[p] = (unsigned)(old >> 32) == epoch ? (int32_t)(old & 0xffffffffull) : -1;
     }
   }
-  if (!(abl & 8)) scatter_stats_pass<real, 3>(G, x, y, wb, noise, n, stats, s_red);
+  scatter_stats_pass<real, 3>(G, x, y, wb, noise, n, stats, s_red);
   if (bad) atomicOr(err, 1);
 }
 

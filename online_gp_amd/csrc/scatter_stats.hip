@@ -368,6 +368,16 @@ static int64_t owner_min_points() {
   return v;
 }
 
+// timing ablations of the owner-computes kernels (wrong results; tools/owner_probe.py): 1 no point visits, 2 no write-back
+static int owner_ablate() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WISKI_OWNER_ABLATE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
                         int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
@@ -392,7 +402,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL((k_bin_points<real>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_stats, d_err,
                        d_u, d_res != nullptr ? 1 : 0, d_mean_out, head, next, rec, epoch, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4,
-                       (const long long*)d_guard, (long long)guard_expect, getenv("WISKI_OWNER_ABLATE") ? atoi(getenv("WISKI_OWNER_ABLATE")) : 0);
+                       (const long long*)d_guard, (long long)guard_expect);
     static int owner_nt = 0;                         // threads per owner block (WISKI_OWNER_THREADS = 256 | 512)
     if (owner_nt == 0) {
       const char* e = getenv("WISKI_OWNER_THREADS");
@@ -408,7 +418,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
         return WISKI_E_LAUNCH;
       lds_set = lds;
     }
-    const int abl = getenv("WISKI_OWNER_ABLATE") ? atoi(getenv("WISKI_OWNER_ABLATE")) : 0;
+    const int abl = owner_ablate();
     if (owner_nt == 512)
       hipLaunchKernelGGL((k_owner_lines<real, 512>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(512), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
                          (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
