@@ -443,6 +443,32 @@ def main():
                 ell_us = event_us(lambda i: grid_ops.gather_ell(idx, val, mu), 6)
                 ell_bytes = nq * (T * (4 + es) + es)
                 fused_us = event_us(lambda i: grid_ops.gather(grid, Xq, mu, errf), 6)
+                # the owner-computes absorb (scatter_owner.h): what a rank pays for the N q points of a point exchange -- 8 q points here
+                own_us = None
+                if d == 3:
+                    import ctypes as _ct
+
+                    nb_pts = 8 * q
+                    Xo, yo = synth_stream(nb_pts * 4, d, 31, dev, dtype, args.stream)
+                    yo1 = yo[:, 0].contiguous()
+                    oneso = torch.ones(nb_pts, dtype=dtype, device=dev)
+                    fbytes = lib.wiski_scatter_bin_bytes
+                    fbytes.restype = _ct.c_int64
+                    nbin = int(fbytes(grid.ref, _ct.c_int64(nb_pts), _ct.c_int32(es)))
+                    binw = torch.zeros(max(nbin, 8), dtype=torch.uint8, device=dev)
+                    cntv, resv, uvec, meanv = torch.zeros_like(bvec), torch.zeros_like(bvec), torch.zeros_like(bvec), torch.empty(nb_pts, dtype=dtype, device=dev)
+                    fstep = _hip.fn("wiski_scatter_stats_step", dtype)
+
+                    def own(i):
+                        sl = slice((i % 4) * nb_pts, (i % 4 + 1) * nb_pts)
+                        rc = fstep(grid.ref, _hip.dptr(Xo[sl]), _hip.dptr(yo1[sl]), _hip.dptr(oneso), _hip.dptr(oneso), _hip.dptr(oneso), _ct.c_int64(nb_pts),
+                                   _hip.dptr(bvec), _hip.dptr(half), _hip.dptr(cntv), _hip.dptr(uvec), _hip.dptr(resv), _hip.dptr(meanv), _hip.dptr(st),
+                                   _hip.dptr(errf), None, _ct.c_int64(0), None, _ct.c_int64(0), None, _ct.c_int64(0), _hip.dptr(binw), _ct.c_int64(nbin),
+                                   _hip.stream_ptr(dev))
+                        if rc:
+                            raise RuntimeError(f"wiski_scatter_stats_step: {rc}")
+                    own(0)
+                    own_us = event_us(own, 4)
                 roofline_secondary = [
                     {"kernel": "k_scatter_stats_sym (statistics scatter of q points; memory-side atomics)", "bound": "hbm",
                      "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -454,6 +480,13 @@ def main():
                      "fused_form_rows_per_s": nq / (fused_us * 1e-6), "note": "the product path uses the fused form (weights recomputed from x, 16 B/row)",
                      "timing": "median of 5 torch.cuda.Event brackets of 6 launches"},
                 ]
+                if own_us is not None:
+                    roofline_secondary.append(
+                        {"kernel": "k_bin_points + k_owner_lines (owner-computes absorb of 8 q points: the batch a rank absorbs after a point exchange at N = 8)",
+                         "bound": "hbm", "achieved": 8 * q * sc_bytes / (own_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": 8 * q * sc_bytes / (own_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": own_us, "algorithmic_bytes_per_point": sc_bytes,
+                         "points_per_s": 8 * q / (own_us * 1e-6), "atomic_form_us_for_the_same_points": 8 * sc_us,
+                         "timing": "median of 5 torch.cuda.Event brackets of 4 absorbs (two kernels each)"})
             except Exception as exc:  # noqa: BLE001
                 extra.setdefault("errors", []).append(("extras (stream / roofline legs): " + repr(exc))[:400])
 
