@@ -77,7 +77,7 @@ def _worker_stream_step(rank, world, port, tmpdir):
 
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(3)
-    q, steps = 256, 6
+    q, steps = 4608, 4            # 9216 gathered points per step: the owner-computes absorb (batches >= 8192) inside the one-call step
     X = torch.as_tensor(rng.uniform(-1, 1, (500 + steps * world * q, 3)), device=dev, dtype=torch.float32)
     y = torch.sin(2 * X[:, :1]) * torch.cos(X[:, 1:2]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=torch.float32)
     gb = torch.tensor([[-1.1, 1.1]] * 3)
