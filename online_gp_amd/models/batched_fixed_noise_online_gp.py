@@ -804,26 +804,44 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         return cached[1], ms, pst
 
     def _density_profile_still_fits(self, pst):
-        """The data volume has doubled since the preconditioner's density profile was last looked at.  Look at it here (3 small
-        reductions + one host read, ~0.2 ms with the stream drained) instead of sending the whole step through the generic
-        three-call path: on a stationary stream the normalised profile has not moved (settings.precond_profile_drift), the
-        eigenbasis stays, and the one-call streaming step carries on -- 4 such looks per 3droad-sized pass used to cost a
-        ~1 ms generic step each.  False: the profile moved (or there is none): the caller falls back and `_precond` re-solves."""
+        """The data volume has doubled since the preconditioner's density profile was last looked at.  Look at it from inside
+        the one-call streaming path instead of sending the step through the generic three-call one (4 looks per 3droad-sized
+        pass used to cost a ~1 ms generic step each), and without draining the pipeline: the 3 small reductions and the copy
+        of the marginals to pinned memory are QUEUED now, the verdict is read by whichever later step finds the copy done;
+        meanwhile the stream carries on with the basis it has.  On a stationary stream the normalised profile has not moved
+        (settings.precond_profile_drift): the eigenbasis stays, only the scale follows.  False: the profile moved (or there is
+        none) -- the caller falls back to the generic path and `_precond` re-solves the eigenbasis."""
         old = pst.get("profiles")
         cnt = self._kernel_cache.get("_cnt") if settings.density_profile_preconditioner.on() else None
         if old is None or cnt is None:
             return False
         g = self._grid.g
-        c3 = cnt[0].reshape(g).double()
-        margs = [c3.sum(dim=[r for r in range(self._grid.d) if r != q]) if self._grid.d > 1 else c3 for q in range(self._grid.d)]
-        margs = torch.stack([torch.nn.functional.pad(mg, (0, max(g) - mg.numel())) for mg in margs]).cpu().numpy()
+        look = self.__dict__.get("_profile_look")
+        if look is None:
+            c3 = cnt[0].reshape(g).double()
+            margs = [c3.sum(dim=[r for r in range(self._grid.d) if r != q]) if self._grid.d > 1 else c3 for q in range(self._grid.d)]
+            margs = torch.stack([torch.nn.functional.pad(mg, (0, max(g) - mg.numel())) for mg in margs])
+            host = self.__dict__.get("_profile_look_host")            # pinned once (a pinned allocation costs ~0.3 ms)
+            if host is None or host.shape != margs.shape:
+                host = torch.empty(margs.shape, dtype=margs.dtype, pin_memory=True)
+                self.__dict__["_profile_look_host"] = host
+            host.copy_(margs, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.__dict__["_profile_look"] = (host, ev, float(self._wsum[0]), margs)
+            return True
+        host, ev, wsum_then, _ = look
+        if not ev.query():
+            return True                                   # still in flight
+        self.__dict__["_profile_look"] = None
+        margs = host.numpy()
         if not margs.max() > 0:
             return False
         for q, gq in enumerate(g):
             t = (margs[q, :gq] / margs[q, :gq].max()).clip(1e-2, None)
             if float(abs(t - old[q]).max()) > settings.precond_profile_drift.value():
                 return False
-        pst["wsum"] = float(self._wsum[0])                # same density shape: keep the eigenbasis, only the scale moves
+        pst["wsum"] = wsum_then                           # same density shape: keep the eigenbasis, only the scale moves
         pst["it0"] = None
         return True
 
