@@ -889,6 +889,13 @@ template <typename real>
 __global__ void k_spec_mode0_bwd_updp(GridDev<real> G, const real* __restrict__ X0, const real* __restrict__ Z0, const real* __restrict__ src, int k,
                                       int it, real* __restrict__ p, real* __restrict__ pt, PcgScal S);   // defined below
 
+// (One launch per preconditioner application was tried at the end of round 2: the three kernels as phases of one launch of
+// 158 co-resident blocks -- one per CU, the slab's 115 KB of LDS -- separated by two grid-wide barriers in the cooperative-
+// groups pattern (block barrier, one thread's release fence + arrival on a counter + spin + acquire fence, block barrier).
+// Correct -- same iterates, 299 tests green -- and SLOWER: 0.258 instead of 0.203 ms per streaming step, i.e. +22 us per
+// iteration.  A launch boundary costs ~5.5 us here (the 4 us an empty kernel takes by the same clock + ~1.5 us between
+// launches); a grid barrier across 8 XCDs costs more than twice that (two L2 write-back / invalidate fences and an atomic
+// round trip through the memory side), and the phases run with one 256-thread block per CU.  Removed.)
 // mode-0 launch: fp32 on the matrix cores (256 threads), fp64 on the register-tile kernels (128 threads)
 template <typename real, bool DOT>
 static int launch_mode0(const GridDev<real>& G, const real* Va, const real* Vb, int split, int transposed, const real* src, real* dst, int ncols,
