@@ -14,7 +14,9 @@
 //                  plain, row-contiguous read-modify-writes.
 // Measured at 50^3 fp32 (tools/owner_probe.py): 69 us per 4 096 uniform points (atomic form 79; clustered 80 / 80), 255 us per
 // 32 768 (585) -- binning 8 us, then per line: heads + records fetched in two batched memory latencies, ~38 point visits of ~110
-// instructions each (33 us in all), and the write-back of the non-zero accumulators (17 us).  History: LDS atomics and one
+// instructions each (33 us in all), and the write-back of the non-zero accumulators (17 us).  At 32 768 points: binning 27 us,
+// scan 13, visits 193 (20 per point, ~720 SIMD cycles each: the record broadcast and index set-up are paid again by each of the
+// 16 lines a point touches), write-back 18.  History: LDS atomics and one
 // (head, record) round trip per 64 candidates 140 us; quarter-of-the-line ownership per wave (no atomics), batched fetches,
 // branch-free visits with one LDS round trip 61 us; 8 or 2 waves per block are slower (88 / 87 us at 4 096 points).
 #pragma once
