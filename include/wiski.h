@@ -212,6 +212,8 @@ typedef struct wiski_pcg_async {
                         accumulated partial vector (wiski_gather_zero): the next START / run skips its own zero launch */
   int32_t guard_ok;  /* set by RESUME: 1 when the poll it waited for found every column converged and no error flag, i.e. when a
                         kernel guarded by that poll (wiski_pcg_async_guard) has run */
+  double shift;      /* wiski_stream_step: the preconditioner shift the pending solve was STARTed with -- its RESUME continues
+                        with it even if the caller has meanwhile set the next step's shift in the argument struct */
 } wiski_pcg_async;
 int wiski_pcg_async_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
 int wiski_pcg_async_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode);
@@ -253,7 +255,8 @@ int wiski_gather_zero_f64(const wiski_grid* grid, const double* d_x, int64_t n, 
  * h_err as in wiski_pcg.
  * handle != NULL selects the deferred form: the call first RESUMEs the solve a previous call started (its iteration count,
  * residual and out-of-grid flag land in h_iters / h_relres / h_err; h_resumed = 1), then queues the absorb of the new
- * batch, then STARTs the new solve (defer != 0: returns WISKI_PENDING) or runs it to convergence (defer == 0).  q = 0 with
+ * batch, then STARTs the new solve (defer != 0: returns WISKI_PENDING) or runs it to convergence (defer == 0: h_iters /
+ * h_relres / h_err then describe THIS solve and h_resumed = 2 says a pending one was finished on the way).  q = 0 with
  * defer = 0 just finishes a pending solve.  So the host-language work between two steps overlaps the GPU's CG iterations.
  * (With a mean requested the absorb is in fact queued BEFORE the RESUME, guarded on the device by the verdict of the pending
  * poll -- wiski_pcg_async_guard -- and queued again unguarded only if that verdict was "not converged" or "error flag set";

@@ -388,11 +388,44 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
   if (n == 0) return WISKI_OK;
-  // large batches on a d = 3 half stencil with a binning workspace: the owner-computes form (scatter_owner.h)
-  if (half && G.d == 3 && d_bin && d_cnt && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
-      n >= owner_min_points() && bin_bytes >= owner_work_bytes<real>(grid, n)) {
+  // argument validation comes first: the owner-computes branch below must not start mutating statistics on arguments the
+  // atomic form would have refused
+  if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
+  if (d_mean_out == nullptr && (d_u != nullptr) != (d_res != nullptr)) return WISKI_E_BADARG;
+  if ((d_res && !d_u) || (d_mean_out && !d_u) || (d_u && !half)) return WISKI_E_BADARG;  // residual carry-over / mean: half-stencil form only
+  if (d_guard && !half) return WISKI_E_BADARG;
+  if ((n1_bytes | n2_bytes) & 3 || (n1_bytes && !z1) || (n2_bytes && !z2) || ((n1_bytes || n2_bytes) && !half)) return WISKI_E_BADARG;
+  // large batches on a d = 3 half stencil with a binning workspace: the owner-computes form (scatter_owner.h).  Its LDS
+  // accumulators ((g2 * 175 + 512) reals per block) must fit the device limit and the opt-in must succeed BEFORE the first
+  // kernel of the pair is queued -- k_bin_points already updates statistics; otherwise the atomic form runs.
+  bool owner = half && G.d == 3 && d_bin && d_cnt && d_A_st && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
+               n >= owner_min_points() && bin_bytes >= owner_work_bytes<real>(grid, n);
+  const size_t owner_lds = ((size_t)G.g[2] * (172 + 3) + 512) * sizeof(real);      // accumulators + one scratch word per thread
+  if (owner) {
+    static int lds_max = -1;
+    static size_t lds_set = 0;
+    if (lds_max < 0) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
+      lds_max = v;
+    }
+    if (owner_lds > (size_t)lds_max) {
+      owner = false;
+    } else if (owner_lds > 48 * 1024 && owner_lds > lds_set) {
+      if (hipFuncSetAttribute((const void*)k_owner_lines<real, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)owner_lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_owner_lines<real, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)owner_lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_owner_lines<real, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)owner_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        owner = false;                               // the atomic form needs no opt-in
+      } else {
+        lds_set = owner_lds;
+      }
+    }
+  }
+  if (owner) {
     static std::atomic<unsigned> epoch_src{0};
-    const unsigned epoch = ++epoch_src == 0 ? ++epoch_src : epoch_src.load();      // never 0 (a zero-initialised head is "empty")
+    unsigned epoch = ++epoch_src;                    // never 0 (a zero-initialised head is "empty")
+    if (!epoch) epoch = ++epoch_src;
     const int64_t ncell = (int64_t)(G.g[0] - 3) * (G.g[1] - 3) * (G.g[2] - 3);
     char* w = static_cast<char*>(d_bin);
     unsigned long long* head = reinterpret_cast<unsigned long long*>(w);
@@ -409,15 +442,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
       owner_nt = e ? atoi(e) : 256;                  // measured at 50^3, 4096 points: 69 us with 256, 88 us with 512
       if (owner_nt != 128 && owner_nt != 512) owner_nt = 256;
     }
-    const size_t lds = ((size_t)G.g[2] * (172 + 3) + 512) * sizeof(real);      // accumulators + one scratch word per thread
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-      if (hipFuncSetAttribute((const void*)k_owner_lines<real, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_owner_lines<real, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_owner_lines<real, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return WISKI_E_LAUNCH;
-      lds_set = lds;
-    }
+    const size_t lds = owner_lds;
     const int abl = owner_ablate();
     if (owner_nt == 512)
       hipLaunchKernelGGL((k_owner_lines<real, 512>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(512), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
@@ -430,11 +455,6 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
                          (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
     return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
   }
-  if (!d_x || !d_y || !d_wa || !d_wb || !d_noise || !d_b || !d_stats || !d_err) return WISKI_E_BADARG;
-  if (d_mean_out == nullptr && (d_u != nullptr) != (d_res != nullptr)) return WISKI_E_BADARG;
-  if ((d_res && !d_u) || (d_mean_out && !d_u) || (d_u && !half)) return WISKI_E_BADARG;  // residual carry-over / mean: half-stencil form only
-  if (d_guard && !half) return WISKI_E_BADARG;
-  if ((n1_bytes | n2_bytes) & 3 || (n1_bytes && !z1) || (n2_bytes && !z2) || ((n1_bytes || n2_bytes) && !half)) return WISKI_E_BADARG;
   const int grp = half ? 64 : (G.T < 64 ? G.T : 64);
   const int64_t ppb = 256 / grp;
   int64_t blocks = (n + ppb - 1) / ppb;

@@ -73,7 +73,11 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
         spec = true;
       }
     }
-    rc = pcg1(grid, a, 2, first_check, h_iters, h_relres, h_err, stream, as, 2);
+    {
+      typename StreamArgs<real>::type ar = *a;     // RESUME with the shift the solve was started with (a->shift is the NEXT solve's)
+      ar.shift = (real)as->shift;
+      rc = pcg1(grid, &ar, 2, first_check, h_iters, h_relres, h_err, stream, as, 2);
+    }
     if (h_resumed) *h_resumed = 1;
     if (rc != WISKI_OK && rc != WISKI_E_NOTCONV) return rc;
     absorbed = spec && as->guard_ok;          // else the guarded kernel was a no-op (and RESUME may have queued more iterations)
@@ -102,10 +106,16 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
   if (defer) {
     int32_t it2 = 0, e2 = 0;
     double r2 = 0;
+    as->shift = (double)a->shift;
     rc = pcg1(grid, a, carry ? 2 : 1, first_check, &it2, &r2, &e2, stream, as, 1);      // outputs of THIS solve arrive with the next call
     return rc == WISKI_PENDING ? (resumed_rc == WISKI_E_NOTCONV ? WISKI_E_NOTCONV : WISKI_PENDING) : rc;
   }
-  return pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream, as, 0);
+  // deferral switched off with a solve pending: the outputs below describe THIS step's synchronous solve; the resumed
+  // one (finished above) is reported as *h_resumed = 2 -- "resumed, but its numbers were overwritten" -- and a resumed
+  // solve that stopped at max_iter still surfaces through the return code
+  if (h_resumed && *h_resumed == 1) *h_resumed = 2;
+  rc = pcg1(grid, a, carry ? 2 : 1, first_check, h_iters, h_relres, h_err, stream, as, 0);
+  return rc == WISKI_OK && resumed_rc == WISKI_E_NOTCONV ? WISKI_E_NOTCONV : rc;
 }
 
 extern "C" {

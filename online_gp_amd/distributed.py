@@ -288,6 +288,7 @@ class ShardedStatsUpdater:
         if "_cnt" in delta and "_cnt" in c:
             c["_cnt"].add_(delta["_cnt"])
         for dst, half in zip(_wtw_ops(c["WtW"]), halves):
+            dst.root = dst.inv_root = None           # the all-reduced increment bypasses the rank-update path: re-derive on demand
             if grid_ops.is_half_stencil(m._grid, dst.stencil):
                 dst.stencil.add_(half)                       # native half storage: plain add
                 half.zero_()

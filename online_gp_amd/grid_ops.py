@@ -304,7 +304,7 @@ class _StreamArgs64(ctypes.Structure):
 
 class _PcgAsync(ctypes.Structure):
     _fields_ = [("state", ctypes.c_int32), ("it", ctypes.c_int32), ("seq", ctypes.c_int64), ("poll", ctypes.c_void_p),
-                ("prezeroed", ctypes.c_int32), ("guard_ok", ctypes.c_int32)]
+                ("prezeroed", ctypes.c_int32), ("guard_ok", ctypes.c_int32), ("shift", ctypes.c_double)]
 
 
 class StreamStep:
@@ -372,7 +372,8 @@ class StreamStep:
         res = (int(self.it.value), float(self.rr.value), int(self.herr.value), rc != -4)
         if not use_handle:
             return res
-        return (res if self.resumed.value else None), self.pending
+        # resumed == 2: a pending solve was finished AND this step's solve ran synchronously -- `res` describes the latter
+        return (res if self.resumed.value == 1 else None), self.pending
 
 
 def kron_eigen(grid, tcol, profiles=None):

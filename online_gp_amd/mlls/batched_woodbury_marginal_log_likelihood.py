@@ -157,6 +157,7 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
 
     def forward(self, distro=None, targets=None, *args):
         model = self.model
+        model._finish_pending()      # the solves below share the model's PCG workspace with a deferred refresh still in flight
         if self.clear_caches_every_iteration:
             model.zero_grad()
         model.check_bounds()

@@ -254,6 +254,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             grid_ops.scatter_stats_cnt(self._grid, X, yo, wa, wb, no, b[o, :, 0], dst[o], half, cnt_o, stats[o], self._err,
                                        u=ms["U"][o] if (carry or carry_delta) else None,
                                        res=ms["R"][o] if carry else (res_delta[o] if carry_delta else None))
+            if (init or half_delta is not None) and getattr(ops[o], "root", None) is not None:
+                # the stencil is being rebuilt (set_train_data) or receives its increment later, after an all-reduce
+                # (data-parallel path): a carried root pair would describe the OLD matrix -- drop it, it is re-derived on demand
+                ops[o].root = ops[o].inv_root = None
             if half_delta is None and getattr(ops[o], "root", None) is not None and n > 0:
                 # the reference's root pair, once somebody asked for it: L L^T follows A by a rank-n root update (URLT:62-119)
                 Wd = grid_ops.wt_columns(self._grid, X, self._err)                 # [n, m]
@@ -295,6 +299,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         describe exactly the points that were absorbed -- a caller may catch the error and carry on."""
         dropped = flag >> 1
         self._err.zero_()
+        self.__dict__.pop("_stream_step_cache", None)
         if dropped:
             self.num_data = self.num_data - dropped
             cnt = self._kernel_cache.get("_cnt")
@@ -790,11 +795,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if pst.get("it0") is not None and its >= pst["it0"] + 2 and wsum_new > 1.1 * pst["wsum"]:
             return None
         tol = _default_tol(self._dtype)
-        key = (ver, id(ms["U"]), id(pst["eig"]), tol, settings.cg_check_every.value(), settings.max_cg_iterations.value())
+        c = self._kernel_cache
+        # raw device pointers go into the prepared call: key it on every one of them (ids of Python wrappers can be reused)
+        key = (ver, ms["U"].data_ptr(), ms["Z"].data_ptr(), ms["R"].data_ptr(), op.stencil.data_ptr(), c["interpolation_cache"].data_ptr(),
+               c["_cnt"].data_ptr(), c["_stats"].data_ptr(), self._err.data_ptr(), pst["eig"][0].data_ptr(), str(self._device), tol,
+               settings.cg_check_every.value(), settings.max_cg_iterations.value())
         cached = self.__dict__.get("_stream_step_cache")
         if cached is None or cached[0] != key:
             tcol, s2, _ = self._hyper()[0]
-            c = self._kernel_cache
             step = grid_ops.StreamStep(self._grid, self._dtype, self._device, op.stencil, c["interpolation_cache"][0, :, 0], c["_cnt"][0],
                                        c["_stats"][0], self._err, ms["U"][0], ms["Z"][0], ms["R"][0], tcol, self._pcg_ws,
                                        settings.max_cg_iterations.value())
@@ -915,6 +923,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if train_targets.dim() == 1:
             train_targets = train_targets[:, None]
         noise = self._canon_noise(train_noise_term, train_targets)
+        self._finish_pending()                      # a deferred solve must not be resumed on zeroed statistics
+        self.__dict__.pop("_stream_step_cache", None)
         cache = self._kernel_cache
         cache["interpolation_cache"].zero_()
         cache["_stats"].zero_()
@@ -922,6 +932,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             cache["_cnt"].zero_()
         for op in _wtw_ops(cache["WtW"]):
             op.stencil.zero_()
+            op.root = op.inv_root = None            # L L^T described the old matrix
         self._wsum_dev.zero_()
         self._wsum_host = [0.0] * self.num_outputs
         self._wsum_dev_host = [0.0] * self.num_outputs
@@ -950,6 +961,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._err = grid_ops.new_err_flag(device)
             self._mean_state = None
             self._memo = {}
+            self.__dict__.pop("_stream_step_cache", None)
         return res
 
     # ------------------------------------------------- distributed statistics --

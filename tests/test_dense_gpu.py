@@ -246,3 +246,32 @@ def test_root_space_objects_match_the_dense_reference_b1():
     grid_ops.root_update_(Lf, Rf, Vf)
     assert (Lf @ Lf.t() - (Af + Vf @ Vf.t())).abs().max() < 1e-4 * Af.abs().max()
     assert (Rf.t() @ Lf - torch.eye(g ** d, device=DEV)).abs().max() < 1e-2
+
+
+def test_root_pair_is_dropped_when_the_stencil_is_rebuilt_or_all_reduced():
+    """set_train_data zeroes the stencil in place; a root pair carried from before must not be
+    rank-updated onto it (L L^T would be A_old + A_new).  Same for the statistics all-reduce of the data-parallel path."""
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = (torch.rand(300, 2, generator=g, dtype=torch.float64) * 2 - 1).to(DEV)
+    y = torch.sin(3 * X.sum(1, keepdim=True))
+    gb = torch.tensor([[-1.1, 1.1]] * 2)
+    model = FixedNoiseOnlineSKIGP(X, y, torch.ones_like(y), grid_bounds=gb, grid_size=10, learn_additional_noise=True)
+    op = model._kernel_cache["WtW"]
+    L0 = op.root_decomposition().root.evaluate().clone()
+    assert op.root is not None
+    X2 = (torch.rand(40, 2, generator=g, dtype=torch.float64) * 2 - 1).to(DEV)       # n <= m / 2: the rank-update branch
+    y2 = torch.cos(2 * X2.sum(1, keepdim=True))
+    model.set_train_data(X2, y2, torch.ones_like(y2))
+    assert op.root is None and op.inv_root is None
+    A = op.evaluate()
+    L = op.root_decomposition().root.evaluate()
+    assert ((L @ L.t()) - A).abs().max().item() < 1e-6 * max(1.0, A.abs().max().item())
+    assert ((L0 @ L0.t()) - A).abs().max().item() > 1e-3          # the old root really described another matrix
+    # data-parallel increment (half_delta path): the roots are dropped as well
+    op.root_decomposition()
+    halves = model._half_buffers()
+    model._absorb(model._kernel_cache, X[:8], y[:8], torch.ones_like(y[:8]), init=False, half_delta=halves)
+    assert op.root is None
+    halves[0].zero_()
