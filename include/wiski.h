@@ -307,6 +307,24 @@ int64_t wiski_root_update_workspace_elems(int32_t m, int32_t r, int32_t q);
 int wiski_root_update_f32(int32_t m, int32_t r, int32_t q, float* d_L, int32_t ldl, float* d_R, int32_t ldr, const float* d_V, int32_t ldv, float* d_ws, int64_t ws_elems, void* stream);
 int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* d_L, int32_t ldl, double* d_R, int32_t ldr, const double* d_V, int32_t ldv, double* d_ws, int64_t ws_elems, void* stream);
 
+/* a10 / a12 / a13 / a17 in a reduced Kronecker eigenbasis -- replaces the reference's rank-limited root space (BFN:343-404 with
+ * gpytorch's root_decomposition capped at max_root_decomposition_size, URLT:74-76) for smooth kernels.  With
+ * K_q = V_q diag(ev_q) V_q^T per dim, basis function j is b_j = kron_q V_q[:, S[q][j]]; the r x r problem
+ * G = B^T A B, C = I + Lam^1/2 G Lam^1/2 runs on wiski_gemm / wiski_potrf / wiski_trsm (fp64).  Not GEMMs:
+ *   wiski_basis_project   F[p][j] = scale_p * colscale_j * (W B)[p][j]  for n points (row-major, leading dimension ldf);
+ *                         d_V: per-dim eigenvector tables [g_q][kmax] (fp64, row-major), concatenated over dims; d_S [d][r]:
+ *                         per-dim eigenvector index of basis function j (< kmax <= 32); d_scale [n] / d_colscale [r] optional;
+ *                         d_prior [n] optional (needs d_tcol [sum g], the Toeplitz columns): prod_q w_q^T K_q w_q, the prior
+ *                         variance w^T Kuu w of each point -- its excess over sum_j lam_j F[p][j]^2 bounds the truncation error
+ *                         of a predictive variance.  Points outside the grid give zero rows and set bit 0 of *d_err.
+ *   wiski_basis_pair_reduce   D[q][a][a'] += sum over pairs (j, j') equal in every dim but q with S[q][j] = a, S[q][j'] = a'
+ *                         of Wt[j][j'] * prod_{p != q} ev[p][S[p][j]]  (Wt r x r row-major, ev [d][kmax], D [d][kmax][kmax] zeroed by
+ *                         the caller): V_q D_q V_q^T summed along its lag diagonals is the gradient of
+ *                         sum_jj' Wt[j][j'] b_j^T (kron_q SymToeplitz(tcol_q)) b_j' w.r.t. tcol_q -- the MLL backward (BWM:19-51). */
+int wiski_basis_project_f32(const wiski_grid* grid, const float* d_x, int64_t n, const double* d_V, int32_t kmax, const int32_t* d_S, int32_t r, const float* d_scale, const double* d_colscale, const double* d_tcol, double* d_F, int64_t ldf, double* d_prior, int32_t* d_err, void* stream);
+int wiski_basis_project_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t kmax, const int32_t* d_S, int32_t r, const double* d_scale, const double* d_colscale, const double* d_tcol, double* d_F, int64_t ldf, double* d_prior, int32_t* d_err, void* stream);
+int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_Wt, const int32_t* d_S, const double* d_ev, double* d_D, void* stream);
+
 /* (e) -- the one collective of the path: in-place RCCL all-reduce(SUM), grouped into one launch, of the
  * statistics that are sums over data points: the half-stencil delta of W^T D^-1 W (n_half reals), W^T D^-1 y (n_b), the
  * row-sum vector W^T D^-1 1 (n_cnt) and fp64 scalars ([y^T D^-1 y, log|D|] per output, point count, weight sums: n_scal

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libwiski_hip.so")
-_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip"]
+_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip", "spectral_basis.hip"]
 _HEADERS = ["wiski_common.h", "spmv_sym_dma.h", "spmm_sym_cols.h", os.path.join("..", "..", "include", "wiski.h")]
 MAX_DIM = 4
 
@@ -41,17 +41,33 @@ def sources():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into csrc/libwiski_hip.so."""
+    """Compile every HIP source for gfx950 into csrc/libwiski_hip.so: one object per source (built concurrently, only when
+    the source or a header is newer than its object), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = sources()
-    deps = srcs + [os.path.join(_CSRC, h) for h in _HEADERS]
-    if not force and os.path.exists(_SO):
-        if all(os.path.getmtime(d) <= os.path.getmtime(_SO) for d in deps if os.path.exists(d)):
-            return _SO
+    hdrs = [os.path.join(_CSRC, h) for h in _HEADERS]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _SO] + srcs + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(_HERE, "..", "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs, todo = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            todo.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+    if not todo and os.path.exists(_SO) and all(os.path.getmtime(o) <= os.path.getmtime(_SO) for o in objs):
+        return _SO
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _SO] + objs + ["-ldl"])
     return _SO
 
 

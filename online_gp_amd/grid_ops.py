@@ -557,3 +557,29 @@ def chol_logdet(L):
                                            _hip.stream_ptr(L.device))
     _hip.check(rc, "wiski_logdiag")
     return 2.0 * out[0]
+
+
+# ------------------------------------------------- reduced Kronecker-eigenbasis factor --
+def basis_project(grid, x, V, kmax, S, scale=None, colscale=None, tcol=None, want_prior=False, err=None):
+    """F = diag(scale) (W(x) B) diag(colscale), fp64 [n, r], for the tensor-product basis b_j = kron_q V_q[:, S[q, j]]
+    (``wiski_basis_project``).  V: fp64 per-dim tables [g_q, kmax] concatenated; S int32 [d, r].  With `want_prior`
+    also returns the prior variances w_p^T Kuu w_p (needs the fp64 Toeplitz columns `tcol`)."""
+    x2 = _x2d(x, grid)
+    n, r = x2.shape[0], S.shape[1]
+    F = torch.empty((n, r), dtype=torch.float64, device=x2.device)
+    prior = torch.empty(n, dtype=torch.float64, device=x2.device) if want_prior else None
+    rc = _hip.fn("wiski_basis_project", x2.dtype)(grid.ref, _hip.dptr(x2), ctypes.c_int64(n), _hip.dptr(V), ctypes.c_int32(kmax), _hip.dptr(S),
+                                                  ctypes.c_int32(r), _hip.dptr(scale), _hip.dptr(colscale), _hip.dptr(tcol), _hip.dptr(F),
+                                                  ctypes.c_int64(r), _hip.dptr(prior), _hip.dptr(err), _hip.stream_ptr(x2.device))
+    _hip.check(rc, "wiski_basis_project")
+    return (F, prior) if want_prior else F
+
+
+def basis_pair_reduce(Wt, S, ev, kmax):
+    """D [d, kmax, kmax] of ``wiski_basis_pair_reduce`` (Wt [r, r] fp64, S int32 [d, r], ev fp64 [d, kmax])."""
+    d, r = S.shape
+    D = torch.zeros((d, kmax, kmax), dtype=torch.float64, device=Wt.device)
+    rc = _hip.lib().wiski_basis_pair_reduce(ctypes.c_int32(d), ctypes.c_int32(r), ctypes.c_int32(kmax), _hip.dptr(Wt.contiguous()), _hip.dptr(S),
+                                            _hip.dptr(ev), _hip.dptr(D), _hip.stream_ptr(Wt.device))
+    _hip.check(rc, "wiski_basis_pair_reduce")
+    return D

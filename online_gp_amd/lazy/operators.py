@@ -239,8 +239,9 @@ class PredictiveCovariance(LazyCovariance):
     evaluated lazily: the k = n* solves U = M W*^T run once, on first use, in
     column chunks; ``diag`` needs only the per-query quadratic forms."""
 
-    def __init__(self, post, x, sigma2, err, chunk=64, block=None):
+    def __init__(self, post, x, sigma2, err, chunk=64, block=None, spectral=None):
         self.post = post
+        self.spectral = spectral  # callable -> (factor, state, fp64 Toeplitz columns) or None: lazy/spectral_woodbury.py
         self.x = x.contiguous()
         self.sigma2 = float(sigma2)
         self.err = err
@@ -275,9 +276,20 @@ class PredictiveCovariance(LazyCovariance):
                 full = full.reshape(n // q, q, q) * self.sigma2
             self._full = 0.5 * (full + full.transpose(-1, -2))
 
+    def _spectral_path(self, sp, want_full):
+        """Reduced-eigenbasis factor (smooth kernels on large grids): one projection, one triangular solve."""
+        fac, st, tcol64 = sp
+        diag, full = fac.query(st, self.x, tcol64, want_full=want_full, block=self.block)
+        self._diag = (diag * self.sigma2).to(self.dtype)
+        if want_full:
+            self._full = (full * self.sigma2).to(self.dtype)
+
     def _solve_chunks(self, want_full):
         if hasattr(self.post, "dense"):
             return self._dense_path(want_full)
+        sp = self.spectral() if self.spectral is not None else None
+        if sp is not None:
+            return self._spectral_path(sp, want_full)
         n = self.x.shape[0]
         grid = self.post.grid
         diag = torch.empty(n, dtype=self.dtype, device=self.device)

@@ -1,0 +1,298 @@
+"""Dense Woodbury factor in the dominant Kronecker eigenspace of Kuu ("spectral factor").
+
+The reference reaches the posterior through a rank-limited root space: L L^T ~ W^T D^-1 W with at most
+``max_root_decomposition_size`` columns, Q = I + L^T Kt L, Cholesky of Q (BFN:343-404, URLT:74-76).  On grids where
+the matrix-free path (wiski_pcg) is the only exact option this module offers the same thing with the roles swapped:
+the low-rank object is the *prior*.  For a smooth stationary kernel Kt = kron_q K_q / sigma2 has a tiny numerical rank:
+with K_q = V_q diag(ev_q) V_q^T the r tensor-product eigenvectors b_j = kron_q V_q[:, S_q[j]] of largest eigenvalue
+lam_j carry all but a fraction ``settings.spectral_tail`` of trace(Kt) (r ~ 400 for the default RBF hyper-parameters
+on a 50^3 grid at 1e-6).  With B = [b_j] and Kt_B = B Lam B^T,
+
+    G = B^T A B,  h = B^T b                      (A = W^T D^-1 W, b = W^T D^-1 y: the model's statistics)
+    C = I + Lam^1/2 G Lam^1/2 = chol chol^T      (SPD, eigenvalues >= 1: no jitter; wiski_potrf, fp64)
+    M_B = (Kt_B^+ + A)^-1 restricted to span(B) = B Lam^1/2 C^-1 Lam^1/2 B^T
+    w^T M_B w = |chol^-1 Lam^1/2 B^T w|^2        (wiski_basis_project + wiski_trsm)
+    b^T M_B b = |chol^-1 Lam^1/2 h|^2,  logdet(I + Kt_B A) = 2 sum log diag chol        (BWM:27-35)
+
+Error control.  K -> (K^-1 + A)^-1 is operator monotone and 0 <= M(Kt) - M(Kt_B) <= Kt - Kt_B, so for every query
+    0 <= w^T M w - w^T M_B w <= w^T Kt w - sum_j lam_j (b_j^T w)^2 =: tail(w),
+and tail(w) costs nothing (the prior variance is a product of d 4x4 quadratic forms).  The returned variance is
+w^T M_B w + tail(w) -- exact wherever the data do not inform the left-out directions, which is what "left out" means --
+and ``last_rel_bound`` records max tail / variance.
+
+Hyper-parameter steps.  The eigenvectors move with the lengthscales, G = B^T A B does not survive that.  The factor
+therefore keeps G_ref, h_ref in a *reference* basis taken with a margin (tail x 1e-2) at the hyper-parameters it was
+built for, follows streaming updates there (G_ref += F^T diag(wa) F with F = W B_ref: one projection kernel + one MFMA
+GEMM), and re-expresses it in the current eigenbasis by the Kronecker-structured change of basis
+T[i, j] = prod_q (V_ref,q^T V_q)[S_ref[q, i], S[q, j]]:  G = T^T G_ref T.  The part of a current basis vector outside
+the reference span ("defect") is monitored, weighted by its eigenvalue; when it exceeds the tail budget the reference
+is rebuilt from the stencil (r_ref SpMV columns).  Everything dense runs in fp64 on wiski_gemm / potrf / trsm.
+"""
+import numpy as np
+import torch
+
+from .. import grid_ops, settings
+
+KMAX = 32
+
+
+def default_tail(dtype):
+    v = settings.spectral_tail.value()
+    if v is not None:
+        return float(v)
+    return 1e-6 if dtype == torch.float32 else 1e-9
+
+
+class SpectralBasis:
+    """Index set + per-dim eigenvector tables for one set of Toeplitz columns."""
+
+    def __init__(self, grid, evs, Vs, S, lam_kuu, kmax, device):
+        self.grid, self.kmax, self.r = grid, kmax, S.shape[1]
+        self.evs, self.Vs = evs, Vs                    # host: per-dim eigenvalues (descending, >= 0) / eigenvectors [g_q, g_q]
+        self.S_host = S                                # [d, r] int
+        self.lam_kuu_host = lam_kuu                    # [r] eigenvalues of Kuu (not yet divided by sigma2), descending
+        tabs = [np.ascontiguousarray(V[:, :kmax]) if V.shape[1] >= kmax else np.pad(V, ((0, 0), (0, kmax - V.shape[1]))) for V in Vs]
+        self.Vtab_host = tabs
+        self.Vtab = torch.as_tensor(np.concatenate([t.reshape(-1) for t in tabs]), dtype=torch.float64).to(device)
+        self.Vq = [torch.as_tensor(t, dtype=torch.float64).to(device) for t in tabs]          # [g_q, kmax] each
+        self.S = torch.as_tensor(S.astype(np.int32)).to(device).contiguous()
+        self.S_long = self.S.long()
+        ev_tab = np.zeros((grid.d, kmax))
+        for q in range(grid.d):
+            kq = min(kmax, len(evs[q]))
+            ev_tab[q, :kq] = evs[q][:kq]
+        self.ev_tab = torch.as_tensor(ev_tab, dtype=torch.float64).to(device)
+        self.lam_kuu = torch.as_tensor(lam_kuu, dtype=torch.float64).to(device)
+
+
+def host_eig(grid, tcol_host):
+    """Per-dim eigen-decomposition (fp64, descending, clamped >= 0) of the symmetric Toeplitz factors."""
+    evs, Vs, off = [], [], 0
+    for g in grid.g:
+        c = tcol_host[off:off + g]
+        idx = np.abs(np.arange(g)[:, None] - np.arange(g)[None, :])
+        w, V = np.linalg.eigh(c[idx])
+        evs.append(np.clip(w[::-1], 0.0, None))
+        Vs.append(np.ascontiguousarray(V[:, ::-1]))
+        off += g
+    return evs, Vs
+
+
+def select_basis(grid, tcol_host, tail, max_rank, device, eig=None):
+    """The smallest set of tensor-product eigenvectors leaving out at most `tail` of trace(Kuu); None if it needs more than
+    `max_rank` vectors (or more than KMAX eigenvectors of one dim)."""
+    evs, Vs = eig if eig is not None else host_eig(grid, tcol_host)
+    d = grid.d
+    total, off = 1.0, 0
+    for g in grid.g:
+        total *= g * float(tcol_host[off])
+        off += g
+    if not total > 0:
+        return None
+    # candidates: per dim, the eigenvalues that can take part in a product above the threshold (ratio to the largest)
+    cut = min(tail, 1e-6) * 1e-3
+    kc = [max(1, int((ev / ev[0] >= cut).sum())) for ev in evs]
+    if max(kc) > KMAX or int(np.prod(kc)) > 400_000:
+        return None
+    lam = evs[0][:kc[0]]
+    for q in range(1, d):
+        lam = np.multiply.outer(lam, evs[q][:kc[q]])
+    flat = lam.reshape(-1)
+    order = np.argsort(-flat, kind="stable")
+    cs = np.cumsum(flat[order])
+    need = total * (1.0 - tail)
+    if cs[-1] < need:
+        return None
+    r = int(np.searchsorted(cs, need) + 1)
+    if r > max_rank:
+        return None
+    sel = order[:r]
+    S = np.stack(np.unravel_index(sel, lam.shape)).astype(np.int64)            # [d, r]
+    kmax = int(S.max()) + 1
+    return SpectralBasis(grid, evs, Vs, S, flat[sel], kmax, device)
+
+
+class SpectralWoodburyFactor:
+    """Reduced-basis statistics (G_ref, h_ref) of ONE output and the factor derived from them for the current
+    hyper-parameters.  Owned by the model, which tells it about every change of the statistics."""
+
+    def __init__(self, grid, dtype, device, err):
+        self.grid, self.dtype, self.device, self.err = grid, dtype, device, err
+        self.ref = None            # SpectralBasis of the reference
+        self.G_ref = self.h_ref = None
+        self.data_version = 0
+        self.cur = None
+        self.rebuilds = 0          # reference builds from the stencil (diagnostics / tests)
+        self.last_rel_bound = 0.0
+
+    # ------------------------------------------------------------------ reference statistics --
+    def _project_grid_vectors(self, basis, Vm):
+        """B^T v for grid vectors: Vm [c, m] (any float dtype) -> fp64 [c, r] by d mode products + a gather."""
+        g = self.grid.g
+        P = Vm.double().reshape((Vm.shape[0],) + tuple(g))
+        for q in range(self.grid.d):
+            P = torch.tensordot(P, basis.Vq[q], dims=([1], [0]))             # contracts the leading grid dim, appends k_q
+        idx = (slice(None),) + tuple(basis.S_long[q] for q in range(self.grid.d))
+        return P[idx]
+
+    def _basis_columns(self, basis, lo, hi):
+        """Basis functions lo..hi as grid vectors [hi - lo, m] in the model dtype."""
+        c = hi - lo
+        Bc = basis.Vq[0][:, basis.S_long[0, lo:hi]].t()                      # [c, g_0]
+        for q in range(1, self.grid.d):
+            col = basis.Vq[q][:, basis.S_long[q, lo:hi]].t()                 # [c, g_q]
+            Bc = Bc.reshape(c, -1, 1) * col.reshape(c, 1, -1)
+        return Bc.reshape(c, self.grid.m).to(self.dtype).contiguous()
+
+    def build_reference(self, basis, stencil, b):
+        """G_ref = B^T A B, h_ref = B^T b from the model's statistics (r SpMV columns in chunks of 64)."""
+        r = basis.r
+        G = torch.empty((r, r), dtype=torch.float64, device=self.device)
+        for lo in range(0, r, 64):
+            hi = min(lo + 64, r)
+            AB = grid_ops.stencil_spmv(self.grid, stencil, self._basis_columns(basis, lo, hi))
+            G[lo:hi] = self._project_grid_vectors(basis, AB)
+        self.G_ref = (0.5 * (G + G.t())).contiguous()
+        self.h_ref = self._project_grid_vectors(basis, b.reshape(1, -1))[0].contiguous()
+        self.ref = basis
+        self.cur = None
+        self.data_version += 1
+        self.rebuilds += 1
+
+    def absorb(self, X, wa, wby):
+        """Statistics += the points X with weights wa (None: unit) and weighted targets wby = y / noise: follow in the
+        reference basis.  One projection kernel + one fp64 MFMA GEMM."""
+        if self.ref is None:
+            return
+        sc = None if wa is None else wa.sqrt().contiguous()
+        F = grid_ops.basis_project(self.grid, X, self.ref.Vtab, self.ref.kmax, self.ref.S, scale=sc, err=self.err)
+        grid_ops.gemm(F, F, ta=True, alpha=1.0, beta=1.0, C=self.G_ref)
+        t = wby.double() if wa is None else wby.double() / sc.double()       # rows of F already carry sqrt(wa)
+        self.h_ref.add_(torch.mv(F.t(), t))
+        self.data_version += 1
+
+    # --------------------------------------------------------------------------- derived state --
+    def state(self, key, tcol64, kscale, eig=None):
+        """The factor for the hyper-parameters identified by `key` (Toeplitz columns tcol64 on the host or device, fp64;
+        Kt = kscale * Kuu).  None when the reduced basis would exceed settings.spectral_max_rank."""
+        cur = self.cur
+        if cur is not None and cur["key"] == key and cur["data_version"] == self.data_version and cur["kscale"] == kscale:
+            return cur
+        tail = default_tail(self.dtype)
+        if cur is not None and cur["key"] == key:
+            basis, TS, defect_ok = cur["basis"], cur["TS"], True
+        else:
+            tc = tcol64.detach().to("cpu", torch.float64).numpy() if torch.is_tensor(tcol64) else np.asarray(tcol64, dtype=np.float64)
+            basis = select_basis(self.grid, tc, tail, settings.spectral_max_rank.value(), self.device, eig=eig)
+            if basis is None:
+                return None
+            TS, defect_ok = None, False
+        if self.ref is None:
+            return {"need_reference": True, "basis": basis, "tail": tail}
+        if TS is None:
+            TS, wdef = self._change_of_basis(basis)
+            defect_ok = wdef <= tail
+            if not defect_ok:
+                return {"need_reference": True, "basis": basis, "tail": tail}
+        lam = basis.lam_kuu * kscale
+        sq = lam.sqrt()
+        GT = grid_ops.gemm(self.G_ref, TS)                                    # [r_ref, r]
+        G = grid_ops.gemm(TS, GT, ta=True)                                    # T^T G_ref T
+        hr = torch.mv(TS.t(), self.h_ref)
+        C = (sq[:, None] * G * sq[None, :]).contiguous()
+        C.diagonal().add_(1.0)
+        info = grid_ops.potrf_(C)                                             # C = I + PSD: cannot fail on finite input
+        ch = grid_ops.trsm_(C, (sq * hr)[:, None].contiguous(), trans=False)  # chol^-1 Lam^1/2 h
+        cur = {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": TS, "lam": lam, "sq": sq, "G": G,
+               "hr": hr, "chol": C, "info": info, "c_half": ch, "bMb": (ch * ch).sum(), "logdet": grid_ops.chol_logdet(C), "tail": tail}
+        self.cur = cur
+        return cur
+
+    def _change_of_basis(self, basis):
+        """T [r_ref, r] and the eigenvalue-weighted defect max_j lam_j (1 - |T[:, j]|^2) / trace (what the reference
+        span misses of each current basis vector, in units of the trace)."""
+        ref = self.ref
+        d = self.grid.d
+        Tq = [torch.as_tensor(ref.Vtab_host[q].T @ basis.Vtab_host[q], dtype=torch.float64).to(self.device) for q in range(d)]
+        TS = Tq[0][ref.S_long[0]][:, basis.S_long[0]]
+        for q in range(1, d):
+            TS = TS * Tq[q][ref.S_long[q]][:, basis.S_long[q]]
+        TS = TS.contiguous()
+        defect = (1.0 - (TS * TS).sum(0)).clamp_min(0.0)
+        total = 1.0
+        for q in range(d):
+            total *= float(basis.evs[q].sum())
+        wdef = float((basis.lam_kuu * defect).max()) / total * basis.r        # as if every vector missed as much as the worst
+        return TS, wdef
+
+    # ----------------------------------------------------------------------------- consumers --
+    def coefficients(self, st):
+        """Posterior-mean coefficients c (mu_u ~= B c) and zeta = B^T Kt^-1 mu_u = c / lam."""
+        if "coef" not in st:
+            t = grid_ops.trsm_(st["chol"], st["c_half"].clone(), trans=True)[:, 0]
+            st["coef"] = st["sq"] * t
+            st["zeta"] = t / st["sq"]
+        return st["coef"], st["zeta"]
+
+    def query(self, st, X, tcol64_dev, want_full=False, block=None):
+        """Un-scaled predictive (co)variances w^T M w of the rows of W(X): returns (diag [n], full or None, mean [n]).
+        `tcol64_dev`: fp64 Toeplitz columns on the device (for the prior variance of the tail term)."""
+        basis = st["basis"]
+        Fs, prior = grid_ops.basis_project(self.grid, X, basis.Vtab, basis.kmax, basis.S, colscale=st["sq"], tcol=tcol64_dev, want_prior=True,
+                                           err=self.err)
+        captured = (Fs * Fs).sum(1)                                           # sum_j lam_j (b_j^T w)^2
+        tailv = (prior * st["kscale"] - captured).clamp_min(0.0)
+        Y = grid_ops.trsm_(st["chol"], Fs.t().contiguous(), trans=False)      # [r, n]
+        diag = (Y * Y).sum(0)
+        self._last = (tailv, diag)
+        full = None
+        if want_full:
+            if block is None:
+                full = grid_ops.gemm(Y, Y, ta=True)
+                full.diagonal().add_(tailv)
+            else:
+                Yb = Y.reshape(Y.shape[0], -1, block).permute(1, 0, 2)        # [nb, r, q]
+                full = torch.bmm(Yb.transpose(1, 2), Yb)
+                full.diagonal(dim1=-2, dim2=-1).add_(tailv.reshape(-1, block))
+        return diag + tailv, full
+
+    def rel_bound(self):
+        """max over the last query batch of tail / variance (host sync; diagnostics and tests)."""
+        tailv, diag = self._last
+        self.last_rel_bound = float((tailv / (diag + tailv).clamp_min(1e-300)).max())
+        return self.last_rel_bound
+
+    def mean(self, st, X):
+        coef, _ = self.coefficients(st)
+        basis = st["basis"]
+        F = grid_ops.basis_project(self.grid, X, basis.Vtab, basis.kmax, basis.S, err=self.err)
+        return torch.mv(F, coef)
+
+    def mll_backward(self, st, g_bMb, g_logdet):
+        """(d/d tcol [sum g] fp64, d/d kscale) of  g_bMb * b^T M b + g_logdet * logdet(I + Kt A)  in the reduced basis:
+        d(b^T M b) = zeta^T (B^T dKt B) zeta,  d logdet = tr(S_B B^T dKt B),  S_B = G - G M_r G,  M_r = Lam^1/2 C^-1 Lam^1/2."""
+        basis, G, sq, chol, kap = st["basis"], st["G"], st["sq"], st["chol"], st["kscale"]
+        _, zeta = self.coefficients(st)
+        Wt = torch.outer(zeta, zeta) * float(g_bMb)
+        if float(g_logdet) != 0.0:
+            Y2 = grid_ops.trsm_(chol, (sq[:, None] * G).contiguous(), trans=False)
+            SB = G - grid_ops.gemm(Y2, Y2, ta=True)
+            Wt = Wt + float(g_logdet) * SB
+        Wt = Wt.contiguous()
+        D = grid_ops.basis_pair_reduce(Wt, basis.S, basis.ev_tab, basis.kmax)
+        g_tcol = torch.zeros(sum(self.grid.g), dtype=torch.float64, device=self.device)
+        off = 0
+        for q, gq in enumerate(self.grid.g):
+            H = basis.Vq[q] @ D[q, :basis.kmax, :basis.kmax] @ basis.Vq[q].t()                     # [g_q, g_q]
+            lag = self._lag_index(gq)
+            g_tcol[off:off + gq].index_add_(0, lag, H.reshape(-1))
+            off += gq
+        g_kap = (Wt.diagonal() * basis.lam_kuu).sum()
+        return g_tcol * kap, g_kap
+
+    def _lag_index(self, g):
+        cache = self.__dict__.setdefault("_lag_cache", {})
+        if g not in cache:
+            i = torch.arange(g, device=self.device)
+            cache[g] = (i[:, None] - i[None, :]).abs().reshape(-1)
+        return cache[g]

@@ -41,6 +41,15 @@ class _WoodburyTerms(torch.autograd.Function):
         b = model._kernel_cache["interpolation_cache"][o, :, 0]
         m = grid.m
         dense = model._use_dense()
+        ctx.spectral = None
+        sp = None if dense else model._spectral_state(o)
+        if sp is not None:
+            # smooth kernel on a large grid: both terms, exactly differentiable, from the dense factor in the dominant
+            # Kronecker eigenspace (lazy/spectral_woodbury.py) -- no probe vectors, no solves
+            fac, st, _ = sp
+            ctx.spectral = (fac, st)
+            logdet = st["logdet"].clone() if want_logdet else torch.zeros((), dtype=torch.float64, device=dev)
+            return st["bMb"].clone(), logdet
         # plain eigenbasis of Kt: the dense factor and the SLQ logdet need it; the streaming hyper step
         # (skip_logdet_forward, large grid) does not -- 3 host eigh + an upload saved per step
         eig = grid_ops.kron_eigen(grid, tcol) if (dense or want_logdet) else None
@@ -95,6 +104,10 @@ class _WoodburyTerms(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_bMb, g_logdet):
+        if ctx.spectral is not None:
+            fac, st = ctx.spectral
+            g_tcol, g_kap = fac.mll_backward(st, g_bMb, g_logdet)
+            return (g_tcol if ctx.needs_input_grad[0] else None), (g_kap if ctx.needs_input_grad[1] else None), None, None, None
         tcol, z, u, S_cols, E = ctx.saved_tensors
         grid, P, kap = ctx.grid, ctx.P, ctx.kap
         # columns [z | s_1..s_P] against [z | e_1..e_P], weighted by the incoming gradients

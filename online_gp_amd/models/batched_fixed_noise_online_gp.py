@@ -262,6 +262,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 # the reference's root pair, once somebody asked for it: L L^T follows A by a rank-n root update (URLT:62-119)
                 Wd = grid_ops.wt_columns(self._grid, X, self._err)                 # [n, m]
                 ops[o].update_roots_((Wd * wa.sqrt()[:, None]).t().contiguous())   # V = W^T diag(wa)^(1/2), BFN:163-168
+            if mine and n > 0:
+                self._spectral_absorb(o, X, None if unit else wa, yo if unit else yo * wb, init=init, bypass=half_delta is not None)
             if cache is self._kernel_cache or init:
                 if unit:
                     self._wsum_host[o] += float(n)
@@ -300,6 +302,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         dropped = flag >> 1
         self._err.zero_()
         self.__dict__.pop("_stream_step_cache", None)
+        self._drop_spectral()          # rows of out-of-grid points were zero for the factor too, but a prepared state may be half-updated
         if dropped:
             self.num_data = self.num_data - dropped
             cnt = self._kernel_cache.get("_cnt")
@@ -397,6 +400,69 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
                                  settings.max_cg_iterations.value(), workspace=self._pcg_ws, check_every=settings.cg_check_every.value(),
                                  eigen=eig, shift=shift, err=self._err)
+
+    # ------------------------------------------------------ spectral factor --
+    def _spectral_state(self, o=0):
+        """(factor, state, fp64 Toeplitz columns on the device) of the reduced-eigenbasis Woodbury factor
+        (lazy/spectral_woodbury.py) for the current hyper-parameters and statistics, or None where it does not apply:
+        dense regime, switched off, or a prior whose numerical rank exceeds settings.spectral_max_rank."""
+        if settings.spectral_factor.off() or self._use_dense():
+            return None
+        from ..lazy import spectral_woodbury as sw
+
+        self._finish_pending()
+        ver = self._hyper_version()
+        key = (ver, sw.default_tail(self._dtype), settings.spectral_max_rank.value())
+        memo = self._memo.setdefault("spectral", {})
+        ent = memo.get(o)
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                bi = o if self.num_outputs > 1 else None
+                tcol64 = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).contiguous()
+            ent = (key, tcol64, tcol64.cpu().numpy())
+            memo[o] = ent
+        if ent[1] is None:
+            return None                                  # not applicable at these hyper-parameters (remembered)
+        _, tcol64, tc_host = ent
+        facs = self.__dict__.setdefault("_spectral", {})
+        fac = facs.get(o)
+        if fac is None:
+            fac = facs[o] = sw.SpectralWoodburyFactor(self._grid, self._dtype, self._device, self._err)
+        kscale = 1.0 / self._hyper()[o][1]
+        if self.__dict__.get("_spectral_dirty", {}).pop(o, False):
+            fac.ref = None                               # statistics changed behind the factor's back: rebuild from the stencil
+        st = fac.state(key, tc_host, kscale)
+        if st is None:
+            memo[o] = (key, None, None)
+            return None
+        if st.get("need_reference"):
+            # reference basis with a margin, so that the eigenbasis may drift with the hyper-parameters before the
+            # reference has to be rebuilt; if the margin does not fit the rank cap, the basis itself
+            refb = sw.select_basis(self._grid, tc_host, st["tail"] * 1e-2, 2 * settings.spectral_max_rank.value(), self._device)
+            op = _wtw_ops(self._kernel_cache["WtW"])[o]
+            fac.build_reference(refb if refb is not None else st["basis"], op.stencil, self._kernel_cache["interpolation_cache"][o, :, 0])
+            st = fac.state(key, tc_host, kscale)
+            if st is None or st.get("need_reference"):
+                memo[o] = (key, None, None)
+                return None
+        return fac, st, tcol64
+
+    def _spectral_absorb(self, o, X, wa, wby, init=False, bypass=False):
+        """Keep the spectral factor of output o (if one exists) in step with the statistics."""
+        fac = self.__dict__.get("_spectral", {}).get(o)
+        if fac is None or fac.ref is None:
+            return
+        if init or bypass or X.shape[0] > 2048:
+            # rebuilt from scratch / changed by an all-reduce / a batch large enough that re-projecting the stencil on
+            # demand (r SpMV columns) is cheaper than following it: mark, rebuild when next asked
+            self.__dict__.setdefault("_spectral_dirty", {})[o] = True
+            return
+        fac.absorb(X, wa, wby)
+
+    def _drop_spectral(self):
+        self.__dict__.pop("_spectral", None)
+        self.__dict__.pop("_spectral_dirty", None)
+        self._memo.pop("spectral", None)
 
     # --------------------------------------------------------------- caches --
     @property
@@ -583,7 +649,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         else:
             chunk = settings.variance_chunk.value()
             covs = [PredictiveCovariance(_wtw_post, Xf, self._hyper()[o][1] if self.has_learnable_noise else 1.0, self._err, chunk=chunk,
-                                         block=block if X.dim() > 2 else None)
+                                         block=block if X.dim() > 2 else None, spectral=(lambda o=o: self._spectral_state(o)))
                     for o, _wtw_post in enumerate(pc["pred_cov"].ops if out > 1 else [pc["pred_cov"]])]
         # output shapes follow :248-252
         if out == 1:
@@ -678,6 +744,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         step.args.shift = float(self._wsum[0]) / pst["norm"]
         y1 = Y.reshape(-1)
         y1 = y1 if y1.is_contiguous() else y1.contiguous()
+        if "_spectral" in self.__dict__:
+            self._spectral_absorb(0, X, None, y1)
         if settings.deferred_refresh.on() or step.pending:
             prev, pending = step(X, y1, ones, ones, ones, mean, carry, fc, defer=settings.deferred_refresh.on())
             self._pending_step = step if pending else None
@@ -938,6 +1006,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self._wsum_dev_host = [0.0] * self.num_outputs
         self._wsum_dirty = False
         self._memo.pop("precond", None)
+        self._drop_spectral()
         self._absorb(cache, train_inputs, train_targets, noise, init=True)
         self.num_data = train_inputs.reshape(-1, self._grid.d).shape[0]
         self._mean_state = None
@@ -962,6 +1031,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._mean_state = None
             self._memo = {}
             self.__dict__.pop("_stream_step_cache", None)
+            self._drop_spectral()
         return res
 
     # ------------------------------------------------- distributed statistics --

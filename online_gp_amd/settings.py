@@ -204,3 +204,26 @@ class density_profile_preconditioner(_feature_flag):
     data, which the constant model gets wrong (4-5x more CG iterations)."""
 
     _state = True
+
+
+class spectral_factor(_feature_flag):
+    """Large grids, smooth kernels: serve predictive variances and the marginal log-likelihood from a dense Woodbury
+    factor in the dominant Kronecker eigenspace of Kuu (``lazy/spectral_woodbury.py``) whenever that space is small
+    (rank <= ``spectral_max_rank`` for the trace tail ``spectral_tail``) -- the reference's own rank-limited root
+    space (BFN:343-404 under ``max_root_decomposition_size``) with a known truncation bound.  Off: everything
+    goes through wiski_pcg.  The posterior mean always does."""
+
+    _state = True
+
+
+class spectral_tail(_value_context):
+    """Fraction of trace(Kuu) the reduced eigenbasis may leave out (None: 1e-6 in fp32, 1e-9 in fp64).  The left-out
+    prior variance of each query is added back to its predictive variance and bounds the remaining error."""
+
+    _global_value = None
+
+
+class spectral_max_rank(_value_context):
+    """Largest reduced basis the spectral factor is built for; beyond it the PCG path serves the request."""
+
+    _global_value = 1024

@@ -1,0 +1,259 @@
+"""GPU: the reduced-eigenbasis ("spectral") Woodbury factor -- predictive variances, covariance blocks and the marginal
+log-likelihood with its gradients from a dense r x r factor in the dominant Kronecker eigenspace of Kuu
+(online_gp_amd/lazy/spectral_woodbury.py; the reference's rank-limited root space BFN:343-404 / BWM:19-51 with the
+low-rank object on the prior side).  Checked against the data-space oracle (exact GP on W Kuu W^T + sigma2 D), against
+the PCG path of the same model, and kernel by kernel against numpy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dataspace, spec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TH = float(np.log(2.0))
+
+
+def _np_basis(gb, g, ell, s):
+    g0, h, gs = spec.make_grid(gb, g)
+    cols = spec.toeplitz_columns("rbf", h, gs, ell, s)
+    evs, Vs = [], []
+    for c in cols:
+        idx = np.abs(np.arange(len(c))[:, None] - np.arange(len(c))[None, :])
+        w, V = np.linalg.eigh(c[idx])
+        evs.append(w[::-1].clip(0)); Vs.append(V[:, ::-1].copy())
+    return g0, h, gs, cols, evs, Vs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("d,g", [(1, 24), (2, 13), (3, 9), (4, 6)])
+def test_basis_project_and_prior_against_numpy(dtype, d, g):
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(d * 10 + g)
+    gb = [[-1.0, 1.0]] * d
+    g0, h, gs, cols, evs, Vs = _np_basis(gb, g, 0.5, 0.8)
+    grid = grid_ops.GridSpec(torch.tensor(gb), g)
+    kmax, r, n = 5, 37, 203
+    S = rng.integers(0, kmax, (d, r))
+    X = rng.uniform(-1, 1, (n, d))
+    X[0] = -1.0; X[1] = 1.0                                   # boundary cells (one-hot rule)
+    X[2, 0] = 7.0                                             # outside the grid: zero row, flag set
+    sc = rng.uniform(0.5, 2, n); cs = rng.uniform(0.5, 2, r)
+    Vtab = torch.as_tensor(np.concatenate([V[:, :kmax].reshape(-1) for V in Vs])).to(DEV)
+    err = grid_ops.new_err_flag(DEV)
+    tcol = torch.as_tensor(np.concatenate(cols)).to(DEV)
+    F, prior = grid_ops.basis_project(grid, torch.as_tensor(X, dtype=dtype).to(DEV), Vtab, kmax, torch.as_tensor(S.astype(np.int32)).to(DEV),
+                                      scale=torch.as_tensor(sc, dtype=dtype).to(DEV), colscale=torch.as_tensor(cs).to(DEV), tcol=tcol,
+                                      want_prior=True, err=err)
+    ok = np.ones(n, bool); ok[2] = False
+    Xc = X.copy(); Xc[2] = 0.0
+    ref = np.ones((n, r)); pr = np.ones(n)
+    for q in range(d):
+        Wq = spec.interp_1d_dense(Xc[:, q].astype(np.float32 if dtype == torch.float32 else np.float64).astype(np.float64), g0[q], h[q], int(gs[q]))
+        ref *= (Wq @ Vs[q][:, :kmax])[:, S[q]]
+        idx = np.abs(np.arange(gs[q])[:, None] - np.arange(gs[q])[None, :])
+        pr *= np.einsum("ij,jk,ik->i", Wq, cols[q][idx], Wq)
+    ref *= sc.astype(np.float32 if dtype == torch.float32 else np.float64)[:, None] * cs[None, :]
+    ref[~ok] = 0; pr[~ok] = 0
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert np.abs(F.cpu().numpy() - ref).max() < tol * max(1.0, np.abs(ref).max())
+    assert np.abs(prior.cpu().numpy() - pr).max() < tol * max(1.0, np.abs(pr).max())
+    assert int(err.item()) & 1
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_pair_reduce_gives_the_toeplitz_column_gradient(d):
+    """sum_jj' Wt[j,j'] b_j^T (kron_q T(tcol_q)) b_j' differentiated w.r.t. tcol by the pair reduction + lag sums equals
+    torch autograd on the dense Kronecker expression."""
+    from online_gp_amd import grid_ops
+
+    rng = np.random.default_rng(d)
+    g, kmax, r = 7, 4, 19
+    S = rng.integers(0, kmax, (d, r))
+    Wt = rng.standard_normal((r, r))
+    tcols = [torch.tensor(np.exp(-0.5 * (np.arange(g) * 0.3) ** 2), dtype=torch.float64, requires_grad=True) for _ in range(d)]
+    idx = torch.as_tensor(np.abs(np.arange(g)[:, None] - np.arange(g)[None, :]))
+    Vs, evs = [], []
+    for q in range(d):
+        w, V = np.linalg.eigh(tcols[q].detach().numpy()[idx.numpy()])
+        Vs.append(torch.as_tensor(V[:, ::-1].copy())); evs.append(w[::-1].copy())
+    val = torch.as_tensor(Wt).clone()
+    for q in range(d):
+        kap = Vs[q][:, :kmax].t() @ tcols[q][idx] @ Vs[q][:, :kmax]                  # [kmax, kmax], diagonal at the current point
+        val = val * kap[S[q]][:, S[q]]
+    val.sum().backward()
+    ev_tab = torch.as_tensor(np.stack([e[:kmax] for e in evs])).to(DEV)
+    D = grid_ops.basis_pair_reduce(torch.as_tensor(Wt).to(DEV), torch.as_tensor(S.astype(np.int32)).to(DEV), ev_tab, kmax).cpu()
+    for q in range(d):
+        H = Vs[q][:, :kmax] @ D[q] @ Vs[q][:, :kmax].t()
+        got = torch.zeros(g, dtype=torch.float64).index_add_(0, idx.reshape(-1), H.reshape(-1))
+        assert (got - tcols[q].grad).abs().max() < 1e-10 * max(1.0, tcols[q].grad.abs().max())
+
+
+def _model(X, y, g, dtype, noise=None, learn=True):
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    Xt = torch.as_tensor(X, device=DEV, dtype=dtype)
+    yt = torch.as_tensor(y, device=DEV, dtype=dtype)[:, None]
+    nt = None if noise is None else torch.as_tensor(noise, device=DEV, dtype=dtype)[:, None]
+    return FixedNoiseOnlineSKIGP(Xt, yt, nt, grid_bounds=torch.tensor([[-1.1, 1.1]] * X.shape[1]), grid_size=g, learn_additional_noise=learn)
+
+
+def _hypers(m):
+    k = m.covar_module.base_kernel
+    return (k.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1), float(k.outputscale), float(m.likelihood.second_noise))
+
+
+@pytest.mark.parametrize("dtype,tol,tail", [(torch.float64, 1e-4, None), (torch.float32, 1e-2, None), (torch.float64, 1e-6, 1e-10)])
+def test_variances_match_the_data_space_oracle_and_follow_the_stream(dtype, tol, tail):
+    from online_gp_amd import settings
+
+    rng = np.random.default_rng(11)
+    d, g, n0, q = 3, 14, 500, 37                                # m = 2744 > max_cholesky_size: the matrix-free regime
+    X = rng.uniform(-1, 1, (n0 + 3 * q, d)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(len(X))
+    nz = rng.uniform(0.5, 2.0, len(X))
+    Xs = rng.uniform(-1, 1, (50, d))
+    with settings.spectral_tail(tail), settings.cg_tolerance(1e-10 if dtype == torch.float64 else 1e-6), settings.spectral_max_rank(2048 if tail else 1024):
+        m = _model(X[:n0], y[:n0], g, dtype, nz[:n0])
+        m.eval()
+        ell, s, s2 = _hypers(m)
+        Xst = torch.as_tensor(Xs, device=DEV, dtype=dtype)
+
+        def check(nn):
+            O = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X[:nn], y[:nn], nz[:nn])
+            mo, vo = O.predict(Xs)
+            mvn = m(Xst)
+            v = mvn.variance.double().cpu().numpy()
+            assert np.abs(mvn.mean.double().cpu().numpy() - mo).max() < tol * np.abs(mo).max()
+            assert np.max(np.abs(v - vo) / vo) < tol
+            return v
+
+        check(n0)
+        fac = m._spectral[0]
+        assert fac.ref is not None and fac.rebuilds == 1       # the factor served the request, built once from the stencil
+        r0 = fac.cur["basis"].r
+        assert r0 <= settings.spectral_max_rank.value()
+        assert fac.rel_bound() < max(10 * (tail or (1e-6 if dtype == torch.float32 else 1e-9)) * 1e3, 1e-9)
+        # streaming updates: the reduced statistics follow by projection + GEMM, no rebuild
+        for i in range(3):
+            lo, hi = n0 + i * q, n0 + (i + 1) * q
+            m.condition_on_observations(torch.as_tensor(X[lo:hi], device=DEV, dtype=dtype), torch.as_tensor(y[lo:hi], device=DEV, dtype=dtype)[:, None],
+                                        torch.as_tensor(nz[lo:hi], device=DEV, dtype=dtype)[:, None], inplace=True)
+        v_sp = check(n0 + 3 * q)
+        assert fac.rebuilds == 1
+        # the PCG path of the same model agrees
+        with settings.spectral_factor(False):
+            v_cg = m(Xst).variance.double().cpu().numpy()
+        assert np.max(np.abs(v_cg - v_sp) / v_sp) < tol
+        # full covariance and per-block covariance
+        O = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, nz)
+        _, co = O.predict(Xs[:12], full_cov=True)
+        cov = m(Xst[:12]).covariance_matrix.double().cpu().numpy()
+        assert np.abs(cov - co).max() < tol * np.abs(co).max()
+        covb = m(Xst[:12].reshape(3, 4, d)).covariance_matrix.double().cpu().numpy()
+        for b in range(3):
+            assert np.abs(covb[b] - co[4 * b:4 * b + 4, 4 * b:4 * b + 4]).max() < tol * np.abs(co).max()
+
+
+def test_factor_follows_hyperparameter_drift_through_the_reference_basis():
+    """A hyper-parameter step changes the eigenbasis; G = T^T G_ref T re-expresses the reduced statistics without going
+    back to the stencil, until the drift leaves the reference span (then one rebuild)."""
+    from online_gp_amd import settings
+
+    rng = np.random.default_rng(12)
+    d, g, n = 3, 14, 600
+    X = rng.uniform(-1, 1, (n, d)); y = np.cos(2 * X[:, 0]) * X[:, 1] + 0.3 * X[:, 2] + 0.1 * rng.standard_normal(n)
+    Xs = rng.uniform(-1, 1, (40, d))
+    dtype = torch.float64
+    with settings.cg_tolerance(1e-10):
+        m = _model(X, y, g, dtype)
+        m.eval()
+        Xst = torch.as_tensor(Xs, device=DEV, dtype=dtype)
+        m(Xst).variance
+        fac = m._spectral[0]
+        k = m.covar_module.base_kernel
+        for step, (fl, fs, fn_) in enumerate([(1.02, 0.97, 1.05), (0.95, 1.0, 0.9), (1.08, 1.1, 1.2)]):
+            with torch.no_grad():
+                k.base_kernel.lengthscale = k.base_kernel.lengthscale * torch.tensor([fl, 1.0 / fl, fl ** 0.5], device=DEV).reshape(1, -1)
+                k.outputscale = k.outputscale * fs
+                m.likelihood.second_noise = float(m.likelihood.second_noise) * fn_
+            m._dump_caches()
+            ell, s, s2 = _hypers(m)
+            mo, vo = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, np.ones(n)).predict(Xs)
+            v = m(Xst).variance.cpu().numpy()
+            assert np.max(np.abs(v - vo) / vo) < 1e-4, step
+        assert fac.rebuilds == 1
+        # a large jump (half the lengthscale) leaves the reference span: rebuilt once, still exact
+        with torch.no_grad():
+            k.base_kernel.lengthscale = k.base_kernel.lengthscale * 0.6
+        m._dump_caches()
+        ell, s, s2 = _hypers(m)
+        mo, vo = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, np.ones(n)).predict(Xs)
+        with settings.spectral_max_rank(2048):
+            v = m(Xst).variance.cpu().numpy()
+        assert np.max(np.abs(v - vo) / vo) < 1e-4
+        assert fac.rebuilds == 2
+
+
+def test_rough_kernels_and_small_rank_caps_fall_back_to_pcg():
+    from online_gp_amd import settings
+    from online_gp_amd.kernels import MaternKernel, ScaleKernel
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(13)
+    X = rng.uniform(-1, 1, (300, 3)); y = np.sin(X.sum(1))
+    Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+    m = FixedNoiseOnlineSKIGP(Xt, yt, None, covar_module=ScaleKernel(MaternKernel(nu=0.5, ard_num_dims=3)), grid_bounds=torch.tensor([[-1.1, 1.1]] * 3),
+                              grid_size=14, learn_additional_noise=True)
+    m.eval()
+    assert m._spectral_state(0) is None                      # Matern-1/2: no spectral gap
+    m2 = _model(X, y, 14, torch.float64)
+    with settings.spectral_max_rank(16):
+        assert m2._spectral_state(0) is None
+    assert m2._spectral_state(0) is not None
+
+
+def test_mll_value_and_gradients_from_the_spectral_factor():
+    """BWM:19-51 on the spectral path: value against the data-space oracle, gradients w.r.t. lengthscales, outputscale and
+    the learnable noise against central differences of the oracle."""
+    from online_gp_amd import settings
+    from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood
+
+    rng = np.random.default_rng(14)
+    d, g, n = 3, 14, 400
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(2 * X[:, 0]) * np.cos(X[:, 1]) + 0.3 * X[:, 2] + 0.1 * rng.standard_normal(n)
+    nz = rng.uniform(0.7, 1.4, n)
+    with settings.spectral_tail(1e-12), settings.spectral_max_rank(2048):
+        m = _model(X, y, g, torch.float64, nz)
+        with torch.no_grad():
+            m.covar_module.base_kernel.base_kernel.lengthscale = torch.tensor([[0.8, 0.6, 0.9]], device=DEV)
+        mll = BatchedWoodburyMarginalLogLikelihood(m.likelihood, m)
+        m.train()
+        v = mll(m(torch.as_tensor(X, device=DEV)), torch.as_tensor(y, device=DEV))
+        v.backward()
+        assert m._spectral[0].cur is not None                 # the spectral factor served the MLL
+        ell, s, s2 = _hypers(m)
+
+        def ref(ell_, s_, s2_):
+            return dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell_, s_, s2_).fit(X, y, nz).mll()
+
+        assert abs(float(v.detach()) - ref(ell, s, s2)) < 1e-8 * abs(ref(ell, s, s2))
+        k = m.covar_module.base_kernel
+        eps = 1e-5
+
+        def dsoft(raw):
+            return torch.sigmoid(raw.detach()).cpu().numpy().reshape(-1)
+
+        g_ell = k.base_kernel.raw_lengthscale.grad.cpu().numpy().reshape(-1) / dsoft(k.base_kernel.raw_lengthscale)
+        for q in range(d):
+            e = np.zeros(d); e[q] = eps * ell[q]
+            fd = (ref(ell + e, s, s2) - ref(ell - e, s, s2)) / (2 * eps * ell[q])
+            assert abs(g_ell[q] - fd) < 1e-5 * max(abs(fd), 1e-3), (q, g_ell[q], fd)
+        g_s = float(k.raw_outputscale.grad) / float(dsoft(k.raw_outputscale)[0])
+        fd = (ref(ell, s * (1 + eps), s2) - ref(ell, s * (1 - eps), s2)) / (2 * eps * s)
+        assert abs(g_s - fd) < 1e-5 * max(abs(fd), 1e-3)
+        raw = m.likelihood.second_noise_covar.raw_noise
+        g_n = float(raw.grad) / float(dsoft(raw)[0])
+        fd = (ref(ell, s, s2 * (1 + eps)) - ref(ell, s, s2 * (1 - eps))) / (2 * eps * s2)
+        assert abs(g_n - fd) < 1e-5 * max(abs(fd), 1e-3)
