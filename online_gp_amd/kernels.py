@@ -73,6 +73,17 @@ class Kernel(torch.nn.Module):
         ell = ls[dim] if ls.numel() > 1 else ls[0]
         return self.profile(lags / ell)
 
+    def lag_columns_cat(self, lags_cat, dim_index, batch_index=None):
+        """All d Toeplitz columns in one pass: `lags_cat` [sum g] holds the lags of every dim back to back, `dim_index` [sum g]
+        the dim each entry belongs to (a handful of launches instead of ~10 per dim: the hyper-parameter graph is on the
+        critical path of every MLL step)."""
+        ls = self.lengthscale
+        if batch_index is not None and ls.dim() > 2:
+            ls = ls[batch_index]
+        ls = ls.reshape(-1)
+        ell = ls[dim_index] if ls.numel() > 1 else ls[0]
+        return self.profile(lags_cat / ell)
+
 
 class RBFKernel(Kernel):
     has_lengthscale = True
@@ -125,6 +136,19 @@ class ScaleKernel(Kernel):
             s = s[batch_index]
         return s * self.base_kernel.lag_column(dim, lags, batch_index)
 
+    def lag_columns_cat(self, lags_cat, dim_index, batch_index=None):
+        s = self.outputscale
+        if batch_index is not None and s.dim() > 0:
+            s = s[batch_index]
+        return s * self.base_kernel.lag_columns_cat(lags_cat, dim_index, batch_index)
+
+
+def _native_stationary(kernel):
+    """Scale(...(RBF | Matern)) chains of this module: their columns have the closed form used by lag_columns_cat."""
+    while isinstance(kernel, ScaleKernel):
+        kernel = kernel.base_kernel
+    return type(kernel) in (RBFKernel, MaternKernel)
+
 
 def _lag_column_any(kernel, dim, lags, num_dims, batch_index=None):
     """Toeplitz column of `kernel` along `dim`.  Native kernels use their closed
@@ -176,6 +200,15 @@ class GridInterpolationKernel(Kernel):
         p = next(self.base_kernel.parameters(), None)
         device = device if device is not None else (p.device if p is not None else "cpu")
         gs = self.grid_spec
+        if _native_stationary(self.base_kernel):
+            key = str(device)
+            cached = self.__dict__.setdefault("_lag_cat", {}).get(key)
+            if cached is None:
+                lags = torch.cat([gs.h[q] * torch.arange(gs.g[q], dtype=torch.float64) for q in range(gs.d)]).to(device)
+                didx = torch.cat([torch.full((gs.g[q],), q, dtype=torch.long) for q in range(gs.d)]).to(device)
+                cached = self.__dict__["_lag_cat"][key] = (lags, didx)
+            out = self.base_kernel.lag_columns_cat(cached[0], cached[1], batch_index).to(torch.float64)
+            return out if dtype is None else out.to(dtype)
         cols = []
         for q in range(gs.d):
             lags = gs.h[q] * torch.arange(gs.g[q], dtype=torch.float64, device=device)

@@ -241,7 +241,7 @@ class PredictiveCovariance(LazyCovariance):
 
     def __init__(self, post, x, sigma2, err, chunk=64, block=None, spectral=None):
         self.post = post
-        self.spectral = spectral  # callable -> (factor, state, fp64 Toeplitz columns) or None: lazy/spectral_woodbury.py
+        self.spectral = spectral  # callable -> SpectralQuery for x (or None): lazy/spectral_woodbury.py
         self.x = x.contiguous()
         self.sigma2 = float(sigma2)
         self.err = err
@@ -278,11 +278,10 @@ class PredictiveCovariance(LazyCovariance):
 
     def _spectral_path(self, sp, want_full):
         """Reduced-eigenbasis factor (smooth kernels on large grids): one projection, one triangular solve."""
-        fac, st, tcol64 = sp
-        diag, full = fac.query(st, self.x, tcol64, want_full=want_full, block=self.block)
-        self._diag = (diag * self.sigma2).to(self.dtype)
+        if self._diag is None:
+            self._diag = (sp.diag() * self.sigma2).to(self.dtype)
         if want_full:
-            self._full = (full * self.sigma2).to(self.dtype)
+            self._full = (sp.full(self.block) * self.sigma2).to(self.dtype)
 
     def _solve_chunks(self, want_full):
         if hasattr(self.post, "dense"):

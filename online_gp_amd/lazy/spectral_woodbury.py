@@ -44,25 +44,35 @@ def default_tail(dtype):
 
 
 class SpectralBasis:
-    """Index set + per-dim eigenvector tables for one set of Toeplitz columns."""
+    """Index set + per-dim eigenvector tables for one set of Toeplitz columns.  Device copies are made with two uploads
+    (one packed fp64 array, one int32 index array; the latter is shared with `like` when the index set did not change)."""
 
-    def __init__(self, grid, evs, Vs, S, lam_kuu, kmax, device):
+    def __init__(self, grid, evs, Vs, S, lam_kuu, kmax, device, like=None):
         self.grid, self.kmax, self.r = grid, kmax, S.shape[1]
         self.evs, self.Vs = evs, Vs                    # host: per-dim eigenvalues (descending, >= 0) / eigenvectors [g_q, g_q]
         self.S_host = S                                # [d, r] int
         self.lam_kuu_host = lam_kuu                    # [r] eigenvalues of Kuu (not yet divided by sigma2), descending
+        d = grid.d
         tabs = [np.ascontiguousarray(V[:, :kmax]) if V.shape[1] >= kmax else np.pad(V, ((0, 0), (0, kmax - V.shape[1]))) for V in Vs]
         self.Vtab_host = tabs
-        self.Vtab = torch.as_tensor(np.concatenate([t.reshape(-1) for t in tabs]), dtype=torch.float64).to(device)
-        self.Vq = [torch.as_tensor(t, dtype=torch.float64).to(device) for t in tabs]          # [g_q, kmax] each
-        self.S = torch.as_tensor(S.astype(np.int32)).to(device).contiguous()
-        self.S_long = self.S.long()
-        ev_tab = np.zeros((grid.d, kmax))
-        for q in range(grid.d):
+        ev_tab = np.zeros((d, kmax))
+        for q in range(d):
             kq = min(kmax, len(evs[q]))
             ev_tab[q, :kq] = evs[q][:kq]
-        self.ev_tab = torch.as_tensor(ev_tab, dtype=torch.float64).to(device)
-        self.lam_kuu = torch.as_tensor(lam_kuu, dtype=torch.float64).to(device)
+        nV = sum(t.size for t in tabs)
+        packed = torch.as_tensor(np.concatenate([t.reshape(-1) for t in tabs] + [ev_tab.reshape(-1), np.asarray(lam_kuu, dtype=np.float64)])).to(device)
+        self.Vtab = packed[:nV]
+        self.Vq, off = [], 0
+        for t in tabs:
+            self.Vq.append(packed[off:off + t.size].view(t.shape))                              # [g_q, kmax] each
+            off += t.size
+        self.ev_tab = packed[nV:nV + d * kmax].view(d, kmax)
+        self.lam_kuu = packed[nV + d * kmax:]
+        if like is not None and like.S_host.shape == S.shape and np.array_equal(like.S_host, S):
+            self.S, self.S_long = like.S, like.S_long
+        else:
+            self.S = torch.as_tensor(S.astype(np.int32)).to(device).contiguous()
+            self.S_long = self.S.long()
 
 
 def host_eig(grid, tcol_host):
@@ -78,7 +88,7 @@ def host_eig(grid, tcol_host):
     return evs, Vs
 
 
-def select_basis(grid, tcol_host, tail, max_rank, device, eig=None):
+def select_basis(grid, tcol_host, tail, max_rank, device, eig=None, like=None):
     """The smallest set of tensor-product eigenvectors leaving out at most `tail` of trace(Kuu); None if it needs more than
     `max_rank` vectors (or more than KMAX eigenvectors of one dim)."""
     evs, Vs = eig if eig is not None else host_eig(grid, tcol_host)
@@ -109,7 +119,7 @@ def select_basis(grid, tcol_host, tail, max_rank, device, eig=None):
     sel = order[:r]
     S = np.stack(np.unravel_index(sel, lam.shape)).astype(np.int64)            # [d, r]
     kmax = int(S.max()) + 1
-    return SpectralBasis(grid, evs, Vs, S, flat[sel], kmax, device)
+    return SpectralBasis(grid, evs, Vs, S, flat[sel], kmax, device, like=like)
 
 
 class SpectralWoodburyFactor:
@@ -183,7 +193,8 @@ class SpectralWoodburyFactor:
             basis, TS, defect_ok = cur["basis"], cur["TS"], True
         else:
             tc = tcol64.detach().to("cpu", torch.float64).numpy() if torch.is_tensor(tcol64) else np.asarray(tcol64, dtype=np.float64)
-            basis = select_basis(self.grid, tc, tail, settings.spectral_max_rank.value(), self.device, eig=eig)
+            basis = select_basis(self.grid, tc, tail, settings.spectral_max_rank.value(), self.device, eig=eig,
+                                 like=None if cur is None else cur["basis"])
             if basis is None:
                 return None
             TS, defect_ok = None, False
@@ -202,9 +213,13 @@ class SpectralWoodburyFactor:
         C = (sq[:, None] * G * sq[None, :]).contiguous()
         C.diagonal().add_(1.0)
         info = grid_ops.potrf_(C)                                             # C = I + PSD: cannot fail on finite input
-        ch = grid_ops.trsm_(C, (sq * hr)[:, None].contiguous(), trans=False)  # chol^-1 Lam^1/2 h
+        # explicit inverse of the factor (one multi-column triangular solve, r^3 / 3 flop): every later solve against it --
+        # mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64 launches
+        Linv = grid_ops.trsm_(C, torch.eye(C.shape[0], dtype=torch.float64, device=self.device), trans=False)
+        ch = torch.mv(Linv, sq * hr)                                          # chol^-1 Lam^1/2 h
         cur = {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": TS, "lam": lam, "sq": sq, "G": G,
-               "hr": hr, "chol": C, "info": info, "c_half": ch, "bMb": (ch * ch).sum(), "logdet": grid_ops.chol_logdet(C), "tail": tail}
+               "hr": hr, "chol": C, "Linv": Linv, "info": info, "c_half": ch, "bMb": (ch * ch).sum(), "logdet": grid_ops.chol_logdet(C),
+               "tail": tail}
         self.cur = cur
         return cur
 
@@ -213,10 +228,14 @@ class SpectralWoodburyFactor:
         span misses of each current basis vector, in units of the trace)."""
         ref = self.ref
         d = self.grid.d
-        Tq = [torch.as_tensor(ref.Vtab_host[q].T @ basis.Vtab_host[q], dtype=torch.float64).to(self.device) for q in range(d)]
-        TS = Tq[0][ref.S_long[0]][:, basis.S_long[0]]
-        for q in range(1, d):
-            TS = TS * Tq[q][ref.S_long[q]][:, basis.S_long[q]]
+        Th = [ref.Vtab_host[q].T @ basis.Vtab_host[q] for q in range(d)]                        # [kmax_ref, kmax] per dim
+        packed = torch.as_tensor(np.concatenate([t.reshape(-1) for t in Th])).to(self.device)
+        TS, off = None, 0
+        for q in range(d):
+            Tq = packed[off:off + Th[q].size].view(Th[q].shape)
+            off += Th[q].size
+            blk = Tq[ref.S_long[q]][:, basis.S_long[q]]
+            TS = blk if TS is None else TS * blk
         TS = TS.contiguous()
         defect = (1.0 - (TS * TS).sum(0)).clamp_min(0.0)
         total = 1.0
@@ -229,44 +248,20 @@ class SpectralWoodburyFactor:
     def coefficients(self, st):
         """Posterior-mean coefficients c (mu_u ~= B c) and zeta = B^T Kt^-1 mu_u = c / lam."""
         if "coef" not in st:
-            t = grid_ops.trsm_(st["chol"], st["c_half"].clone(), trans=True)[:, 0]
-            st["coef"] = st["sq"] * t
-            st["zeta"] = t / st["sq"]
+            if "t" not in st:
+                st["t"] = torch.mv(st["Linv"].t(), st["c_half"])
+            st["coef"] = st["sq"] * st["t"]
+            st["zeta"] = st["t"] / st["sq"]
         return st["coef"], st["zeta"]
 
-    def query(self, st, X, tcol64_dev, want_full=False, block=None):
-        """Un-scaled predictive (co)variances w^T M w of the rows of W(X): returns (diag [n], full or None, mean [n]).
-        `tcol64_dev`: fp64 Toeplitz columns on the device (for the prior variance of the tail term)."""
-        basis = st["basis"]
-        Fs, prior = grid_ops.basis_project(self.grid, X, basis.Vtab, basis.kmax, basis.S, colscale=st["sq"], tcol=tcol64_dev, want_prior=True,
-                                           err=self.err)
-        captured = (Fs * Fs).sum(1)                                           # sum_j lam_j (b_j^T w)^2
-        tailv = (prior * st["kscale"] - captured).clamp_min(0.0)
-        Y = grid_ops.trsm_(st["chol"], Fs.t().contiguous(), trans=False)      # [r, n]
-        diag = (Y * Y).sum(0)
-        self._last = (tailv, diag)
-        full = None
-        if want_full:
-            if block is None:
-                full = grid_ops.gemm(Y, Y, ta=True)
-                full.diagonal().add_(tailv)
-            else:
-                Yb = Y.reshape(Y.shape[0], -1, block).permute(1, 0, 2)        # [nb, r, q]
-                full = torch.bmm(Yb.transpose(1, 2), Yb)
-                full.diagonal(dim1=-2, dim2=-1).add_(tailv.reshape(-1, block))
-        return diag + tailv, full
+    def query(self, st, X, tcol64_dev):
+        return SpectralQuery(self, st, X, tcol64_dev)
 
     def rel_bound(self):
         """max over the last query batch of tail / variance (host sync; diagnostics and tests)."""
         tailv, diag = self._last
         self.last_rel_bound = float((tailv / (diag + tailv).clamp_min(1e-300)).max())
         return self.last_rel_bound
-
-    def mean(self, st, X):
-        coef, _ = self.coefficients(st)
-        basis = st["basis"]
-        F = grid_ops.basis_project(self.grid, X, basis.Vtab, basis.kmax, basis.S, err=self.err)
-        return torch.mv(F, coef)
 
     def mll_backward(self, st, g_bMb, g_logdet):
         """(d/d tcol [sum g] fp64, d/d kscale) of  g_bMb * b^T M b + g_logdet * logdet(I + Kt A)  in the reduced basis:
@@ -275,7 +270,7 @@ class SpectralWoodburyFactor:
         _, zeta = self.coefficients(st)
         Wt = torch.outer(zeta, zeta) * float(g_bMb)
         if float(g_logdet) != 0.0:
-            Y2 = grid_ops.trsm_(chol, (sq[:, None] * G).contiguous(), trans=False)
+            Y2 = grid_ops.gemm(st["Linv"], (sq[:, None] * G).contiguous())       # chol^-1 Lam^1/2 G
             SB = G - grid_ops.gemm(Y2, Y2, ta=True)
             Wt = Wt + float(g_logdet) * SB
         Wt = Wt.contiguous()
@@ -296,3 +291,48 @@ class SpectralWoodburyFactor:
             i = torch.arange(g, device=self.device)
             cache[g] = (i[:, None] - i[None, :]).abs().reshape(-1)
         return cache[g]
+
+
+class SpectralQuery:
+    """Predictive moments of one query batch from a factor state: ONE projection kernel (F = W(X) B Lam^1/2 and the prior
+    variances), then mean = F t with t = chol^-T chol^-1 Lam^1/2 h, variances = column norms of chol^-1 F^T + the left-out
+    prior variance, covariance blocks by one more GEMM.  Everything un-scaled (multiply by sigma2 for BFN:227-228)."""
+
+    def __init__(self, fac, st, X, tcol64_dev):
+        self.fac, self.st = fac, st
+        basis = st["basis"]
+        self.Fs, prior = grid_ops.basis_project(fac.grid, X, basis.Vtab, basis.kmax, basis.S, colscale=st["sq"], tcol=tcol64_dev, want_prior=True,
+                                                err=fac.err)
+        self.prior = prior
+        self._Y = self._diag = self._tail = None
+
+    def mean(self):
+        st = self.st
+        if "t" not in st:
+            st["t"] = torch.mv(st["Linv"].t(), st["c_half"])
+        return torch.mv(self.Fs, st["t"])
+
+    def _solve(self):
+        if self._Y is None:
+            st = self.st
+            captured = (self.Fs * self.Fs).sum(1)                                # sum_j lam_j (b_j^T w)^2
+            self._tail = (self.prior * st["kscale"] - captured).clamp_min(0.0)
+            self._Y = grid_ops.gemm(st["Linv"], self.Fs, tb=True)                # chol^-1 F^T  [r, n]
+            self._diag = (self._Y * self._Y).sum(0)
+            self.fac._last = (self._tail, self._diag)
+        return self._Y
+
+    def diag(self):
+        self._solve()
+        return self._diag + self._tail
+
+    def full(self, block=None):
+        Y = self._solve()
+        if block is None:
+            full = grid_ops.gemm(Y, Y, ta=True)
+            full.diagonal().add_(self._tail)
+            return full
+        Yb = Y.reshape(Y.shape[0], -1, block).permute(1, 0, 2)                   # [nb, r, q]
+        full = torch.bmm(Yb.transpose(1, 2), Yb)
+        full.diagonal(dim1=-2, dim2=-1).add_(self._tail.reshape(-1, block))
+        return full

@@ -325,7 +325,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if ps is None:
             ps = list(self.covar_module.parameters()) + (list(self.likelihood.second_noise_covar.parameters()) if self.has_learnable_noise else [])
             self.__dict__["_hyper_params"] = ps
-        return tuple(p._version for p in ps)
+        return (self.__dict__.get("_hyper_epoch", 0),) + tuple(p._version for p in ps)
 
     def _hyper(self):
         """Per-output (tcol on device in the data dtype, sigma2 float); memoised on
@@ -337,8 +337,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             with torch.no_grad():
                 for o in range(self.num_outputs):
                     bi = o if self.num_outputs > 1 else None
-                    tcol = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).to(self._dtype).contiguous()
-                    vals.append((tcol, self._sigma2(o), None))
+                    tcol64 = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).contiguous()
+                    vals.append((tcol64.to(self._dtype).contiguous(), self._sigma2(o), tcol64))
             h = (ver, vals)
             self._memo["hyper"] = h
         return h[1]
@@ -416,9 +416,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         memo = self._memo.setdefault("spectral", {})
         ent = memo.get(o)
         if ent is None or ent[0] != key:
-            with torch.no_grad():
-                bi = o if self.num_outputs > 1 else None
-                tcol64 = self.covar_module.toeplitz_columns(batch_index=bi, device=self._device).contiguous()
+            tcol64 = self._hyper()[o][2]                 # fp64 Toeplitz columns, computed once per hyper-parameter version
             ent = (key, tcol64, tcol64.cpu().numpy())
             memo[o] = ent
         if ent[1] is None:
@@ -603,8 +601,18 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         # counters and survives streaming updates: only a hyper-parameter change invalidates it
 
     def zero_grad(self, *args, **kwargs):
+        # the reference calls gp.zero_grad() after every optimiser step (OSR:146, BFN:416-418): treat it as "the
+        # hyper-parameters may have moved".  The memoisation below keys on the parameters' version counters, which a
+        # *fused* optimiser (torch.optim.Adam(fused=True)) does not advance -- the epoch covers that.
+        self.__dict__["_hyper_epoch"] = self.__dict__.get("_hyper_epoch", 0) + 1
         self._dump_caches()
         return super().zero_grad(*args, **kwargs)
+
+    def hyperparameters_changed(self):
+        """Tell the model that hyper-parameters were modified in a way autograd's version counters do not see (fused
+        optimisers, writes through .data): every hyper-parameter-dependent cache is recomputed on next use."""
+        self.__dict__["_hyper_epoch"] = self.__dict__.get("_hyper_epoch", 0) + 1
+        self._dump_caches()
 
     # -------------------------------------------------------------- forward --
     def forward(self, X, **kwargs):
@@ -638,8 +646,19 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             block = X.shape[-2]
         Xf = X.reshape(-1, grid.d).contiguous()
         n = Xf.shape[0]
-        pc = self.prediction_cache
-        mean = grid_ops.gather(grid, Xf, pc["pred_mean"][..., 0], self._err)      # [n, out]   left_interp, :206-210
+        # smooth kernel on a large grid, variances wanted: mean AND variance of the batch from the spectral factor (one
+        # projection kernel shared by both; its truncation error is far below the CG tolerance) -- no solve at all
+        sq = None
+        if settings.skip_posterior_variances.off():
+            sps = [self._spectral_state(o) for o in range(out)]
+            if all(sp is not None for sp in sps):
+                sq = [sp[0].query(sp[1], Xf, sp[2]) for sp in sps]
+        if sq is not None:
+            pc = None
+            mean = torch.stack([s_.mean() for s_ in sq], dim=1).to(self._dtype)   # [n, out]
+        else:
+            pc = self.prediction_cache
+            mean = grid_ops.gather(grid, Xf, pc["pred_mean"][..., 0], self._err)  # [n, out]   left_interp, :206-210
         if settings.deferred_bounds_check.off():
             flag = grid_ops.read_flag(self._err)       # gpytorch raises inside this call for queries outside the grid
             if flag:
@@ -648,9 +667,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             covs = None
         else:
             chunk = settings.variance_chunk.value()
+            if sq is not None:
+                posts = [None] * out
+            else:
+                posts = pc["pred_cov"].ops if out > 1 else [pc["pred_cov"]]
             covs = [PredictiveCovariance(_wtw_post, Xf, self._hyper()[o][1] if self.has_learnable_noise else 1.0, self._err, chunk=chunk,
-                                         block=block if X.dim() > 2 else None, spectral=(lambda o=o: self._spectral_state(o)))
-                    for o, _wtw_post in enumerate(pc["pred_cov"].ops if out > 1 else [pc["pred_cov"]])]
+                                         block=block if X.dim() > 2 else None, spectral=None if sq is None else (lambda o=o: sq[o]))
+                    for o, _wtw_post in enumerate(posts)]
         # output shapes follow :248-252
         if out == 1:
             mean_o = mean[:, 0].reshape(lead)
