@@ -469,7 +469,22 @@ def main():
                             raise RuntimeError(f"wiski_scatter_stats_step: {rc}")
                     own(0)
                     own_us = event_us(own, 4)
+                # the multi-column half-stencil product of the PCG variance / probe solves: A_h once + V in + out
+                spmm = {}
+                for kc in (16, 64):
+                    Vm = torch.randn((kc, grid.m), device=dev, dtype=dtype)
+                    Ah = model._kernel_cache["WtW"].stencil
+                    grid_ops.stencil_spmv(grid, Ah, Vm)
+                    spmm[kc] = event_us(lambda i: grid_ops.stencil_spmv(grid, Ah, Vm), 4)
+                    del Vm
+                spmm_bytes = lambda kc: ((grid.R + 1) // 2 * grid.m + 2 * kc * grid.m) * es
                 roofline_secondary = [
+                    {"kernel": "k_spmm_sym_cols (+ k_transpose_cm_rm): half-stencil A_h . V for 64 right-hand sides (PCG variance / probe solves)",
+                     "bound": "hbm", "achieved": spmm_bytes(64) / (spmm[64] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": spmm_bytes(64) / (spmm[64] * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": spmm[64], "algorithmic_bytes_per_launch": spmm_bytes(64),
+                     "flop_per_launch": 2 * grid.R * grid.m * 64, "vector_fma_frac_of_157_TFLOPs": 2 * grid.R * grid.m * 64 / (spmm[64] * 1e-6) / 157e12,
+                     "k16_us_4_columns_per_pass_kernel": spmm[16], "k16_frac": spmm_bytes(16) / (spmm[16] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "timing": "median of 5 torch.cuda.Event brackets of 4 products (wiski_stencil_spmv_sym, back to back)"},
                     {"kernel": "k_scatter_stats_sym (statistics scatter of q points; memory-side atomics)", "bound": "hbm",
                      "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_us": sc_us, "algorithmic_bytes_per_point": sc_bytes, "points_per_s": q / (sc_us * 1e-6),
@@ -492,71 +507,89 @@ def main():
 
     if world == 1 and not args.no_extras:
         try:
-            # predictive variances: latency of one 64-query chunk (one 64-column PCG solve) and the reference-fidelity step
+            # predictive variances of 64 queries, two ways: the product's default path (on this grid and kernel the spectral
+            # Woodbury factor, lazy/spectral_woodbury.py: one projection kernel + one fp64 GEMM against the cached factor) and
+            # the PCG path (one 64-column solve), each the median of 3 -- a single 2-4 ms measurement can swallow a device stall
+            def med3(fn):
+                fn()
+                ts = []
+                for rep in range(3):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    out = fn()
+                    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                return float(np.median(ts)), out
+
             with settings.cg_tolerance(tol), torch.no_grad():
-                Xv, _ = synth_stream(128, d, 99, dev, dtype, args.stream)
-                model(Xv[64:128]).variance                 # warm the 64-column PCG workspace (first call allocates ~0.8 GB)
-                tvs = []
-                for rep in range(3):                       # median of 3: a single 2-4 ms measurement can swallow a device stall
-                    torch.cuda.synchronize(); tv = time.perf_counter()
-                    v_same = model(Xv[:64]).variance
-                    torch.cuda.synchronize(); tvs.append(time.perf_counter() - tv)
-                tv = float(np.median(tvs))
-                # quadratic forms converge with the square of the residual: variance solves stopped at 3e-3 (settings.variance_cg_tolerance)
-                with settings.variance_cg_tolerance(3e-3):
-                    model(Xv[64:128]).variance
-                    tqs = []
-                    for rep in range(3):
-                        torch.cuda.synchronize(); tq = time.perf_counter()
-                        v_loose = model(Xv[:64]).variance
-                        torch.cuda.synchronize(); tqs.append(time.perf_counter() - tq)
-                    tq = float(np.median(tqs))
-                with settings.cg_tolerance(1e-7):
-                    v_tight = model(Xv[:64]).variance
+                Xv, _ = synth_stream(1152, d, 99, dev, dtype, args.stream)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                model(Xv[64:128]).variance                 # first request: builds the factor's reference statistics from the stencil
+                torch.cuda.synchronize(); t_first = time.perf_counter() - t0
+                tv, v_def = med3(lambda: model(Xv[:64]).variance)
+                tv1k, _ = med3(lambda: model(Xv[128:1152]).variance)
+                fac = model.__dict__.get("_spectral", {}).get(0)
+                spectral_on = fac is not None and fac.cur is not None
+                with settings.spectral_factor(False):
+                    model(Xv[64:128]).variance             # warm the 64-column PCG workspace (first call allocates ~0.8 GB)
+                    tp, v_same = med3(lambda: model(Xv[:64]).variance)
+                    # quadratic forms converge with the square of the residual: variance solves stopped at 3e-3 (settings.variance_cg_tolerance)
+                    with settings.variance_cg_tolerance(3e-3):
+                        tq, v_loose = med3(lambda: model(Xv[:64]).variance)
+                    with settings.cg_tolerance(1e-7):
+                        v_tight = model(Xv[:64]).variance
             extra["variance_ms_per_64_queries"] = tv * 1e3
-            extra["variance_ms_per_64_queries_tol3e-3"] = tq * 1e3
-            extra["variance_rel_err_vs_tight_solve"] = {"cg_tol": float(((v_same - v_tight).abs() / v_tight).max()),
-                                                        "variance_cg_tolerance_3e-3": float(((v_loose - v_tight).abs() / v_tight).max())}
+            extra["variance_ms_per_1024_queries"] = tv1k * 1e3
+            extra["variance_path"] = ("spectral Woodbury factor (rank %d of m = %d, trace tail %.0e, left-out prior variance <= %.1e of the variance; "
+                                      "first request incl. the factor build: %.1f ms)" % (fac.cur["basis"].r, model._grid.m, fac.cur["tail"], fac.rel_bound(), t_first * 1e3)
+                                      if spectral_on else "wiski_pcg, 64 columns per solve")
+            extra["variance_ms_per_64_queries_pcg"] = tp * 1e3
+            extra["variance_ms_per_64_queries_pcg_tol3e-3"] = tq * 1e3
+            extra["variance_rel_err_vs_tight_solve"] = {"default_path": float(((v_def - v_tight).abs() / v_tight).max()),
+                                                        "pcg_cg_tol": float(((v_same - v_tight).abs() / v_tight).max()),
+                                                        "pcg_variance_cg_tolerance_3e-3": float(((v_loose - v_tight).abs() / v_tight).max())}
             del model
             torch.cuda.empty_cache()
             gc_settle()
             # the reference's timed step at full fidelity (experiments/regression.py:48-54, OSR:56-146): evaluate = predictive
             # mean AND variance (rmse, nll) of the incoming batch, update = one Adam step on the Woodbury MLL + condition
             X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
-            Xr, yr = synth_stream(8192, d, 31337, dev, dtype, args.stream)
+            Xr, yr = synth_stream(16384, d, 31337, dev, dtype, args.stream)
             with settings.cg_tolerance(tol), settings.variance_cg_tolerance(3e-3):
                 reg = OnlineSKIRegression(Identity(d), X0, y0, 1e-3, args.grid, 1.0)
-                for qs, nst in ((1, 6), (64, 4), (1024, 3)):
-                    ts = []
-                    for i in range(nst):
-                        xb, yb = Xr[i * qs:(i + 1) * qs], yr[i * qs:(i + 1) * qs]
-                        torch.cuda.synchronize(); t0 = time.perf_counter()
-                        reg.evaluate(xb, yb)
-                        reg.update(xb, yb)
-                        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-                    extra[f"reference_step_ms_q{qs}"] = float(np.median(ts[1:])) * 1e3
-                    extra[f"reference_step_updates_per_s_q{qs}"] = qs / float(np.median(ts[1:]))
-                # the same step under the reference's own solver setting (config/regression.yaml:24-27: cg_tolerance 1e-2 for every solve)
-                with settings.cg_tolerance(1e-2):
-                    for qs, nst in ((1, 6), (64, 4), (1024, 3)):
+
+                def ref_steps(tag, lo0):
+                    for qs, nst in ((1, 8), (64, 6), (1024, 5)):
                         ts = []
                         for i in range(nst):
-                            lo = 4096 + i * qs
+                            lo = lo0 + i * qs
                             xb, yb = Xr[lo:lo + qs], yr[lo:lo + qs]
                             torch.cuda.synchronize(); t0 = time.perf_counter()
                             reg.evaluate(xb, yb)
                             reg.update(xb, yb)
                             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-                        extra[f"reference_step_ms_q{qs}_at_cg_tolerance_1e-2"] = float(np.median(ts[1:])) * 1e3
+                        extra[f"reference_step_ms_q{qs}{tag}"] = float(np.median(ts[2:])) * 1e3
+                        extra[f"reference_step_updates_per_s_q{qs}{tag}"] = qs / float(np.median(ts[2:]))
+
+                # default path: mean, variance and the MLL with its exact gradient from the spectral factor where it applies
+                ref_steps("", 0)
+                fac = reg.gp.__dict__.get("_spectral", {}).get(0)
+                extra["reference_step_path"] = ("spectral Woodbury factor for mean / variance / MLL (rank %d, %d reference builds)" % (fac.cur["basis"].r, fac.rebuilds)
+                                                if fac is not None and fac.cur is not None else "wiski_pcg (mean, 64-column variance solves, Hutchinson MLL gradient)")
+                # the PCG path of the same step (what every kernel / grid falls back to): 64-column variance solves, 10 Hutchinson probes
+                with settings.spectral_factor(False):
+                    ref_steps("_pcg", 5120)
+                    # ... and under the reference's own solver setting (config/regression.yaml:24-27: cg_tolerance 1e-2 for every solve)
+                    with settings.cg_tolerance(1e-2):
+                        ref_steps("_pcg_at_cg_tolerance_1e-2", 2048)
                 gc_settle()
                 # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
                 gp = reg.gp
                 with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():
-                    for qs in (1, 64):
+                    for qs in (1, 64, 1024):
                         # the three model calls of the reference surface, one after the other
                         torch.cuda.synchronize(); tq = time.perf_counter()
                         for i in range(10):
-                            xq, yq = Xr[2048 + i * qs:2048 + (i + 1) * qs], yr[2048 + i * qs:2048 + (i + 1) * qs]
+                            lo = (2048 + i * qs) % (Xr.shape[0] - qs)
+                            xq, yq = Xr[lo:lo + qs], yr[lo:lo + qs]
                             gp(xq).mean
                             gp.condition_on_observations(xq, yq, inplace=True)
                             gp.prediction_cache
@@ -568,7 +601,7 @@ def main():
                             for rep in range(8):                                  # rep 0 warms the path; median of 7 blocks of 10 steps
                                 torch.cuda.synchronize(); tq = time.perf_counter()  # (a preconditioner-profile refresh lands in a block now and then)
                                 for i in range(10):
-                                    lo = 2048 + 640 + (rep * 10 + i) * qs
+                                    lo = (2048 + 640 + (rep * 10 + i) * qs) % (Xr.shape[0] - qs)
                                     gp.stream_step(Xr[lo:lo + qs], yr[lo:lo + qs])
                                 gp._finish_pending()
                                 torch.cuda.synchronize()
@@ -608,7 +641,7 @@ def main():
         # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (tools/pmc_traffic.py),
         # NOT in this run -- read back from the committed profile and labelled with its source
         traffic, traffic_source = None, None
-        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if args.grid == 50 and d == 3 and kname in pmc["kernels"]:
@@ -622,19 +655,30 @@ def main():
         try:
             import csv
 
-            with open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")) as fh:
-                for row in csv.DictReader(fh):
-                    if args.grid == 50 and d == 3 and args.dtype == "f32" and row["Name"].replace("void ", "").startswith(kname):
-                        rp_us, rp_src = float(row["AverageNs"]) / 1e3, "profiles/r02_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)"
-                        break
+            for fn in ("r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
+                if not os.path.exists(os.path.join(ROOT, "profiles", fn)):
+                    continue
+                with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                    for row in csv.DictReader(fh):
+                        if args.grid == 50 and d == 3 and args.dtype == "f32" and row["Name"].replace("void ", "").startswith(kname):
+                            rp_us, rp_src = float(row["AverageNs"]) / 1e3, f"profiles/{fn} (rocprofv3 --kernel-trace --stats of this command, an earlier take)"
+                            break
+                break
         except Exception:  # noqa: BLE001
             pass
         par = "single"
         if world > 1:
             par = f"dp{world} (" + ("shard all-gather + replicated scatter: divides no work, every rank scatters all N q points and solves"
                                     if exchange_used == "points" else "all-reduce of the half-stencil statistics") + ")"
+        # what an empty dispatch costs by the clock of `roofline.avg_launch_us` (events attached to the dispatch packet)
+        empty_us = ctypes.c_double(0)
+        if lib.wiski_prof_empty(ctypes.c_int32(64), ctypes.byref(empty_us), _hip.stream_ptr(dev)) != 0:
+            empty_us.value = float("nan")
+        net_us = avg_ms * 1e3 - empty_us.value
         res = {
             "metric": "streaming updates/sec (WISKI, 50^3 inducing grid)",
+            "timed_region_s": float(np.sum(block_s)),
+            "timed_steps": R * K,
             "value": world * K * q / sec,
             "unit": "updates/s",
             "n_gpus": world,
@@ -646,7 +690,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": ("clustered (64 poly-lines, sigma 0.02) " if args.stream == "clustered" else "") + f"3droad-like synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
+            "config": {"workload": ("road-like CLUSTERED (64 poly-lines, sigma 0.02) " if args.stream == "clustered" else "UNIFORM ") + f"3droad-sized synthetic stream d={d} (the road-like clustered variant of SURVEY 8d: extra.clustered_stream_*), {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}; {R} timed blocks of {K} steps (all steps / summed block time)",
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -654,6 +698,12 @@ def main():
                          "launches": spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
                          "rocprofv3_avg_launch_us": rp_us, "rocprofv3_frac": (spmv_bytes / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
                          "rocprofv3_source": rp_src,
+                         # how to read `frac`: the 86 MB operand is re-read every launch and is served by the 256 MB Infinity
+                         # Cache, not by HBM (a bare LDS-DMA read of it runs at 7.2-8 TB/s, profiles/r02_stream_ubench.txt);
+                         # and every per-dispatch time contains what an empty dispatch costs by the same clock
+                         "infinity_cache_resident": bool(spmv_bytes < 200e6),
+                         "empty_dispatch_us": empty_us.value,
+                         "net_of_empty_dispatch_frac": (spmv_bytes / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if net_us > 0 else None,
                          "timing": "start/stop HIP events attached to each SpMV dispatch (hipExtLaunchKernel) on its launch stream, every 4th timed step; read once per block after it has drained",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
@@ -662,6 +712,16 @@ def main():
         }
         if roofline_secondary:
             res["roofline_secondary"] = roofline_secondary
+            # which kernel the timed step spends most of its time in, from this run's own measurements: the absorb (one launch per
+            # step) against the SpMVs of the solve (iterations x per-dispatch time); the roofline kernel is the latter (the metric's MVM)
+            sc = next((r_ for r_ in roofline_secondary if r_["kernel"].startswith("k_scatter_stats_sym")), None)
+            if sc is not None and spmv_n:
+                step_us = sec / K * 1e6
+                it_mean = float(np.mean(iters))
+                res["dominant_by_time"] = {"kernel": "k_scatter_stats_sym (absorb of q points)", "us_per_step": sc["avg_launch_us"],
+                                           "share_of_step": sc["avg_launch_us"] / step_us,
+                                           "roofline_kernel_us_per_step": it_mean * avg_ms * 1e3, "roofline_kernel_share_of_step": it_mean * avg_ms * 1e3 / step_us,
+                                           "note": "kernel-only times of this run (event brackets / per-dispatch events) over the measured ms_per_step"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, tol)

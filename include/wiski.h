@@ -355,6 +355,9 @@ int wiski_prof_stop(double* total_ms, int64_t* launches);
 /* between start and stop: switch the event attachment off / on again without touching what has been recorded (sample some
  * steps of a pipelined loop, read all events once the loop has drained) */
 int wiski_prof_enable(int32_t on);
+/* the same clock on an EMPTY dispatch (average of n launches, microseconds; synchronises the stream): the per-dispatch
+ * floor contained in every kernel time measured this way */
+int wiski_prof_empty(int32_t n, double* avg_us, void* stream);
 
 #ifdef __cplusplus
 }

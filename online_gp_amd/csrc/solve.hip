@@ -53,6 +53,28 @@ extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
   return WISKI_OK;
 }
 
+// What an EMPTY dispatch costs by the same clock (start / stop events attached to the dispatch packet): the floor every
+// per-dispatch kernel time measured through launch_timed contains.  Average over n launches, microseconds.
+__global__ void k_prof_empty() {}
+extern "C" int wiski_prof_empty(int32_t n, double* avg_us, void* stream) {
+  if (n < 1 || !avg_us) return WISKI_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return WISKI_E_LAUNCH;
+  for (int i = 0; i < n; ++i) hipExtLaunchKernelGGL(k_prof_empty, dim3(1), dim3(64), 0, s, ev[2 * i], ev[2 * i + 1], 0);
+  int rc = hipStreamSynchronize(s) == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+  double tot = 0;
+  for (int i = 0; i < n && rc == WISKI_OK; ++i) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = WISKI_E_LAUNCH;
+    tot += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *avg_us = tot * 1e3 / n;
+  return rc;
+}
+
 // ---------------------------------------------------------- stencil SpMV ---
 // out[c][i] = beta*add[c][i] + sum_o A_st[o][i] * V[c][clamp(i + off(o))]
 // HBM-bound: A_st (R*m reals) is streamed exactly once, fully coalesced along

@@ -450,9 +450,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         fac = self.__dict__.get("_spectral", {}).get(o)
         if fac is None or fac.ref is None:
             return
-        if init or bypass or X.shape[0] > 2048:
+        if init or bypass or X.shape[0] > 2048 or fac.idle_absorbs >= 8:
             # rebuilt from scratch / changed by an all-reduce / a batch large enough that re-projecting the stencil on
-            # demand (r SpMV columns) is cheaper than following it: mark, rebuild when next asked
+            # demand (r SpMV columns) is cheaper than following it / nobody has asked the factor anything for 8 batches (a
+            # streaming loop that only wants means must not pay a projection + GEMM per step): mark, rebuild when next asked
             self.__dict__.setdefault("_spectral_dirty", {})[o] = True
             return
         fac.absorb(X, wa, wby)

@@ -129,6 +129,26 @@ class StreamingBaseline:
         self.solved = True
         return it, float(res.value)
 
+    def variance(self, Xs, tol=1e-9, max_iter=5000):
+        """Predictive variances sigma2 * w^T (Kt^-1 + A)^-1 w of the rows of W(Xs) (BFN:222-228), one cold solve per query
+        with the density-profile preconditioner.  Checker for the GPU paths at full size; not timed."""
+        Xs = np.asarray(Xs, np.float64).reshape(-1, self.d)
+        st, shift = self._profile_basis()
+        out = np.empty(Xs.shape[0])
+        gi = [int(v) for v in self.g]
+        for p in range(Xs.shape[0]):
+            w = None
+            for q in range(self.d):
+                wq = spec.interp_1d_dense(Xs[p:p + 1, q], float(self.g0[q]), float(self.h[q]), gi[q])[0]
+                w = wq if w is None else np.multiply.outer(w, wq)
+            rhs = np.ascontiguousarray(w.reshape(-1), self.dt)
+            u, z = np.zeros(self.m, self.dt), np.zeros(self.m, self.dt)
+            res = ctypes.c_double(0)
+            self._fn("wb_pcg_profile")(_p(self.A), self.d, _p(self.g), ctypes.c_long(self.m), self.creal(1.0 / self.sigma2), _p(st["X"]), _p(st["Z"]),
+                                       _p(st["D"]), self.creal(shift), _p(rhs), 0, ctypes.c_double(tol), max_iter, _p(u), _p(z), ctypes.byref(res))
+            out[p] = self.sigma2 * float(rhs.astype(np.float64) @ u.astype(np.float64))
+        return out
+
     def predict_mean(self, Xs):
         Xs = np.ascontiguousarray(Xs, self.dt).reshape(-1, self.d)
         out = np.empty(Xs.shape[0], self.dt)

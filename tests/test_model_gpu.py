@@ -347,6 +347,17 @@ def test_c3_full_stream_checkpoints_vs_cpu_port(kind):
         print(f"{kind} checkpoint {mark:6d} points: max |mean - cpu| / max |cpu| = {dev:.2e}")
         assert dev <= 1e-2
         assert dev <= 2e-4        # what fp32 statistics + a 1e-5 solve actually give (about 1e-5)
+    # predictive VARIANCE at the end of the full stream (64 of the fixed test points) against the fp64 port: the product's default
+    # path (the spectral Woodbury factor on this grid and kernel) and the PCG path of the same model
+    want_v = B.variance(Xt.numpy()[:64])
+    with settings.cg_tolerance(1e-5), torch.no_grad():
+        v_def = model(Xtg[:64]).variance.double().cpu().numpy()
+        with settings.spectral_factor(False):
+            v_pcg = model(Xtg[:64]).variance.double().cpu().numpy()
+    for name, v in (("default path", v_def), ("pcg path", v_pcg)):
+        dv = np.max(np.abs(v - want_v) / want_v)
+        print(f"{kind} end of stream, 64 variances, {name}: max rel dev vs the fp64 port = {dv:.2e}")
+        assert dv <= 1e-2
 
 
 def test_c2_scale_30pow4_fp64_parity():

@@ -159,3 +159,18 @@ def test_openmp_baseline_matches_scalar_oracle():
         got = B.predict_mean(X[:50]).astype(np.float64)
         assert np.abs(got - ref).max() < (1e-7 if dt == np.float64 else 5e-4) * np.abs(ref).max()
     assert baseline.num_threads() >= 1
+
+
+def test_openmp_port_variance_matches_the_data_space_oracle():
+    """The fp64 port's per-query variance solve (the checker of the full-size C3 variance checkpoint) against oracle O."""
+    from oracle import baseline
+
+    baseline.build()
+    rng = np.random.default_rng(0)
+    d, g, n = 3, 10, 400
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(X.sum(1)); Xs = rng.uniform(-1, 1, (5, d)); nz = rng.uniform(0.5, 2, n)
+    B = baseline.StreamingBaseline([[-1.1, 1.1]] * d, g, sigma2=0.7, dtype=np.float64)
+    B.absorb(X, y, nz)
+    O = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, sigma2=0.7).fit(X, y, nz)
+    _, vo = O.predict(Xs)
+    assert np.abs(B.variance(Xs) - vo).max() < 1e-10 * vo.max()
