@@ -266,7 +266,12 @@ def main():
             gc_settle()                                    # the previous pass's model (reference cycles) goes before the new one allocates
             model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
             model.eval()
-            upd = ShardedStatsUpdater(model, equal_shards=True, exchange=exchange)   # every rank streams q points per step
+            # N > 1, "auto": the stencil-sharded step (the one exchange that divides the step's work; distributed.py) where it
+            # applies -- d = 3, fp32 -- else the cheaper of the point / statistics exchanges
+            ex = exchange
+            if ex == "auto" and world > 1 and d == 3 and dtype == torch.float32 and os.environ.get("WISKI_BENCH_NO_STENCIL_SHARD") != "1":
+                ex = "stencil"
+            upd = ShardedStatsUpdater(model, equal_shards=True, exchange=ex)   # every rank streams q points per step
 
             def step(xb, yb):
                 if world == 1:                             # evaluate -> absorb -> refresh behind one C-ABI call (wiski_stream_step)
@@ -345,7 +350,7 @@ def main():
             try:                                   # same on every rank (deterministic legs): a failure is recorded, the headline line survives
                 # both exchanges, timed the same way: the point exchange divides no work (every rank scatters
                 # all N q points and solves), the statistics all-reduce is the north-star form
-                for ex in ("points", "stats"):
+                for ex in ("stencil", "points", "stats"):
                     _, _, bs, its, _, _ = run_stream(args.stream, ex, max(3, R // 4), 0, profile=False)
                     extra[f"updates_per_s_exchange_{ex}"] = world * K * q / block_seconds(bs)[0]
                     extra[f"cg_iters_exchange_{ex}"] = float(np.mean(its))
@@ -668,8 +673,10 @@ def main():
             pass
         par = "single"
         if world > 1:
-            par = f"dp{world} (" + ("shard all-gather + replicated scatter: divides no work, every rank scatters all N q points and solves"
-                                    if exchange_used == "points" else "all-reduce of the half-stencil statistics") + ")"
+            par = f"dp{world} (" + {"points": "shard all-gather + replicated scatter: divides no work, every rank scatters all N q points and solves",
+                                    "stencil": "shard all-gather, then every rank scatters and multiplies only its 1/N of the half-stencil groups; one m-vector "
+                                               "all-reduce per CG iteration (wiski_shard)",
+                                    "stats": "all-reduce of the half-stencil statistics"}.get(exchange_used, str(exchange_used)) + ")"
         # what an empty dispatch costs by the clock of `roofline.avg_launch_us` (events attached to the dispatch packet)
         empty_us = ctypes.c_double(0)
         if lib.wiski_prof_empty(ctypes.c_int32(64), ctypes.byref(empty_us), _hip.stream_ptr(dev)) != 0:

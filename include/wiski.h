@@ -197,6 +197,24 @@ int64_t wiski_pcg_workspace_bytes(const wiski_grid* grid, int32_t k, int32_t max
 int wiski_pcg_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream);
 int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream);
 
+/* Stencil-sharded replicas (multi-GPU step that DIVIDES the work).  Rank r of n owns the groups
+ * [r G / n, (r + 1) G / n) of the symmetric half stencil (G = (7^(d-1) + 1) / 2 groups, wiski_shard_groups): it scatters only
+ * the tap pairs of its groups (wiski_scatter_stats_step_sharded: 1 / n of the atomics per point; b, cnt, the statistics and
+ * the carried residual stay replicated, so every rank must see every point) and computes only its groups' share of A p
+ * (wiski_pcg_sharded), which ONE all-reduce(SUM) of an m-vector plus the p . Ap slots per product turns into the full
+ * product on the solve's stream.  Vectors, preconditioner and scalars are replicated: all ranks take identical iterations.
+ * comm != NULL: RCCL (an ncclComm_t, see wiski_comm_*); else `allreduce(ctx, d_vec, n_vec, elem_bytes, d_dots, n_dots, stream)`
+ * is called -- in place, SUM, d_dots fp64, must be ordered after the work already queued on `stream` and before what is
+ * queued next (tests route it through another transport).  d = 3, fp32, one right-hand side, half stencil only. */
+typedef int (*wiski_allreduce_fn)(void* ctx, void* d_vec, int64_t n_vec, int32_t elem_bytes, double* d_dots, int64_t n_dots, void* stream);
+typedef struct wiski_shard {
+  int32_t rank, nranks;
+  void* comm;
+  wiski_allreduce_fn allreduce;
+  void* ctx;
+} wiski_shard;
+int wiski_shard_groups(int32_t d, int32_t rank, int32_t nranks, int32_t* g_lo, int32_t* g_hi);
+
 /* Deferred convergence poll.  wiski_pcg_async_* = wiski_pcg_* plus a host-side handle (zero-initialised by the caller,
  * released with wiski_pcg_async_free) and a mode: 0 = as wiski_pcg; 1 = START: queue the iterations up to the first poll
  * (first_check), queue the poll, return WISKI_PENDING without waiting -- the host gets its time back while the GPU iterates;
@@ -267,6 +285,7 @@ typedef struct wiski_stream_args_f32 {
   const float* d_tcol; float kscale; const float* d_evec; const float* d_evec2; const float* d_eval; float shift;
   double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
   void* d_bin; int64_t bin_bytes;                 /* optional binning workspace of the absorb (wiski_scatter_bin_bytes), or NULL / 0 */
+  const wiski_shard* shard;                      /* NULL, or: this replica owns a share of the half stencil (see wiski_shard) */
 } wiski_stream_args_f32;
 typedef struct wiski_stream_args_f64 {
   double* d_A_half; double* d_b; double* d_cnt; double* d_stats; int32_t* d_err;
@@ -274,9 +293,18 @@ typedef struct wiski_stream_args_f64 {
   const double* d_tcol; double kscale; const double* d_evec; const double* d_evec2; const double* d_eval; double shift;
   double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
   void* d_bin; int64_t bin_bytes;
+  const wiski_shard* shard;
 } wiski_stream_args_f64;
 int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* args, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
 int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* args, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
+
+/* The two halves of a stencil-sharded step on their own (wiski_stream_step uses them when args->shard is set): the absorb
+ * restricted to the stencil groups [g_lo, g_hi) (same arguments as wiski_scatter_stats_step; always the atomic form), and
+ * wiski_pcg_async with every A . v product summed over the ranks of `shard`. */
+int wiski_scatter_stats_step_sharded_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, float* d_b, float* d_A_half, float* d_cnt, const float* d_u, float* d_res, float* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, const void* d_guard, int64_t guard_expect, int32_t g_lo, int32_t g_hi, void* stream);
+int wiski_scatter_stats_step_sharded_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_cnt, const double* d_u, double* d_res, double* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, const void* d_guard, int64_t guard_expect, int32_t g_lo, int32_t g_hi, void* stream);
+int wiski_pcg_sharded_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard);
+int wiski_pcg_sharded_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
                                                            real* __restrict__ cnt, const real* __restrict__ u, real* __restrict__ res,
                                                            real* __restrict__ mean_out = nullptr, uint32_t* __restrict__ z1 = nullptr,
                                                            int64_t n1 = 0, uint32_t* __restrict__ z2 = nullptr, int64_t n2 = 0,
-                                                           const long long* __restrict__ guard = nullptr, long long guard_expect = 0) {
+                                                           const long long* __restrict__ guard = nullptr, long long guard_expect = 0,
+                                                           int g_lo = 0, int g_hi = 1 << 30) {
+  // [g_lo, g_hi): the stencil groups this replica owns (wiski_shard: a rank of a stencil-sharded step scatters the tap pairs
+  // of ITS groups only -- 1 / N of the atomics per point; b, cnt, res and the statistics stay replicated)
   // speculative launch behind a solve whose convergence poll the host has not read yet (wiski_pcg_async_guard): the poll's
   // publishing block decides on the device whether this absorb happens
   if (guard && *guard != guard_expect) return;
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
   __shared__ int s_scan[4];
   __shared__ double s_red[16];
   const int lane = threadIdx.x & 63, loc = threadIdx.x >> 6;
+  int npair = 0;
   {  // compact list of the valid prefix pairs (block-cooperative stream compaction)
     int running = 0;
     for (int base = 0; base < TP * TP; base += 256) {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
         ca = ca * 7 + ((pa >> (2 * (D - 2 - q))) & 3);
         cb = cb * 7 + ((pb >> (2 * (D - 2 - q))) & 3);
       }
-      const bool ok = idx < TP * TP && cb >= ca;
+      const bool ok = idx < TP * TP && cb >= ca && cb - ca >= g_lo && cb - ca < g_hi;
       const unsigned long long mask = __ballot(ok);
       if (lane == 0) s_scan[loc] = __popcll(mask);
       __syncthreads();
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
       running += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
       __syncthreads();
     }
+    npair = running;                              // block-uniform: NPAIR for the whole stencil, fewer for a shard
   }
   bool bad = false;
   const int64_t m = G.m;
@@ -282,9 +287,9 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
     if (valid && A) {
       const int a2 = lane & 3, b2 = (lane >> 2) & 3, ps = lane >> 4;
 #pragma unroll 2
-      for (int t0 = 0; t0 < NPAIR; t0 += 4) {
+      for (int t0 = 0; t0 < npair; t0 += 4) {
         const int t = t0 + ps;
-        if (t < NPAIR) {
+        if (t < npair) {
           const int pk = s_pair[t];
           const int g = pk >> 16;
           const int a = (pk & 0xff) * 4 + a2;
@@ -383,7 +388,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
                         int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
                         real* d_cnt = nullptr, const real* d_u = nullptr, real* d_res = nullptr, real* d_mean_out = nullptr,
                         void* z1 = nullptr, int64_t n1_bytes = 0, void* z2 = nullptr, int64_t n2_bytes = 0, const void* d_guard = nullptr,
-                        int64_t guard_expect = 0, void* d_bin = nullptr, int64_t bin_bytes = 0) {
+                        int64_t guard_expect = 0, void* d_bin = nullptr, int64_t bin_bytes = 0, int g_lo = 0, int g_hi = 1 << 30) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -398,7 +403,9 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   // large batches on a d = 3 half stencil with a binning workspace: the owner-computes form (scatter_owner.h).  Its LDS
   // accumulators ((g2 * 175 + 512) reals per block) must fit the device limit and the opt-in must succeed BEFORE the first
   // kernel of the pair is queued -- k_bin_points already updates statistics; otherwise the atomic form runs.
-  bool owner = half && G.d == 3 && d_bin && d_cnt && d_A_st && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
+  const bool ranged = g_lo > 0 || g_hi < (1 << 30);      // a stencil shard: atomic form only (the owner form walks whole lines)
+  if (ranged && !half) return WISKI_E_BADARG;
+  bool owner = !ranged && half && G.d == 3 && d_bin && d_cnt && d_A_st && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
                n >= owner_min_points() && bin_bytes >= owner_work_bytes<real>(grid, n);
   const size_t owner_lds = ((size_t)G.g[2] * (172 + 3) + 512) * sizeof(real);      // accumulators + one scratch word per thread
   if (owner) {
@@ -462,7 +469,7 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   dim3 grd((unsigned)blocks);
 #define CALL(DD)                                                                                                                              \
   do {                                                                                                                                        \
-    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4, (const long long*)d_guard, (long long)guard_expect); \
+    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4, (const long long*)d_guard, (long long)guard_expect, g_lo, g_hi); \
     else hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
   } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
@@ -495,6 +502,12 @@ int wiski_scatter_stats_step_f32(const wiski_grid* g, const float* x, const floa
 }
 int wiski_scatter_stats_step_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, void* bin, int64_t bin_bytes, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect, bin, bin_bytes);
+}
+int wiski_scatter_stats_step_sharded_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, float* b, float* A_half, float* cnt, const float* u, float* res, float* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, int32_t g_lo, int32_t g_hi, void* s) {
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect, nullptr, 0, g_lo, g_hi);
+}
+int wiski_scatter_stats_step_sharded_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, int32_t g_lo, int32_t g_hi, void* s) {
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect, nullptr, 0, g_lo, g_hi);
 }
 int64_t wiski_scatter_bin_bytes(const wiski_grid* g, int64_t n, int32_t elem_size) {
   if (!g || g->d != 3 || n < 0 || (elem_size != 4 && elem_size != 8)) return -1;

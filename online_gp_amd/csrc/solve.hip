@@ -891,9 +891,30 @@ static inline void launch_timed(F kern, dim3 grd, dim3 blk, size_t sh, hipStream
 
 // partial SpMV launcher on the half stencil (requires m % 4 == 0).  part holds (sym_nch(G, k) + 1) * k * m reals;
 // part[sym_nch(G, k)] must be zero on entry (see the kernel comments).
+// Stencil-sharded replicas (wiski_shard): rank r of n owns the groups [r ng / n, (r + 1) ng / n) of the half stencil.
+static inline void shard_group_range(int ng, int rank, int nranks, int* lo, int* hi) {
+  *lo = (int)((int64_t)rank * ng / nranks);
+  *hi = (int)((int64_t)(rank + 1) * ng / nranks);
+}
+// d = 3: the parts (runs of groups inside one leading digit d0) that cover [lo, hi); returns their number (<= 8)
+static inline int shard_parts_d3(int lo, int hi, SymDmaParts* tab) {
+  int n = 0;
+  for (int g = lo; g < hi && n < 8;) {
+    const int d0 = (g + 3) / 7, p1 = (g + 3) % 7;
+    int run = 7 - p1;
+    if (g + run > hi) run = hi - g;
+    tab->d0[n] = (unsigned char)d0; tab->p1lo[n] = (unsigned char)p1; tab->ntile[n] = (unsigned char)run;
+    ++n;
+    g += run;
+  }
+  tab->n = n;
+  return n;
+}
+
 template <typename real>
 static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, real* part, const real* add, real beta, double* dots,
-                            hipStream_t s) {
+                            hipStream_t s, const SymDmaParts* shard_tab = nullptr) {
+  if (shard_tab && !(sizeof(real) == 4 && sym_use_dma<real>(G, k))) return WISKI_E_BADARG;   // sharded products: d = 3, fp32, k = 1 only
   if (sym_use_cols(k)) {
     // part[0] <- A V (column-major, written by the product itself); the row-major copy of V lives behind it
     const int m = G.m, kp = spmmc_kp(k);
@@ -921,7 +942,13 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     if (sym_use_dma<real>(G, k)) {
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
       const size_t sh = symdma_lds_bytes(G.g[2], g_sym_dma_nst);
-      dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)g_sym_dma_parts);
+      SymDmaParts tab{};
+      if (shard_tab) tab = *shard_tab;
+      // partial vectors written: part[0 .. np); the accumulated one always lives at part[g_sym_dma_parts], whatever np is
+      // (the zero regions of wiski_pcg_zero_regions must not depend on the sharding)
+      const int np = tab.n ? tab.n : g_sym_dma_parts;
+      if (np > g_sym_dma_parts) return WISKI_E_BADARG;
+      dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)np);
       // the light chunk joins when the heavy ones are ~3 / 7 through their stream: proportional to the stream's length
       const int delay = (int)((int64_t)g_sym_dma_delay * G.m / 125000);
 #define SYMDMA(NST, DOT)                                                                                                          \
@@ -932,7 +959,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         return WISKI_E_LAUNCH;                                                                                                    \
       lds_set = sh;                                                                                                               \
     }                                                                                                                             \
-    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay); \
+    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab); \
   } while (0)
       if (g_sym_dma_nst == 3) {
         if (dots) SYMDMA(3, true); else SYMDMA(3, false);
@@ -1663,6 +1690,22 @@ __global__ __launch_bounds__(256) void k_pcg_update_x(int m, int it, double tol2
   }
 }
 
+// Stencil-sharded solve: this rank's share of A p = its direct partials + its accumulated (transposed-term) partial, summed
+// into ONE vector that is then all-reduced over the ranks; the accumulated partial is re-zeroed on the way.
+template <typename real>
+__global__ __launch_bounds__(256) void k_shard_reduce(int m4, int m, const real* __restrict__ part, int np, real* __restrict__ acc,
+                                                      real* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m4; i += gridDim.x * blockDim.x) {
+    Vec4<real> t = load4<real>(acc + 4 * i);
+    for (int p = 0; p < np; ++p) {
+      const Vec4<real> v = load4<real>(part + (int64_t)p * m + 4 * i);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    store4<real>(out + 4 * i, t.x, t.y, t.z, t.w);
+    store4<real>(acc + 4 * i, (real)0, (real)0, (real)0, (real)0);
+  }
+}
+
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 static int64_t pcg_ws_bytes(int m, int k, int max_iter, int es) {
@@ -1676,7 +1719,10 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
                     const int32_t* d_err, int32_t* h_err, int32_t a_sym, real* d_R, void* stream, wiski_pcg_async* as = nullptr,
-                    int32_t amode = 0) {
+                    int32_t amode = 0, const wiski_shard* shard = nullptr) {
+  // shard (wiski_shard, nranks > 1): d_A holds only this rank's groups of the half stencil; every A . v product is this rank's
+  // share, summed over the ranks by ONE all-reduce of an m-vector (+ the p . Ap slots) per product on the solve's stream.
+  // Everything else -- preconditioner, vector updates, scalars -- is replicated, so all ranks take identical iterations.
   // amode (with `as`): 0 = run to convergence; 1 = START: queue the iterations up to the first convergence poll, queue the
   // poll and return WISKI_PENDING without waiting for it; 2 = RESUME a started solve (same arguments): wait for that poll
   // (normally long over), finish with synchronous polls if it was not converged.  Nothing but the resume call may use
@@ -1713,8 +1759,34 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   // atomically accumulated transposed term: zero here, re-zeroed by every consumer (zl)
   int zl = 0;
   const int nch = wide ? (sym ? sym_partials<real>(G, k, &zl) : spmv_nch(G.d)) : 0;
-  auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) {
-    return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
+  const bool sharded = shard && shard->nranks > 1;
+  SymDmaParts stab{};
+  if (sharded) {
+    if (!sym || !wide || G.d != 3 || k != 1 || sizeof(real) != 4 || shard->rank < 0 || shard->rank >= shard->nranks) return WISKI_E_BADARG;
+    if (!shard->comm && !shard->allreduce) return WISKI_E_BADARG;
+    int glo, ghi;
+    shard_group_range(sym_groups(G.d), shard->rank, shard->nranks, &glo, &ghi);
+    shard_parts_d3(glo, ghi, &stab);           // may be empty (more ranks than groups): that rank contributes zeros
+  }
+  // what the consumers of a product read: the partial vectors of the local launch, or the all-reduced sum
+  real* cpart = sharded ? hp : part;
+  const int cnch = sharded ? 1 : nch, czl = sharded ? 0 : zl;
+  auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) -> int {
+    if (!sharded)
+      return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
+    if (stab.n) {
+      if (int r1 = launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s, &stab)) return r1;
+    }
+    const int m4 = m / 4;
+    hipLaunchKernelGGL((k_shard_reduce<real>), dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, s, m4, m, (const real*)part, stab.n,
+                       part + (int64_t)(nch - 1) * k * m, hp);
+    if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
+    const int64_t nd = dots ? (int64_t)k * PCG_DOT_COL : 0;
+    if (shard->comm) {
+      if constexpr (sizeof(real) == 4) return wiski_allreduce_stats_f32(shard->comm, nullptr, 0, (float*)hp, m, nullptr, 0, dots, nd, s);
+      else return WISKI_E_BADARG;
+    }
+    return shard->allreduce(shard->ctx, hp, (int64_t)m, (int32_t)sizeof(real), dots, nd, s);
   };
   auto spmv_narrow = [&](const real* v, const real* add, real beta, real* out, double* dots) {
     return sym ? launch_spmv_sym<real>(G, d_A, v, k, add, beta, out, dots, s) : launch_spmv<real>(G, d_A, v, k, add, beta, out, dots, s);
@@ -1758,7 +1830,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (wide) {
       rc = spmv_wide(d_U, nullptr, (real)0, nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, part, nch, zl, 0, r, S);
+      hipLaunchKernelGGL((k_pcg_init<real, 4>), vgrid, dim3(256), 0, s, m, d_RHS, (const real*)d_Z, cpart, cnch, czl, 0, r, S);
     } else {
       rc = spmv_narrow(d_U, d_Z, (real)1, hp, nullptr);
       if (rc) return rc;
@@ -1843,7 +1915,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     if (pending) {
       if (publish) seq = ++P.seq;
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it - 1, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S, publish ? P.d : (double*)nullptr, d_err, seq, P.g);
+                         cpart, cnch, czl, d_U, d_Z, r, S, publish ? P.d : (double*)nullptr, d_err, seq, P.g);
       pending = false;
     }
     return seq;
@@ -1855,7 +1927,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       constexpr bool fuse_upd = sizeof(real) == 4;
       if (!fuse_upd) flush_update();
       const bool init_now = init_in_fwd && it == 0;
-      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, part, nch, zl,
+      rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, cpart, cnch, czl,
                                           d_U, d_Z, S, s, init_now ? d_RHS : (const real*)nullptr);
       pending = false;
       if (rc) return rc;
@@ -1897,10 +1969,10 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     const long long useq = pub ? ++P.seq : 0;
     if (wide)
       hipLaunchKernelGGL((k_pcg_update_x<real, 4>), vgrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq, P.g);
+                         cpart, cnch, czl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq, P.g);
     else
       hipLaunchKernelGGL((k_pcg_update_x<real, 1>), egrid, dim3(256), 0, s, m, it, tol2, (const real*)p, (const real*)pt, (const real*)hp,
-                         part, nch, zl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq, P.g);
+                         cpart, cnch, czl, d_U, d_Z, r, S, pub ? P.d : (double*)nullptr, d_err, useq, P.g);
     ++it;
     if (due(it)) {
       rc = fetch(it, useq);
@@ -2034,6 +2106,20 @@ int wiski_pcg_async_f32(const wiski_grid* g, const float* A, const float* tcol, 
 }
 int wiski_pcg_async_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* R, void* s, wiski_pcg_async* as, int32_t amode) {
   return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode);
+}
+int wiski_pcg_sharded_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s, wiski_pcg_async* as, int32_t amode, const wiski_shard* shard) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode, shard);
+}
+int wiski_pcg_sharded_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* R, void* s, wiski_pcg_async* as, int32_t amode, const wiski_shard* shard) {
+  return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode, shard);
+}
+int wiski_shard_groups(int32_t d, int32_t rank, int32_t nranks, int32_t* g_lo, int32_t* g_hi) {
+  if (d < 1 || d > WISKI_MAX_DIM || nranks < 1 || rank < 0 || rank >= nranks || !g_lo || !g_hi) return WISKI_E_BADARG;
+  int lo, hi;
+  shard_group_range(sym_groups(d), rank, nranks, &lo, &hi);
+  *g_lo = lo;
+  *g_hi = hi;
+  return WISKI_OK;
 }
 int wiski_pcg_async_free(wiski_pcg_async* as) {
   if (!as) return WISKI_E_BADARG;

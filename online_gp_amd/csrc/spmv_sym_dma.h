@@ -110,10 +110,17 @@ static inline size_t symdma_lds_bytes(int g2, int nst) {
   return (size_t)(nst * SYMDMA_TILE + 256 + symdma_vwf(g2) + symdma_wp(g2)) * sizeof(float);
 }
 
+// Explicit work split of a launch (stencil-sharded replicas, wiski_shard): part y covers the groups
+// 7 d0[y] + p1lo[y] - 3 ... + ntile[y] of ONE leading stencil digit d0.  n == 0: the built-in splits below.
+struct SymDmaParts {
+  unsigned char d0[8], p1lo[8], ntile[8];
+  int n;
+};
+
 template <int NST, bool DOT>
 __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const float* __restrict__ A_h, const float* __restrict__ V, int W4, int WP,
                                                      int nparts, float* __restrict__ part, const float* __restrict__ add, float beta,
-                                                     double* __restrict__ dots, int delay) {
+                                                     double* __restrict__ dots, int delay, SymDmaParts tab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int m = G.m, S0 = G.stride[0], S1 = G.stride[1];
@@ -122,7 +129,8 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   int d0, p1lo, ntile;
   {
     const int y = blockIdx.y;
-    if (nparts == 4) { d0 = (y + 1) & 3; p1lo = d0 == 0 ? 3 : 0; ntile = d0 == 0 ? 4 : 7; }
+    if (tab.n) { d0 = tab.d0[y]; p1lo = tab.p1lo[y]; ntile = tab.ntile[y]; }
+    else if (nparts == 4) { d0 = (y + 1) & 3; p1lo = d0 == 0 ? 3 : 0; ntile = d0 == 0 ? 4 : 7; }
     else if (nparts == 5) {   // 7, 7, 4 (d0 = 3, digits 0..3), 4 (centre chunk), 3 (d0 = 3, digits 4..6)
       if (y < 2) { d0 = y + 1; p1lo = 0; ntile = 7; }
       else if (y == 2) { d0 = 3; p1lo = 0; ntile = 4; }
@@ -142,11 +150,11 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   // All waves of a 4-part launch are resident at once (1 956 <= 8 per CU) and the CU arbitrates oldest-first: the chunks
   // dispatched last (y = 2: 7 tiles, y = 3: 4 tiles) get their first DMA issued 2.5 us after the others and finish last.
   // Raising their priority evens the finish times (19.3 -> 18.4..18.7 us; graded maps 0-1-2-3 / 0-1-2-0: no better).
-  if (nparts == 4 && blockIdx.y >= 2) __builtin_amdgcn_s_setprio(3);
+  if (!tab.n && nparts == 4 && blockIdx.y >= 2) __builtin_amdgcn_s_setprio(3);
   // The 4-tile chunk (d0 = 0) carries half the bytes of the others: started with them it is gone after 8.7 us and the 7-tile
   // chunks stream on alone, then everybody's epilogue is exposed.  Started `delay` x 0.43 us late it joins when the others
   // are about three tiles in (50^3: delay = 12, 18.5 -> 18.1 us back to back; 6..8 and 14..20 are no better than 0, 24+ worse).
-  if (nparts == 4 && blockIdx.y == 3)
+  if (!tab.n && nparts == 4 && blockIdx.y == 3)
     for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(16);
   const int iw0 = blockIdx.x * 256;
   const int i4 = iw0 + 4 * lane;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
     if (live) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) pd += (double)xo[r] * (2.0 * (double)acc[r] - (double)dg[r]);
-      if (d0 == 0 && add) {   // exactly one part has d0 == 0
+      if (g0 == 0 && add) {   // exactly one part starts at the centre group (in a sharded launch: on exactly one rank)
         const float4 ad = *reinterpret_cast<const float4*>(add + i4);
         pd += (double)beta * ((double)xo[0] * ad.x + (double)xo[1] * ad.y + (double)xo[2] * ad.z + (double)xo[3] * ad.w);
       }

@@ -127,11 +127,14 @@ class ShardedStatsUpdater:
 
     def __init__(self, model, group=None, exchange="auto", equal_shards=False, comm=None):
         """exchange: "stats" (all-reduce the statistics deltas), "points" (all-gather the shards, scatter them all
-        on every rank) or "auto" (the cheaper of the two by a simple cost model).  The point exchange needs the same
+        on every rank), "stencil" (``stream_step`` only: all-gather the shards, then every rank scatters and multiplies
+        only ITS groups of the half stencil and one m-vector all-reduce per CG iteration completes the product -- the one
+        exchange that divides the step's work; d = 3, fp32, one output, else it behaves like "points") or "auto" (the
+        cheaper of the first two by a simple cost model).  The point exchange needs the same
         shard length on every rank; ``equal_shards=True`` promises that (no size check), otherwise the sizes are
         compared first (one tiny all-reduce + host read) and unequal shards fall back to the statistics exchange."""
-        if exchange not in ("auto", "stats", "points"):
-            raise ValueError("exchange must be 'auto', 'stats' or 'points'")
+        if exchange not in ("auto", "stats", "points", "stencil"):
+            raise ValueError("exchange must be 'auto', 'stats', 'points' or 'stencil'")
         self.model = model
         self.group = group
         self.exchange = exchange
@@ -190,8 +193,9 @@ class ShardedStatsUpdater:
             Y = Y[:, None]
         d = m._grid.d
         q = X.reshape(-1, d).shape[0]
-        if self.comm is None and m.num_outputs == 1 and self._use_points(q, world, m._device):
-            self.last_exchange = "points"
+        stencil = self.exchange == "stencil" and self.comm is None and self._enter_stencil_shard(world)
+        if stencil or (self.comm is None and m.num_outputs == 1 and (self.exchange == "stencil" or self._use_points(q, world, m._device))):
+            self.last_exchange = "stencil" if stencil else "points"
             packed = torch.cat([X.reshape(-1, d).to(m._device, m._dtype), Y.to(m._device, m._dtype)], dim=1).contiguous()
             parts = [torch.empty_like(packed) for _ in range(world)]
             dist.all_gather(parts, packed, group=self.group)
@@ -209,6 +213,29 @@ class ShardedStatsUpdater:
         self.update(X, Y)
         m.prediction_cache
         return mean
+
+    def _enter_stencil_shard(self, world):
+        """Put the model into stencil-sharded mode (idempotent); False where it does not apply."""
+        m = self.model
+        if m.__dict__.get("_stencil_shard") is not None:
+            return True
+        group = self.group
+        gloo_cuda = dist.get_backend(group) == "gloo"
+
+        def allreduce(vec, dots):
+            if gloo_cuda and vec.is_cuda:
+                # test transport (several ranks on one GPU): through the host, which also orders it against the stream
+                for t in (vec, dots):
+                    if t is not None:
+                        h = t.cpu()
+                        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                        t.copy_(h)
+                return
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)          # RCCL: ordered against the current stream by torch
+            if dots is not None:
+                dist.all_reduce(dots, op=dist.ReduceOp.SUM, group=group)
+
+        return m.enter_stencil_shard(dist.get_rank(group), world, allreduce)
 
     def _delta_cache(self):
         """Zeroed delta copies of (b, stats); the W^T W delta lives in the model's symmetric
@@ -232,6 +259,7 @@ class ShardedStatsUpdater:
         from .models.batched_fixed_noise_online_gp import _wtw_ops
 
         m = self.model
+        m.leave_stencil_shard()                      # (collective; a no-op unless the model is stencil-sharded)
         if Y.dim() == 1:
             Y = Y[:, None]
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1

@@ -295,11 +295,39 @@ class _StreamArgs32(ctypes.Structure):
                 ("d_tcol", ctypes.c_void_p), ("kscale", ctypes.c_float), ("d_evec", ctypes.c_void_p), ("d_evec2", ctypes.c_void_p),
                 ("d_eval", ctypes.c_void_p), ("shift", ctypes.c_float), ("tol", ctypes.c_double), ("max_iter", ctypes.c_int32),
                 ("check_every", ctypes.c_int32), ("d_work", ctypes.c_void_p), ("work_bytes", ctypes.c_int64),
-                ("d_bin", ctypes.c_void_p), ("bin_bytes", ctypes.c_int64)]
+                ("d_bin", ctypes.c_void_p), ("bin_bytes", ctypes.c_int64), ("shard", ctypes.c_void_p)]
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                ctypes.c_void_p)
+
+
+class _Shard(ctypes.Structure):
+    """include/wiski.h: wiski_shard"""
+    _fields_ = [("rank", ctypes.c_int32), ("nranks", ctypes.c_int32), ("comm", ctypes.c_void_p), ("allreduce", ALLREDUCE_FN), ("ctx", ctypes.c_void_p)]
+
+
+def shard_groups(d, rank, nranks):
+    """[g_lo, g_hi): the stencil groups rank `rank` of `nranks` owns (wiski_shard_groups; pure host arithmetic)."""
+    lo, hi = ctypes.c_int32(0), ctypes.c_int32(0)
+    _hip.check(_hip.lib().wiski_shard_groups(ctypes.c_int32(d), ctypes.c_int32(rank), ctypes.c_int32(nranks), ctypes.byref(lo), ctypes.byref(hi)),
+               "wiski_shard_groups")
+    return int(lo.value), int(hi.value)
+
+
+def half_stencil_group_slices(grid, g_lo, g_hi):
+    """Element ranges [(start, stop), ...] of the flat row-interleaved half stencil that hold the groups [g_lo, g_hi):
+    group 0 is A_h[0 : 4 m], group g >= 1 is A_h[(7 g - 3) m : (7 g + 4) m] (include/wiski.h)."""
+    m = grid.m
+    out = []
+    for g in range(g_lo, g_hi):
+        out.append((0, 4 * m) if g == 0 else ((7 * g - 3) * m, (7 * g + 4) * m))
+    return out
 
 
 class _StreamArgs64(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double if t is ctypes.c_float else t) for n, t in _StreamArgs32._fields_]
+
 
 
 class _PcgAsync(ctypes.Structure):
@@ -338,6 +366,34 @@ class StreamStep:
                 _hip.lib().wiski_pcg_async_free(ctypes.byref(self.handle))
         except Exception:  # noqa: BLE001
             pass
+
+    def set_shard(self, rank, nranks, comm=None, allreduce=None):
+        """Stencil-sharded step (wiski_shard): this replica owns the groups shard_groups(d, rank, nranks) of the half stencil.
+        comm: an ncclComm_t handle (int) for the RCCL route; allreduce(vec, dots): a Python callable that all-reduces (SUM, in
+        place) the two torch views it is given -- the views alias the solver's workspace."""
+        if nranks <= 1:
+            self.args.shard = None
+            self._shard = None
+            return
+        buf = self.keep[-1]                      # the PCG workspace tensor the device pointers of the callback point into
+        base = buf.data_ptr()
+
+        def cb(ctx, d_vec, n_vec, elem_bytes, d_dots, n_dots, stream):
+            try:
+                dt = torch.float32 if elem_bytes == 4 else torch.float64
+                vec = buf[d_vec - base:d_vec - base + n_vec * elem_bytes].view(dt)
+                dots = buf[d_dots - base:d_dots - base + n_dots * 8].view(torch.float64) if (d_dots and n_dots) else None
+                allreduce(vec, dots)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return -2
+
+        self._shard_cb = ALLREDUCE_FN(cb) if allreduce is not None else ALLREDUCE_FN()
+        self._shard = _Shard(rank, nranks, comm, self._shard_cb, None)
+        self.args.shard = ctypes.addressof(self._shard)
 
     def set_solver(self, kscale, eig, shift, tol, check_every):
         a = self.args

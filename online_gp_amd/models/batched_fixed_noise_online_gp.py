@@ -209,6 +209,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         buffers instead, for the caller to all-reduce and add; `res_delta` ([out, m], zeroed) then receives this shard's
         innovation W^T (wb y - wa (W U)) of the carried residual, to be all-reduced and added to R alongside."""
         self._finish_pending()
+        if cache is self._kernel_cache:
+            self.leave_stencil_shard()               # the generic absorb writes every group
         X = X.reshape(-1, self._grid.d).to(self._device, self._dtype).contiguous()
         Y = Y.to(self._device, self._dtype)
         if Y.dim() == 1:
@@ -393,6 +395,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         return st["eig"], wsum / st["norm"]
 
     def _posterior_op(self, o):
+        self.leave_stencil_shard()                   # solves outside the sharded streaming step need the whole stencil
         tcol, s2, _ = self._hyper()[o]
         if self._use_dense():
             return DenseInducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, grid_ops.kron_eigen(self._grid, tcol))
@@ -400,6 +403,44 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
                                  settings.max_cg_iterations.value(), workspace=self._pcg_ws, check_every=settings.cg_check_every.value(),
                                  eigen=eig, shift=shift, err=self._err)
+
+    # ------------------------------------------------------- stencil shard --
+    def enter_stencil_shard(self, rank, world, allreduce, allreduce_full=None, comm=None):
+        """Multi-GPU step that divides the work (include/wiski.h: wiski_shard): from now on this replica keeps
+        only ITS groups of the half stencil current -- the streaming step scatters 1 / world of the tap pairs per point and
+        computes 1 / world of A p, one all-reduce of an m-vector per CG iteration makes the product whole.  Every rank must
+        see every point (the caller all-gathers the shards) and must make the same calls.  `allreduce(vec, dots)`: in-place
+        SUM over the ranks of the two tensors (dots may be None); `allreduce_full(t)`: the same for one large tensor, used
+        when a consumer needs the whole stencil again (leave_stencil_shard).  Returns False where the sharded step does not
+        apply (then nothing changes): d = 3, fp32, one output, native half stencil only."""
+        op = _wtw_ops(self._kernel_cache["WtW"])[0]
+        if (world <= 1 or self.num_outputs != 1 or self._grid.d != 3 or self._dtype != torch.float32 or self._use_dense() or not op.is_half
+                or self._grid.m % 4 or op.root is not None):
+            return False
+        if self.__dict__.get("_stencil_shard") is not None:
+            return True
+        self._finish_pending()
+        lo, hi = grid_ops.shard_groups(self._grid.d, rank, world)
+        ng = (self._grid.R // 7 + 1) // 2
+        flat = op.stencil.reshape(-1)
+        for a, b in grid_ops.half_stencil_group_slices(self._grid, 0, lo) + grid_ops.half_stencil_group_slices(self._grid, hi, ng):
+            flat[a:b].zero_()
+        self.__dict__["_stencil_shard"] = {"rank": rank, "world": world, "allreduce": allreduce, "allreduce_full": allreduce_full or (lambda t: allreduce(t, None)),
+                                           "comm": comm}
+        self.__dict__.pop("_stream_step_cache", None)
+        self._drop_spectral()
+        return True
+
+    def leave_stencil_shard(self):
+        """Collective: sum the disjoint stencil shards back into a full replica on every rank (one all-reduce of the half
+        stencil).  Called automatically by every consumer that reads the stencil outside the sharded streaming step."""
+        sh = self.__dict__.get("_stencil_shard")
+        if sh is None:
+            return
+        self._finish_pending()
+        self.__dict__["_stencil_shard"] = None
+        self.__dict__.pop("_stream_step_cache", None)
+        sh["allreduce_full"](_wtw_ops(self._kernel_cache["WtW"])[0].stencil)
 
     # ------------------------------------------------------ spectral factor --
     def _spectral_state(self, o=0):
@@ -411,6 +452,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         from ..lazy import spectral_woodbury as sw
 
         self._finish_pending()
+        self.leave_stencil_shard()
         ver = self._hyper_version()
         key = (ver, sw.default_tail(self._dtype), settings.spectral_max_rank.value())
         memo = self._memo.setdefault("spectral", {})
@@ -483,6 +525,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         lazy pred_cov operator(s).  The mean solve is warm-started from the
         previous solution (U, Z) after every streaming update."""
         self._finish_pending()
+        self.leave_stencil_shard()                   # whoever asks for the cache may go on to solve with the whole stencil
         self._apply_pending_rank_update()
         pc = self._memo.get("prediction_cache")
         if pc is not None:
@@ -745,6 +788,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         st = self._stream_fast_state(X, Y)
         if st is None:
             self._finish_pending()
+            self.leave_stencil_shard()               # the generic path below reads and writes the whole stencil
             mean = None
             if want_mean:
                 with settings.skip_posterior_variances(True):
@@ -889,7 +933,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         tol = _default_tol(self._dtype)
         c = self._kernel_cache
         # raw device pointers go into the prepared call: key it on every one of them (ids of Python wrappers can be reused)
-        key = (ver, ms["U"].data_ptr(), ms["Z"].data_ptr(), ms["R"].data_ptr(), op.stencil.data_ptr(), c["interpolation_cache"].data_ptr(),
+        sh = self.__dict__.get("_stencil_shard")
+        key = (None if sh is None else (sh["rank"], sh["world"]), ver, ms["U"].data_ptr(), ms["Z"].data_ptr(), ms["R"].data_ptr(), op.stencil.data_ptr(), c["interpolation_cache"].data_ptr(),
                c["_cnt"].data_ptr(), c["_stats"].data_ptr(), self._err.data_ptr(), pst["eig"][0].data_ptr(), str(self._device), tol,
                settings.cg_check_every.value(), settings.max_cg_iterations.value())
         cached = self.__dict__.get("_stream_step_cache")
@@ -899,6 +944,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                                        c["_stats"][0], self._err, ms["U"][0], ms["Z"][0], ms["R"][0], tcol, self._pcg_ws,
                                        settings.max_cg_iterations.value())
             step.set_solver(1.0 / s2, pst["eig"], 0.0, tol, 1)
+            if sh is not None:
+                step.set_shard(sh["rank"], sh["world"], comm=sh.get("comm"), allreduce=sh["allreduce"])
             cached = (key, step)
             self.__dict__["_stream_step_cache"] = cached
         return cached[1], ms, pst

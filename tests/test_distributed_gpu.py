@@ -104,6 +104,84 @@ def _worker_stream_step(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
+def _worker_stencil_shard(rank, world, port, tmpdir):
+    """The work-dividing exchange (wiski_shard): after the all-gather of the shards every rank scatters and
+    multiplies only ITS groups of the half stencil, one m-vector all-reduce per CG iteration completes A p (here through gloo:
+    both ranks share the one GPU).  Checked on every rank: identical CG iteration counts to a single-process model fed the
+    concatenated batches, the same means, and -- after leave_stencil_shard() sums the disjoint shards -- the same statistics."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.distributed import ShardedStatsUpdater
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7)
+    q, steps, n0 = 1024, 6, 3000
+    X = torch.as_tensor(rng.uniform(-1, 1, (n0 + steps * world * q, 3)), device=dev, dtype=torch.float32)
+    y = torch.sin(2 * X[:, :1]) * torch.cos(X[:, 1:2]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=torch.float32)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    ok = True
+    msgs = []
+    with settings.cg_tolerance(1e-5), settings.skip_posterior_variances(True), settings.deferred_refresh(True), settings.deferred_bounds_check(True), torch.no_grad():
+        ref = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], torch.ones_like(y[:n0]), grid_bounds=gb, grid_size=24, learn_additional_noise=True).eval()
+        model = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], torch.ones_like(y[:n0]), grid_bounds=gb, grid_size=24, learn_additional_noise=True).eval()
+        ref.prediction_cache; model.prediction_cache
+        upd = ShardedStatsUpdater(model, equal_shards=True, exchange="stencil")
+        its_ref, its_got = [], []
+        for s in range(steps):
+            lo = n0 + s * world * q
+            mine = slice(lo + rank * q, lo + (rank + 1) * q)
+            want = ref.stream_step(X[lo:lo + world * q], y[lo:lo + world * q])
+            got = upd.stream_step(X[mine], y[mine])
+            ok = ok and got.shape == (q,) and torch.allclose(got, want[rank * q:(rank + 1) * q], rtol=1e-3, atol=2e-4)
+        ref._finish_pending(); model._finish_pending()
+        its_ref, its_got = ref._last_iters, model._last_iters
+        ok = ok and upd.last_exchange == "stencil" and model.__dict__.get("_stencil_shard") is not None
+        ok = ok and model.num_data == ref.num_data == n0 + steps * world * q
+        ok = ok and its_ref == its_got
+        msgs.append(f"iters ref {its_ref} got {its_got}")
+        # this rank's stencil holds its groups only ...
+        lo_g, hi_g = grid_ops.shard_groups(3, rank, world)
+        flat = model._kernel_cache["WtW"].stencil.reshape(-1)
+        reff = ref._kernel_cache["WtW"].stencil.reshape(-1)
+        for a, b in grid_ops.half_stencil_group_slices(model._grid, 0, lo_g) + grid_ops.half_stencil_group_slices(model._grid, hi_g, 25):
+            ok = ok and float(flat[a:b].abs().max()) == 0.0
+        for a, b in grid_ops.half_stencil_group_slices(model._grid, lo_g, hi_g):
+            ok = ok and (flat[a:b] - reff[a:b]).abs().max().item() < 1e-5 * float(reff.abs().max())
+        # ... and the posterior mean is that of the single-process model
+        Xs = X[:64]
+        m1 = grid_ops.gather(model._grid, Xs, model._mean_state["U"], model._err)[:, 0]
+        m2 = grid_ops.gather(ref._grid, Xs, ref._mean_state["U"], ref._err)[:, 0]
+        ok = ok and torch.allclose(m1, m2, rtol=1e-3, atol=2e-4)
+        msgs.append(f"mean dev {(m1 - m2).abs().max().item():.2e}")
+        # a consumer that needs the whole stencil (predictive variances) sums the shards back first (collective)
+        with settings.skip_posterior_variances(False), settings.spectral_factor(False), settings.variance_cg_tolerance(1e-4):
+            v1 = model(Xs[:8]).variance
+            v2 = ref(Xs[:8]).variance
+        ok = ok and model.__dict__.get("_stencil_shard") is None
+        ok = ok and (model._kernel_cache["WtW"].stencil - ref._kernel_cache["WtW"].stencil).abs().max().item() < 1e-5 * float(reff.abs().max())
+        ok = ok and torch.allclose(v1, v2, rtol=1e-2, atol=1e-7)
+        # and the sharded step can be re-entered afterwards
+        lo = n0
+        got = upd.stream_step(X[lo + rank * q:lo + (rank + 1) * q], y[lo + rank * q:lo + (rank + 1) * q])
+        want = ref.stream_step(X[lo:lo + world * q], y[lo:lo + world * q])
+        ok = ok and torch.allclose(got, want[rank * q:(rank + 1) * q], rtol=1e-3, atol=2e-4) and model.__dict__.get("_stencil_shard") is not None
+    open(os.path.join(tmpdir, f"st_{rank}"), "w").write(("1" if ok else "0") + " " + "; ".join(msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stencil_sharded_stream_step_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_stencil_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = open(tmp_path / f"st_{r}").read()
+        assert res.startswith("1"), res
+
+
 def test_sharded_stream_step_world2(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker_stream_step, args=(2, port, str(tmp_path)), nprocs=2, join=True)

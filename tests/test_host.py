@@ -183,3 +183,21 @@ def test_constraints_and_priors_follow_gpytorch_parameterisation():
         RBFKernel(ard_num_dims=2, lengthscale_prio=GammaPrior(3.0, 6.0))
     with pytest.raises(TypeError):
         ScaleKernel(RBFKernel(), outputscale_priors=None, foo=1)
+
+
+def test_stencil_shard_group_arithmetic_is_a_partition():
+    """wiski_shard_groups (pure host arithmetic, no GPU): the ranks' group ranges tile [0, G) without gaps or overlap for
+    every world size, and half_stencil_group_slices maps them onto disjoint element ranges that cover the whole half stencil."""
+    import torch
+
+    from online_gp_amd import grid_ops
+
+    for d, G in ((1, 1), (2, 4), (3, 25), (4, 172)):
+        grid = grid_ops.GridSpec(torch.tensor([[-1.0, 1.0]] * d), 6)
+        for world in (1, 2, 3, 4, 8):
+            ranges = [grid_ops.shard_groups(d, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == G
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            covered = sorted(sl for lo, hi in ranges for sl in grid_ops.half_stencil_group_slices(grid, lo, hi))
+            assert covered[0][0] == 0 and covered[-1][1] == (grid.R + 1) // 2 * grid.m
+            assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
