@@ -48,15 +48,52 @@ def _chol_solve(L, B):
     return torch.linalg.solve_triangular(L.transpose(-1, -2), Y, upper=True)
 
 
+class MultiOutputFantasyPosterior:
+    """Posterior of a batch of fantasy models with several independent outputs (BFN:37-55 carries `num_outputs` as a
+    batch dimension; BoTorch's multi-output convention puts it last): ``mean`` / ``variance`` [*batch, q', out],
+    ``mvn`` batch-first like the model's own eval forward ([out, *batch, q'] / [out, *batch, q', q'])."""
+
+    def __init__(self, mvns):
+        self.mvns = list(mvns)
+        self.mvn = MultivariateNormal(torch.stack([v.mean for v in self.mvns]), torch.stack([v.covariance_matrix for v in self.mvns]))
+
+    @property
+    def mean(self):
+        return torch.stack([v.mean for v in self.mvns], dim=-1)
+
+    @property
+    def variance(self):
+        return torch.stack([v.variance for v in self.mvns], dim=-1)
+
+    @property
+    def device(self):
+        return self.mvns[0].mean.device
+
+    @property
+    def dtype(self):
+        return self.mvns[0].mean.dtype
+
+    def rsample(self, sample_shape=torch.Size(), base_samples=None):
+        return torch.stack([v.rsample(sample_shape) for v in self.mvns], dim=-1)
+
+
 class BatchedFantasyModel:
-    """A batch of conditioned copies of a single-output ``FixedNoiseOnlineSKIGP``.
+    """A batch of conditioned copies of a ``FixedNoiseOnlineSKIGP``.
 
-    ``batch_shape`` = targets.shape[:-1] = [num_fantasies] + inputs.shape[:-2] (or inputs.shape[:-2] when the targets
-    carry no extra leading dimension).  ``posterior(X)`` broadcasts X's leading dimensions against it."""
+    Single output: ``batch_shape`` = targets.shape[:-1] = [num_fantasies] + inputs.shape[:-2] (or inputs.shape[:-2] when
+    the targets carry no extra leading dimension).  Several outputs: targets (and noise) carry them as their LAST
+    dimension, [..., q, out]; the outputs are independent GPs (own statistics, hyper-parameters and noise, BFN:37-55), so
+    the batch is one single-output core per output on that output's posterior, and ``posterior(X)`` returns a
+    :class:`MultiOutputFantasyPosterior`.  ``posterior(X)`` broadcasts X's leading dimensions against the batch."""
 
-    def __init__(self, base, inputs, targets, noise):
-        if base.num_outputs != 1:
-            raise NotImplementedError("batched fantasies are implemented for single-output models")
+    def __new__(cls, base, inputs, targets, noise, _output=None):
+        if base.num_outputs > 1 and _output is None:
+            return object.__new__(_MultiOutputFantasyModel)
+        return object.__new__(cls)
+
+    def __init__(self, base, inputs, targets, noise, _output=None):
+        o = 0 if _output is None else _output
+        self._o = o
         self.base = base
         grid = base._grid
         dt, dev = base._dtype, base._device
@@ -83,9 +120,9 @@ class BatchedFantasyModel:
         self.num_data = base.num_data + q
 
         pc = base.prediction_cache
-        self._post = pc["pred_cov"]
-        self._mu = pc["pred_mean"][0, :, 0].contiguous()                                   # [m]
-        self._sigma2 = base._sigma2(0)
+        self._post = pc["pred_cov"].ops[o] if base.num_outputs > 1 else pc["pred_cov"]
+        self._mu = pc["pred_mean"][o, :, 0].contiguous()                                   # [m]
+        self._sigma2 = base._sigma2(o)
         Xf = X.reshape(-1, grid.d).contiguous()
         W = grid_ops.wt_columns(grid, Xf, base._err)                                       # [Bq, m] dense rows (small grids) ...
         P = self._apply_M(W)                                                               # ... and W M, row by row
@@ -164,3 +201,28 @@ class BatchedFantasyModel:
 
     def train(self, mode=True):
         return self
+
+
+class _MultiOutputFantasyModel(BatchedFantasyModel):
+    """num_outputs > 1: one single-output core per output (see BatchedFantasyModel)."""
+
+    def __init__(self, base, inputs, targets, noise, _output=None):
+        out = base.num_outputs
+        Y = targets
+        if Y.shape[-1] != out:
+            raise RuntimeError(f"multi-output fantasy targets must be [..., q, {out}] (outputs last), got {tuple(Y.shape)}")
+        N = noise
+        if N is not None and (N.dim() == 0 or N.shape[-1] != out):
+            N = N.unsqueeze(-1).expand(N.shape + (out,)) if N.dim() == Y.dim() - 1 else N.expand(Y.shape)
+        self.base = base
+        self.cores = [BatchedFantasyModel(base, inputs, Y[..., o], None if N is None else N[..., o], _output=o) for o in range(out)]
+        c0 = self.cores[0]
+        self.batch_shape, self.input_batch_shape, self.q, self.num_data = c0.batch_shape, c0.input_batch_shape, c0.q, c0.num_data
+        self.train_inputs = c0.train_inputs
+        self.train_targets = torch.stack([c.train_targets for c in self.cores], dim=-1)
+
+    def posterior(self, X, observation_noise=False, **kwargs):
+        return MultiOutputFantasyPosterior([c.posterior(X, observation_noise=observation_noise, **kwargs).mvn for c in self.cores])
+
+    def __call__(self, X):
+        return self.posterior(X).mvn

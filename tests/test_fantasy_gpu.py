@@ -101,3 +101,46 @@ def test_get_fantasy_model_shapes_and_errors():
         xq = torch.rand(6, 2, device=DEV, dtype=torch.float64) * 0.8 + 0.1
         a, bb = one(xq), fbm.posterior(xq).mvn
         assert torch.allclose(a.mean, bb.mean[0], rtol=1e-7, atol=1e-10) and torch.allclose(a.variance, bb.variance[0], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("g,dense", [(8, True), (14, False)])
+def test_multi_output_fantasies_match_per_output_oracle(g, dense):
+    """num_outputs = 2 (the Dirichlet classifier's layout: per-output targets AND per-output fixed noise): a batch of
+    fantasy models with targets [F, b, q, out] equals, output by output, an exact GP re-fitted on that output's data plus
+    the fantasy -- dense factor (8^2) and PCG path (14^3 is past max_cholesky_size)."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    d = 2 if dense else 3
+    rng = np.random.default_rng(4)
+    n, out = 50, 2
+    X = rng.uniform(0, 1, (n, d))
+    Y = np.stack([np.sin(4 * X[:, 0]) * np.cos(3 * X[:, -1]), np.cos(5 * X[:, 0]) + X[:, -1]], axis=1) + 0.05 * rng.standard_normal((n, out))
+    NZ = rng.uniform(0.3, 0.9, (n, out))
+    gb = [[0.0, 1.0]] * d
+    with settings.dense_small_grids(dense), settings.cg_tolerance(1e-11), settings.spectral_factor(False):
+        m = FixedNoiseOnlineSKIGP(torch.as_tensor(X, device=DEV), torch.as_tensor(Y, device=DEV), torch.as_tensor(NZ, device=DEV),
+                                  grid_bounds=torch.tensor(gb, dtype=torch.float64), grid_size=g, learn_additional_noise=True).eval()
+        b, q, F = 2, 3, 2
+        Xc = torch.as_tensor(rng.uniform(0.1, 0.9, (b, q, d)), device=DEV)
+        Yf = torch.as_tensor(rng.standard_normal((F, b, q, out)), device=DEV)
+        Nf = torch.as_tensor(rng.uniform(0.2, 0.6, (b, q, out)), device=DEV)
+        fm = m.get_fantasy_model(Xc, Yf, Nf)
+        assert tuple(fm.batch_shape) == (F, b) and fm.num_data == n + q
+        Xq = torch.as_tensor(rng.uniform(0.05, 0.95, (5, d)), device=DEV)
+        post = fm.posterior(Xq)
+        assert post.mean.shape == (F, b, 5, out) and post.variance.shape == (F, b, 5, out)
+        assert post.mvn.mean.shape == (out, F, b, 5) and post.mvn.covariance_matrix.shape == (out, F, b, 5, 5)
+        k = m.covar_module.base_kernel
+        for o in range(out):
+            ell = k.base_kernel.lengthscale.detach().double().cpu().numpy()[o].reshape(-1)
+            osc = float(k.outputscale.detach().double()[o])
+            s2 = float(m._sigma2(o))
+            for f in range(F):
+                for j in range(b):
+                    Xa = np.concatenate([X, Xc[j].cpu().numpy()]); ya = np.concatenate([Y[:, o], Yf[f, j, :, o].cpu().numpy()])
+                    na = np.concatenate([NZ[:, o], Nf[j, :, o].cpu().numpy()])
+                    O = dataspace.DataSpaceGP(gb, g, "rbf", ell, osc, s2).fit(Xa, ya, na)
+                    mo, co = O.predict(Xq.cpu().numpy(), full_cov=True)
+                    assert np.abs(post.mean[f, j, :, o].cpu().numpy() - mo).max() < 1e-6 * max(np.abs(mo).max(), 1e-2)
+                    assert np.abs(post.mvn.covariance_matrix[o, f, j].cpu().numpy() - co).max() < 1e-6 * np.abs(co).max()
