@@ -328,9 +328,10 @@ int wiski_logdiag_f64(int32_t n, const double* d_A, int32_t lda, double* d_out, 
  * inverse-root pair.  On entry L L^T = A and R^T L = I (R = L^-T), both [m][r] row-major with leading
  * dimensions ldl / ldr; V [m][q] (ldv) holds the new columns (W^T scaled by 1/sqrt(noise), BFN:163-168).  On
  * return L L^T = A + V V^T and R^T L = I.  O(m r q) on the MFMA GEMM through the thin factor of
- * p = R^T V (the reference builds a full r x r U: O(m r^2)); the q x q eigenproblem of p^T p is solved on
- * the host, so the call synchronises the stream.  L differs from the reference's L U S~ by a right orthogonal
- * factor.  d_ws: wiski_root_update_workspace_elems(m, r, q) reals of device scratch. */
+ * p = R^T V (the reference builds a full r x r U: O(m r^2)); the q x q eigenproblem of p^T p is solved on the
+ * device (one-workgroup parallel Jacobi, fp64) for q <= 32 -- the call is then asynchronous on `stream` like every
+ * other entry point -- and on the host beyond (one small copy and a stream synchronisation).  L differs from the
+ * reference's L U S~ by a right orthogonal factor.  d_ws: wiski_root_update_workspace_elems(m, r, q) reals of device scratch. */
 int64_t wiski_root_update_workspace_elems(int32_t m, int32_t r, int32_t q);
 int wiski_root_update_f32(int32_t m, int32_t r, int32_t q, float* d_L, int32_t ldl, float* d_R, int32_t ldr, const float* d_V, int32_t ldv, float* d_ws, int64_t ws_elems, void* stream);
 int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* d_L, int32_t ldl, double* d_R, int32_t ldr, const double* d_V, int32_t ldv, double* d_ws, int64_t ws_elems, void* stream);

@@ -400,6 +400,102 @@ static void jacobi_eigh(int n, std::vector<double>& a, std::vector<double>& v) {
   }
 }
 
+// The same eigenproblem on the device for small q (streaming batches): one workgroup, parallel cyclic Jacobi in fp64 with the
+// round-robin ("tournament") ordering -- n / 2 disjoint rotations per step, n - 1 steps per sweep -- on the q x q Gram matrix
+// in LDS, followed by the coefficient matrix W S^-1 and the two scale vectors root_update_impl needs.  Keeps
+// wiski_root_update asynchronous on the caller's stream for q <= ROOT_JACOBI_MAXQ (the host Jacobi above serves larger q and
+// synchronises: an O(q^3) eigensolve is cheaper on the host than in one workgroup beyond a few dozen columns).
+constexpr int ROOT_JACOBI_MAXQ = 32;
+template <typename real>
+__global__ __launch_bounds__(256) void k_gram_eigh(int q, const real* __restrict__ gram, real* __restrict__ coef, real* __restrict__ sc) {
+  constexpr int N = ROOT_JACOBI_MAXQ;
+  __shared__ double a[N][N + 1], v[N][N + 1], cs[N / 2][2], red[256];
+  __shared__ int pr[N / 2][2];
+  const int t = threadIdx.x;
+  const int n = (q + 1) & ~1;                              // even size: an odd q gets a decoupled dummy row / column
+  for (int e = t; e < N * N; e += 256) {
+    const int i = e / N, j = e % N;
+    a[i][j] = (i < q && j < q) ? 0.5 * ((double)gram[i * q + j] + (double)gram[j * q + i]) : 0.0;
+    v[i][j] = i == j ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int np = n / 2;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    // convergence: off-diagonal mass against the diagonal's
+    double off = 0, dg = 0;
+    for (int e = t; e < n * n; e += 256) {
+      const int i = e / n, j = e % n;
+      const double x = a[i][j] * a[i][j];
+      if (i == j) dg += x; else off += x;
+    }
+    red[t] = off;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+    off = red[0];
+    __syncthreads();
+    red[t] = dg;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+    dg = red[0];
+    __syncthreads();
+    if (off <= 1e-30 * (dg > 0 ? dg : 1.0)) break;
+    for (int step = 0; step < n - 1; ++step) {
+      if (t < np) {                                        // tournament pairing of step `step`
+        int p_, q_;
+        if (t == 0) { p_ = n - 1; q_ = step; }
+        else { p_ = (step + t) % (n - 1); q_ = (step - t + (n - 1)) % (n - 1); }
+        if (p_ > q_) { const int x = p_; p_ = q_; q_ = x; }
+        pr[t][0] = p_; pr[t][1] = q_;
+        const double apq = a[p_][q_];
+        double c = 1.0, sn = 0.0;
+        if (apq != 0.0) {
+          const double theta = (a[q_][q_] - a[p_][p_]) / (2.0 * apq);
+          const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(tt * tt + 1.0);
+          sn = tt * c;
+        }
+        cs[t][0] = c; cs[t][1] = sn;
+      }
+      __syncthreads();
+      for (int e = t; e < np * n; e += 256) {              // columns p, q of A and V (the rotations of a step are disjoint)
+        const int pi = e / n, k = e % n;
+        const int p_ = pr[pi][0], q_ = pr[pi][1];
+        const double c = cs[pi][0], sn = cs[pi][1];
+        const double akp = a[k][p_], akq = a[k][q_];
+        a[k][p_] = c * akp - sn * akq; a[k][q_] = sn * akp + c * akq;
+        const double vkp = v[k][p_], vkq = v[k][q_];
+        v[k][p_] = c * vkp - sn * vkq; v[k][q_] = sn * vkp + c * vkq;
+      }
+      __syncthreads();
+      for (int e = t; e < np * n; e += 256) {              // rows p, q of A
+        const int pi = e / n, k = e % n;
+        const int p_ = pr[pi][0], q_ = pr[pi][1];
+        const double c = cs[pi][0], sn = cs[pi][1];
+        const double apk = a[p_][k], aqk = a[q_][k];
+        a[p_][k] = c * apk - sn * aqk; a[q_][k] = sn * apk + c * aqk;
+      }
+      __syncthreads();
+    }
+  }
+  // coef = W S^-1 (columns of directions with a non-negligible singular value), sc = [sqrt(S^2 + 1) - 1 | 1 / sqrt(S^2 + 1) - 1]
+  red[t] = t < q ? a[t][t] : 0.0;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (t < w) red[t] = red[t] > red[t + w] ? red[t] : red[t + w]; __syncthreads(); }
+  const double smax = red[0] > 1e-300 ? red[0] : 1e-300;
+  for (int e = t; e < q * q; e += 256) {
+    const int i = e / q, j = e % q;
+    const double s2 = a[j][j];
+    coef[e] = s2 > 1e-14 * smax ? (real)(v[i][j] / sqrt(s2)) : (real)0;
+  }
+  if (t < q) {
+    const double s2 = a[t][t];
+    const bool keep = s2 > 1e-14 * smax;
+    const double sp = sqrt(s2 + 1.0);
+    sc[t] = keep ? (real)(sp - 1.0) : (real)0;
+    sc[q + t] = keep ? (real)(1.0 / sp - 1.0) : (real)0;
+  }
+}
+
 template <typename real>
 __global__ __launch_bounds__(256) void k_scale_cols(int rows, int cols, real* __restrict__ X, int ldx, const real* __restrict__ sc) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,7 +519,13 @@ static int root_update_impl(int m, int r, int q, real* d_L, int ldl, real* d_R, 
   if (rc) return rc;
   rc = launch_gemm<real>(1, 0, q, q, r, (real)1, p, q, p, q, (real)0, gram, q, s);                       // p^T p
   if (rc) return rc;
-  std::vector<real> hg((size_t)q * q);
+  const bool on_device = q <= ROOT_JACOBI_MAXQ;           // small batches: eigenproblem on the device, the call stays asynchronous
+  if (on_device) {
+    hipLaunchKernelGGL((k_gram_eigh<real>), dim3(1), dim3(256), 0, s, q, (const real*)gram, coef, sc);
+    if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
+  }
+  std::vector<real> hg((size_t)(on_device ? 0 : q) * q);
+  if (!on_device) {
   if (hipMemcpyAsync(hg.data(), gram, sizeof(real) * q * q, hipMemcpyDeviceToHost, s) != hipSuccess) return WISKI_E_LAUNCH;
   if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;
   std::vector<double> a((size_t)q * q), vec;
@@ -444,6 +546,8 @@ static int root_update_impl(int m, int r, int q, real* d_L, int ldl, real* d_R, 
   }
   if (hipMemcpyAsync(coef, hcoef.data(), sizeof(real) * q * q, hipMemcpyHostToDevice, s) != hipSuccess) return WISKI_E_LAUNCH;
   if (hipMemcpyAsync(sc, hsc.data(), sizeof(real) * 2 * q, hipMemcpyHostToDevice, s) != hipSuccess) return WISKI_E_LAUNCH;
+  if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;     // the host staging buffers go out of scope at the brace
+  }
   rc = launch_gemm<real>(0, 0, r, q, q, (real)1, p, q, coef, q, (real)0, Uq, q, s);                      // U_q = p W S^-1 (orthonormal columns)
   if (rc) return rc;
   const unsigned blocks = (unsigned)(((int64_t)m * q + 255) / 256);
@@ -456,7 +560,6 @@ static int root_update_impl(int m, int r, int q, real* d_L, int ldl, real* d_R, 
     rc = launch_gemm<real>(0, 1, m, r, q, (real)1, T, q, Uq, q, (real)1, X, ldx, s);                     // X += (X U_q) diag(.) U_q^T
     if (rc) return rc;
   }
-  if (hipStreamSynchronize(s) != hipSuccess) return WISKI_E_LAUNCH;     // the host staging buffers above go out of scope
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 

@@ -111,6 +111,69 @@ class MaternKernel(Kernel):
         return (1.0 + s + s * s / 3.0) * torch.exp(-s)
 
 
+class SpectralMixtureKernel(Kernel):
+    """gpytorch.kernels.SpectralMixtureKernel (the covariance of the reference's 1-D notebook,
+    notebooks/regression_viz_1D.ipynb: ``SpectralMixtureKernel(num_mixtures=3)`` handed to ``OnlineSKIRegression``):
+
+        k(tau) = sum_q w_q  prod_dims exp(-2 pi^2 tau_d^2 s_qd^2) cos(2 pi tau_d mu_qd)
+
+    with ``mixture_weights`` w [Q], ``mixture_means`` mu [Q, 1, d], ``mixture_scales`` s [Q, 1, d], all positive (softplus
+    of raw parameters initialised at 0, as upstream).  On an inducing grid gpytorch evaluates it per dimension
+    (``last_dim_is_batch``) and multiplies the per-dimension Toeplitz factors, so the column of dimension d is
+    sum_q w_q exp(-2 pi^2 tau^2 s_qd^2) cos(2 pi tau mu_qd) -- a sum over mixtures inside every factor, which is what
+    ``lag_column`` returns.  Not of the k(r / lengthscale) form: it has no ``lengthscale`` and no ``profile``."""
+
+    has_lengthscale = False
+
+    def __init__(self, num_mixtures=None, ard_num_dims=1, batch_shape=torch.Size([]), mixture_scales_constraint=None,
+                 mixture_means_constraint=None, mixture_weights_constraint=None, **kwargs):
+        if num_mixtures is None:
+            raise RuntimeError("num_mixtures is a required argument")
+        super().__init__(ard_num_dims=ard_num_dims, batch_shape=batch_shape, **kwargs)
+        self.num_mixtures = int(num_mixtures)
+        nd = 1 if ard_num_dims is None else int(ard_num_dims)
+        bs = self.batch_shape
+        self.register_parameter("raw_mixture_weights", torch.nn.Parameter(torch.zeros(bs + torch.Size([self.num_mixtures]))))
+        self.register_parameter("raw_mixture_means", torch.nn.Parameter(torch.zeros(bs + torch.Size([self.num_mixtures, 1, nd]))))
+        self.register_parameter("raw_mixture_scales", torch.nn.Parameter(torch.zeros(bs + torch.Size([self.num_mixtures, 1, nd]))))
+        self.raw_mixture_weights_constraint = mixture_weights_constraint if mixture_weights_constraint is not None else Positive()
+        self.raw_mixture_means_constraint = mixture_means_constraint if mixture_means_constraint is not None else Positive()
+        self.raw_mixture_scales_constraint = mixture_scales_constraint if mixture_scales_constraint is not None else Positive()
+
+    def _get(self, name):
+        return getattr(self, f"raw_{name}_constraint").transform(getattr(self, f"raw_{name}"))
+
+    def _set(self, name, value):
+        raw = getattr(self, f"raw_{name}")
+        v = torch.as_tensor(value, dtype=torch.float64).expand(raw.shape)
+        with torch.no_grad():
+            raw.copy_(getattr(self, f"raw_{name}_constraint").inverse_transform(v).to(raw))
+
+    mixture_weights = property(lambda self: self._get("mixture_weights"), lambda self, v: self._set("mixture_weights", v))
+    mixture_means = property(lambda self: self._get("mixture_means"), lambda self, v: self._set("mixture_means", v))
+    mixture_scales = property(lambda self: self._get("mixture_scales"), lambda self, v: self._set("mixture_scales", v))
+
+    def _params(self, batch_index):
+        w, mu, sc = self.mixture_weights, self.mixture_means, self.mixture_scales
+        if batch_index is not None and w.dim() > 1:
+            w, mu, sc = w[batch_index], mu[batch_index], sc[batch_index]
+        return w.double(), mu[:, 0, :].double(), sc[:, 0, :].double()          # [Q], [Q, d], [Q, d]
+
+    def lag_column(self, dim, lags, batch_index=None):
+        w, mu, sc = self._params(batch_index)
+        dq = dim if mu.shape[1] > 1 else 0
+        tau = lags.double()[None, :]                                             # [1, g]
+        terms = torch.exp(-2.0 * math.pi ** 2 * (tau * sc[:, dq:dq + 1]) ** 2) * torch.cos(2.0 * math.pi * tau * mu[:, dq:dq + 1])
+        return (w[:, None] * terms).sum(0)
+
+    def lag_columns_cat(self, lags_cat, dim_index, batch_index=None):
+        w, mu, sc = self._params(batch_index)
+        di = dim_index if mu.shape[1] > 1 else torch.zeros_like(dim_index)
+        tau = lags_cat.double()[None, :]
+        terms = torch.exp(-2.0 * math.pi ** 2 * (tau * sc[:, di]) ** 2) * torch.cos(2.0 * math.pi * tau * mu[:, di])
+        return (w[:, None] * terms).sum(0)
+
+
 class ScaleKernel(Kernel):
     def __init__(self, base_kernel, batch_shape=torch.Size([]), outputscale_prior=None, outputscale_constraint=None, **kwargs):
         super().__init__(batch_shape=batch_shape, **kwargs)
@@ -147,7 +210,7 @@ def _native_stationary(kernel):
     """Scale(...(RBF | Matern)) chains of this module: their columns have the closed form used by lag_columns_cat."""
     while isinstance(kernel, ScaleKernel):
         kernel = kernel.base_kernel
-    return type(kernel) in (RBFKernel, MaternKernel)
+    return type(kernel) in (RBFKernel, MaternKernel, SpectralMixtureKernel)
 
 
 def _lag_column_any(kernel, dim, lags, num_dims, batch_index=None):

@@ -17,10 +17,11 @@ from . import spec
 
 class DataSpaceGP:
     def __init__(self, grid_bounds, grid_size, kind="rbf", lengthscale=spec.SOFTPLUS0,
-                 outputscale=spec.SOFTPLUS0, sigma2=1.0):
+                 outputscale=spec.SOFTPLUS0, sigma2=1.0, cols=None):
         self.g0, self.h, self.g = spec.make_grid(grid_bounds, grid_size)
         self.d = len(self.g)
-        self.cols = spec.toeplitz_columns(kind, self.h, self.g, lengthscale, outputscale)
+        # cols: explicit Toeplitz columns per dim (kernels that are not of the k(r / lengthscale) form, e.g. the spectral mixture)
+        self.cols = cols if cols is not None else spec.toeplitz_columns(kind, self.h, self.g, lengthscale, outputscale)
         self.Kd = [sla.toeplitz(c) for c in self.cols]
         self.sigma2 = float(sigma2)
 

@@ -83,3 +83,19 @@ def interp_1d_dense(x, g0, h, g):
         else:
             Wd[p, j0[p]:j0[p] + 4] = w[p]
     return Wd
+
+
+def spectral_mixture_columns(h, g, weights, means, scales):
+    """First columns of the per-dim Toeplitz factors of gpytorch's SpectralMixtureKernel on the inducing grid
+    (restated from its published formula; the reference's 1-D notebook, notebooks/regression_viz_1D.ipynb, uses
+    ``SpectralMixtureKernel(num_mixtures=3)``): column_d(tau) = sum_q w_q exp(-2 pi^2 tau^2 s_qd^2) cos(2 pi tau mu_qd).
+    weights [Q]; means, scales [Q, d] (or [Q, 1], shared by the dims)."""
+    w = np.asarray(weights, dtype=np.float64).reshape(-1)
+    mu = np.asarray(means, dtype=np.float64).reshape(len(w), -1)
+    sc = np.asarray(scales, dtype=np.float64).reshape(len(w), -1)
+    cols = []
+    for i in range(len(g)):
+        tau = np.arange(int(g[i]), dtype=np.float64) * h[i]
+        dq = i if mu.shape[1] > 1 else 0
+        cols.append((w[:, None] * np.exp(-2.0 * np.pi ** 2 * (tau[None] * sc[:, dq:dq + 1]) ** 2) * np.cos(2.0 * np.pi * tau[None] * mu[:, dq:dq + 1])).sum(0))
+    return cols

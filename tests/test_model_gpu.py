@@ -676,3 +676,46 @@ def test_deferred_stream_of_random_batch_sizes_matches_a_rebuilt_model(dtype, to
         assert float((pa - pc).abs().max()) <= tol * float(pc.abs().max())
         sa, sc = a._kernel_cache["_stats"], c._kernel_cache["_stats"]
         assert torch.allclose(sa, sc, rtol=1e-5 if dtype == torch.float32 else 1e-11)
+
+
+def test_c1_notebook_setup_with_the_spectral_mixture_kernel():
+    """BASELINE config 1 as the reference's notebook builds it (notebooks/regression_viz_1D.ipynb cell 22:
+    ``OnlineSKIRegression(stem, init_x, init_y, lr=1e-1, grid_size=12, grid_bound=1, covar_module=SpectralMixtureKernel(3))``):
+    streamed predictions equal the data-space oracle on the same spectral-mixture Toeplitz column, and fit() moves the
+    mixture parameters downhill."""
+    from online_gp_amd.kernels import SpectralMixtureKernel
+    from online_gp_amd.models import Identity, OnlineSKIRegression
+
+    rng = np.random.default_rng(0)
+    x = np.linspace(-1, 1, 39); y = np.sin(4 * x) + 0.4 * rng.standard_normal(39)
+    perm = rng.permutation(39)
+    x, y = x[perm], y[perm]
+    Xt = torch.as_tensor(x, device=DEV)[:, None]; yt = torch.as_tensor(y, device=DEV)[:, None]
+    sm = SpectralMixtureKernel(num_mixtures=3)
+    sm.mixture_weights = [0.6, 0.3, 0.1]
+    sm.mixture_means = torch.tensor([[[0.3]], [[0.7]], [[1.4]]])
+    sm.mixture_scales = torch.tensor([[[0.2]], [[0.4]], [[0.8]]])
+    reg = OnlineSKIRegression(Identity(1), Xt[:10], yt[:10], 1e-1, 12, 1, covar_module=sm)
+    for t in range(10, 39):
+        reg.update(Xt[t:t + 1], yt[t:t + 1], update_stem=False, update_gp=False)     # hyper-parameters held: pure streaming
+    s2 = float(reg.gp.likelihood.second_noise.detach())
+    g0, h, g = spec.make_grid([[-1.1, 1.1]], 12)
+    w = sm.mixture_weights.detach().double().cpu().numpy(); mu = sm.mixture_means.detach().double().cpu().numpy().reshape(3, 1)
+    sc = sm.mixture_scales.detach().double().cpu().numpy().reshape(3, 1)
+    O = dataspace.DataSpaceGP([[-1.1, 1.1]], 12, sigma2=s2, cols=spec.spectral_mixture_columns(h, g, w, mu, sc)).fit(x[:, None], y, np.ones(39))
+    xs = np.linspace(-0.95, 0.95, 17)
+    mo, vo = O.predict(xs[:, None])
+    mean, var = reg.predict(torch.as_tensor(xs, device=DEV)[:, None])
+    assert np.abs(mean[:, 0].detach().cpu().numpy() - mo).max() < 1e-6 * np.abs(mo).max()
+    assert np.abs(var[:, 0].detach().cpu().numpy() - (vo + s2)).max() < 1e-6 * (vo + s2).max()
+    # the notebook's pre-training: the MLL gradient reaches the mixture parameters
+    before = [p.detach().clone() for p in sm.parameters()]
+    recs = reg.fit(Xt[:10], yt[:10], 15)
+    assert recs[-1]["train_loss"] < recs[0]["train_loss"]
+    assert any((p.detach() - b).abs().max() > 1e-3 for p, b in zip(sm.parameters(), before))
+    # updates with hyper-parameter steps run (the notebook's online loop)
+    reg.set_lr(1e-2)
+    for t in range(10, 14):
+        reg.update(Xt[t:t + 1], yt[t:t + 1])
+    m2, v2 = reg.predict(torch.as_tensor(xs, device=DEV)[:, None])
+    assert torch.isfinite(m2).all() and (v2 > 0).all()
