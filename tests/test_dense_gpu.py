@@ -275,3 +275,25 @@ def test_root_pair_is_dropped_when_the_stencil_is_rebuilt_or_all_reduced():
     model._absorb(model._kernel_cache, X[:8], y[:8], torch.ones_like(y[:8]), init=False, half_delta=halves)
     assert op.root is None
     halves[0].zero_()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("q", [1, 7, 32, 40])
+def test_root_update_device_and_host_eigensolve(dtype, tol, q):
+    """wiski_root_update for batch sizes on both sides of the device-Jacobi limit (q <= 32: one-workgroup parallel Jacobi,
+    asynchronous; beyond: host Jacobi), including odd q and a rank-deficient V."""
+    from online_gp_amd import grid_ops
+
+    g = torch.Generator(device="cpu").manual_seed(q)
+    m = 96
+    Rm = torch.randn(m, m, generator=g, dtype=torch.float64)
+    A = Rm @ Rm.t() / m + torch.eye(m, dtype=torch.float64)
+    L0 = torch.linalg.cholesky(A)
+    V = torch.randn(m, q, generator=g, dtype=torch.float64)
+    if q >= 7:
+        V[:, -1] = V[:, 0] + V[:, 1]                        # a direction already spanned by the others
+    L = L0.to(DEV, dtype).contiguous(); R = torch.linalg.inv(L0).t().to(DEV, dtype).contiguous(); Vd = V.to(DEV, dtype).contiguous()
+    grid_ops.root_update_(L, R, Vd)
+    want = A + V @ V.t()
+    assert ((L @ L.t()).double().cpu() - want).abs().max() < tol * want.abs().max()
+    assert ((R.t() @ L).double().cpu() - torch.eye(m, dtype=torch.float64)).abs().max() < 50 * tol
