@@ -827,6 +827,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 }
 
 #include "spmv_sym_dma.h"
+#include "spmv_sym_dma_mc.h"
 #include "spmm_sym_cols.h"
 
 // Which wide half-stencil kernel serves (G, k): the LDS-DMA pipelined one (d = 3, fp32, one right-hand side; 4 chunks)
@@ -863,9 +864,25 @@ static inline bool sym_use_cols(int k) {
   return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 240 us at k = 64 (670)
 }
 static inline int spmmc_kp(int k) { return (k + 15) / 16 * 16; }
+// A few right-hand sides (2 <= k < 32; d = 3, fp32): the multi-column LDS-DMA kernel (spmv_sym_dma_mc.h), 4 (2) columns per pass
+// over A_h with the built-in 4-part split.  WISKI_SYM_DMA_MC=0 falls back to the LDS-window kernel.
+static int g_sym_dma_mc = -1;
+template <typename real>
+static inline bool sym_use_dma_mc(const GridDev<real>& G, int k) {
+  if constexpr (sizeof(real) != 4) return false;
+  if (g_sym_dma_mc < 0) {
+    const char* e = getenv("WISKI_SYM_DMA_MC");
+    g_sym_dma_mc = e ? atoi(e) : 1;
+  }
+  return g_sym_dma_mc != 0 && G.d == 3 && k >= 2 && !sym_use_cols(k) && (G.m % 4) == 0 && G.g[2] >= 4 &&
+         symdma_mc_lds_bytes(G.g[2], k >= 4 ? 4 : 2) <= 64 * 1024;
+}
 // number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
 template <typename real>
-static inline int sym_nch(const GridDev<real>& G, int k) { return sym_use_dma<real>(G, k) ? g_sym_dma_parts : sym_nch_lds(G.d); }
+static inline int sym_nch(const GridDev<real>& G, int k) {
+  if (sym_use_dma<real>(G, k)) return g_sym_dma_parts;
+  return sym_use_dma_mc<real>(G, k) ? 4 : sym_nch_lds(G.d);
+}
 // total number of partial vectors the consumers of launch_spmv4_sym have to sum, and whether the last one is the
 // atomically accumulated one (to be re-zeroed once consumed)
 template <typename real>
@@ -967,6 +984,28 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         if (dots) SYMDMA(2, true); else SYMDMA(2, false);
       }
 #undef SYMDMA
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
+  }
+  if constexpr (sizeof(real) == 4) {
+    if (sym_use_dma_mc<real>(G, k)) {
+      const int kc = k >= 4 ? 4 : 2;
+      const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
+      const size_t sh = symdma_mc_lds_bytes(G.g[2], kc);
+      dim3 grd((unsigned)((G.m + 255) / 256), 4u, (unsigned)((k + kc - 1) / kc));
+#define SYMDMAMC(KC, DOT)                                                                                                          \
+  do {                                                                                                                             \
+    static size_t lds_set = 0;                                                                                                     \
+    if (sh > 48 * 1024 && sh > lds_set) {                                                                                          \
+      if (hipFuncSetAttribute((const void*)k_spmv_sym_dma_mc<KC, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) \
+        return WISKI_E_LAUNCH;                                                                                                     \
+      lds_set = sh;                                                                                                                \
+    }                                                                                                                              \
+    launch_timed(k_spmv_sym_dma_mc<KC, DOT>, grd, dim3(64), sh, s, G, A_h, V, k, W4, WP, part, add, beta, dots);                   \
+  } while (0)
+      if (kc == 4) { if (dots) SYMDMAMC(4, true); else SYMDMAMC(4, false); }
+      else { if (dots) SYMDMAMC(2, true); else SYMDMAMC(2, false); }
+#undef SYMDMAMC
       return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
     }
   }

@@ -27,6 +27,15 @@ class num_trace_samples(settings._value_context):
     _global_value = 10
 
 
+class fixed_trace_probes(settings._feature_flag):
+    """Matrix-free MLL: keep the Rademacher probe vectors of the trace estimator fixed from step to step (a sample-average
+    objective: the same probes score every hyper-parameter setting) and warm-start their solves from the previous step's
+    solutions -- streaming steps change (A, hyper-parameters) a little at a time, so the probe solves then cost 2-3 CG
+    iterations instead of a cold solve each.  Off: fresh probes seeded by the data count, cold solves (gpytorch's habit)."""
+
+    _state = True
+
+
 class _WoodburyTerms(torch.autograd.Function):
     """(b^T M b, logdet(I + Kt A)) as a differentiable function of (tcol, kappa = 1/sigma2)."""
 
@@ -77,24 +86,47 @@ class _WoodburyTerms(torch.autograd.Function):
         tol = settings.cg_tolerance.value() or (1e-7 if dt == torch.float32 else 1e-11)
         kw = dict(tol=tol, max_iter=settings.max_cg_iterations.value(), check_every=settings.cg_check_every.value(), workspace=model._pcg_ws,
                   eigen=peig, shift=shift)
-        # warm start from the last posterior mean: keep the pre-image z, re-derive u = Kt_new z
-        U0 = Z0 = None
         ms = model._mean_state
-        if ms is not None:
-            Z0 = ms["Z"][o:o + 1].clone()
-            U0 = grid_ops.kron_toeplitz_mm(grid, tcol, Z0, kap)
-        U, Z, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, b[None], U=U0, Z=Z0, warm=U0 is not None, **kw)
-        bMb = (b.double() * U[0].double()).sum()
-        # probes for tr(S dKt): Rademacher (Hutchinson)
-        gen = torch.Generator(device=dev).manual_seed(0x5EED + model.num_data)
-        E = torch.randint(0, 2, (num_trace_samples.value(), m), generator=gen, device=dev).to(dt) * 2 - 1
-        P = E.shape[0]
-        S_cols = torch.empty_like(E)
+        P = num_trace_samples.value()
         chunk = settings.variance_chunk.value()
-        for s in range(0, P, chunk):
-            rhs = grid_ops.stencil_spmv(grid, A.stencil, E[s:s + chunk])
-            _, Zs, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, rhs, **kw)
-            S_cols[s:s + chunk] = Zs
+        if fixed_trace_probes.on() and P + 1 <= chunk:
+            # ONE multi-column solve per step: column 0 is the mean (rhs b, warm-started from the last posterior mean),
+            # columns 1..P the trace probes (rhs A e_j, FIXED e_j, warm-started from the previous step's solutions: keep
+            # the pre-images z, re-derive u = Kt_new z).  The k = P + 1 products read A_h once per 4 columns.
+            ps = model.__dict__.get("_mll_probes", {}).get(o)
+            if ps is None or ps["E"].shape != (P, m) or ps["E"].dtype != dt or ps["E"].device != dev:
+                gen = torch.Generator(device=dev).manual_seed(0x5EED + o)
+                E = torch.randint(0, 2, (P, m), generator=gen, device=dev).to(dt) * 2 - 1
+                ps = {"E": E, "Z": None}
+                model.__dict__.setdefault("_mll_probes", {})[o] = ps
+            E = ps["E"]
+            RHS = torch.cat([b[None], grid_ops.stencil_spmv(grid, A.stencil, E)])
+            warm = ms is not None and ps["Z"] is not None
+            U0 = Z0 = None
+            if warm:
+                Z0 = torch.cat([ms["Z"][o:o + 1], ps["Z"]])
+                U0 = grid_ops.kron_toeplitz_mm(grid, tcol, Z0, kap)
+            Uall, Zall, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, RHS, U=U0, Z=Z0, warm=warm, **kw)
+            U, Z = Uall[:1], Zall[:1]
+            S_cols = Zall[1:].clone()
+            ps["Z"] = S_cols
+        else:
+            # warm start from the last posterior mean: keep the pre-image z, re-derive u = Kt_new z
+            U0 = Z0 = None
+            if ms is not None:
+                Z0 = ms["Z"][o:o + 1].clone()
+                U0 = grid_ops.kron_toeplitz_mm(grid, tcol, Z0, kap)
+            U, Z, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, b[None], U=U0, Z=Z0, warm=U0 is not None, **kw)
+            # probes for tr(S dKt): Rademacher (Hutchinson), fresh per data count
+            gen = torch.Generator(device=dev).manual_seed(0x5EED + model.num_data)
+            E = torch.randint(0, 2, (P, m), generator=gen, device=dev).to(dt) * 2 - 1
+            S_cols = torch.empty_like(E)
+            for s in range(0, P, chunk):
+                rhs = grid_ops.stencil_spmv(grid, A.stencil, E[s:s + chunk])
+                _, Zs, _, _ = grid_ops.pcg(grid, A.stencil, tcol, kap, rhs, **kw)
+                S_cols[s:s + chunk] = Zs
+        bMb = (b.double() * U[0].double()).sum()
+        P = E.shape[0]
         logdet = torch.zeros((), dtype=torch.float64, device=dev)
         if want_logdet:
             logdet = _logdet_value(grid, A, eig, kap, E, False)

@@ -90,7 +90,33 @@ def test_mll_stochastic_trace_and_slq_on_a_larger_grid():
     m = FixedNoiseOnlineSKIGP(Xt, yt, None, grid_bounds=torch.tensor([[-1.1, 1.1]] * 3), grid_size=10, learn_additional_noise=True)
     mll = BatchedWoodburyMarginalLogLikelihood(m.likelihood, m)
     m.train()
-    with num_trace_samples(64), settings.dense_small_grids(False):
+    with num_trace_samples(64), settings.dense_small_grids(False), settings.spectral_factor(False):
+        v = mll(m(Xt), yt)
+        v.backward()
+        # fixed probes + warm starts: a second step after a streamed batch re-uses the probe vectors and starts their solves
+        # from the first step's solutions; its gradient is compared with the exact (dense) one on the same statistics
+        with num_trace_samples(48):
+            for p_ in m.parameters():
+                p_.grad = None
+            mll(m(Xt), yt).backward()
+            Z_first = m._mll_probes[0]["Z"].clone()
+            m.condition_on_observations(Xt[:20] * 0.9, yt[:20], None, inplace=True)
+            for p_ in m.parameters():
+                p_.grad = None
+            mll(m(Xt), yt).backward()
+            g_second = m.covar_module.base_kernel.base_kernel.raw_lengthscale.grad.clone()
+            assert m._mll_probes[0]["Z"].shape == (48, 1000) and not torch.equal(m._mll_probes[0]["Z"], Z_first)
+        with settings.dense_small_grids(True):
+            for p_ in m.parameters():
+                p_.grad = None
+            m.zero_grad()
+            mll(m(Xt), yt).backward()
+            g_second_dense = m.covar_module.base_kernel.base_kernel.raw_lengthscale.grad.clone()
+        assert torch.isfinite(g_second).all() and (g_second - g_second_dense).abs().max() < 0.35 * g_second_dense.abs().max()
+        m.set_train_data(Xt, yt, torch.ones_like(yt))           # back to the original statistics for the comparisons below
+        m.train()
+        for p_ in m.parameters():
+            p_.grad = None
         v = mll(m(Xt), yt)
         v.backward()
     g_stoch = m.covar_module.base_kernel.base_kernel.raw_lengthscale.grad.clone()
