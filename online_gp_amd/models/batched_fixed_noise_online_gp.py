@@ -978,7 +978,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self.__dict__["_profile_look"] = (host, ev, float(self._wsum[0]), margs)
             return True
         host, ev, wsum_then, _ = look
-        if not ev.query():
+        if self.__dict__.get("_stencil_shard") is not None:
+            ev.synchronize()                              # sharded replicas must all read the verdict at the SAME step (control flow
+        elif not ev.query():                              # that depends on copy timing would let the ranks' collectives diverge)
             return True                                   # still in flight
         self.__dict__["_profile_look"] = None
         margs = host.numpy()
