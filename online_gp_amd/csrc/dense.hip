@@ -10,6 +10,8 @@
 #include "wiski_common.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -117,10 +119,155 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, real alpha, c
       }
 }
 
+// Large products (round 3): 128 x 128 block tile, 4 waves each computing a 64 x 64 sub-tile as 4 x 4 MFMA tiles (16 MFMAs per
+// 8 LDS operand reads), K tile BK = 32 (fp32) / 16 (fp64) -- 64 MFMAs = 2048 / 4096 matrix-core cycles per wave and tile --
+// with the NEXT K tile's global loads in flight in registers while the current one is in the matrix cores (one LDS buffer,
+// register prefetch): the 64 x 64 kernel above stages, waits, computes 16 MFMAs and waits again.  LDS rows are k-major with
+// a stride of 144 reals (= 16 mod 32 banks): the 16-lane groups of an operand read fall on disjoint banks.
+// Global loads are 16-byte vectors where a tile is interior and the leading dimension allows it, scalar and predicated at the
+// edges.  Used from 128 x 128 outputs with >= 2 * (number of CUs) ... see launch_gemm.
+constexpr int G2M = 128, G2N = 128, G2LD = 144;
+template <typename real> struct G2K { static constexpr int value = sizeof(real) == 4 ? 32 : 16; };
+
+template <typename real, bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm128(int M, int N, int K, real alpha, const real* __restrict__ A, int lda, const real* __restrict__ B,
+                                                 int ldb, real beta, real* __restrict__ C, int ldc) {
+  constexpr int BK = G2K<real>::value, EPT = BK / 2;      // elements per thread and operand tile
+  constexpr int VW = 16 / (int)sizeof(real);              // reals per 16-byte vector
+  __shared__ real sA[BK][G2LD];
+  __shared__ real sB[BK][G2LD];
+  using acc_t = typename Acc4<real>::type;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int m0 = blockIdx.y * G2M, n0 = blockIdx.x * G2N;
+  acc_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = (real)0;
+
+  // operand tile X (128 along `long`, BK along k) from a row-major matrix P:
+  //   ALONG_K = true : P[(l0 + l) * ld + (k0 + k)]   (contiguous along k): thread -> l = tid >> 1, k in [(tid & 1) * EPT, + EPT)
+  //   ALONG_K = false: P[(k0 + k) * ld + (l0 + l)]   (contiguous along l): thread -> k = tid / (256 / BK), l in [(tid % (256 / BK)) * EPT, + EPT)
+  auto fetch = [&](auto along_k_tag, const real* __restrict__ P, int ld, int l0, int L, int k0, real (&reg)[EPT]) {
+    constexpr bool ALONG_K = decltype(along_k_tag)::value;
+    if constexpr (ALONG_K) {
+      const int l = tid >> 1, kb = (tid & 1) * EPT;
+      const int gl = l0 + l, gk = k0 + kb;
+      const real* __restrict__ src = P + (int64_t)gl * ld + gk;
+      if (gl < L && gk + EPT <= K && (ld % VW) == 0 && ((uintptr_t)P % 16) == 0) {
+#pragma unroll
+        for (int u = 0; u < EPT; u += VW) {
+          if constexpr (VW == 4) { const float4 v = *reinterpret_cast<const float4*>(src + u); reg[u] = v.x; reg[u + 1] = v.y; reg[u + 2] = v.z; reg[u + 3] = v.w; }
+          else { const double2 v = *reinterpret_cast<const double2*>(src + u); reg[u] = v.x; reg[u + 1] = v.y; }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) reg[u] = (gl < L && gk + u < K) ? src[u] : (real)0;
+      }
+    } else {
+      constexpr int TPR = 256 / BK;
+      const int k = tid / TPR, lb = (tid % TPR) * EPT;
+      const int gk = k0 + k, gl = l0 + lb;
+      const real* __restrict__ src = P + (int64_t)gk * ld + gl;
+      if (gk < K && gl + EPT <= L && (ld % VW) == 0 && ((uintptr_t)P % 16) == 0) {
+#pragma unroll
+        for (int u = 0; u < EPT; u += VW) {
+          if constexpr (VW == 4) { const float4 v = *reinterpret_cast<const float4*>(src + u); reg[u] = v.x; reg[u + 1] = v.y; reg[u + 2] = v.z; reg[u + 3] = v.w; }
+          else { const double2 v = *reinterpret_cast<const double2*>(src + u); reg[u] = v.x; reg[u + 1] = v.y; }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) reg[u] = (gk < K && gl + u < L) ? src[u] : (real)0;
+      }
+    }
+  };
+  auto stash = [&](auto along_k_tag, real (*S)[G2LD], const real (&reg)[EPT]) {
+    constexpr bool ALONG_K = decltype(along_k_tag)::value;
+    if constexpr (ALONG_K) {
+      const int l = tid >> 1, kb = (tid & 1) * EPT;
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) S[kb + u][l] = reg[u];
+    } else {
+      constexpr int TPR = 256 / BK;
+      const int k = tid / TPR, lb = (tid % TPR) * EPT;
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) S[k][lb + u] = reg[u];
+    }
+  };
+  using AK = std::integral_constant<bool, !TA>;           // op(A)[i][k]: A row-major [M][K] is contiguous along k unless transposed
+  using BKt = std::integral_constant<bool, TB>;           // op(B)[k][j]: B row-major [K][N] is contiguous along j unless transposed
+  real ra[EPT], rb[EPT];
+  fetch(AK{}, A, lda, m0, M, 0, ra);
+  fetch(BKt{}, B, ldb, n0, N, 0, rb);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();                                      // everybody is done reading the previous tile
+    stash(AK{}, sA, ra);
+    stash(BKt{}, sB, rb);
+    __syncthreads();
+    if (k0 + BK < K) {                                    // the next tile's loads fly while this one is in the matrix cores
+      fetch(AK{}, A, lda, m0, M, k0 + BK, ra);
+      fetch(BKt{}, B, ldb, n0, N, k0 + BK, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      real af[4], bf[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = sA[ks + (lane >> 4)][wr * 64 + a * 16 + (lane & 15)];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = sB[ks + (lane >> 4)][wc * 64 + b * 16 + (lane & 15)];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = m0 + wr * 64 + a * 16 + frag_row<real>(lane, r);
+        const int gj = n0 + wc * 64 + b * 16 + (lane & 15);
+        if (gi < M && gj < N) {
+          const int64_t e = (int64_t)gi * ldc + gj;
+          const real v = alpha * acc[a][b][r];
+          C[e] = beta == (real)0 ? v : v + beta * C[e];
+        }
+      }
+}
+
+static int gemm128_min_blocks() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WISKI_GEMM128_MIN_BLOCKS");    // 0 disables the large-tile kernel (A/B hook for tools/bench_dense.py)
+    v = e ? atoi(e) : 128;
+  }
+  return v;
+}
+
 template <typename real>
 static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const real* A, int lda, const real* B, int ldb, real beta, real* C,
                        int ldc, hipStream_t s) {
   if (M <= 0 || N <= 0) return WISKI_OK;
+  {
+    // the 128 x 128 kernel once its grid covers at least half the chip (n >= ~1500 square): below that the 64 x 64 tiles fill more CUs
+    const int64_t nb = (int64_t)((N + G2N - 1) / G2N) * ((M + G2M - 1) / G2M);
+    const int minb = gemm128_min_blocks();
+    // (K >= 256: the rank-64 trailing updates of wiski_potrf / wiski_trsm are 4 K tiles of fp64 -- prologue-bound here, faster on the
+    // small kernel; fp64 needs twice the grid before the large tile wins: 24 vs 27 TF at n = 1536, 42 vs 39 at 2048)
+    if (minb > 0 && nb >= (sizeof(real) == 8 ? 2 * minb : minb) && K >= 256) {
+      dim3 g2((unsigned)((N + G2N - 1) / G2N), (unsigned)((M + G2M - 1) / G2M));
+      if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else hipLaunchKernelGGL((k_gemm128<real, true, true>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
+  }
   dim3 grd((unsigned)((N + GBN - 1) / GBN), (unsigned)((M + GBM - 1) / GBM));
   if (!ta && !tb) hipLaunchKernelGGL((k_gemm<real, false, false>), grd, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
   else if (ta && !tb) hipLaunchKernelGGL((k_gemm<real, true, false>), grd, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);

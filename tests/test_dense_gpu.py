@@ -27,6 +27,33 @@ def test_gemm_all_transposes(dtype, tol, ta, tb, M, N, K):
         assert torch.equal(grid_ops.gemm(I, B), B)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K,pad", [(2048, 2048, 256, 0), (2100, 1937, 333, 0), (1929, 2201, 290, 3)])
+def test_gemm_large_tile_kernel(dtype, tol, ta, tb, M, N, K, pad):
+    """The 128 x 128 register-prefetch kernel (grids of >= 128 blocks): aligned interior tiles (vector loads), ragged edges in
+    all three dimensions (scalar predicated loads), and leading dimensions that defeat the 16-byte loads (`pad`: operands are
+    column slices of wider matrices)."""
+    from online_gp_amd import _hip, grid_ops
+    import ctypes
+
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    Ash = (K, M) if ta else (M, K)
+    Bsh = (N, K) if tb else (K, N)
+    Aw = torch.randn(Ash[0], Ash[1] + pad, generator=g, dtype=dtype).to(DEV)
+    Bw = torch.randn(Bsh[0], Bsh[1] + pad, generator=g, dtype=dtype).to(DEV)
+    A, B = Aw[:, :Ash[1]], Bw[:, :Bsh[1]]
+    C0 = torch.randn((M, N), generator=g, dtype=dtype).to(DEV)
+    ref = 0.7 * ((A.t() if ta else A).double() @ (B.t() if tb else B).double()) - 0.3 * C0.double()
+    C = C0.clone()
+    cr = _hip.creal(dtype)
+    rc = _hip.fn("wiski_gemm", dtype)(ctypes.c_int32(int(ta)), ctypes.c_int32(int(tb)), ctypes.c_int32(M), ctypes.c_int32(N), ctypes.c_int32(K), cr(0.7),
+                                      ctypes.c_void_p(Aw.data_ptr()), ctypes.c_int32(Aw.shape[1]), ctypes.c_void_p(Bw.data_ptr()), ctypes.c_int32(Bw.shape[1]),
+                                      cr(-0.3), _hip.dptr(C), ctypes.c_int32(N), _hip.stream_ptr(C.device))
+    assert rc == 0
+    assert (C.double() - ref).abs().max().item() <= tol * K ** 0.5 * 10
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
 @pytest.mark.parametrize("n", [17, 64, 200, 1000])
 def test_cholesky_trsm_logdet(dtype, tol, n):

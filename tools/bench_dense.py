@@ -9,7 +9,7 @@ def tm(f, reps=5):
     for _ in range(reps): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / reps
 for dt, name in ((torch.float32, 'f32'), (torch.float64, 'f64')):
-    for n in (1024, 2048, 4096):
+    for n in (1024, 1536, 2048, 4096):
         A = torch.randn(n, n, device=dev, dtype=dt); B = torch.randn(n, n, device=dev, dtype=dt)
         t = tm(lambda: grid_ops.gemm(A, B, ta=True))
         S = (A @ A.t() / n + torch.eye(n, device=dev, dtype=dt)).contiguous()
