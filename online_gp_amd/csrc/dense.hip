@@ -288,13 +288,16 @@ constexpr int NB = 64;
 
 // Column c of the inverse of the lower-triangular 64 x 64 matrix in sM (LDS), by forward substitution on e_c with the
 // whole column in registers (compile-time indices, fully unrolled: 2016 FMAs fed by broadcast LDS reads).
-template <typename real>
+// RECIP: the diagonal of sM holds the RECIPROCALS of the factor's diagonal (an fp64 division is ~20 dependent instructions and
+// this chain has 64 of them; a separate reciprocal array reached through a pointer parameter made the compiler fall back to
+// flat loads -- 3x slower than the divisions it was meant to remove).
+template <typename real, bool RECIP = false>
 __device__ __forceinline__ void tri_inv_column(const real (*sM)[NB + 1], int c, real x[NB]) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) x[i] = i == c ? (real)1 : (real)0;
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    const real xk = x[k] / sM[k][k];          // rows k < c: x[k] == 0 stays 0
+    const real xk = RECIP ? x[k] * sM[k][k] : x[k] / sM[k][k];          // rows k < c: x[k] == 0 stays 0
     x[k] = xk;
 #pragma unroll
     for (int i = k + 1; i < NB; ++i) x[i] -= sM[i][k] * xk;
@@ -307,8 +310,9 @@ __device__ __forceinline__ void tri_inv_column(const real (*sM)[NB + 1], int c, 
 template <typename real>
 __global__ __launch_bounds__(64) void k_potrf_diag(int nb, real* __restrict__ A, int lda, real* __restrict__ Linv, int32_t* __restrict__ info) {
   __shared__ real sM[NB][NB + 1];
-  __shared__ real sCol[NB];
+  __shared__ real sCol[2][NB];
   const int t = threadIdx.x;
+  real myri = (real)1;
   for (int r = 0; r < NB; ++r) sM[r][t] = (r < nb && t < nb) ? A[(int64_t)r * lda + t] : (r == t ? (real)1 : (real)0);   // coalesced rows
   __syncthreads();
   real row[NB];
@@ -317,17 +321,29 @@ __global__ __launch_bounds__(64) void k_potrf_diag(int nb, real* __restrict__ A,
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    const real piv = __shfl(row[k], k, 64);
-    if (!(piv > (real)0)) bad = true;
-    const real d = sqrt(piv > (real)0 ? piv : (real)1);
-    const real lk = t > k ? row[k] / d : (t == k ? d : (real)0);
+    // pivot by a lane read; 1 / sqrt(pivot) once (rsqrt + one Newton step: full precision without the division and square-root
+    // expansions, which dominated this 64-step dependent chain in fp64), the column published through a 2-deep LDS slot (one
+    // barrier per step: the slot written two steps ago has no readers left)
+    const real piv0 = __shfl(row[k], k, 64);
+    if (!(piv0 > (real)0)) bad = true;
+    const real piv = piv0 > (real)0 ? piv0 : (real)1;
+    real ri;
+    if constexpr (sizeof(real) == 4) {
+      ri = __builtin_amdgcn_rsqf(piv);                     // v_rsq_f32 (1 ulp) + one Newton step
+      ri = ri * (1.5f - 0.5f * piv * ri * ri);
+    } else {
+      ri = __builtin_amdgcn_rsq(piv);                      // v_rsq_f64 (~26 bits) + two Newton steps
+      ri = ri * (1.5 - 0.5 * piv * ri * ri);
+      ri = ri * (1.5 - 0.5 * piv * ri * ri);
+    }
+    const real lk = t > k ? row[k] * ri : (t == k ? piv * ri : (real)0);
     row[k] = lk;
-    __syncthreads();                 // previous step's readers of sCol are done
-    sCol[t] = lk;
+    if (t == k) myri = ri;
+    sCol[k & 1][t] = lk;
     __syncthreads();
     if (t > k) {
 #pragma unroll
-      for (int j = k + 1; j < NB; ++j) row[j] -= lk * sCol[j];      // entries j > t are never used (upper triangle)
+      for (int j = k + 1; j < NB; ++j) row[j] -= lk * sCol[k & 1][j];      // entries j > t are never used (upper triangle)
     }
   }
   if (bad && t == 0) atomicOr(info, 1);
@@ -337,8 +353,11 @@ __global__ __launch_bounds__(64) void k_potrf_diag(int nb, real* __restrict__ A,
   __syncthreads();
   for (int r = 0; r < nb; ++r)
     if (t < nb) A[(int64_t)r * lda + t] = sM[r][t];
+  __syncthreads();
+  sM[t][t] = myri;                                                   // the inversion below multiplies by the reciprocal diagonal
+  __syncthreads();
   real x[NB];
-  tri_inv_column<real>(sM, t, x);
+  tri_inv_column<real, true>(sM, t, x);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NB; ++i) sM[i][t] = x[i];                      // column t of the inverse
@@ -354,8 +373,10 @@ __global__ __launch_bounds__(64) void k_tri_inv_blocks(int n, const real* __rest
   const int nb = n - i0 < NB ? n - i0 : NB;
   for (int r = 0; r < NB; ++r) sM[r][t] = (r < nb && t < nb && t <= r) ? L[(int64_t)(i0 + r) * ldl + i0 + t] : (r == t ? (real)1 : (real)0);
   __syncthreads();
+  sM[t][t] = (real)1 / sM[t][t];                           // one division per row instead of one per substitution step
+  __syncthreads();
   real x[NB];
-  tri_inv_column<real>(sM, t, x);
+  tri_inv_column<real, true>(sM, t, x);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NB; ++i) sM[i][t] = x[i];
@@ -371,9 +392,13 @@ __global__ __launch_bounds__(64) void k_tri_inv_blocks(int n, const real* __rest
 // One block per 64 rows (MODE 0) or 64 columns (MODE 1, 2); 256 threads, 16 outputs each.
 template <typename real, int MODE>
 __global__ __launch_bounds__(256) void k_apply_inv(int ext, int nb, const real* __restrict__ Linv, real* __restrict__ T, int ldt) {
+  // 64 x 64 x 64 tile product on the matrix cores (round 3; the scalar-FMA version it replaces spent 29 us per fp64 tile on one
+  // LDS read per FMA): 4 waves, each a 32 x 32 quadrant as 2 x 2 MFMA tiles over 16 k-steps.
   __shared__ real sI[NB][NB + 1];
   __shared__ real sT[NB][NB + 1];
-  const int tid = threadIdx.x;
+  using acc_t = typename Acc4<real>::type;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
   const int o0 = blockIdx.x * NB;                        // first row (MODE 0) / column (MODE 1, 2) of this tile
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e >> 6, j = e & 63;
@@ -384,27 +409,43 @@ __global__ __launch_bounds__(256) void k_apply_inv(int ext, int nb, const real* 
     sT[i][j] = v;
   }
   __syncthreads();
-  const int i = tid >> 2, j0 = (tid & 3) * 16;
-  real acc[16];
+  acc_t acc[2][2];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) acc[u] = (real)0;
-  for (int k = 0; k < NB; ++k) {
-    if (MODE == 0) {                                     // out[i][j] = sum_k T[i][k] Linv[j][k]
-      const real t = sT[i][k];
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] += t * sI[j0 + u][k];
-    } else {                                             // out[i][j] = sum_k Linv[i][k] T[k][j]   (MODE 2: Linv[k][i])
-      const real l = MODE == 1 ? sI[i][k] : sI[k][i];
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] += l * sT[k][j0 + u];
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = (real)0;
+#pragma unroll
+  for (int ks = 0; ks < NB; ks += 4) {
+    const int kk = ks + (lane >> 4);
+    real af[2], bf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int i = wr * 32 + a * 16 + (lane & 15);
+      af[a] = MODE == 0 ? sT[i][kk] : (MODE == 1 ? sI[i][kk] : sI[kk][i]);      // A operand (i, k)
     }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = wc * 32 + b * 16 + (lane & 15);
+      bf[b] = MODE == 0 ? sI[j][kk] : sT[kk][j];                                   // B operand (k, j)
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
   }
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int j = j0 + u;
-    if (MODE == 0) { if (o0 + i < ext && j < nb) T[(int64_t)(o0 + i) * ldt + j] = acc[u]; }
-    else { if (i < nb && o0 + j < ext) T[(int64_t)i * ldt + o0 + j] = acc[u]; }
-  }
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wr * 32 + a * 16 + frag_row<real>(lane, r);
+        const int j = wc * 32 + b * 16 + (lane & 15);
+        if (MODE == 0) { if (o0 + i < ext && j < nb) T[(int64_t)(o0 + i) * ldt + j] = acc[a][b][r]; }
+        else { if (i < nb && o0 + j < ext) T[(int64_t)i * ldt + o0 + j] = acc[a][b][r]; }
+      }
 }
 
 template <typename real>

@@ -5,8 +5,8 @@ The reference reaches the posterior through a rank-limited root space: L L^T ~ W
 the matrix-free path (wiski_pcg) is the only exact option this module offers the same thing with the roles swapped:
 the low-rank object is the *prior*.  For a smooth stationary kernel Kt = kron_q K_q / sigma2 has a tiny numerical rank:
 with K_q = V_q diag(ev_q) V_q^T the r tensor-product eigenvectors b_j = kron_q V_q[:, S_q[j]] of largest eigenvalue
-lam_j carry all but a fraction ``settings.spectral_tail`` of trace(Kt) (r ~ 430 for the default RBF hyper-parameters
-on a 50^3 grid at 1e-7).  With B = [b_j] and Kt_B = B Lam B^T,
+lam_j carry all but a fraction ``settings.spectral_tail`` of trace(Kt) (r ~ 330 for the default RBF hyper-parameters
+on a 50^3 grid at 1e-6, 430 at 1e-7).  With B = [b_j] and Kt_B = B Lam B^T,
 
     G = B^T A B,  h = B^T b                      (A = W^T D^-1 W, b = W^T D^-1 y: the model's statistics)
     C = I + Lam^1/2 G Lam^1/2 = chol chol^T      (SPD, eigenvalues >= 1: no jitter; wiski_potrf, fp64)
@@ -40,7 +40,7 @@ def default_tail(dtype):
     v = settings.spectral_tail.value()
     if v is not None:
         return float(v)
-    return 1e-7 if dtype == torch.float32 else 1e-9
+    return 1e-6 if dtype == torch.float32 else 1e-9
 
 
 class SpectralBasis:

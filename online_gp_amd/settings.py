@@ -217,7 +217,7 @@ class spectral_factor(_feature_flag):
 
 
 class spectral_tail(_value_context):
-    """Fraction of trace(Kuu) the reduced eigenbasis may leave out (None: 1e-7 in fp32, 1e-9 in fp64).  The left-out
+    """Fraction of trace(Kuu) the reduced eigenbasis may leave out (None: 1e-6 in fp32 -- 4e-4 of a variance at 50^3, against the fp32 parity bar of 1e-2 -- and 1e-9 in fp64).  The left-out
     prior variance of each query is added back to its predictive variance and bounds the remaining error."""
 
     _global_value = None

@@ -134,7 +134,7 @@ def test_variances_match_the_data_space_oracle_and_follow_the_stream(dtype, tol,
         assert fac.ref is not None and fac.rebuilds == 1       # the factor served the request, built once from the stencil
         r0 = fac.cur["basis"].r
         assert r0 <= settings.spectral_max_rank.value()
-        assert fac.rel_bound() < max(10 * (tail or (1e-7 if dtype == torch.float32 else 1e-9)) * 1e3, 1e-9)
+        assert fac.rel_bound() < max(10 * (tail or (1e-6 if dtype == torch.float32 else 1e-9)) * 1e3, 1e-9)
         # streaming updates: the reduced statistics follow by projection + GEMM, no rebuild
         for i in range(3):
             lo, hi = n0 + i * q, n0 + (i + 1) * q

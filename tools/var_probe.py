@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from online_gp_amd import settings
 from online_gp_amd.models import FixedNoiseOnlineSKIGP
+if os.environ.get("WISKI_NO_SPECTRAL") == "1":
+    settings.spectral_factor._set_state(False)
 dev, dt = torch.device("cuda:0"), torch.float32
 X0, y0 = bench.synth_stream(100000, 3, 0, dev, dt, "uniform")
 Xv, _ = bench.synth_stream(4096, 3, 99, dev, dt, "uniform")
