@@ -1293,6 +1293,71 @@ __global__ __launch_bounds__(256) void k_lag_correlate(int g, int post, int m, i
     if (s_bins[l] != 0.0) unsafeAtomicAdd(out + l, s_bins[l]);
 }
 
+// The same sums through tile Gram matrices (round 3; used for g <= 64): a block takes a g x 64 tile of X and of Yq -- one
+// (column, outer index) slab and 64 consecutive elements of the unit-stride direction -- into LDS with coalesced loads, forms the
+// g x g products sum_s X[i][s] Yq[j][s] from LDS (fp32 partial sums of 64 terms, accumulated in fp64) and bins THEM by lag:
+// g^2 LDS atomics per 64 g elements instead of g per element, and no strided global re-reads (k_lag_correlate re-reads each
+// Yq line g times: 125 us per call at 50^3 with 11 columns; this form: see DESIGN.md 3.6).
+//   element (i, s) of a tile = base + i * stride_i + s * stride_s with (stride_i, stride_s) = (post, 1) when post > 1 and (1, g)
+//   for the innermost mode (the tile then spans 64 consecutive lines).
+template <typename real>
+__global__ __launch_bounds__(256) void k_lag_gram(int g, int post, int m, int k, const real* __restrict__ X, const real* __restrict__ Yq,
+                                                  double* __restrict__ out) {
+  constexpr int TS = 64;
+  __shared__ real sX[64][TS + 1], sY[64][TS + 1];
+  __shared__ double s_bins[64];
+  const int t = threadIdx.x;
+  if (t < 64) s_bins[t] = 0.0;
+  const int c = blockIdx.y;
+  const real* __restrict__ Xc = X + (int64_t)c * m;
+  const real* __restrict__ Yc = Yq + (int64_t)c * m;
+  // tiles of this column: post > 1: (outer index pp, chunk of s); post == 1: chunks of 64 lines
+  const int nchunk = post > 1 ? (post + TS - 1) / TS : 1;
+  const int nouter = post > 1 ? m / (g * post) : (m / g + TS - 1) / TS;
+  for (int tile = blockIdx.x; tile < nouter * nchunk; tile += gridDim.x) {
+    int64_t base;
+    int si, ss, ns;
+    if (post > 1) {
+      const int pp = tile / nchunk, s0 = (tile % nchunk) * TS;
+      base = (int64_t)pp * g * post + s0;
+      si = post; ss = 1;
+      ns = post - s0 < TS ? post - s0 : TS;
+    } else {
+      const int l0 = tile * TS;
+      base = (int64_t)l0 * g;
+      si = 1; ss = g;
+      ns = m / g - l0 < TS ? m / g - l0 : TS;
+    }
+    __syncthreads();                                       // previous tile's readers are done
+    if (post > 1) {                                        // unit stride along s
+      for (int e = t; e < g * TS; e += 256) {
+        const int i = e / TS, sidx = e % TS;
+        const bool ok = sidx < ns;
+        sX[i][sidx] = ok ? Xc[base + (int64_t)i * si + sidx] : (real)0;
+        sY[i][sidx] = ok ? Yc[base + (int64_t)i * si + sidx] : (real)0;
+      }
+    } else {                                               // unit stride along i (g contiguous reals per line)
+      for (int e = t; e < g * TS; e += 256) {
+        const int sidx = e / g, i = e % g;
+        const bool ok = sidx < ns;
+        sX[i][sidx] = ok ? Xc[base + (int64_t)sidx * ss + i] : (real)0;
+        sY[i][sidx] = ok ? Yc[base + (int64_t)sidx * ss + i] : (real)0;
+      }
+    }
+    __syncthreads();
+    for (int p = t; p < g * g; p += 256) {
+      const int i = p / g, j = p % g;
+      real acc = (real)0;
+#pragma unroll 16
+      for (int sidx = 0; sidx < TS; ++sidx) acc += sX[i][sidx] * sY[j][sidx];
+      const int lag = i > j ? i - j : j - i;
+      atomicAdd(&s_bins[lag], (double)acc);
+    }
+  }
+  __syncthreads();
+  if (t < g && s_bins[t] != 0.0) unsafeAtomicAdd(out + t, s_bins[t]);
+}
+
 // d_grad[sum g] (double, accumulated into) ; d_tmp: 2*k*m reals of scratch.
 template <typename real>
 static int kron_grad_impl(const wiski_grid* grid, const real* d_tcol, const real* d_X, const real* d_Y, int32_t k, real* d_tmp,
@@ -1323,8 +1388,21 @@ static int kron_grad_impl(const wiski_grid* grid, const real* d_tcol, const real
       }
       off2 += G.g[r];
     }
-    hipLaunchKernelGGL((k_lag_correlate<real>), dim3((unsigned)((m + 255) / 256), (unsigned)((k + 31) / 32)), dim3(256), 0, s, G.g[q], G.stride[q],
-                       m, k, d_X, src, d_grad + toff);
+    static int lag_gram = -1;
+    if (lag_gram < 0) {
+      const char* e = getenv("WISKI_LAG_GRAM");
+      lag_gram = e ? atoi(e) : 1;
+    }
+    if (lag_gram && G.g[q] <= 64 && k <= 4096 && m % G.g[q] == 0) {
+      const int post = G.stride[q];
+      const int ntile = post > 1 ? (m / (G.g[q] * post)) * ((post + 63) / 64) : (m / G.g[q] + 63) / 64;
+      int bx = ntile < 1 ? 1 : ntile;
+      if ((int64_t)bx * k > 4096) bx = (int)(4096 / k) > 0 ? (int)(4096 / k) : 1;      // grid-stride over the tiles of a column
+      hipLaunchKernelGGL((k_lag_gram<real>), dim3((unsigned)bx, (unsigned)k), dim3(256), 0, s, G.g[q], post, m, k, d_X, src, d_grad + toff);
+    } else {
+      hipLaunchKernelGGL((k_lag_correlate<real>), dim3((unsigned)((m + 255) / 256), (unsigned)((k + 31) / 32)), dim3(256), 0, s, G.g[q], G.stride[q],
+                         m, k, d_X, src, d_grad + toff);
+    }
     toff += G.g[q];
   }
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;

@@ -481,3 +481,28 @@ def test_half_stencil_spmv_dma_kernel_on_3d_grids(gs):
         out = grid_ops.stencil_spmv(grid, A, _t(V, torch.float32), _t(add, torch.float32), -0.3)
         ref = B2.stencil_mv(V) - 0.3 * add
         assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 1e-11)])
+@pytest.mark.parametrize("gs,k", [((9,), 3), ((6, 11), 4), ((5, 8, 70), 2), ((7, 4, 9), 11), ((4, 5, 4, 6), 3)])
+def test_kron_toeplitz_grad_against_autograd(dtype, tol, gs, k):
+    """d/d tcol of sum_c x_c^T (kron_q T(tcol_q)) y_c (the MLL backward's contraction, BWM:19-51) against torch autograd on the
+    dense Kronecker matrix: tile-Gram form (g <= 64; innermost and strided modes) and the per-element form (g = 70)."""
+    from online_gp_amd import grid_ops
+
+    d = len(gs)
+    grid = grid_ops.GridSpec(torch.tensor([[-1.0, 1.0]] * d), list(gs))
+    g = torch.Generator(device="cpu").manual_seed(sum(gs) + k)
+    cols = [torch.rand(n, generator=g, dtype=torch.float64).add(0.1).requires_grad_(True) for n in gs]
+    X = torch.randn(k, grid.m, generator=g, dtype=torch.float64)
+    Y = torch.randn(k, grid.m, generator=g, dtype=torch.float64)
+    K = torch.ones(1, 1, dtype=torch.float64)
+    for c in cols:
+        n = c.numel()
+        idx = (torch.arange(n)[:, None] - torch.arange(n)[None, :]).abs()
+        K = torch.kron(K, c[idx])
+    ((X @ K) * Y).sum().backward()
+    want = torch.cat([c.grad for c in cols])
+    tcol = torch.cat([c.detach() for c in cols]).to("cuda", dtype)
+    got = grid_ops.kron_toeplitz_grad(grid, tcol, X.to("cuda", dtype), Y.to("cuda", dtype)).cpu()
+    assert (got - want).abs().max() < tol * want.abs().max()
