@@ -335,7 +335,17 @@ def main():
     with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), settings.deferred_refresh(True), \
             torch.no_grad():
         # headline: the configured stream; N > 1: the exchange the cost model picks ("auto")
-        model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=os.environ.get("WISKI_BENCH_NOSAMPLE") != "1")
+        try:
+            model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=os.environ.get("WISKI_BENCH_NOSAMPLE") != "1")
+            headline_note = None
+        except Exception as exc:  # noqa: BLE001
+            if world == 1:
+                raise
+            # N > 1: the stencil-sharded step has only ever run with two ranks on one GPU; if it fails on a real multi-GPU node the
+            # line falls back to the point / statistics exchange and says so (every rank takes this branch: the failure is collective)
+            headline_note = ("stencil-sharded step failed, fell back: " + repr(exc))[:300]
+            os.environ["WISKI_BENCH_NO_STENCIL_SHARD"] = "1"
+            model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=False)
         R = len(block_s)
         med = float(np.median(block_s))
         sec, dropped = block_seconds(block_s)
@@ -345,6 +355,8 @@ def main():
                  "stream_points_per_pass": int(model.num_data), "note": "each pass re-starts from the init data and streams at most a 3droad-sized "
                  "stream (434 874 points) of fresh synthetic points"}
         exchange_used = upd.last_exchange
+        if headline_note:
+            extra["headline_note"] = headline_note
 
         if world > 1 and not args.no_extras:
             try:                                   # same on every rank (deterministic legs): a failure is recorded, the headline line survives

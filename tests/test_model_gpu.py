@@ -719,3 +719,35 @@ def test_c1_notebook_setup_with_the_spectral_mixture_kernel():
         reg.update(Xt[t:t + 1], yt[t:t + 1])
     m2, v2 = reg.predict(torch.as_tensor(xs, device=DEV)[:, None])
     assert torch.isfinite(m2).all() and (v2 > 0).all()
+
+
+def test_hyperparameter_caches_follow_a_fused_optimizer():
+    """torch.optim.Adam(fused=True) does not advance the parameters' autograd version counters; the model's caches key on
+    zero_grad() calls as well (the reference calls gp.zero_grad() after every step) and on hyperparameters_changed()."""
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(2)
+    X = torch.as_tensor(rng.uniform(-1, 1, (120, 2)), device=DEV); y = torch.sin(3 * X[:, :1])
+    m = FixedNoiseOnlineSKIGP(X, y, None, grid_bounds=torch.tensor([[-1.1, 1.1]] * 2), grid_size=12, learn_additional_noise=True)
+    m.eval()
+    Xs = X[:7]
+    v0 = m(Xs).variance.clone()
+    ls = m.covar_module.base_kernel.base_kernel.raw_lengthscale
+    with torch.no_grad():
+        ls.data.mul_(1.0).add_(0.5)                     # a write the version counter does not see
+    m.hyperparameters_changed()
+    v1 = m(Xs).variance.clone()
+    assert (v1 - v0).abs().max() > 1e-6 * v0.abs().max()
+    opt = torch.optim.Adam([ls], lr=0.3, fused=True)
+    ver = ls._version
+    ls.grad = torch.ones_like(ls)
+    opt.step()
+    assert ls._version == ver                           # the premise: a fused step leaves the counter alone
+    m.zero_grad()
+    v2 = m(Xs).variance.clone()
+    assert (v2 - v1).abs().max() > 1e-6 * v1.abs().max()
+    O = dataspace.DataSpaceGP([[-1.1, 1.1]] * 2, 12, "rbf", m.covar_module.base_kernel.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1),
+                              float(m.covar_module.base_kernel.outputscale.detach()), float(m.likelihood.second_noise.detach())).fit(
+        X.cpu().numpy(), y[:, 0].cpu().numpy(), np.ones(120))
+    _, vo = O.predict(Xs.cpu().numpy())
+    assert np.abs(v2.cpu().numpy() - vo).max() < 1e-6 * vo.max()
