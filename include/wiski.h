@@ -298,6 +298,13 @@ typedef struct wiski_stream_args_f64 {
 int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* args, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
 int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* args, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
 
+/* Several independent outputs in ONE absorb launch (BFN:37-55 carries num_outputs as a batch dimension; the Dirichlet classifier has 2):
+ * as wiski_scatter_stats_cnt on the half stencil, with output o reading d_y + o * y_stride, weights at + o * w_stride (0: one weight
+ * vector shared by all outputs) and accumulating into d_b / d_cnt / d_res (+ d_u) at + o * m, d_A_half + o * A_stride, d_stats + 2 o.
+ * A point outside the grid is dropped for every output and counted once. */
+int wiski_scatter_stats_multi_f32(const wiski_grid* grid, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t n, int32_t nout, int64_t y_stride, int64_t w_stride, float* d_b, float* d_A_half, int64_t A_stride, float* d_cnt, const float* d_u, float* d_res, double* d_stats, int32_t* d_err, void* stream);
+int wiski_scatter_stats_multi_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, int32_t nout, int64_t y_stride, int64_t w_stride, double* d_b, double* d_A_half, int64_t A_stride, double* d_cnt, const double* d_u, double* d_res, double* d_stats, int32_t* d_err, void* stream);
+
 /* The two halves of a stencil-sharded step on their own (wiski_stream_step uses them when args->shard is set): the absorb
  * restricted to the stencil groups [g_lo, g_hi) (same arguments as wiski_scatter_stats_step; always the atomic form), and
  * wiski_pcg_async with every A . v product summed over the ranks of `shard`. */

@@ -17,6 +17,11 @@
 // serialise at the memory side (~12 ns each): with one pair per block the 1 024 blocks of a q = 4 096 absorb spent 25 us of
 // their 87 us queueing on these two doubles.  So a few designated blocks sweep the points once more (x, y, wb, noise: 24 B per
 // point) and issue one pair each.
+// strides (in elements) between the outputs of a batched launch; all zero for a single output
+struct ScatterBatch {
+  int64_t y_stride = 0, w_stride = 0, vec_stride = 0, A_stride = 0;
+};
+
 template <typename real, int D>
 __device__ __forceinline__ void scatter_stats_pass(const GridDev<real>& G, const real* __restrict__ x, const real* __restrict__ y,
                                                    const real* __restrict__ wb, const real* __restrict__ noise, int64_t n,
@@ -166,7 +171,18 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
                                                            real* __restrict__ mean_out = nullptr, uint32_t* __restrict__ z1 = nullptr,
                                                            int64_t n1 = 0, uint32_t* __restrict__ z2 = nullptr, int64_t n2 = 0,
                                                            const long long* __restrict__ guard = nullptr, long long guard_expect = 0,
-                                                           int g_lo = 0, int g_hi = 1 << 30) {
+                                                           int g_lo = 0, int g_hi = 1 << 30, ScatterBatch bt = ScatterBatch{}) {
+  // several independent outputs in ONE launch (BFN:37-55 carries num_outputs as a batch dimension): blockIdx.y = output;
+  // same points, per-output targets / weights / statistics at fixed strides (a weight stride of 0 shares one weight vector)
+  {
+    const int64_t o = blockIdx.y;
+    y += o * bt.y_stride; wa += o * bt.w_stride; wb += o * bt.w_stride; noise += o * bt.w_stride;
+    b += o * bt.vec_stride; stats += 2 * o;
+    if (A) A += o * bt.A_stride;
+    if (cnt) cnt += o * bt.vec_stride;
+    if (u) u += o * bt.vec_stride;
+    if (res) res += o * bt.vec_stride;
+  }
   // [g_lo, g_hi): the stencil groups this replica owns (wiski_shard: a rank of a stencil-sharded step scatters the tap pairs
   // of ITS groups only -- 1 / N of the atomics per point; b, cnt, res and the statistics stay replicated)
   // speculative launch behind a solve whose convergence poll the host has not read yet (wiski_pcg_async_guard): the poll's
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
       const bool inside = point_stencil<real, D>(G, xp, j0, w);
       if (!inside) {
         bad = true;
-        if (lane == 0) atomicAdd(err, 2);      // bits 1..: number of training points dropped (bit 0: any point outside)
+        if (lane == 0 && blockIdx.y == 0) atomicAdd(err, 2);      // bits 1..: number of training points dropped (bit 0: any point outside)
       }
       yp = y[p];
       wap = wa[p];
@@ -388,7 +404,8 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
                         int64_t n, real* d_b, real* d_A_st, double* d_stats, int32_t* d_err, void* stream, bool half = false,
                         real* d_cnt = nullptr, const real* d_u = nullptr, real* d_res = nullptr, real* d_mean_out = nullptr,
                         void* z1 = nullptr, int64_t n1_bytes = 0, void* z2 = nullptr, int64_t n2_bytes = 0, const void* d_guard = nullptr,
-                        int64_t guard_expect = 0, void* d_bin = nullptr, int64_t bin_bytes = 0, int g_lo = 0, int g_hi = 1 << 30) {
+                        int64_t guard_expect = 0, void* d_bin = nullptr, int64_t bin_bytes = 0, int g_lo = 0, int g_hi = 1 << 30, int nout = 1,
+                        ScatterBatch bt = ScatterBatch{}) {
   GridDev<real> G;
   int rc = make_grid_dev<real>(grid, &G);
   if (rc) return rc;
@@ -405,7 +422,8 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   // kernel of the pair is queued -- k_bin_points already updates statistics; otherwise the atomic form runs.
   const bool ranged = g_lo > 0 || g_hi < (1 << 30);      // a stencil shard: atomic form only (the owner form walks whole lines)
   if (ranged && !half) return WISKI_E_BADARG;
-  bool owner = !ranged && half && G.d == 3 && d_bin && d_cnt && d_A_st && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
+  if (nout < 1 || (nout > 1 && (!half || d_mean_out || n1_bytes || n2_bytes || d_guard))) return WISKI_E_BADARG;   // batched outputs: plain absorb only
+  bool owner = !ranged && nout == 1 && half && G.d == 3 && d_bin && d_cnt && d_A_st && G.g[2] <= 64 && G.g[0] > 3 && G.g[1] > 3 && G.g[2] > 3 && n < (int64_t)1 << 31 &&
                n >= owner_min_points() && bin_bytes >= owner_work_bytes<real>(grid, n);
   const size_t owner_lds = ((size_t)G.g[2] * (172 + 3) + 512) * sizeof(real);      // accumulators + one scratch word per thread
   if (owner) {
@@ -466,10 +484,10 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
   const int64_t ppb = 256 / grp;
   int64_t blocks = (n + ppb - 1) / ppb;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  dim3 grd((unsigned)blocks);
+  dim3 grd((unsigned)blocks, (unsigned)nout);
 #define CALL(DD)                                                                                                                              \
   do {                                                                                                                                        \
-    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4, (const long long*)d_guard, (long long)guard_expect, g_lo, g_hi); \
+    if (half) hipLaunchKernelGGL((k_scatter_stats_sym<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt, d_u, d_res, d_mean_out, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4, (const long long*)d_guard, (long long)guard_expect, g_lo, g_hi, bt); \
     else hipLaunchKernelGGL((k_scatter_stats<real, DD>), grd, dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_b, d_A_st, d_stats, d_err, d_cnt);   \
   } while (0)
   WISKI_DISPATCH_D(G.d, CALL)
@@ -508,6 +526,14 @@ int wiski_scatter_stats_step_sharded_f32(const wiski_grid* g, const float* x, co
 }
 int wiski_scatter_stats_step_sharded_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, double* b, double* A_half, double* cnt, const double* u, double* res, double* mean_out, double* stats, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, const void* guard, int64_t guard_expect, int32_t g_lo, int32_t g_hi, void* s) {
   return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, mean_out, z1, n1, z2, n2, guard, guard_expect, nullptr, 0, g_lo, g_hi);
+}
+int wiski_scatter_stats_multi_f32(const wiski_grid* g, const float* x, const float* y, const float* wa, const float* wb, const float* noise, int64_t n, int32_t nout, int64_t y_stride, int64_t w_stride, float* b, float* A_half, int64_t A_stride, float* cnt, const float* u, float* res, double* stats, int32_t* err, void* s) {
+  ScatterBatch bt; bt.y_stride = y_stride; bt.w_stride = w_stride; bt.vec_stride = g ? (int64_t)g->g[0] * (g->d > 1 ? g->g[1] : 1) * (g->d > 2 ? g->g[2] : 1) * (g->d > 3 ? g->g[3] : 1) : 0; bt.A_stride = A_stride;
+  return scatter_impl<float>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1 << 30, nout, bt);
+}
+int wiski_scatter_stats_multi_f64(const wiski_grid* g, const double* x, const double* y, const double* wa, const double* wb, const double* noise, int64_t n, int32_t nout, int64_t y_stride, int64_t w_stride, double* b, double* A_half, int64_t A_stride, double* cnt, const double* u, double* res, double* stats, int32_t* err, void* s) {
+  ScatterBatch bt; bt.y_stride = y_stride; bt.w_stride = w_stride; bt.vec_stride = g ? (int64_t)g->g[0] * (g->d > 1 ? g->g[1] : 1) * (g->d > 2 ? g->g[2] : 1) * (g->d > 3 ? g->g[3] : 1) : 0; bt.A_stride = A_stride;
+  return scatter_impl<double>(g, x, y, wa, wb, noise, n, b, A_half, stats, err, s, true, cnt, u, res, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1 << 30, nout, bt);
 }
 int64_t wiski_scatter_bin_bytes(const wiski_grid* g, int64_t n, int32_t elem_size) {
   if (!g || g->d != 3 || n < 0 || (elem_size != 4 && elem_size != 8)) return -1;

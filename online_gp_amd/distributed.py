@@ -259,7 +259,7 @@ class ShardedStatsUpdater:
         from .models.batched_fixed_noise_online_gp import _wtw_ops
 
         m = self.model
-        m.leave_stencil_shard()                      # (collective; a no-op unless the model is stencil-sharded)
+        getattr(m, "leave_stencil_shard", lambda: None)()      # (collective; a no-op unless the model is stencil-sharded)
         if Y.dim() == 1:
             Y = Y[:, None]
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1

@@ -199,6 +199,19 @@ def scatter_stats_cnt(grid, x, y, wa, wb, noise, b, A, half, cnt, stats, err, u=
     _hip.check(rc, "wiski_scatter_stats_cnt")
 
 
+def scatter_stats_multi(grid, x, Yt, wa, wb, noise, b, A_pack, cnt, stats, err, u=None, res=None):
+    """ONE absorb launch for all outputs (``wiski_scatter_stats_multi``): Yt [out, n]; wa / wb / noise [out, n] or [n] (shared by
+    the outputs); b / cnt / u / res [out, m]; A_pack [out, H, m] half stencils; stats [out, 2]."""
+    x = _x2d(x, grid)
+    out, n = Yt.shape
+    shared = wa.dim() == 1
+    rc = _hip.fn("wiski_scatter_stats_multi", x.dtype)(grid.ref, _hip.dptr(x), _hip.dptr(Yt), _hip.dptr(wa), _hip.dptr(wb), _hip.dptr(noise), ctypes.c_int64(n),
+                                                       ctypes.c_int32(out), ctypes.c_int64(n), ctypes.c_int64(0 if shared else n), _hip.dptr(b), _hip.dptr(A_pack),
+                                                       ctypes.c_int64(A_pack.shape[1] * A_pack.shape[2]), _hip.dptr(cnt), _hip.dptr(u), _hip.dptr(res), _hip.dptr(stats),
+                                                       _hip.dptr(err), _hip.stream_ptr(x.device))
+    _hip.check(rc, "wiski_scatter_stats_multi")
+
+
 def stencil_expand_add(grid, A_half, A_st):
     """A_st += expand(A_half) (delta and its mirror image); A_half is zeroed."""
     rc = _hip.fn("wiski_stencil_expand_add", A_st.dtype)(grid.ref, _hip.dptr(A_half), _hip.dptr(A_st), _hip.stream_ptr(A_st.device))

@@ -170,7 +170,10 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         out, m = self.num_outputs, self._grid.m
         b = torch.zeros((out, m, 1), dtype=self._dtype, device=self._device)
         stats = torch.zeros((out, 2), dtype=torch.float64, device=self._device)
-        ops = [StencilWtW.zeros(self._grid, self._dtype, self._device) for _ in range(out)]
+        # the half stencils of all outputs live in ONE [out, H, m] tensor (each operator holds a view), so that an absorb of
+        # several outputs is a single launch (wiski_scatter_stats_multi)
+        pack = torch.zeros((out, (self._grid.R + 1) // 2, m), dtype=self._dtype, device=self._device)
+        ops = [StencilWtW(self._grid, pack[o]) for o in range(out)]
         cnt = torch.zeros((out, m), dtype=self._dtype, device=self._device)
         return self._pack_cache(b, stats, ops, cnt)
 
@@ -190,7 +193,32 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
     def _clone_cache(self, cache):
         stats = cache["_stats"].clone()
         cnt = cache["_cnt"].clone() if "_cnt" in cache else None
-        return self._pack_cache(cache["interpolation_cache"].clone(), stats, [op.clone() for op in _wtw_ops(cache["WtW"])], cnt)
+        ops = _wtw_ops(cache["WtW"])
+        pack = self._stencil_pack(ops)
+        if pack is not None and len(ops) > 1:           # keep the outputs' stencils in one tensor (see _fresh_cache)
+            cp = pack.clone()
+            cl = lambda t: None if t is None else t.clone()
+            new_ops = [StencilWtW(self._grid, cp[o], cl(op.root), cl(op.inv_root)) for o, op in enumerate(ops)]
+        else:
+            new_ops = [op.clone() for op in ops]
+        return self._pack_cache(cache["interpolation_cache"].clone(), stats, new_ops, cnt)
+
+    def _stencil_pack(self, ops):
+        """The [out, H, m] tensor the outputs' half stencils are views of, if they (still) are: consecutive, same shape."""
+        st = [op.stencil for op in ops]
+        if not all(grid_ops.is_half_stencil(self._grid, t) and t.is_contiguous() for t in st):
+            return None
+        H, m = st[0].shape
+        es = st[0].element_size()
+        base = st[0].data_ptr()
+        if any(t.shape != (H, m) or t.data_ptr() != base + o * H * m * es for o, t in enumerate(st)):
+            return None
+        if len(st) == 1:
+            return st[0][None]
+        root = st[0]._base if st[0]._base is not None else None
+        if root is None or root.dim() != 3 or root.shape != (len(st), H, m) or root.data_ptr() != base:
+            return None
+        return root
 
     def _half_buffers(self):
         """Per-output symmetric half-stencil delta buffers [(R+1)/2, m] for the data-parallel
@@ -239,6 +267,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             ms["R_ok"] = False
         if getattr(self, "_scratch_stats", None) is None:
             self._scratch_stats = torch.zeros(2, dtype=torch.float64, device=self._device)
+        if self._absorb_all_outputs(cache, X, Y, noise, unit, init, half_delta, ops, dst, carry, ms, mine, n):
+            return carry_delta
         for o in range(self.num_outputs):
             yo = Y[:, o].contiguous()
             if unit:
@@ -273,6 +303,38 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                     self._wsum_dev[o] += wa.sum(dtype=torch.float64)
                     self._wsum_dirty = True
         return carry_delta
+
+    def _absorb_all_outputs(self, cache, X, Y, noise, unit, init, half_delta, ops, dst, carry, ms, mine, n):
+        """Several outputs, native packed half stencils, no root pairs to carry: ONE scatter launch for all of them
+        (wiski_scatter_stats_multi) instead of one per output.  False: not applicable, the caller loops."""
+        out = self.num_outputs
+        if out == 1 or half_delta is not None or n == 0 or "_cnt" not in cache or any(getattr(op, "root", None) is not None for op in ops):
+            return False
+        pack = self._stencil_pack(ops)
+        if pack is None:
+            return False
+        Yt = Y.t().contiguous()                                   # [out, n]
+        if unit:
+            wa = wb = no = self._ones_cache[:n]
+        else:
+            no = noise.t().contiguous()
+            wb = 1.0 / no
+            wa = wb if init else 1.0 / no.clamp_min(1e-7)        # clamp_min(1e-7)**0.5 of :163, squared
+        b = cache["interpolation_cache"][:, :, 0]
+        if not b.is_contiguous():
+            return False
+        grid_ops.scatter_stats_multi(self._grid, X, Yt, wa, wb, no, b, pack, cache["_cnt"], cache["_stats"], self._err,
+                                     u=ms["U"] if carry else None, res=ms["R"] if carry else None)
+        for o in range(out):
+            if mine:
+                self._spectral_absorb(o, X, None if unit else wa[o], Yt[o] if unit else Yt[o] * wb[o], init=init)
+            if mine or init:
+                if unit:
+                    self._wsum_host[o] += float(n)
+                else:
+                    self._wsum_dev[o] += wa[o].sum(dtype=torch.float64)
+                    self._wsum_dirty = True
+        return True
 
     # (the return value of _absorb tells the data-parallel caller whether res_delta was filled)
     @property
@@ -1097,8 +1159,15 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if device is not None and self._kernel_cache is not None and torch.device(device) != self._device:
             c = self._kernel_cache
             stats = c["_stats"].to(device)
-            self._kernel_cache = self._pack_cache(c["interpolation_cache"].to(device), stats, [op.to(device) for op in _wtw_ops(c["WtW"])],
-                                                  c["_cnt"].to(device) if "_cnt" in c else None)
+            ops = _wtw_ops(c["WtW"])
+            pack = self._stencil_pack(ops)
+            if pack is not None and len(ops) > 1:
+                pk = pack.to(device)
+                mv = lambda t: None if t is None else t.to(device)
+                new_ops = [StencilWtW(self._grid, pk[o], mv(op.root), mv(op.inv_root)) for o, op in enumerate(ops)]
+            else:
+                new_ops = [op.to(device) for op in ops]
+            self._kernel_cache = self._pack_cache(c["interpolation_cache"].to(device), stats, new_ops, c["_cnt"].to(device) if "_cnt" in c else None)
             self._device = torch.device(device)
             self._err = grid_ops.new_err_flag(device)
             self._mean_state = None

@@ -751,3 +751,61 @@ def test_hyperparameter_caches_follow_a_fused_optimizer():
         X.cpu().numpy(), y[:, 0].cpu().numpy(), np.ones(120))
     _, vo = O.predict(Xs.cpu().numpy())
     assert np.abs(v2.cpu().numpy() - vo).max() < 1e-6 * vo.max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("d,g", [(2, 12), (3, 14)])
+def test_multi_output_absorb_in_one_launch_equals_the_per_output_loop(dtype, d, g):
+    """num_outputs as a kernel batch dimension (BFN:37-55): the statistics of all outputs are absorbed by ONE launch
+    (wiski_scatter_stats_multi, packed half stencils) -- same caches and posterior as the per-output launches of a model whose
+    stencils were un-packed, for heteroscedastic per-output noise, unit noise, and with the carried residual."""
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.lazy.operators import StencilWtW
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(d + g)
+    n0, q, out = 200, 64, 3
+    X = torch.as_tensor(rng.uniform(-1, 1, (n0 + 3 * q, d)), device=DEV, dtype=dtype)
+    Y = torch.as_tensor(rng.standard_normal((n0 + 3 * q, out)), device=DEV, dtype=dtype) + torch.sin(2 * X[:, :1])
+    NZ = torch.as_tensor(rng.uniform(0.4, 1.6, (n0 + 3 * q, out)), device=DEV, dtype=dtype)
+    gb = torch.tensor([[-1.1, 1.1]] * d)
+    calls = {"multi": 0}
+    orig = grid_ops.scatter_stats_multi
+
+    def counting(*a, **k):
+        calls["multi"] += 1
+        return orig(*a, **k)
+
+    grid_ops.scatter_stats_multi = counting
+    try:
+        with settings.cg_tolerance(1e-10 if dtype == torch.float64 else 1e-6), settings.spectral_factor(False):
+            a = FixedNoiseOnlineSKIGP(X[:n0], Y[:n0], NZ[:n0], grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+            assert calls["multi"] == 1 and a._stencil_pack(a._kernel_cache["WtW"].ops) is not None
+            b = FixedNoiseOnlineSKIGP(X[:n0], Y[:n0], NZ[:n0], grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+            for op in b._kernel_cache["WtW"].ops:                    # un-pack: every stencil its own tensor -> per-output launches
+                op.stencil = op.stencil.clone()
+            assert b._stencil_pack(b._kernel_cache["WtW"].ops) is None
+            a.prediction_cache; b.prediction_cache                   # posterior-mean state: the next absorbs carry the residual
+            before = calls["multi"]
+            for i in range(3):
+                sl = slice(n0 + i * q, n0 + (i + 1) * q)
+                nz = NZ[sl] if i < 2 else None                       # the last batch with unit noise
+                a.condition_on_observations(X[sl], Y[sl], nz, inplace=True)
+                b.condition_on_observations(X[sl], Y[sl], nz, inplace=True)
+                a.prediction_cache; b.prediction_cache
+            assert calls["multi"] == before + 3
+            ca, cb = a._kernel_cache, b._kernel_cache
+            tol = 1e-12 if dtype == torch.float64 else 2e-5
+            for o in range(out):
+                sa, sb = ca["WtW"].ops[o].stencil, cb["WtW"].ops[o].stencil
+                assert (sa - sb).abs().max() <= tol * sb.abs().max()
+            for key in ("interpolation_cache", "_cnt", "_stats"):
+                assert (ca[key] - cb[key]).abs().max() <= tol * cb[key].abs().max()
+            if a._mean_state is not None:                            # matrix-free regime (14^3): the carried residuals agree too
+                assert (a._mean_state["R"] - b._mean_state["R"]).abs().max() <= 50 * tol * max(1.0, float(b._mean_state["R"].abs().max()))
+            else:
+                assert d == 2                                        # 12^2 is the dense regime: no solver state
+            ma, mb = a(X[:9]), b(X[:9])
+            assert torch.allclose(ma.mean, mb.mean, rtol=1e-4, atol=1e-6) and torch.allclose(ma.variance, mb.variance, rtol=1e-4, atol=1e-8)
+    finally:
+        grid_ops.scatter_stats_multi = orig
