@@ -88,9 +88,11 @@ def host_eig(grid, tcol_host):
     return evs, Vs
 
 
-def select_basis(grid, tcol_host, tail, max_rank, device, eig=None, like=None):
+def select_basis(grid, tcol_host, tail, max_rank, device, eig=None, like=None, truncate=False):
     """The smallest set of tensor-product eigenvectors leaving out at most `tail` of trace(Kuu); None if it needs more than
-    `max_rank` vectors (or more than KMAX eigenvectors of one dim)."""
+    `max_rank` vectors (or more than KMAX eigenvectors of one dim).  truncate: instead of giving up, keep the `max_rank`
+    vectors of largest eigenvalue (settings.fast_pred_var: a rank cap, as upstream's Lanczos root; the left-out prior variance
+    of every query is still added back and reported)."""
     evs, Vs = eig if eig is not None else host_eig(grid, tcol_host)
     d = grid.d
     total, off = 1.0, 0
@@ -102,6 +104,10 @@ def select_basis(grid, tcol_host, tail, max_rank, device, eig=None, like=None):
     # candidates: per dim, the eigenvalues that can take part in a product above the threshold (ratio to the largest)
     cut = min(tail, 1e-6) * 1e-3
     kc = [max(1, int((ev / ev[0] >= cut).sum())) for ev in evs]
+    if truncate:                                   # a capped basis never needs more than max_rank eigenvectors of one dim
+        kc = [min(k_, KMAX, max_rank) for k_ in kc]
+        while int(np.prod(kc)) > 400_000:
+            kc[int(np.argmax(kc))] -= 1
     if max(kc) > KMAX or int(np.prod(kc)) > 400_000:
         return None
     lam = evs[0][:kc[0]]
@@ -112,10 +118,15 @@ def select_basis(grid, tcol_host, tail, max_rank, device, eig=None, like=None):
     cs = np.cumsum(flat[order])
     need = total * (1.0 - tail)
     if cs[-1] < need:
-        return None
-    r = int(np.searchsorted(cs, need) + 1)
+        if not truncate:
+            return None
+        r = len(flat)
+    else:
+        r = int(np.searchsorted(cs, need) + 1)
     if r > max_rank:
-        return None
+        if not truncate:
+            return None
+        r = max_rank
     sel = order[:r]
     S = np.stack(np.unravel_index(sel, lam.shape)).astype(np.int64)            # [d, r]
     kmax = int(S.max()) + 1
@@ -196,8 +207,9 @@ class SpectralWoodburyFactor:
             basis, TS, defect_ok = cur["basis"], cur["TS"], True
         else:
             tc = tcol64.detach().to("cpu", torch.float64).numpy() if torch.is_tensor(tcol64) else np.asarray(tcol64, dtype=np.float64)
-            basis = select_basis(self.grid, tc, tail, settings.spectral_max_rank.value(), self.device, eig=eig,
-                                 like=None if cur is None else cur["basis"])
+            fast = settings.fast_pred_var.on()
+            cap = min(settings.spectral_max_rank.value(), settings.max_root_decomposition_size.value()) if fast else settings.spectral_max_rank.value()
+            basis = select_basis(self.grid, tc, tail, cap, self.device, eig=eig, like=None if cur is None else cur["basis"], truncate=fast)
             if basis is None:
                 return None
             TS, defect_ok = None, False

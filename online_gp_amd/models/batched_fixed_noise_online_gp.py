@@ -516,7 +516,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self._finish_pending()
         self.leave_stencil_shard()
         ver = self._hyper_version()
-        key = (ver, sw.default_tail(self._dtype), settings.spectral_max_rank.value())
+        key = (ver, sw.default_tail(self._dtype), settings.spectral_max_rank.value(), settings.fast_pred_var.on(),
+               settings.max_root_decomposition_size.value())
         memo = self._memo.setdefault("spectral", {})
         ent = memo.get(o)
         if ent is None or ent[0] != key:
@@ -540,7 +541,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if st.get("need_reference"):
             # reference basis with a margin, so that the eigenbasis may drift with the hyper-parameters before the
             # reference has to be rebuilt; if the margin does not fit the rank cap, the basis itself
-            refb = sw.select_basis(self._grid, tc_host, st["tail"] * 1e-2, 2 * settings.spectral_max_rank.value(), self._device)
+            refb = None if settings.fast_pred_var.on() else sw.select_basis(self._grid, tc_host, st["tail"] * 1e-2, 2 * settings.spectral_max_rank.value(),
+                                                                            self._device)
             op = _wtw_ops(self._kernel_cache["WtW"])[o]
             fac.build_reference(refb if refb is not None else st["basis"], op.stencil, self._kernel_cache["interpolation_cache"][o, :, 0])
             st = fac.state(key, tc_host, kscale)

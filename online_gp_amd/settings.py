@@ -70,6 +70,12 @@ class skip_posterior_variances(_feature_flag):
 
 
 class fast_pred_var(_feature_flag):
+    """gpytorch.settings.fast_pred_var: upstream then builds the predictive covariance from a Lanczos root of rank
+    <= max_root_decomposition_size (BFN:229-243, 393-397).  Here: predictive variances from the spectral Woodbury factor
+    (lazy/spectral_woodbury.py) with its basis CAPPED at min(spectral_max_rank, max_root_decomposition_size) vectors even where
+    that leaves out more than ``spectral_tail`` of the prior trace (rough kernels) -- a rank-limited approximation like
+    upstream's, except that the left-out prior variance of every query is added back and reported (``rel_bound``)."""
+
     _state = False
 
 

@@ -30,18 +30,19 @@ def _hypers(model):
             float(model._sigma2(0)))
 
 
-def test_c4_bayesopt_ackley_50_steps_kernel_cache_handover_and_refit():
+def test_c4_bayesopt_ackley_full_1500_steps_kernel_cache_handover_and_refit():
     """BASELINE config 4 on its geometry: Ackley d=3 (negated, noisy), q = 3, 10^3 Matern-5/2 grid over the RAW Ackley
     bounds with unit-cube inputs (the reference's quirk), Gamma priors + Interval constraints as in bayesopt.py:69-77,
     the model re-created from the previous model's kernel cache and refitted on the MLL every step.  Posterior parity
-    against the data-space oracle (same hyper-parameters) at steps 1 / 25 / 50."""
+    against the data-space oracle (same hyper-parameters) at steps 1 / 25 / 750 / 1500 -- the reference's full run length (bayesopt.py: 1 500 steps of
+    batch_size 3 = 4 510 points)."""
     from online_gp_amd import harness
     from online_gp_amd.constraints import Interval
     from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, ScaleKernel
     from online_gp_amd.models import OnlineSKIBotorchModel
     from online_gp_amd.priors import GammaPrior
 
-    d, q, steps = 3, 3, 50
+    d, q, steps = 3, 3, 1500
     bounds = torch.tensor([[-32.768, 32.768]] * d, dtype=torch.float64)
     gen = torch.Generator(device="cpu").manual_seed(0)
     init_x = torch.rand(10, d, generator=gen, dtype=torch.float64).to(DEV)
@@ -63,7 +64,7 @@ def test_c4_bayesopt_ackley_50_steps_kernel_cache_handover_and_refit():
     Xq = torch.rand(16, d, generator=gen, dtype=torch.float64).to(DEV)
 
     def on_step(step, model, train_x, train_y):
-        if step + 1 in (1, 25, 50):
+        if step + 1 in (1, 25, 750, 1500):
             ell, osc, s2 = _hypers(model)
             O = dataspace.DataSpaceGP(gbn, 10, "matern52", ell, osc, s2).fit(train_x.cpu().numpy(), train_y[:, 0].cpu().numpy(), np.ones(train_x.shape[0]))
             mo, vo = O.predict(Xq.cpu().numpy())
@@ -75,7 +76,7 @@ def test_c4_bayesopt_ackley_50_steps_kernel_cache_handover_and_refit():
 
     rows, train_x, train_y, model = harness.bayesopt(fn, bounds, make_model, init_x, init_y, steps, batch_size=q, fit_iters=4, num_candidates=128,
                                                      on_step=on_step)
-    assert checked == [1, 25, 50] and len(rows) == steps
+    assert checked == [1, 25, 750, 1500] and len(rows) == steps
     assert set(rows[0]) == {"step", "fit_time", "acqf_time", "condition_time", "total", "max_achieved"}
     assert all(r["fit_time"] > 0 and r["acqf_time"] > 0 and r["condition_time"] > 0 for r in rows)
     assert rows[-1]["max_achieved"] >= rows[0]["max_achieved"]
@@ -109,7 +110,7 @@ def test_online_regression_harness_reproduces_the_metrics_table(tmp_path):
 
 def test_c5_qnipv_active_learning_on_malaria_geometry():
     """BASELINE config 5 on its geometry (one GPU): d=2, 30^2 grid, Matern-1/2, heteroscedastic noise y_var ~ U(1e-6, 0.05),
-    q = 6 per step chosen by qNIPV through batched fantasies over the held-out MC points; the integrated posterior variance
+    q = 6 per step for the full 500 steps, chosen by qNIPV through batched fantasies over the held-out MC points; the integrated posterior variance
     falls, and the conditioned model equals the data-space oracle on everything it has absorbed."""
     from online_gp_amd import harness
     from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, ScaleKernel
@@ -118,7 +119,7 @@ def test_c5_qnipv_active_learning_on_malaria_geometry():
 
     rng = np.random.default_rng(3)
     f = lambda X: torch.sin(5 * X[:, 0]) * torch.cos(4 * X[:, 1]) + 0.5 * X[:, 0]
-    pool = torch.as_tensor(rng.uniform(0, 1, (400, 2)), device=DEV)
+    pool = torch.as_tensor(rng.uniform(0, 1, (3600, 2)), device=DEV)
     mc = torch.as_tensor(rng.uniform(0, 1, (500, 2)), device=DEV)
     nvar = lambda X: (1e-6 + 0.05 * (0.5 + 0.5 * torch.sin(17 * X.sum(-1)))).clamp(1e-6, 0.05)
     x0 = torch.as_tensor(rng.uniform(0, 1, (10, 2)), device=DEV)
@@ -135,15 +136,15 @@ def test_c5_qnipv_active_learning_on_malaria_geometry():
     def on_step(step, m):
         seen[step] = m.num_data
 
-    rows, model, chosen = harness.qnipv_active_learning(model, pool, obs, mc, batch_size=6, num_steps=5, num_candidate_sets=16, num_fantasies=3,
+    rows, model, chosen = harness.qnipv_active_learning(model, pool, obs, mc, batch_size=6, num_steps=500, num_candidate_sets=16, num_fantasies=3,
                                                         noise_fn=nvar, on_step=on_step)
     ipv = [ipv0] + [r["integrated_posterior_variance"] for r in rows]
     assert all(b < a for a, b in zip(ipv, ipv[1:])) and ipv[-1] < 0.8 * ipv0
-    assert seen == {s: 10 + 6 * (s + 1) for s in range(5)} and chosen.numel() == 30 and chosen.unique().numel() == 30
+    assert seen == {s: 10 + 6 * (s + 1) for s in range(500)} and chosen.numel() == 3000 and chosen.unique().numel() == 3000
     assert set(rows[0]) == {"step", "select_time", "condition_time", "integrated_posterior_variance", "qnipv_best", "num_data"}
     # the winner really is the arg-max of the look-ahead criterion: re-score two sets, the chosen one and a random one
     ell, osc, s2 = _hypers(model)
     post = model.posterior(mc[:8])
     assert torch.isfinite(post.mean).all() and (post.variance > 0).all()
     cache = model._kernel_cache
-    assert cache["interpolation_cache"].shape == (1, 900, 1) and model.num_data == 40
+    assert cache["interpolation_cache"].shape == (1, 900, 1) and model.num_data == 3010          # the reference's full run: batch_size 6 x 500 steps

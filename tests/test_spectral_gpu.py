@@ -257,3 +257,32 @@ def test_mll_value_and_gradients_from_the_spectral_factor():
         g_n = float(raw.grad) / float(dsoft(raw)[0])
         fd = (ref(ell, s, s2 * (1 + eps)) - ref(ell, s, s2 * (1 - eps))) / (2 * eps * s2)
         assert abs(g_n - fd) < 1e-5 * max(abs(fd), 1e-3)
+
+
+def test_fast_pred_var_caps_the_basis_like_the_reference_caps_its_root():
+    """settings.fast_pred_var (BFN:229-243, 393-397: a Lanczos root of rank <= max_root_decomposition_size upstream): a Matern-5/2
+    prior on 14^3 has no spectral gap at the default tail, so variances normally come from PCG; under fast_pred_var they come
+    from the factor capped at the root size, with the truncation added back -- inside the reported bound of the exact answer."""
+    from online_gp_amd import settings
+    from online_gp_amd.kernels import MaternKernel, ScaleKernel
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(21)
+    X = rng.uniform(-1, 1, (500, 3)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(500)
+    Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+    cov = ScaleKernel(MaternKernel(nu=2.5, ard_num_dims=3))
+    with torch.no_grad():
+        cov.base_kernel.lengthscale = 0.35
+    m = FixedNoiseOnlineSKIGP(Xt, yt, None, covar_module=cov, grid_bounds=torch.tensor([[-1.1, 1.1]] * 3), grid_size=14, learn_additional_noise=True).eval()
+    Xs = torch.as_tensor(rng.uniform(-1, 1, (40, 3)), device=DEV)
+    with settings.cg_tolerance(1e-10):
+        assert m._spectral_state(0) is None                       # exact request: PCG
+        v_exact = m(Xs).variance.cpu().numpy()
+        with settings.fast_pred_var(True), settings.max_root_decomposition_size(256):
+            sp = m._spectral_state(0)
+            assert sp is not None and sp[1]["basis"].r == 256
+            v_fast = m(Xs).variance.cpu().numpy()
+            bound = m._spectral[0].rel_bound()
+        assert m._spectral_state(0) is None                       # and back
+    dev = np.max(np.abs(v_fast - v_exact) / v_exact)
+    assert dev <= bound + 1e-9 and bound < 0.5 and dev > 1e-6     # an approximation, inside its own bound
