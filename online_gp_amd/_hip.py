@@ -48,6 +48,10 @@ def build(force=False, verbose=False):
     srcs = sources()
     hdrs = [os.path.join(_CSRC, h) for h in _HEADERS]
     hdr_time = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
+    if not force and os.path.exists(_SO):
+        deps = srcs + [h for h in hdrs if os.path.exists(h)]
+        if all(os.path.getmtime(d_) <= os.path.getmtime(_SO) for d_ in deps):
+            return _SO                               # the shipped library is current (the object cache need not exist)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(_HERE, "..", "build", "obj")
     os.makedirs(objdir, exist_ok=True)
