@@ -235,7 +235,17 @@ class ShardedStatsUpdater:
             if dots is not None:
                 dist.all_reduce(dots, op=dist.ReduceOp.SUM, group=group)
 
-        return m.enter_stencil_shard(dist.get_rank(group), world, allreduce)
+        # WISKI_SHARD_TRANSPORT=rccl: the all-reduce of a product is issued from C (wiski_allreduce_stats on an ncclComm_t of
+        # our own: vector + p.Ap slots in ONE grouped launch on the solve's stream, no re-entry into Python).  Default: the
+        # callback above through torch.distributed's communicator (the path the two-rank test exercises).
+        comm = None
+        import os
+
+        if os.environ.get("WISKI_SHARD_TRANSPORT") == "rccl" and not gloo_cuda:
+            if getattr(self, "_shard_comm", None) is None:
+                self._shard_comm = RcclCommunicator(group)
+            comm = self._shard_comm.handle
+        return m.enter_stencil_shard(dist.get_rank(group), world, allreduce, comm=comm)
 
     def _delta_cache(self):
         """Zeroed delta copies of (b, stats); the W^T W delta lives in the model's symmetric
