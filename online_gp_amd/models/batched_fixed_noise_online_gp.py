@@ -533,7 +533,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             fac = facs[o] = sw.SpectralWoodburyFactor(self._grid, self._dtype, self._device, self._err)
         kscale = 1.0 / self._hyper()[o][1]
         if self.__dict__.get("_spectral_dirty", {}).pop(o, False):
-            fac.ref = None                               # statistics changed behind the factor's back: rebuild from the stencil
+            # statistics changed behind the factor's back: rebuild from the stencil (and forget the state derived from the old ones)
+            fac.ref = fac.cur = None
+            fac.data_version += 1
         st = fac.state(key, tc_host, kscale)
         if st is None:
             memo[o] = (key, None, None)

@@ -286,3 +286,41 @@ def test_fast_pred_var_caps_the_basis_like_the_reference_caps_its_root():
         assert m._spectral_state(0) is None                       # and back
     dev = np.max(np.abs(v_fast - v_exact) / v_exact)
     assert dev <= bound + 1e-9 and bound < 0.5 and dev > 1e-6     # an approximation, inside its own bound
+
+
+def test_factor_is_rebuilt_after_statistics_changed_behind_its_back():
+    """Batches too large to follow (> 2048 points), 8 batches nobody asked the factor about, and set_train_data all mark the
+    factor dirty: the next request re-projects the stencil instead of answering from the stale state."""
+    from online_gp_amd import settings
+
+    rng = np.random.default_rng(31)
+    d, g = 3, 14
+    X = rng.uniform(-1, 1, (6000, d)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(6000)
+    Xs = rng.uniform(-1, 1, (30, d))
+    dtype = torch.float64
+    Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+    Xst = torch.as_tensor(Xs, device=DEV)
+    with settings.cg_tolerance(1e-10):
+        m = _model(X[:300], y[:300], g, dtype)
+        m.eval()
+        ell, s, s2 = _hypers(m)
+
+        def check(nn):
+            _, vo = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X[:nn], y[:nn], np.ones(nn)).predict(Xs)
+            v = m(Xst).variance.cpu().numpy()
+            assert np.max(np.abs(v - vo) / vo) < 1e-4, nn
+
+        check(300)
+        fac = m._spectral[0]
+        m.condition_on_observations(Xt[300:3300], yt[300:3300], None, inplace=True)          # 3000 points: not followed
+        check(3300)
+        assert fac.rebuilds == 2
+        with settings.skip_posterior_variances(True):
+            for i in range(10):                                                            # ten small batches, means only
+                lo = 3300 + 20 * i
+                m.condition_on_observations(Xt[lo:lo + 20], yt[lo:lo + 20], None, inplace=True)
+                m(Xst).mean
+        check(3500)
+        assert fac.rebuilds == 3
+        m.set_train_data(Xt[:500], yt[:500], torch.ones_like(yt[:500]))
+        check(500)
