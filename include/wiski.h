@@ -320,12 +320,18 @@ int wiski_pcg_sharded_f64(const wiski_grid* grid, const double* d_A_st, const do
  *   wiski_gemm   C[M,N] = alpha op(A) op(B) + beta C   (ta/tb != 0: transposed operand), MFMA
  *   wiski_potrf  in-place lower Cholesky (upper triangle zeroed); *d_info |= 1 on a
  *                non-positive pivot (caller adds jitter and retries, like psd_safe_cholesky)
+ *                n <= 480: ONE launch (one workgroup, 32-wide panels in LDS, MFMA trailing updates)
+ *   wiski_potrf_inverse  the same factorisation plus the explicit inverse X = L^-1 (n x n, ldx; n <= 480: one more launch, one
+ *                workgroup per 32-column block) -- what a consumer wants that solves against the factor many times (the
+ *                spectral Woodbury factor: mean, variances, MLL terms are then single GEMM / GEMV launches)
  *   wiski_trsm   in-place solve  L X = B (trans = 0)  or  L^T X = B (trans = 1), B is n x nrhs
  *   wiski_logdiag  *d_out += sum_i log A[i,i]   (double) */
 int wiski_gemm_f32(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, float alpha, const float* d_A, int32_t lda, const float* d_B, int32_t ldb, float beta, float* d_C, int32_t ldc, void* stream);
 int wiski_gemm_f64(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, double alpha, const double* d_A, int32_t lda, const double* d_B, int32_t ldb, double beta, double* d_C, int32_t ldc, void* stream);
 int wiski_potrf_f32(int32_t n, float* d_A, int32_t lda, int32_t* d_info, void* stream);
 int wiski_potrf_f64(int32_t n, double* d_A, int32_t lda, int32_t* d_info, void* stream);
+int wiski_potrf_inverse_f32(int32_t n, float* d_A, int32_t lda, float* d_X, int32_t ldx, int32_t* d_info, void* stream);
+int wiski_potrf_inverse_f64(int32_t n, double* d_A, int32_t lda, double* d_X, int32_t ldx, int32_t* d_info, void* stream);
 int wiski_trsm_f32(int32_t trans, int32_t n, int32_t nrhs, const float* d_L, int32_t ldl, float* d_B, int32_t ldb, void* stream);
 int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* d_L, int32_t ldl, double* d_B, int32_t ldb, void* stream);
 int wiski_logdiag_f32(int32_t n, const float* d_A, int32_t lda, double* d_out, void* stream);
@@ -360,6 +366,12 @@ int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* d_L, int32_t 
 int wiski_basis_project_f32(const wiski_grid* grid, const float* d_x, int64_t n, const double* d_V, int32_t kmax, const int32_t* d_S, int32_t r, const float* d_scale, const double* d_colscale, const double* d_tcol, double* d_F, int64_t ldf, double* d_prior, int32_t* d_err, void* stream);
 int wiski_basis_project_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t kmax, const int32_t* d_S, int32_t r, const double* d_scale, const double* d_colscale, const double* d_tcol, double* d_F, int64_t ldf, double* d_prior, int32_t* d_err, void* stream);
 int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_Wt, const int32_t* d_S, const double* d_ev, double* d_D, void* stream);
+/* Dominant eigenvectors of the d symmetric-Toeplitz factors after a small change of their first columns, refined ON THE DEVICE from
+ * the previous ones (no host eigh, no device-to-host copy): d_tcol [sum g] the new columns, d_Vin / d_Vout per-dim tables [g_q][kw]
+ * (row-major, concatenated; kw even, <= 32; g_q <= 64; d_g [d] on the device), d_ev [d][kw] Ritz values (descending), d_resid [d]
+ * the largest residual |K v - theta v|_inf / theta_1 over the first kuse vectors.  Two subspace-iteration steps + Rayleigh-Ritz
+ * (parallel Jacobi), fp64, one workgroup per dim. */
+int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout, double* d_ev, double* d_resid, void* stream);
 
 /* (e) -- the one collective of the path: in-place RCCL all-reduce(SUM), grouped into one launch, of the
  * statistics that are sums over data points: the half-stencil delta of W^T D^-1 W (n_half reals), W^T D^-1 y (n_b), the

@@ -46,7 +46,9 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
 
     srcs = sources()
-    hdrs = [os.path.join(_CSRC, h) for h in _HEADERS]
+    import glob
+
+    hdrs = sorted(set([os.path.join(_CSRC, h) for h in _HEADERS] + glob.glob(os.path.join(_CSRC, "*.h"))))   # every header in csrc/ counts
     hdr_time = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
     if not force and os.path.exists(_SO):
         deps = srcs + [h for h in hdrs if os.path.exists(h)]

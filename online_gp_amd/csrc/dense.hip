@@ -448,6 +448,8 @@ __global__ __launch_bounds__(256) void k_apply_inv(int ext, int nb, const real* 
       }
 }
 
+#include "dense_small.h"
+
 template <typename real>
 static int potrf_impl(int n, real* d_A, int lda, int32_t* d_info, hipStream_t s) {
   if (n < 1 || !d_A || !d_info || lda < n) return WISKI_E_BADARG;
@@ -526,14 +528,56 @@ __global__ __launch_bounds__(256) void k_logdiag(int n, const real* __restrict__
   if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
 }
 
+static bool small_path_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("WISKI_POTRF_SMALL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// n <= 480: the one-workgroup factorisation of dense_small.h (and, with d_X, the explicit inverse of the factor)
+template <typename real>
+static int potrf_small_entry(int n, real* d_A, int lda, real* d_X, int ldx, int32_t* d_info, hipStream_t s) {
+  if (n < 1 || !d_A || !d_info || lda < n || (d_X && ldx < n)) return WISKI_E_BADARG;
+  const int nblk = (n + SNB - 1) / SNB;
+  real* dinv = nullptr;
+  if (hipMallocAsync((void**)&dinv, (size_t)nblk * SNB * SNB * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+  const int rc = potrf_small<real>(n, d_A, lda, dinv, d_X, ldx, d_info, s);
+  (void)hipFreeAsync(dinv, s);
+  return rc;
+}
+
+template <typename real>
+__global__ __launch_bounds__(256) void k_set_identity(int n, real* __restrict__ X, int ldx) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  const int i = (int)(e / n), j = (int)(e % n);
+  X[(int64_t)i * ldx + j] = i == j ? (real)1 : (real)0;
+}
+
 template <typename real>
 static int potrf_full(int n, real* d_A, int lda, int32_t* d_info, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (n <= SMALL_N_MAX && small_path_enabled()) return potrf_small_entry<real>(n, d_A, lda, (real*)nullptr, 0, d_info, s);
   int rc = potrf_impl<real>(n, d_A, lda, d_info, s);
   if (rc) return rc;
   const int64_t tot = (int64_t)n * n;
   hipLaunchKernelGGL((k_zero_upper<real>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, d_A, lda);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// Cholesky factor in place AND its explicit inverse X = L^-1 (every later solve against the factor is then one GEMM / GEMV).
+template <typename real>
+static int potrf_inverse(int n, real* d_A, int lda, real* d_X, int ldx, int32_t* d_info, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d_X || ldx < n) return WISKI_E_BADARG;
+  if (n <= SMALL_N_MAX && small_path_enabled()) return potrf_small_entry<real>(n, d_A, lda, d_X, ldx, d_info, s);
+  int rc = potrf_full<real>(n, d_A, lda, d_info, stream);
+  if (rc) return rc;
+  const int64_t tot = (int64_t)n * n;
+  hipLaunchKernelGGL((k_set_identity<real>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, d_X, ldx);
+  return trsm_impl<real>(0, n, n, (const real*)d_A, lda, d_X, ldx, s);
 }
 
 template <typename real>
@@ -762,6 +806,8 @@ int wiski_gemm_f64(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, doub
 }
 int wiski_potrf_f32(int32_t n, float* A, int32_t lda, int32_t* info, void* s) { return potrf_full<float>(n, A, lda, info, s); }
 int wiski_potrf_f64(int32_t n, double* A, int32_t lda, int32_t* info, void* s) { return potrf_full<double>(n, A, lda, info, s); }
+int wiski_potrf_inverse_f32(int32_t n, float* A, int32_t lda, float* X, int32_t ldx, int32_t* info, void* s) { return potrf_inverse<float>(n, A, lda, X, ldx, info, s); }
+int wiski_potrf_inverse_f64(int32_t n, double* A, int32_t lda, double* X, int32_t ldx, int32_t* info, void* s) { return potrf_inverse<double>(n, A, lda, X, ldx, info, s); }
 int wiski_trsm_f32(int32_t trans, int32_t n, int32_t nrhs, const float* L, int32_t ldl, float* B, int32_t ldb, void* s) { return trsm_impl<float>(trans, n, nrhs, L, ldl, B, ldb, (hipStream_t)s); }
 int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* L, int32_t ldl, double* B, int32_t ldb, void* s) { return trsm_impl<double>(trans, n, nrhs, L, ldl, B, ldb, (hipStream_t)s); }
 int wiski_logdiag_f32(int32_t n, const float* A, int32_t lda, double* out, void* s) { return logdiag_impl<float>(n, A, lda, out, s); }

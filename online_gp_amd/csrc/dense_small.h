@@ -1,0 +1,328 @@
+// Cholesky factorisation and triangular inverse of SMALL matrices (n <= 480) in one launch each.
+// Included by dense.hip (uses its MFMA helpers mfma16 / Acc4 / frag_row).
+//
+// The spectral Woodbury factor (lazy/spectral_woodbury.py) refactorises an r x r fp64 matrix, r ~ 300-500, after every
+// hyper-parameter step.  At that size the blocked multi-launch wiski_potrf is pure latency: 3 launches per 64-wide panel, the
+// one-wave diagonal kernel alone 56 us, 0.57 ms for n = 327 although the arithmetic is 12 MFLOP.  Here ONE workgroup
+// (8 waves, one CU, the matrix resident in L2, the current panel in LDS) runs the whole right-looking factorisation with
+// 32-wide panels:
+//   A  load the diagonal block and the panel below it into LDS
+//   B  wave 0 factorises the 32 x 32 block (rows in registers) and inverts the factor (column per lane)
+//   C  panel  L21 = A21 L11^-T      32 x 32 MFMA tile products, one row tile per wave
+//   D  trailing update A22 -= L21 L21^T   lower tiles dealt to the waves, operands from the LDS panel
+// and stores the inverses of the diagonal blocks.  k_tri_inv_small then builds the explicit inverse of the factor, one
+// workgroup per 32-column block (the block columns of a triangular inverse are independent):
+//   X_JJ = L_JJ^-1,   X_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK X_KJ.
+#pragma once
+
+constexpr int SNB = 32;        // panel width
+constexpr int SLD = 34;        // LDS row stride (reals)
+constexpr int SMALL_N_MAX = 480;
+constexpr int SWG = 512;       // threads of the factorisation workgroup (8 waves: 256 registers each -- the one-wave diagonal step wants them)
+constexpr int SNW = SWG / 64;
+
+// 32 x 32 output tile of one wave as 2 x 2 MFMA tiles: acc[a][b] += sum_k A(i, k) B(k, j), i = a*16 + (lane & 15) etc.
+// opA(i, k), opB(k, j) are accessors into LDS.
+template <typename real, typename FA, typename FB>
+__device__ __forceinline__ void wave_tile32(int lane, int K, FA opA, FB opB, typename Acc4<real>::type (&acc)[2][2]) {
+  for (int ks = 0; ks < K; ks += 4) {
+    const int kk = ks + (lane >> 4);
+    real af[2], bf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[a] = opA(a * 16 + (lane & 15), kk);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[b] = opB(kk, b * 16 + (lane & 15));
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+  }
+}
+
+template <typename real>
+__device__ __forceinline__ void zero_acc(typename Acc4<real>::type (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = (real)0;
+}
+
+// Lane `src` of a wave-uniform read (compile-time lane: v_readlane, no LDS permute round trip).
+__device__ __forceinline__ float read_lane(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+__device__ __forceinline__ double read_lane(double v, int src) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// One wave: sD (32 x 32, LDS, identity-padded beyond nb) -> its Cholesky factor in place (strict upper zeroed) and the
+// inverse of the factor in sI.  The two halves of the wave run the SAME instruction stream on different data: lane t < 32
+// holds row t of the matrix, lane 32 + t holds e_t, the right-hand side whose forward substitution gives column t of the
+// inverse.  Step k: the pivot by a lane read, a_k = v[k] / sqrt(pivot) in every lane (the factor's column entry l_tk in the
+// lower half, the inverse's entry x_kt in the upper half), column k of the factor published through LDS, and
+// v[j] -= a_k l_jk for j > k -- which is the rank-1 update of the factorisation in the lower half and the substitution step in
+// the upper half.  The inverse costs no extra instructions.  Returns true if a pivot was not positive.
+template <typename real>
+__device__ __forceinline__ bool wave_potrf32(real (*sD)[SLD], real (*sI)[SLD], real (*sCol)[2 * SNB], int lane) {
+  const int t = lane & 31;
+  const bool fac = lane < SNB;
+  // (an opaque zero added to the LDS bases: the ~600 constant addresses of the unrolled loop below then stay immediate offsets of
+  // one base register instead of being materialised and hoisted out of the caller's loop, which spilled ~500 registers)
+  int opaque = 0;
+  asm volatile("" : "+v"(opaque));
+  sCol += opaque;
+  sD += opaque;
+  sI += opaque;
+  real v[SNB];
+#pragma unroll
+  for (int j = 0; j < SNB; ++j) v[j] = fac ? sD[t][j] : (j == t ? (real)1 : (real)0);
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < SNB; ++k) {
+    const real piv0 = read_lane(v[k], k);
+    if (!(piv0 > (real)0)) bad = true;
+    const real piv = piv0 > (real)0 ? piv0 : (real)1;
+    real ri;
+    if constexpr (sizeof(real) == 4) {
+      ri = __builtin_amdgcn_rsqf(piv);
+      ri = ri * (1.5f - 0.5f * piv * ri * ri);
+    } else {
+      ri = __builtin_amdgcn_rsq(piv);
+      ri = ri * (1.5 - 0.5 * piv * ri * ri);
+      ri = ri * (1.5 - 0.5 * piv * ri * ri);
+    }
+    const real ak = (fac && t < k) ? (real)0 : v[k] * ri;      // rows above the pivot take no part (their v[k] is upper-triangle data)
+    v[k] = ak;
+    sCol[k & 1][lane] = ak;                      // (unconditional: slots 32..63 take the upper half's values and are never read; a branch here
+                                                 //  splits the block and the compiler then sinks the updates below to their distant uses -- spills)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = k + 1; j < SNB; ++j) v[j] -= ak * sCol[k & 1][j];
+    __builtin_amdgcn_sched_barrier(0);           // finish this step's updates here: deferring them keeps the loaded columns live (spills)
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < SNB; ++j) {
+    if (fac) sD[t][j] = j <= t ? v[j] : (real)0;
+    else sI[j][t] = v[j];
+  }
+  return bad;
+}
+
+// A (n x n, lda) -> lower Cholesky factor in place (strict upper zeroed), inverses of the 32 x 32 diagonal blocks of the
+// factor in dinv [nblk][32][32] (identity-padded).  One workgroup of SWG threads.  Dynamic LDS: (nrow_pad + 64) * SLD + 128 reals.
+template <typename real>
+__global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A, int lda, real* __restrict__ dinv, int32_t* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real(*sD)[SLD] = reinterpret_cast<real(*)[SLD]>(smem_raw);
+  real(*sI)[SLD] = sD + SNB;
+  real(*sCol)[2 * SNB] = reinterpret_cast<real(*)[2 * SNB]>(sI + SNB);
+  real(*sP)[SLD] = reinterpret_cast<real(*)[SLD]>(reinterpret_cast<real*>(sCol) + 4 * SNB);
+  using acc_t = typename Acc4<real>::type;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int k0 = 0, blk = 0; k0 < n; k0 += SNB, ++blk) {
+    const int nb = n - k0 < SNB ? n - k0 : SNB;
+    const int mt = n - k0 - nb;                              // rows below the diagonal block
+    const int mtp = (mt + SNB - 1) / SNB * SNB;
+    // ---- A: diagonal block and panel into LDS
+    {
+      // (loads in batches of 8 per thread: issued back to back, one wait -- a load-store loop pays the L2 latency per row)
+      constexpr int RP = SWG / 32;                           // rows per pass
+      const int j = tid & 31, i0 = tid >> 5;
+      real v[8];
+#pragma unroll
+      for (int u = 0; u < SNB / RP; ++u) {
+        const int i = i0 + u * RP;
+        v[u] = (i < nb && j < nb) ? A[(int64_t)(k0 + i) * lda + k0 + j] : (i == j ? (real)1 : (real)0);
+      }
+#pragma unroll
+      for (int u = 0; u < SNB / RP; ++u) sD[i0 + u * RP][j] = v[u];
+      for (int rb = 0; rb < mtp; rb += 8 * RP) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = rb + u * RP + i0;
+          v[u] = (r < mt && j < nb) ? A[(int64_t)(k0 + nb + r) * lda + k0 + j] : (real)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = rb + u * RP + i0;
+          if (r < mtp) sP[r][j] = v[u];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B: factor + inverse of the diagonal block (wave 0)
+    if (w == 0) {
+      const bool bad = wave_potrf32<real>(sD, sI, sCol, lane);
+      if (bad && lane == 0) atomicOr(info, 1);
+    }
+    __syncthreads();
+    for (int i = tid >> 5; i < SNB; i += SWG / 32) {
+      const int j = tid & 31;
+      if (i < nb && j < nb) A[(int64_t)(k0 + i) * lda + k0 + j] = sD[i][j];
+      dinv[(int64_t)blk * SNB * SNB + i * SNB + j] = sI[i][j];
+    }
+    // ---- C: panel L21 = A21 L11^-T, one 32-row tile per wave (in place in LDS, and to global)
+    for (int rt = w; rt * SNB < mt; rt += SNW) {
+      const int r0 = rt * SNB;
+      acc_t acc[2][2];
+      zero_acc<real>(acc);
+      wave_tile32<real>(lane, SNB, [&](int i, int k) { return sP[r0 + i][k]; }, [&](int k, int j) { return sI[j][k]; }, acc);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();                      // every lane has read its operands of this tile
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = r0 + a * 16 + frag_row<real>(lane, r), j = b * 16 + (lane & 15);
+            sP[i][j] = acc[a][b][r];
+            if (i < mt && j < nb) A[(int64_t)(k0 + nb + i) * lda + k0 + j] = acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    // ---- D: trailing update, lower tiles (ti >= tj) dealt to the waves
+    const int nt = mtp / SNB;
+    const int ntile = nt * (nt + 1) / 2;
+    for (int tl = w; tl < ntile; tl += SNW) {
+      int ti = 0, rem = tl;                                  // tl -> (ti, tj), tj <= ti
+      while (rem > ti) { rem -= ti + 1; ++ti; }
+      const int tj = rem;
+      // the tile of A22 first (16 independent loads in flight under the MFMA loop), then the product, then the stores
+      real cv[2][2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ti * SNB + a * 16 + frag_row<real>(lane, r), j = tj * SNB + b * 16 + (lane & 15);
+            cv[a][b][r] = (i < mt && j <= i) ? A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] : (real)0;
+          }
+      acc_t acc[2][2];
+      zero_acc<real>(acc);
+      wave_tile32<real>(lane, SNB, [&](int i, int k) { return sP[ti * SNB + i][k]; }, [&](int k, int j) { return sP[tj * SNB + j][k]; }, acc);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ti * SNB + a * 16 + frag_row<real>(lane, r), j = tj * SNB + b * 16 + (lane & 15);
+            if (i < mt && j <= i) A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] = cv[a][b][r] - acc[a][b][r];
+          }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // strict upper triangle: zero
+  for (int i = tid >> 6; i < n; i += SNW)
+    for (int j = i + 1 + lane; j < n; j += 64) A[(int64_t)i * lda + j] = (real)0;
+}
+
+// Explicit inverse X = L^-1 (n x n lower, ldx), block column J by workgroup J (256 threads); dinv from k_potrf_small.
+// Dynamic LDS: (nrows_pad + 3 * 32) * SLD reals.
+template <typename real>
+__global__ __launch_bounds__(256) void k_tri_inv_small(int n, const real* __restrict__ L, int ldl, const real* __restrict__ dinv, real* __restrict__ X, int ldx) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real(*sL)[SLD] = reinterpret_cast<real(*)[SLD]>(smem_raw);          // staged tile of L (or of dinv)
+  real(*sS)[SLD] = sL + SNB;                                          // the accumulated sum, as an operand
+  real(*sX)[SLD] = sS + SNB;                                          // block column J of X, rows from J * 32
+  using acc_t = typename Acc4<real>::type;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int J = blockIdx.x, j0 = J * SNB;
+  const int nblk = (n + SNB - 1) / SNB;
+  const int nbj = n - j0 < SNB ? n - j0 : SNB;
+  const int qa = w >> 1, qb = w & 1;                                  // this wave's 16 x 16 quadrant of a 32 x 32 tile
+  // zero the part of the block column above the diagonal block, X_JJ = dinv[J]
+  for (int e = tid; e < j0 * SNB; e += 256) {
+    const int i = e / SNB, j = e % SNB;
+    if (j < nbj) X[(int64_t)i * ldx + j0 + j] = (real)0;
+  }
+  for (int e = tid; e < SNB * SNB; e += 256) {
+    const int i = e / SNB, j = e % SNB;
+    const real v = dinv[(int64_t)J * SNB * SNB + e];
+    sX[i][j] = v;
+    if (i < nbj && j < nbj) X[(int64_t)(j0 + i) * ldx + j0 + j] = v;
+  }
+  __syncthreads();
+  for (int I = J + 1; I < nblk; ++I) {
+    const int i0 = I * SNB;
+    const int nbi = n - i0 < SNB ? n - i0 : SNB;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (real)0;
+    for (int K = J; K < I; ++K) {
+      for (int e = tid; e < SNB * SNB; e += 256) {
+        const int i = e / SNB, k = e % SNB;
+        sL[i][k] = i < nbi ? L[(int64_t)(i0 + i) * ldl + K * SNB + k] : (real)0;      // (K < I: columns always inside the matrix)
+      }
+      __syncthreads();
+      const int xr = (K - J) * SNB;
+#pragma unroll
+      for (int ks = 0; ks < SNB; ks += 4) {
+        const int kk = ks + (lane >> 4);
+        acc = mfma16(sL[qa * 16 + (lane & 15)][kk], sX[xr + kk][qb * 16 + (lane & 15)], acc);
+      }
+      __syncthreads();
+    }
+    // S -> LDS, dinv[I] -> LDS, X_IJ = -dinv[I] S
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sS[qa * 16 + frag_row<real>(lane, r)][qb * 16 + (lane & 15)] = acc[r];
+    for (int e = tid; e < SNB * SNB; e += 256) sL[e / SNB][e % SNB] = dinv[(int64_t)I * SNB * SNB + e];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (real)0;
+#pragma unroll
+    for (int ks = 0; ks < SNB; ks += 4) {
+      const int kk = ks + (lane >> 4);
+      acc = mfma16(sL[qa * 16 + (lane & 15)][kk], sS[kk][qb * 16 + (lane & 15)], acc);
+    }
+    const int xr = (I - J) * SNB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = qa * 16 + frag_row<real>(lane, r), j = qb * 16 + (lane & 15);
+      const real v = -acc[r];
+      sX[xr + i][j] = v;
+      if (i < nbi && j < nbj) X[(int64_t)(i0 + i) * ldx + j0 + j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename real>
+static inline size_t potrf_small_lds(int n) {
+  const int mtp = (n + SNB - 1) / SNB * SNB;
+  return (size_t)((mtp + 2 * SNB) * SLD + 4 * SNB) * sizeof(real);
+}
+template <typename real>
+static inline size_t tri_inv_small_lds(int n) {
+  const int mtp = (n + SNB - 1) / SNB * SNB;
+  return (size_t)((mtp + 3 * SNB) * SLD) * sizeof(real);
+}
+
+// Factor (and optionally invert: d_X != nullptr) a small matrix.  d_dinv: scratch [nblk][32][32].
+template <typename real>
+static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int ldx, int32_t* d_info, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) != hipSuccess) {
+      (void)hipGetLastError();
+      return WISKI_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_potrf_small<real>), dim3(1), dim3(SWG), potrf_small_lds<real>(n), s, n, d_A, lda, d_dinv, d_info);
+  if (d_X) {
+    const int nblk = (n + SNB - 1) / SNB;
+    hipLaunchKernelGGL((k_tri_inv_small<real>), dim3((unsigned)nblk), dim3(256), tri_inv_small_lds<real>(n), s, n, (const real*)d_A, lda, (const real*)d_dinv, d_X,
+                       ldx);
+  }
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}

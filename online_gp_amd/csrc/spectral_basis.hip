@@ -145,3 +145,181 @@ int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 }
+
+// ---------------------------------------------------------------- eigen-update ---
+// Hyper-parameter steps move the Toeplitz factors a little at a time, and the spectral factor only needs their DOMINANT
+// eigenvectors.  Instead of a host eigh of every factor per step (0.4 ms for three 50 x 50 matrices, plus the device-to-host
+// copy of the columns that forces a synchronisation), the previous step's eigenvectors are refined on the device:
+// two steps of subspace iteration Z = K V, V = orth(Z) (modified Gram-Schmidt, fp64) on kw >= kmax working vectors, then
+// Rayleigh-Ritz -- H = V^T K V (kw x kw), parallel cyclic Jacobi -- and V <- V U with the Ritz values sorted descending.
+// The spectrum of a smooth kernel's factor decays geometrically, so the wanted vectors converge at (lam_{kw+1} / lam_j)^2 per
+// call from an O(drift) start; the largest residual |K v - theta v| / theta_1 of the vectors actually used is written out and
+// checked by the host one step later (a failed check falls back to the host eigh).  One workgroup per dim; g <= 64, kw <= 32.
+constexpr int EIG_G = 64, EIG_K = 32;
+
+__global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict__ gs, const double* __restrict__ tcol, const double* __restrict__ Vin,
+                                                    int kw, int kuse, double* __restrict__ Vout, double* __restrict__ ev_out,
+                                                    double* __restrict__ resid_out) {
+  __shared__ double sT[EIG_G], sV[EIG_G][EIG_K + 1], sZ[EIG_G][EIG_K + 1], sH[EIG_K][EIG_K + 1], sU[EIG_K][EIG_K + 1], sCS[EIG_K / 2][2], sTh[EIG_K];
+  __shared__ int sPr[EIG_K / 2][2], sRank[EIG_K];
+  __shared__ double sRed[4], sRed2[4];
+  const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int g = gs[q], toff = 0, voff = 0;
+  for (int p = 0; p < q; ++p) { toff += gs[p]; voff += gs[p] * kw; }
+  if (t < g) sT[t] = tcol[toff + t];
+  for (int e = t; e < g * kw; e += 256) sV[e / kw][e % kw] = Vin[voff + e];
+  __syncthreads();
+  auto applyK = [&]() {                               // sZ = K sV,  K[i][j] = sT[|i - j|]
+    for (int e = t; e < g * kw; e += 256) {
+      const int i = e / kw, c = e % kw;
+      double acc = 0;
+      for (int j = 0; j < g; ++j) acc += sT[i > j ? i - j : j - i] * sV[j][c];
+      sZ[i][c] = acc;
+    }
+    __syncthreads();
+  };
+  for (int iter = 0; iter < 2; ++iter) {
+    applyK();
+    // modified Gram-Schmidt on the columns of sZ (rows = lanes of a wave, g <= 64); column c is normalised by wave 0, the
+    // later columns are dealt to the 4 waves
+    for (int c = 0; c < kw; ++c) {
+      if (wv == 0) {
+        const double v = lane < g ? sZ[lane][c] : 0.0;
+        const double nrm = sqrt(wave_reduce_sum<double>(v * v));
+        if (lane < g) sZ[lane][c] = nrm > 0 ? v / nrm : 0.0;
+      }
+      __syncthreads();
+      for (int c2 = c + 1 + wv; c2 < kw; c2 += 4) {
+        const double qv = lane < g ? sZ[lane][c] : 0.0, zv = lane < g ? sZ[lane][c2] : 0.0;
+        const double dot = wave_reduce_sum<double>(qv * zv);
+        if (lane < g) sZ[lane][c2] = zv - dot * qv;
+      }
+      __syncthreads();
+    }
+    for (int e = t; e < g * kw; e += 256) sV[e / kw][e % kw] = sZ[e / kw][e % kw];
+    __syncthreads();
+  }
+  applyK();                                           // sZ = K V
+  for (int e = t; e < kw * kw; e += 256) {            // H = V^T K V (symmetrised)
+    const int a = e / kw, b = e % kw;
+    double acc = 0;
+    for (int i = 0; i < g; ++i) acc += sV[i][a] * sZ[i][b];
+    sH[a][b] = acc;
+    sU[a][b] = a == b ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int e = t; e < kw * kw; e += 256) {
+    const int a = e / kw, b = e % kw;
+    if (a < b) { const double s = 0.5 * (sH[a][b] + sH[b][a]); sH[a][b] = s; sH[b][a] = s; }
+  }
+  __syncthreads();
+  const int n = (kw + 1) & ~1, np = n / 2;            // Jacobi on an even size (kw is even by construction of the caller)
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    // converged?  (the start is nearly diagonal -- the previous eigenvectors -- so two or three sweeps is the rule)
+    double off2 = 0, dg2 = 0;
+    for (int e = t; e < kw * kw; e += 256) {
+      const double v = sH[e / kw][e % kw];
+      if (e / kw == e % kw) dg2 += v * v; else off2 += v * v;
+    }
+    off2 = wave_reduce_sum<double>(off2);
+    dg2 = wave_reduce_sum<double>(dg2);
+    __syncthreads();                                  // sRed is reused below
+    if (lane == 0) { sRed[wv] = off2; sRed2[wv] = dg2; }
+    __syncthreads();
+    if ((sRed[0] + sRed[1] + sRed[2] + sRed[3]) <= 1e-30 * (sRed2[0] + sRed2[1] + sRed2[2] + sRed2[3])) break;
+    for (int step = 0; step < n - 1; ++step) {
+      if (t < np) {
+        int p_, q_;
+        if (t == 0) { p_ = n - 1; q_ = step; }
+        else { p_ = (step + t) % (n - 1); q_ = (step - t + (n - 1)) % (n - 1); }
+        if (p_ > q_) { const int x = p_; p_ = q_; q_ = x; }
+        sPr[t][0] = p_; sPr[t][1] = q_;
+        double c = 1.0, sn = 0.0;
+        if (q_ < kw) {
+          const double apq = sH[p_][q_];
+          if (apq != 0.0) {
+            const double theta = (sH[q_][q_] - sH[p_][p_]) / (2.0 * apq);
+            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(tt * tt + 1.0);
+            sn = tt * c;
+          }
+        }
+        sCS[t][0] = c; sCS[t][1] = sn;
+      }
+      __syncthreads();
+      for (int e = t; e < np * kw; e += 256) {
+        const int pi = e / kw, k = e % kw;
+        const int p_ = sPr[pi][0], q_ = sPr[pi][1];
+        if (q_ >= kw) continue;
+        const double c = sCS[pi][0], sn = sCS[pi][1];
+        const double akp = sH[k][p_], akq = sH[k][q_];
+        sH[k][p_] = c * akp - sn * akq; sH[k][q_] = sn * akp + c * akq;
+        const double ukp = sU[k][p_], ukq = sU[k][q_];
+        sU[k][p_] = c * ukp - sn * ukq; sU[k][q_] = sn * ukp + c * ukq;
+      }
+      __syncthreads();
+      for (int e = t; e < np * kw; e += 256) {
+        const int pi = e / kw, k = e % kw;
+        const int p_ = sPr[pi][0], q_ = sPr[pi][1];
+        if (q_ >= kw) continue;
+        const double c = sCS[pi][0], sn = sCS[pi][1];
+        const double apk = sH[p_][k], aqk = sH[q_][k];
+        sH[p_][k] = c * apk - sn * aqk; sH[q_][k] = sn * apk + c * aqk;
+      }
+      __syncthreads();
+    }
+  }
+  if (t < kw) sTh[t] = sH[t][t];
+  __syncthreads();
+  if (t < kw) {                                       // rank of each Ritz value (descending; ties by index)
+    int rk = 0;
+    for (int b = 0; b < kw; ++b) rk += (sTh[b] > sTh[t]) || (sTh[b] == sTh[t] && b < t);
+    sRank[t] = rk;
+  }
+  __syncthreads();
+  for (int e = t; e < g * kw; e += 256) {             // V <- V U, columns in descending order of the Ritz values
+    const int i = e / kw, a = e % kw;
+    double acc = 0;
+    for (int b = 0; b < kw; ++b) acc += sV[i][b] * sU[b][a];
+    sZ[i][sRank[a]] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < g * kw; e += 256) {
+    sV[e / kw][e % kw] = sZ[e / kw][e % kw];
+    Vout[voff + e] = sZ[e / kw][e % kw];
+  }
+  if (t < kw) ev_out[q * kw + sRank[t]] = sTh[t] > 0 ? sTh[t] : 0.0;
+  __syncthreads();
+  // residual of the vectors that are used (the first kuse): max_i |K v - theta v|_i / theta_max
+  applyK();
+  double worst = 0;
+  for (int e = t; e < g * kuse; e += 256) {
+    const int i = e / kuse, a = e % kuse;
+    int src = 0;                                      // Ritz value of sorted column a
+    for (int b = 0; b < kw; ++b) if (sRank[b] == a) src = b;
+    const double r = fabs(sZ[i][a] - sTh[src] * sV[i][a]);
+    worst = r > worst ? r : worst;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(worst, off, 64);
+    worst = o > worst ? o : worst;
+  }
+  __syncthreads();
+  if (lane == 0) sRed[wv] = worst;
+  __syncthreads();
+  if (t == 0) {
+    double w = sRed[0];
+    for (int i = 1; i < 4; ++i) w = sRed[i] > w ? sRed[i] : w;
+    double tmax = 0;
+    for (int b = 0; b < kw; ++b) tmax = sTh[b] > tmax ? sTh[b] : tmax;
+    resid_out[q] = tmax > 0 ? w / tmax : 0.0;
+  }
+}
+
+extern "C" int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout,
+                                      double* d_ev, double* d_resid, void* stream) {
+  if (d < 1 || d > WISKI_MAX_DIM || !d_g || !d_tcol || !d_Vin || !d_Vout || !d_ev || !d_resid || kw < 2 || kw > EIG_K || (kw & 1) || kuse < 1 || kuse > kw)
+    return WISKI_E_BADARG;
+  hipLaunchKernelGGL(k_eig_update, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, d_tcol, d_Vin, (int)kw, (int)kuse, d_Vout, d_ev, d_resid);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}

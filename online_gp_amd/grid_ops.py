@@ -580,6 +580,19 @@ def potrf_(A, info=None):
     return info
 
 
+def potrf_inverse_(A, info=None):
+    """In-place lower Cholesky AND the explicit inverse of the factor (``wiski_potrf_inverse``: two launches for n <= 480).
+    Returns (Linv, info)."""
+    assert A.dim() == 2 and A.shape[0] == A.shape[1] and A.is_contiguous()
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    X = torch.empty_like(A)
+    rc = _hip.fn("wiski_potrf_inverse", A.dtype)(ctypes.c_int32(A.shape[0]), _hip.dptr(A), ctypes.c_int32(A.shape[1]), _hip.dptr(X),
+                                                 ctypes.c_int32(X.shape[1]), _hip.dptr(info), _hip.stream_ptr(A.device))
+    _hip.check(rc, "wiski_potrf_inverse")
+    return X, info
+
+
 def psd_safe_cholesky(A, jitter=None, max_tries=6):
     """Cholesky with gpytorch's jitter escalation (psd_safe_cholesky; imported by the
     reference at updated_root_lazy_tensor.py:5): try plain, then add jitter*10^i."""
@@ -642,6 +655,19 @@ def basis_project(grid, x, V, kmax, S, scale=None, colscale=None, tcol=None, wan
                                                   ctypes.c_int64(r), _hip.dptr(prior), _hip.dptr(err), _hip.stream_ptr(x2.device))
     _hip.check(rc, "wiski_basis_project")
     return (F, prior) if want_prior else F
+
+
+def basis_eig_update(g_dev, tcol64, Vin, kw, kuse):
+    """``wiski_basis_eig_update``: the per-dim eigenvector tables Vin ([sum g_q * kw] fp64, row-major [g_q, kw] blocks) refined for the
+    Toeplitz columns tcol64, all on the device.  Returns (Vout, ev [d, kw] descending, resid [d])."""
+    d = g_dev.shape[0]
+    Vout = torch.empty_like(Vin)
+    ev = torch.empty((d, kw), dtype=torch.float64, device=Vin.device)
+    resid = torch.empty(d, dtype=torch.float64, device=Vin.device)
+    rc = _hip.lib().wiski_basis_eig_update(ctypes.c_int32(d), _hip.dptr(g_dev), _hip.dptr(tcol64), _hip.dptr(Vin), ctypes.c_int32(kw),
+                                           ctypes.c_int32(kuse), _hip.dptr(Vout), _hip.dptr(ev), _hip.dptr(resid), _hip.stream_ptr(Vin.device))
+    _hip.check(rc, "wiski_basis_eig_update")
+    return Vout, ev, resid
 
 
 def basis_pair_reduce(Wt, S, ev, kmax):

@@ -34,6 +34,8 @@ import torch
 from .. import grid_ops, settings
 
 KMAX = 32
+GUARD = 6          # extra eigenvectors per dim carried for the device-side subspace iteration
+RESELECT_EVERY = 64
 
 
 def default_tail(dtype):
@@ -73,6 +75,32 @@ class SpectralBasis:
         else:
             self.S = torch.as_tensor(S.astype(np.int32)).to(device).contiguous()
             self.S_long = self.S.long()
+        self.kuse = int(S.max()) + 1                   # eigenvectors per dim the index set actually refers to
+        self.short0 = 0.0                              # fraction of trace(Kuu) the index set left out when it was selected
+        self.total = None                              # trace(Kuu) as a device scalar (device-refreshed bases only)
+
+    @classmethod
+    def on_device(cls, like, Vtab, ev_tab, total):
+        """The basis with `like`'s index set and device-refreshed eigenvector tables (wiski_basis_eig_update): no host copies."""
+        self = cls.__new__(cls)
+        self.grid, self.kmax, self.r, self.kuse, self.short0 = like.grid, like.kmax, like.r, like.kuse, like.short0
+        self.evs = self.Vs = self.Vtab_host = self.lam_kuu_host = None
+        self.S_host, self.S, self.S_long = like.S_host, like.S, like.S_long
+        self.Vtab, self.ev_tab, self.total = Vtab, ev_tab, total
+        self.Vq, off = [], 0
+        for g in like.grid.g:
+            self.Vq.append(Vtab[off:off + g * like.kmax].view(g, like.kmax))
+            off += g * like.kmax
+        lam = ev_tab[0][self.S_long[0]]
+        for q in range(1, like.grid.d):
+            lam = lam * ev_tab[q][self.S_long[q]]
+        self.lam_kuu = lam
+        return self
+
+    def device_refreshable(self):
+        """wiski_basis_eig_update's limits: even table width <= 32 that leaves room for guard vectors, factors of <= 64 nodes."""
+        return self.kmax % 2 == 0 and self.kmax <= KMAX and self.kmax >= min(self.kuse + 2, min(self.grid.g)) and max(self.grid.g) <= 64 \
+            and self.kmax <= min(self.grid.g)
 
 
 def host_eig(grid, tcol_host):
@@ -130,7 +158,12 @@ def select_basis(grid, tcol_host, tail, max_rank, device, eig=None, like=None, t
     sel = order[:r]
     S = np.stack(np.unravel_index(sel, lam.shape)).astype(np.int64)            # [d, r]
     kmax = int(S.max()) + 1
-    return SpectralBasis(grid, evs, Vs, S, flat[sel], kmax, device, like=like)
+    # table width: a few guard vectors beyond the ones the index set uses, even -- what the device-side refresh of the
+    # eigenvectors after a hyper-parameter step (wiski_basis_eig_update: subspace iteration) wants; costs nothing elsewhere
+    kw = min(KMAX, (kmax + GUARD + 1) & ~1, min(grid.g) & ~1)
+    basis = SpectralBasis(grid, evs, Vs, S, flat[sel], max(kmax, kw), device, like=like)
+    basis.short0 = max(0.0, 1.0 - float(cs[r - 1]) / total)
+    return basis
 
 
 class SpectralWoodburyFactor:
@@ -146,6 +179,10 @@ class SpectralWoodburyFactor:
         self.rebuilds = 0          # reference builds from the stencil (diagnostics / tests)
         self.idle_absorbs = 0      # batches followed since anybody last asked for a state (see the model's _spectral_absorb)
         self.last_rel_bound = 0.0
+        self._chk = None           # pending verdict of a device-side eigenvector refresh
+        self._dev_refreshes = 0
+        self.device_refreshes = 0  # diagnostics / tests
+        self.last_verdict = None
 
     # ------------------------------------------------------------------ reference statistics --
     def _project_grid_vectors(self, basis, Vm):
@@ -195,7 +232,7 @@ class SpectralWoodburyFactor:
         self.idle_absorbs += 1
 
     # --------------------------------------------------------------------------- derived state --
-    def state(self, key, tcol64, kscale, eig=None):
+    def state(self, key, tcol64, kscale, eig=None, _host_path=False):
         """The factor for the hyper-parameters identified by `key` (Toeplitz columns tcol64 on the host or device, fp64;
         Kt = kscale * Kuu).  None when the reduced basis would exceed settings.spectral_max_rank."""
         cur = self.cur
@@ -205,7 +242,13 @@ class SpectralWoodburyFactor:
         tail = default_tail(self.dtype)
         if cur is not None and cur["key"] == key:
             basis, TS, defect_ok = cur["basis"], cur["TS"], True
+        elif not _host_path and cur is not None and self.ref is not None and torch.is_tensor(tcol64) and tcol64.is_cuda \
+                and self._device_refresh_ok(cur, key):
+            basis, TS = self._device_refresh(cur, tcol64, tail)
+            defect_ok = True
         else:
+            self._chk = None
+            self._dev_refreshes = 0
             tc = tcol64.detach().to("cpu", torch.float64).numpy() if torch.is_tensor(tcol64) else np.asarray(tcol64, dtype=np.float64)
             fast = settings.fast_pred_var.on()
             cap = min(settings.spectral_max_rank.value(), settings.max_root_decomposition_size.value()) if fast else settings.spectral_max_rank.value()
@@ -227,22 +270,86 @@ class SpectralWoodburyFactor:
         hr = torch.mv(TS.t(), self.h_ref)
         C = (sq[:, None] * G * sq[None, :]).contiguous()
         C.diagonal().add_(1.0)
-        info = grid_ops.potrf_(C)                                             # C = I + PSD: cannot fail on finite input
-        # explicit inverse of the factor (one multi-column triangular solve, r^3 / 3 flop): every later solve against it --
-        # mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64 launches
-        Linv = grid_ops.trsm_(C, torch.eye(C.shape[0], dtype=torch.float64, device=self.device), trans=False)
+        # C = I + PSD: cannot fail on finite input.  With the factor its explicit inverse (r^3 / 3 flop more): every later solve
+        # against it -- mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64
+        # launches.  Two launches in all for r <= 480 (dense_small.h).
+        Linv, info = grid_ops.potrf_inverse_(C)
         ch = torch.mv(Linv, sq * hr)                                          # chol^-1 Lam^1/2 h
         cur = {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": TS, "lam": lam, "sq": sq, "G": G,
                "hr": hr, "chol": C, "Linv": Linv, "info": info, "c_half": ch, "bMb": (ch * ch).sum(), "logdet": grid_ops.chol_logdet(C),
                "tail": tail}
+        if self._chk is not None and not self._verdict():
+            # the device-refreshed basis failed its check (eigen-residual, trace left out by the kept index set, defect of the
+            # reference span): nothing built on it is used -- the host path selects afresh.  The verdict was copied back right
+            # after the change of basis was queued, so by now (a factorisation's worth of launches later) it has arrived.
+            self.cur = None
+            return self.state(key, tcol64, kscale, eig=eig, _host_path=True)
         self.cur = cur
         return cur
+
+    # ---- hyper-parameter step without a host round trip: refine the eigenvectors on the device, keep the index set, verify late
+    def _device_refresh_ok(self, cur, key):
+        basis = cur["basis"]
+        if key[1:] != cur["key"][1:] or not basis.device_refreshable() or not settings.spectral_device_refresh.on():
+            return False
+        if self._dev_refreshes >= RESELECT_EVERY:      # re-select the index set now and then (it only ever grows stale)
+            return False
+        return True
+
+    def _verdict(self):
+        """Verdict of the device refresh just queued (its three numbers were copied to pinned memory asynchronously)."""
+        host, ev, lim = self._chk
+        ev.synchronize()
+        resid, short, wdef = (float(v) for v in host)
+        self._chk = None
+        self.last_verdict = (resid, short, wdef)
+        return resid <= lim[0] and short <= lim[1] and wdef <= lim[2]
+
+    def _device_refresh(self, cur, tcol64, tail):
+        old = cur["basis"]
+        d, g = self.grid.d, self.grid.g
+        gd = self.__dict__.get("_g_dev")
+        if gd is None:
+            offs, o = [], 0
+            for gq in g:
+                offs.append(o)
+                o += gq
+            gd = self._g_dev = (torch.tensor(list(g), dtype=torch.int32, device=self.device), torch.tensor(offs, device=self.device),
+                                float(np.prod([float(x) for x in g])))
+        Vtab, ev_tab, resid = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse)
+        total = tcol64[gd[1]].prod() * gd[2]
+        basis = SpectralBasis.on_device(old, Vtab, ev_tab, total)
+        ref = self.ref
+        TS = None
+        for q in range(d):
+            Tq = ref.Vq[q].t() @ basis.Vq[q]
+            blk = Tq[ref.S_long[q]][:, basis.S_long[q]]
+            TS = blk if TS is None else TS * blk
+        TS = TS.contiguous()
+        defect = (1.0 - (TS * TS).sum(0)).clamp_min(0.0)
+        wdef = (basis.lam_kuu * defect).max() / total * basis.r
+        short = 1.0 - basis.lam_kuu.sum() / total
+        verdict = torch.stack([resid.max(), short, wdef])
+        host = self.__dict__.get("_chk_host")
+        if host is None:
+            host = self._chk_host = torch.empty(3, dtype=torch.float64).pin_memory()
+        host.copy_(verdict, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        # limits: the eigen-residual far below the tail; the index set may leave out up to 1.5 x the tail (or what a rank-capped
+        # selection left out to begin with) before it is re-selected
+        self._chk = (host, ev, (tail * 1e-3, 1.5 * max(tail, old.short0), tail))
+        self._dev_refreshes += 1
+        self.device_refreshes += 1
+        return basis, TS
 
     def _change_of_basis(self, basis):
         """T [r_ref, r] and the eigenvalue-weighted defect max_j lam_j (1 - |T[:, j]|^2) / trace (what the reference
         span misses of each current basis vector, in units of the trace)."""
         ref = self.ref
         d = self.grid.d
+        if ref.Vtab_host is None or basis.Vtab_host is None:
+            raise RuntimeError("change of basis on the host needs host copies of both bases")
         Th = [ref.Vtab_host[q].T @ basis.Vtab_host[q] for q in range(d)]                        # [kmax_ref, kmax] per dim
         packed = torch.as_tensor(np.concatenate([t.reshape(-1) for t in Th])).to(self.device)
         TS, off = None, 0
@@ -283,19 +390,28 @@ class SpectralWoodburyFactor:
         d(b^T M b) = zeta^T (B^T dKt B) zeta,  d logdet = tr(S_B B^T dKt B),  S_B = G - G M_r G,  M_r = Lam^1/2 C^-1 Lam^1/2."""
         basis, G, sq, chol, kap = st["basis"], st["G"], st["sq"], st["chol"], st["kscale"]
         _, zeta = self.coefficients(st)
-        Wt = torch.outer(zeta, zeta) * float(g_bMb)
-        if float(g_logdet) != 0.0:
-            Y2 = grid_ops.gemm(st["Linv"], (sq[:, None] * G).contiguous())       # chol^-1 Lam^1/2 G
-            SB = G - grid_ops.gemm(Y2, Y2, ta=True)
-            Wt = Wt + float(g_logdet) * SB
-        Wt = Wt.contiguous()
+        # (the incoming gradients stay on the device: reading them would stall the host behind everything queued so far)
+        Y2 = grid_ops.gemm(st["Linv"], (sq[:, None] * G).contiguous())           # chol^-1 Lam^1/2 G
+        SB = G - grid_ops.gemm(Y2, Y2, ta=True)
+        if not torch.is_tensor(g_bMb):
+            g_bMb = torch.tensor(float(g_bMb), dtype=torch.float64, device=self.device)
+        if not torch.is_tensor(g_logdet):
+            g_logdet = torch.tensor(float(g_logdet), dtype=torch.float64, device=self.device)
+        Wt = torch.addcmul(g_logdet.double() * SB, zeta[:, None] * g_bMb.double(), zeta[None, :]).contiguous()
         D = grid_ops.basis_pair_reduce(Wt, basis.S, basis.ev_tab, basis.kmax)
-        g_tcol = torch.zeros(sum(self.grid.g), dtype=torch.float64, device=self.device)
-        off = 0
-        for q, gq in enumerate(self.grid.g):
-            H = basis.Vq[q] @ D[q, :basis.kmax, :basis.kmax] @ basis.Vq[q].t()                     # [g_q, g_q]
-            g_tcol[off:off + gq] = torch.mv(self._lag_matrix(gq), H.reshape(-1))                   # sums along the lag diagonals
-            off += gq
+        gs = self.grid.g
+        if len(set(gs)) == 1:
+            # equal factors (the usual grid): the d congruences V_q D_q V_q^T as two batched products, the lag sums as one GEMM
+            V = basis.Vtab.view(len(gs), gs[0], basis.kmax)
+            H = torch.bmm(torch.bmm(V, D), V.transpose(1, 2))                                      # [d, g, g]
+            g_tcol = (H.reshape(len(gs), -1) @ self._lag_matrix(gs[0]).t()).reshape(-1)
+        else:
+            g_tcol = torch.zeros(sum(gs), dtype=torch.float64, device=self.device)
+            off = 0
+            for q, gq in enumerate(gs):
+                H = basis.Vq[q] @ D[q, :basis.kmax, :basis.kmax] @ basis.Vq[q].t()                 # [g_q, g_q]
+                g_tcol[off:off + gq] = torch.mv(self._lag_matrix(gq), H.reshape(-1))               # sums along the lag diagonals
+                off += gq
         g_kap = (Wt.diagonal() * basis.lam_kuu).sum()
         return g_tcol * kap, g_kap
 

@@ -43,8 +43,6 @@ class _WoodburyTerms(torch.autograd.Function):
     def forward(ctx, tcol64, kappa, model, o, want_logdet):
         grid = model._grid
         dt, dev = model._dtype, model._device
-        tcol = tcol64.detach().to(dt).contiguous()
-        kap = float(kappa.detach())
         A = model._kernel_cache["WtW"]
         A = A.ops[o] if hasattr(A, "ops") else A
         b = model._kernel_cache["interpolation_cache"][o, :, 0]
@@ -59,6 +57,8 @@ class _WoodburyTerms(torch.autograd.Function):
             ctx.spectral = (fac, st)
             logdet = st["logdet"].clone() if want_logdet else torch.zeros((), dtype=torch.float64, device=dev)
             return st["bMb"].clone(), logdet
+        tcol = tcol64.detach().to(dt).contiguous()
+        kap = float(kappa.detach())
         # plain eigenbasis of Kt: the dense factor and the SLQ logdet need it; the streaming hyper step
         # (skip_logdet_forward, large grid) does not -- 3 host eigh + an upload saved per step
         eig = grid_ops.kron_eigen(grid, tcol) if (dense or want_logdet) else None

@@ -522,11 +522,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         ent = memo.get(o)
         if ent is None or ent[0] != key:
             tcol64 = self._hyper()[o][2]                 # fp64 Toeplitz columns, computed once per hyper-parameter version
-            ent = (key, tcol64, tcol64.cpu().numpy())
+            ent = (key, tcol64)
             memo[o] = ent
         if ent[1] is None:
             return None                                  # not applicable at these hyper-parameters (remembered)
-        _, tcol64, tc_host = ent
+        _, tcol64 = ent
         facs = self.__dict__.setdefault("_spectral", {})
         fac = facs.get(o)
         if fac is None:
@@ -536,20 +536,23 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             # statistics changed behind the factor's back: rebuild from the stencil (and forget the state derived from the old ones)
             fac.ref = fac.cur = None
             fac.data_version += 1
-        st = fac.state(key, tc_host, kscale)
+        # the columns go in as a device tensor: after a hyper-parameter step the factor refreshes its eigenvectors on the
+        # device (no host copy, no synchronisation) unless it has to re-select its index set
+        st = fac.state(key, tcol64, kscale)
         if st is None:
-            memo[o] = (key, None, None)
+            memo[o] = (key, None)
             return None
         if st.get("need_reference"):
+            tc_host = tcol64.detach().cpu().numpy()
             # reference basis with a margin, so that the eigenbasis may drift with the hyper-parameters before the
             # reference has to be rebuilt; if the margin does not fit the rank cap, the basis itself
             refb = None if settings.fast_pred_var.on() else sw.select_basis(self._grid, tc_host, st["tail"] * 1e-2, 2 * settings.spectral_max_rank.value(),
                                                                             self._device)
             op = _wtw_ops(self._kernel_cache["WtW"])[o]
             fac.build_reference(refb if refb is not None else st["basis"], op.stencil, self._kernel_cache["interpolation_cache"][o, :, 0])
-            st = fac.state(key, tc_host, kscale)
+            st = fac.state(key, tcol64, kscale)
             if st is None or st.get("need_reference"):
-                memo[o] = (key, None, None)
+                memo[o] = (key, None)
                 return None
         return fac, st, tcol64
 

@@ -229,6 +229,15 @@ class spectral_tail(_value_context):
     _global_value = None
 
 
+class spectral_device_refresh(_feature_flag):
+    """After a hyper-parameter step, refine the spectral factor's per-dim eigenvectors on the device (subspace iteration from the
+    previous ones, ``wiski_basis_eig_update``) and keep the index set, instead of a host eigh + re-selection; the refinement's
+    residual, the trace the kept index set leaves out and the reference-span defect are read back before the state is handed out
+    (the copy is queued ahead of the factorisation, so the wait is short); a failed check (or every 64th step) takes the host path."""
+
+    _state = True
+
+
 class spectral_max_rank(_value_context):
     """Largest reduced basis the spectral factor is built for; beyond it the PCG path serves the request."""
 

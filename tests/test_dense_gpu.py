@@ -77,6 +77,42 @@ def test_cholesky_trsm_logdet(dtype, tol, n):
     assert ((L.t() @ Y).double() - B.double()).abs().max().item() < tol * 50
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 65, 100, 327, 449, 480, 481, 700])
+def test_cholesky_with_explicit_inverse(dtype, tol, n):
+    """wiski_potrf_inverse: factor in place + X = L^-1.  n <= 480 is the one-workgroup path (dense_small.h: every panel
+    boundary case -- partial last block, exactly full blocks, one block), beyond it the blocked path + a triangular solve."""
+    from online_gp_amd import grid_ops
+
+    g = torch.Generator(device="cpu").manual_seed(1000 + n)
+    R = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = (R @ R.t() / n + torch.eye(n, dtype=torch.float64)).to(DEV, dtype)
+    pad = torch.full((n, n + 3), float("nan"), device=DEV, dtype=dtype)      # a leading dimension larger than n is honoured
+    L = A.clone()
+    X, info = grid_ops.potrf_inverse_(L)
+    assert int(info.item()) == 0
+    Lref = torch.linalg.cholesky(A.double())
+    assert torch.equal(L, torch.tril(L)) and torch.equal(X, torch.tril(X))
+    assert (L.double() - Lref).abs().max().item() < tol * 10
+    Xref = torch.linalg.inv(Lref)
+    assert (X.double() - Xref).abs().max().item() < tol * 10 * max(1.0, Xref.abs().max().item())
+    assert ((X @ L).double() - torch.eye(n, dtype=torch.float64, device=DEV)).abs().max().item() < tol * 50
+    # plain potrf takes the same small path
+    L2 = A.clone()
+    assert int(grid_ops.potrf_(L2).item()) == 0
+    assert torch.equal(L2, L)
+    del pad
+
+
+def test_small_cholesky_reports_a_non_positive_pivot():
+    from online_gp_amd import grid_ops
+
+    v = torch.randn(200, 3, device=DEV, dtype=torch.float64)
+    A = v @ v.t()
+    X, info = grid_ops.potrf_inverse_(A.clone())
+    assert int(info.item()) != 0
+
+
 def test_not_pd_sets_info_and_psd_safe_adds_jitter():
     from online_gp_amd import grid_ops
 

@@ -324,3 +324,125 @@ def test_factor_is_rebuilt_after_statistics_changed_behind_its_back():
         assert fac.rebuilds == 3
         m.set_train_data(Xt[:500], yt[:500], torch.ones_like(yt[:500]))
         check(500)
+
+
+@pytest.mark.parametrize("g,kw,kuse,drift", [(50, 16, 10, 1.02), (50, 14, 8, 0.95), (30, 12, 7, 1.05), (64, 32, 20, 1.01), (9, 8, 5, 1.03)])
+def test_device_eigen_update_tracks_the_host_eigh(g, kw, kuse, drift):
+    """wiski_basis_eig_update: subspace iteration + Rayleigh-Ritz from the previous eigenvectors reproduces numpy's eigh of the
+    drifted Toeplitz factors on the vectors that are used (eigenvalues, invariant subspace, orthonormality, reported residual)."""
+    from online_gp_amd import grid_ops
+
+    d = 3
+    ells = np.array([0.35, 0.5, 0.42])
+    h = 2.2 / (g - 1)
+
+    def cols(e):
+        return [np.exp(-0.5 * (np.arange(g) * h / e[q]) ** 2) * (1.3 if q == 0 else 1.0) for q in range(d)]
+
+    def eig(cs_):
+        out = []
+        for c in cs_:
+            idx = np.abs(np.arange(g)[:, None] - np.arange(g)[None, :])
+            w, V = np.linalg.eigh(c[idx])
+            out.append((w[::-1].clip(0), V[:, ::-1].copy()))
+        return out
+
+    e0 = eig(cols(ells))
+    new = ells * np.array([drift, 1.0 / drift, drift ** 0.5])
+    c1 = cols(new)
+    e1 = eig(c1)
+    Vin = torch.as_tensor(np.concatenate([V[:, :kw].reshape(-1) for _, V in e0])).to(DEV)
+    g_dev = torch.tensor([g] * d, dtype=torch.int32, device=DEV)
+    Vout, ev, resid = grid_ops.basis_eig_update(g_dev, torch.as_tensor(np.concatenate(c1)).to(DEV), Vin, kw, kuse)
+    Vout = Vout.cpu().numpy().reshape(d, g, kw); ev = ev.cpu().numpy(); resid = resid.cpu().numpy()
+    for q in range(d):
+        w, V = e1[q]
+        assert np.abs(ev[q, :kuse] - w[:kuse]).max() < 1e-11 * w[0], q
+        assert np.all(np.diff(ev[q]) <= 0)
+        Vd = Vout[q]
+        assert np.abs(Vd[:, :kuse].T @ Vd[:, :kuse] - np.eye(kuse)).max() < 1e-12
+        assert np.abs(Vd.T @ Vd - np.eye(kw)).max() < 1e-9          # guard vectors (eigenvalues at rounding level): Gram-Schmidt once
+        # the used vectors: same up to sign (the spectrum of an RBF factor is simple)
+        sig = w[:kuse] > 1e-8 * w[0]                  # (below that eigh's own vectors are rounding noise)
+        dots = np.abs(np.einsum("ia,ia->a", Vd[:, :kuse], V[:, :kuse]))[sig]
+        assert sig.sum() >= min(kuse, 5) and np.abs(dots - 1).max() < 1e-7, (q, dots)
+        idx = np.abs(np.arange(g)[:, None] - np.arange(g)[None, :])
+        R = c1[q][idx] @ Vd[:, :kuse] - Vd[:, :kuse] * ev[q, :kuse]
+        assert abs(np.abs(R).max() / w[0] - resid[q]) < 1e-13
+        # geometric spectra (production grids) converge in the two iterations; a 9-node factor with one vector left out does not,
+        # and says so -- which is what sends such a step through the host path
+        assert resid[q] < (1e-11 if g >= 30 else 1e-6)
+
+
+def test_hyperparameter_steps_refresh_the_factor_on_the_device():
+    """Small optimiser-like steps keep the index set and refine the eigenvectors on the device (no host eigh): same predictions
+    as the host path, verdict within its limits; a jump that the kept index set cannot serve is caught before use."""
+    from online_gp_amd import settings
+
+    rng = np.random.default_rng(21)
+    d, g, n = 3, 16, 700
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(2 * X[:, 0]) * X[:, 1] + 0.2 * X[:, 2] + 0.1 * rng.standard_normal(n)
+    Xs = rng.uniform(-1, 1, (50, d))
+    for dtype, tol in [(torch.float64, 1e-4), (torch.float32, 1e-2)]:
+        m = _model(X, y, g, dtype)
+        m.eval()
+        Xst = torch.as_tensor(Xs, device=DEV, dtype=dtype)
+        m(Xst).variance
+        fac = m._spectral[0]
+        k = m.covar_module.base_kernel
+        assert fac.cur["basis"].device_refreshable()
+        for step in range(6):
+            f = 1.0 + 0.01 * (-1) ** step * (1 + step % 3)
+            with torch.no_grad():
+                k.base_kernel.lengthscale = k.base_kernel.lengthscale * torch.tensor([f, 1.0 / f, f ** 0.5], device=DEV).reshape(1, -1)
+                k.outputscale = k.outputscale * (2 - f)
+                m.likelihood.second_noise = float(m.likelihood.second_noise) * f
+            m._dump_caches()
+            post = m(Xst)
+            mu, v = post.mean.cpu().numpy(), post.variance.cpu().numpy()
+            assert fac.device_refreshes == step + 1, step
+            assert fac.cur["basis"].Vtab_host is None
+            resid, short, wdef = fac.last_verdict
+            assert resid < fac.cur["tail"] * 1e-3 and short < 1.5 * fac.cur["tail"]
+            ell, s, s2 = _hypers(m)
+            mo, vo = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, np.ones(n)).predict(Xs)
+            assert np.max(np.abs(v - vo) / vo) < tol, (dtype, step)
+            assert np.max(np.abs(mu - mo)) < tol * max(1.0, np.abs(mo).max()), (dtype, step)
+        # the MLL and its gradients on a device-refreshed basis agree with the host path
+        from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood
+        m.train()
+        mll = BatchedWoodburyMarginalLogLikelihood(m.likelihood, m)
+        m.zero_grad()
+        l_dev = mll(m(torch.as_tensor(X, device=DEV, dtype=dtype)), torch.as_tensor(y, device=DEV, dtype=dtype))
+        l_dev.backward()
+        g_dev = [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        with settings.spectral_device_refresh(False):
+            m.zero_grad()
+            m._drop_spectral()
+            l_host = mll(m(torch.as_tensor(X, device=DEV, dtype=dtype)), torch.as_tensor(y, device=DEV, dtype=dtype))
+            l_host.backward()
+            g_host = [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        assert abs(float(l_dev) - float(l_host)) < tol * max(1.0, abs(float(l_host)))
+        for a, b in zip(g_dev, g_host):
+            assert torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max())), (a, b)
+        # a jump to 0.6 x the lengthscale: the kept index set leaves out too much -> the host path serves this step
+        m.eval()
+        before = fac.device_refreshes
+        with torch.no_grad():
+            k.base_kernel.lengthscale = k.base_kernel.lengthscale * 0.6
+        m._dump_caches()
+        post = m(Xst)
+        sp = m._spectral_state(0)
+        if sp is not None:                          # (may legitimately exceed the rank cap and fall back to PCG)
+            v = post.variance.cpu().numpy()
+            ell, s, s2 = _hypers(m)
+            mo, vo = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, np.ones(n)).predict(Xs)
+            assert np.max(np.abs(v - vo) / vo) < tol
+            assert sp[1]["basis"].Vtab_host is not None
+        assert fac.last_verdict[1] > 1.5 * default_tail_of(dtype) or fac.device_refreshes == before   # caught by the verdict (or never tried)
+
+
+def default_tail_of(dtype):
+    from online_gp_amd.lazy.spectral_woodbury import default_tail
+
+    return default_tail(dtype)

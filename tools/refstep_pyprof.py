@@ -19,4 +19,4 @@ with settings.cg_tolerance(1e-4), settings.variance_cg_tolerance(3e-3):
     pr = cProfile.Profile(); pr.enable(); t0 = time.perf_counter()
     for i in range(4, 24): step(i)
     torch.cuda.synchronize(); print("ms per step", (time.perf_counter() - t0) / 20 * 1e3)
-    pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(70)
+    pr.disable(); pstats.Stats(pr).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "cumulative").print_stats(70)
