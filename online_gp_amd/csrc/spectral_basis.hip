@@ -323,3 +323,197 @@ extern "C" int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const doubl
   hipLaunchKernelGGL(k_eig_update, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, d_tcol, d_Vin, (int)kw, (int)kuse, d_Vout, d_ev, d_resid);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
+
+// ------------------------------------------------------------ change of basis ---
+// After wiski_basis_eig_update: everything that connects the refreshed eigenvectors to the factor's reference statistics, in
+// ONE launch (it was ~35 small torch launches):
+//   T_q = Vref_q^T Vnew_q  (kref x kw per dim, recomputed by every block in LDS: 3 x 32 x 32 x g FMAs)
+//   TS[i, j] = prod_q T_q[Sref[q, i], S[q, j]]          the Kronecker-structured change of basis, r_ref x r
+//   lam[j]   = prod_q ev[q, S[q, j]]                    eigenvalues of Kuu on the kept index set
+//   verdict  = [ max_q resid_q,  1 - sum_j lam_j / trace(Kuu),  r * max_j lam_j (1 - |TS[:, j]|^2) / trace(Kuu) ]
+// (eigen-residual of the refresh, trace left out by the kept index set, eigenvalue-weighted defect of the reference span --
+// the three numbers the host checks before it uses the refreshed factor).  Column norms are accumulated with atomics into
+// work[0 .. r) (zero on entry, re-zeroed by the last block, which also writes lam and the verdict); work[r] is the block counter.
+constexpr int BC_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_basis_change(int d, const int* __restrict__ gs, int kref, int kw, int r_ref, int r, const double* __restrict__ Vref,
+                                                      const double* __restrict__ Vnew, const int32_t* __restrict__ Sref, const int32_t* __restrict__ S,
+                                                      const double* __restrict__ ev, const double* __restrict__ tcol, const double* __restrict__ resid,
+                                                      double* __restrict__ TS, double* __restrict__ lam, double* __restrict__ work,
+                                                      double* __restrict__ verdict) {
+  __shared__ double sT[WISKI_MAX_DIM][SPB_KMAX][SPB_KMAX + 1];
+  __shared__ double s_red[3][4];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int goff[WISKI_MAX_DIM + 1];
+  goff[0] = 0;
+  for (int q = 0; q < d; ++q) goff[q + 1] = goff[q] + gs[q];
+  for (int e = tid; e < d * kref * kw; e += 256) {
+    const int q = e / (kref * kw), a = (e / kw) % kref, b = e % kw;
+    const int g = goff[q + 1] - goff[q];
+    const double* __restrict__ vr = Vref + (int64_t)goff[q] * kref + a;
+    const double* __restrict__ vn = Vnew + (int64_t)goff[q] * kw + b;
+    double acc = 0;
+    for (int i = 0; i < g; ++i) acc += vr[(int64_t)i * kref] * vn[(int64_t)i * kw];
+    sT[q][a][b] = acc;
+  }
+  __syncthreads();
+  const int i0 = blockIdx.x * BC_ROWS;
+  int sref[BC_ROWS][WISKI_MAX_DIM];
+#pragma unroll
+  for (int u = 0; u < BC_ROWS; ++u)
+    for (int q = 0; q < d; ++q) sref[u][q] = i0 + u < r_ref ? Sref[(int64_t)q * r_ref + i0 + u] : 0;
+  for (int j = tid; j < r; j += 256) {
+    int sj[WISKI_MAX_DIM];
+    for (int q = 0; q < d; ++q) sj[q] = S[(int64_t)q * r + j];
+    double nrm = 0;
+#pragma unroll
+    for (int u = 0; u < BC_ROWS; ++u) {
+      if (i0 + u >= r_ref) break;
+      double v = 1.0;
+      for (int q = 0; q < d; ++q) v *= sT[q][sref[u][q]][sj[q]];
+      TS[(int64_t)(i0 + u) * r + j] = v;
+      nrm += v * v;
+    }
+    unsafeAtomicAdd(&work[j], nrm);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(work + r), 1ull);
+    s_last = done + 1 == gridDim.x;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double total = 1.0;
+  for (int q = 0; q < d; ++q) total *= (double)(goff[q + 1] - goff[q]) * tcol[goff[q]];
+  double sum = 0, wmax = 0;
+  for (int j = tid; j < r; j += 256) {
+    double l = 1.0;
+    for (int q = 0; q < d; ++q) l *= ev[q * kw + S[(int64_t)q * r + j]];
+    lam[j] = l;
+    const double nrm = __hip_atomic_load(&work[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    work[j] = 0.0;
+    const double def = 1.0 - nrm > 0 ? 1.0 - nrm : 0.0;
+    sum += l;
+    wmax = l * def > wmax ? l * def : wmax;
+  }
+  sum = wave_reduce_sum<double>(sum);
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(wmax, off, 64);
+    wmax = o > wmax ? o : wmax;
+  }
+  if (lane == 0) { s_red[0][wv] = sum; s_red[1][wv] = wmax; }
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0, w = 0, rs = 0;
+    for (int i = 0; i < 4; ++i) { s += s_red[0][i]; w = s_red[1][i] > w ? s_red[1][i] : w; }
+    for (int q = 0; q < d; ++q) rs = resid[q] > rs ? resid[q] : rs;
+    verdict[0] = rs;
+    verdict[1] = total > 0 ? 1.0 - s / total : 1.0;
+    verdict[2] = total > 0 ? w / total * (double)r : 1.0;
+    *reinterpret_cast<unsigned long long*>(work + r) = 0ull;
+  }
+}
+
+// C = I + Lam^1/2 G Lam^1/2 with lam = lam_kuu * kscale (also written out, with its square root): the matrix the spectral
+// Woodbury factor factorises, in one launch.
+__global__ __launch_bounds__(256) void k_woodbury_c(int r, const double* __restrict__ G, const double* __restrict__ lam_kuu, double kscale,
+                                                    double* __restrict__ C, double* __restrict__ lam, double* __restrict__ sq) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)r * r) return;
+  const int i = (int)(e / r), j = (int)(e % r);
+  const double li = lam_kuu[i] * kscale, lj = lam_kuu[j] * kscale;
+  C[e] = sqrt(li) * G[e] * sqrt(lj) + (i == j ? 1.0 : 0.0);
+  if (j == 0) { lam[i] = li; sq[i] = sqrt(li); }
+}
+
+extern "C" int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, int32_t kw, int32_t r_ref, int32_t r, const double* d_Vref,
+                                  const double* d_Vnew, const int32_t* d_Sref, const int32_t* d_S, const double* d_ev, const double* d_tcol,
+                                  const double* d_resid, double* d_TS, double* d_lam, double* d_work, double* d_verdict, void* stream) {
+  if (d < 1 || d > WISKI_MAX_DIM || !d_g || kref < 1 || kref > SPB_KMAX || kw < 1 || kw > SPB_KMAX || r_ref < 1 || r < 1 || !d_Vref || !d_Vnew || !d_Sref ||
+      !d_S || !d_ev || !d_tcol || !d_resid || !d_TS || !d_lam || !d_work || !d_verdict)
+    return WISKI_E_BADARG;
+  const unsigned nb = (unsigned)((r_ref + BC_ROWS - 1) / BC_ROWS);
+  hipLaunchKernelGGL(k_basis_change, dim3(nb), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, (int)kref, (int)kw, (int)r_ref, (int)r, d_Vref, d_Vnew, d_Sref,
+                     d_S, d_ev, d_tcol, d_resid, d_TS, d_lam, d_work, d_verdict);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+extern "C" int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_lam_kuu, double kscale, double* d_C, double* d_lam, double* d_sq, void* stream) {
+  if (r < 1 || !d_G || !d_lam_kuu || !d_C || !d_lam || !d_sq) return WISKI_E_BADARG;
+  const int64_t tot = (int64_t)r * r;
+  hipLaunchKernelGGL(k_woodbury_c, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)r, d_G, d_lam_kuu, kscale, d_C, d_lam, d_sq);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// ------------------------------------------------------------- lag gradient ---
+// MLL backward, last step: the pair-reduced weights D_q (kw x kw per dim, wiski_basis_pair_reduce) back to the Toeplitz columns,
+//   g_tcol_q[l] = scale * sum_{|i - j| = l} (V_q D_q V_q^T)[i, j],
+// one workgroup per dim (it was two batched GEMMs and a [d, g^2] x [g^2, g] GEMM for which the BLAS picked a 139 us kernel).
+__global__ __launch_bounds__(256) void k_lag_grad(int d, const int* __restrict__ gs, int kw, const double* __restrict__ V, const double* __restrict__ D,
+                                                  double scale, double* __restrict__ out) {
+  __shared__ double sV[EIG_G][SPB_KMAX + 1], sU[EIG_G][SPB_KMAX + 1], sD[SPB_KMAX][SPB_KMAX + 1], sAcc[4][EIG_G];
+  const int q = blockIdx.x, t = threadIdx.x;
+  const int g = gs[q];
+  int toff = 0;
+  for (int p = 0; p < q; ++p) toff += gs[p];
+  for (int e = t; e < g * kw; e += 256) sV[e / kw][e % kw] = V[(int64_t)toff * kw + e];
+  for (int e = t; e < kw * kw; e += 256) sD[e / kw][e % kw] = D[(int64_t)q * kw * kw + e];
+  __syncthreads();
+  for (int e = t; e < g * kw; e += 256) {
+    const int i = e / kw, b = e % kw;
+    double acc = 0;
+    for (int a = 0; a < kw; ++a) acc += sV[i][a] * sD[a][b];
+    sU[i][b] = acc;
+  }
+  __syncthreads();
+  const int l = t & 63, part = t >> 6;                 // lag l, rows i = part, part + 4, ...
+  double acc = 0;
+  if (l < g) {
+    for (int i = part; i + l < g; i += 4) {
+      double h1 = 0, h2 = 0;
+      for (int b = 0; b < kw; ++b) {
+        h1 += sU[i][b] * sV[i + l][b];                  // H[i, i + l]
+        h2 += sU[i + l][b] * sV[i][b];                  // H[i + l, i]
+      }
+      acc += l == 0 ? h1 : h1 + h2;
+    }
+  }
+  sAcc[part][l] = acc;
+  __syncthreads();
+  if (t < g) out[toff + t] = scale * (sAcc[0][t] + sAcc[1][t] + sAcc[2][t] + sAcc[3][t]);
+}
+
+extern "C" int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double* d_V, const double* d_D, double scale, double* d_out, void* stream) {
+  if (d < 1 || d > WISKI_MAX_DIM || !d_g || kw < 1 || kw > SPB_KMAX || !d_V || !d_D || !d_out) return WISKI_E_BADARG;
+  hipLaunchKernelGGL(k_lag_grad, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, (int)kw, d_V, d_D, scale, d_out);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+// --------------------------------------------------------- query variances ---
+// diag_j = |Y[:, j]|^2 (Y = chol^-1 F^T, [r, n]),  tail_j = max(prior_j * kscale - |F[j, :]|^2, 0) (the prior variance the
+// reduced basis leaves out of query j): the two vectors a predictive variance is the sum of, in one launch.
+__global__ __launch_bounds__(256) void k_spectral_var(int n, int r, const double* __restrict__ Y, const double* __restrict__ F, const double* __restrict__ prior,
+                                                      double kscale, double* __restrict__ diag, double* __restrict__ tail) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  double dsum = 0, cap = 0;
+  for (int i = 0; i < r; ++i) {
+    const double y = Y[(int64_t)i * n + j];
+    dsum += y * y;
+  }
+  const double* __restrict__ f = F + (int64_t)j * r;
+  for (int k = 0; k < r; ++k) cap += f[k] * f[k];
+  diag[j] = dsum;
+  const double tl = prior[j] * kscale - cap;
+  tail[j] = tl > 0 ? tl : 0.0;
+}
+
+extern "C" int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, double kscale, double* d_diag,
+                                  double* d_tail, void* stream) {
+  if (n < 1 || r < 1 || !d_Y || !d_F || !d_prior || !d_diag || !d_tail) return WISKI_E_BADARG;
+  hipLaunchKernelGGL(k_spectral_var, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_Y, d_F, d_prior, kscale, d_diag, d_tail);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}

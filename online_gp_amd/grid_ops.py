@@ -670,6 +670,55 @@ def basis_eig_update(g_dev, tcol64, Vin, kw, kuse):
     return Vout, ev, resid
 
 
+def basis_change(g_dev, ref_Vtab, kref, ref_S, Vtab, kw, S, ev, tcol64, resid, work):
+    """``wiski_basis_change``: (TS [r_ref, r], lam [r], verdict [3]) for a device-refreshed basis; work: r + 1 zeroed doubles."""
+    d, r_ref = ref_S.shape
+    r = S.shape[1]
+    TS = torch.empty((r_ref, r), dtype=torch.float64, device=Vtab.device)
+    lam = torch.empty(r, dtype=torch.float64, device=Vtab.device)
+    verdict = torch.empty(3, dtype=torch.float64, device=Vtab.device)
+    rc = _hip.lib().wiski_basis_change(ctypes.c_int32(d), _hip.dptr(g_dev), ctypes.c_int32(kref), ctypes.c_int32(kw), ctypes.c_int32(r_ref),
+                                       ctypes.c_int32(r), _hip.dptr(ref_Vtab), _hip.dptr(Vtab), _hip.dptr(ref_S), _hip.dptr(S), _hip.dptr(ev),
+                                       _hip.dptr(tcol64), _hip.dptr(resid), _hip.dptr(TS), _hip.dptr(lam), _hip.dptr(work), _hip.dptr(verdict),
+                                       _hip.stream_ptr(Vtab.device))
+    _hip.check(rc, "wiski_basis_change")
+    return TS, lam, verdict
+
+
+def woodbury_c(G, lam_kuu, kscale):
+    """``wiski_woodbury_c``: (C = I + Lam^1/2 G Lam^1/2, lam = lam_kuu * kscale, sqrt(lam)) in one launch."""
+    r = G.shape[0]
+    C = torch.empty_like(G)
+    lam = torch.empty(r, dtype=torch.float64, device=G.device)
+    sq = torch.empty(r, dtype=torch.float64, device=G.device)
+    rc = _hip.lib().wiski_woodbury_c(ctypes.c_int32(r), _hip.dptr(G), _hip.dptr(lam_kuu), ctypes.c_double(float(kscale)), _hip.dptr(C), _hip.dptr(lam),
+                                     _hip.dptr(sq), _hip.stream_ptr(G.device))
+    _hip.check(rc, "wiski_woodbury_c")
+    return C, lam, sq
+
+
+def basis_lag_grad(g_dev, Vtab, kw, D, scale):
+    """``wiski_basis_lag_grad``: [sum g] fp64 gradient w.r.t. the Toeplitz columns from the pair-reduced weights D [d, kw, kw]."""
+    out = torch.empty(Vtab.shape[0] // kw, dtype=torch.float64, device=Vtab.device)
+    rc = _hip.lib().wiski_basis_lag_grad(ctypes.c_int32(g_dev.shape[0]), _hip.dptr(g_dev), ctypes.c_int32(kw), _hip.dptr(Vtab), _hip.dptr(D.contiguous()),
+                                         ctypes.c_double(float(scale)), _hip.dptr(out), _hip.stream_ptr(Vtab.device))
+    _hip.check(rc, "wiski_basis_lag_grad")
+    return out
+
+
+def spectral_var(Y, F, prior, kscale):
+    """``wiski_spectral_var``: (|Y[:, j]|^2, max(prior_j * kscale - |F[j]|^2, 0)) for Y [r, n], F [n, r] (fp64, contiguous)."""
+    r, n = Y.shape
+    diag = torch.empty(n, dtype=torch.float64, device=Y.device)
+    tail = torch.empty(n, dtype=torch.float64, device=Y.device)
+    if n == 0:
+        return diag, tail
+    rc = _hip.lib().wiski_spectral_var(ctypes.c_int32(n), ctypes.c_int32(r), _hip.dptr(Y), _hip.dptr(F), _hip.dptr(prior), ctypes.c_double(float(kscale)),
+                                       _hip.dptr(diag), _hip.dptr(tail), _hip.stream_ptr(Y.device))
+    _hip.check(rc, "wiski_spectral_var")
+    return diag, tail
+
+
 def basis_pair_reduce(Wt, S, ev, kmax):
     """D [d, kmax, kmax] of ``wiski_basis_pair_reduce`` (Wt [r, r] fp64, S int32 [d, r], ev fp64 [d, kmax])."""
     d, r = S.shape

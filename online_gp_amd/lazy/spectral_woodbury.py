@@ -80,7 +80,7 @@ class SpectralBasis:
         self.total = None                              # trace(Kuu) as a device scalar (device-refreshed bases only)
 
     @classmethod
-    def on_device(cls, like, Vtab, ev_tab, total):
+    def on_device(cls, like, Vtab, ev_tab, total, lam=None):
         """The basis with `like`'s index set and device-refreshed eigenvector tables (wiski_basis_eig_update): no host copies."""
         self = cls.__new__(cls)
         self.grid, self.kmax, self.r, self.kuse, self.short0 = like.grid, like.kmax, like.r, like.kuse, like.short0
@@ -91,9 +91,10 @@ class SpectralBasis:
         for g in like.grid.g:
             self.Vq.append(Vtab[off:off + g * like.kmax].view(g, like.kmax))
             off += g * like.kmax
-        lam = ev_tab[0][self.S_long[0]]
-        for q in range(1, like.grid.d):
-            lam = lam * ev_tab[q][self.S_long[q]]
+        if lam is None:
+            lam = ev_tab[0][self.S_long[0]]
+            for q in range(1, like.grid.d):
+                lam = lam * ev_tab[q][self.S_long[q]]
         self.lam_kuu = lam
         return self
 
@@ -263,13 +264,10 @@ class SpectralWoodburyFactor:
             defect_ok = wdef <= tail
             if not defect_ok:
                 return {"need_reference": True, "basis": basis, "tail": tail}
-        lam = basis.lam_kuu * kscale
-        sq = lam.sqrt()
         GT = grid_ops.gemm(self.G_ref, TS)                                    # [r_ref, r]
         G = grid_ops.gemm(TS, GT, ta=True)                                    # T^T G_ref T
         hr = torch.mv(TS.t(), self.h_ref)
-        C = (sq[:, None] * G * sq[None, :]).contiguous()
-        C.diagonal().add_(1.0)
+        C, lam, sq = grid_ops.woodbury_c(G, basis.lam_kuu, kscale)            # I + Lam^1/2 G Lam^1/2
         # C = I + PSD: cannot fail on finite input.  With the factor its explicit inverse (r^3 / 3 flop more): every later solve
         # against it -- mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64
         # launches.  Two launches in all for r <= 480 (dense_small.h).
@@ -305,31 +303,24 @@ class SpectralWoodburyFactor:
         self.last_verdict = (resid, short, wdef)
         return resid <= lim[0] and short <= lim[1] and wdef <= lim[2]
 
+    def _grid_dev(self):
+        gd = self.__dict__.get("_g_dev")
+        if gd is None:
+            gd = self._g_dev = (torch.tensor(list(self.grid.g), dtype=torch.int32, device=self.device),)
+        return gd
+
     def _device_refresh(self, cur, tcol64, tail):
         old = cur["basis"]
         d, g = self.grid.d, self.grid.g
-        gd = self.__dict__.get("_g_dev")
-        if gd is None:
-            offs, o = [], 0
-            for gq in g:
-                offs.append(o)
-                o += gq
-            gd = self._g_dev = (torch.tensor(list(g), dtype=torch.int32, device=self.device), torch.tensor(offs, device=self.device),
-                                float(np.prod([float(x) for x in g])))
+        gd = self._grid_dev()
+        # three launches: the eigenvector refresh, the change of basis with its verdict, the verdict's copy to pinned memory
         Vtab, ev_tab, resid = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse)
-        total = tcol64[gd[1]].prod() * gd[2]
-        basis = SpectralBasis.on_device(old, Vtab, ev_tab, total)
         ref = self.ref
-        TS = None
-        for q in range(d):
-            Tq = ref.Vq[q].t() @ basis.Vq[q]
-            blk = Tq[ref.S_long[q]][:, basis.S_long[q]]
-            TS = blk if TS is None else TS * blk
-        TS = TS.contiguous()
-        defect = (1.0 - (TS * TS).sum(0)).clamp_min(0.0)
-        wdef = (basis.lam_kuu * defect).max() / total * basis.r
-        short = 1.0 - basis.lam_kuu.sum() / total
-        verdict = torch.stack([resid.max(), short, wdef])
+        work = self.__dict__.get("_bc_work")
+        if work is None or work.shape[0] < old.r + 1:
+            work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
+        TS, lam, verdict = grid_ops.basis_change(gd[0], ref.Vtab, ref.kmax, ref.S, Vtab, old.kmax, old.S, ev_tab, tcol64, resid, work[:old.r + 1])
+        basis = SpectralBasis.on_device(old, Vtab, ev_tab, None, lam=lam)
         host = self.__dict__.get("_chk_host")
         if host is None:
             host = self._chk_host = torch.empty(3, dtype=torch.float64).pin_memory()
@@ -400,11 +391,11 @@ class SpectralWoodburyFactor:
         Wt = torch.addcmul(g_logdet.double() * SB, zeta[:, None] * g_bMb.double(), zeta[None, :]).contiguous()
         D = grid_ops.basis_pair_reduce(Wt, basis.S, basis.ev_tab, basis.kmax)
         gs = self.grid.g
-        if len(set(gs)) == 1:
-            # equal factors (the usual grid): the d congruences V_q D_q V_q^T as two batched products, the lag sums as one GEMM
-            V = basis.Vtab.view(len(gs), gs[0], basis.kmax)
-            H = torch.bmm(torch.bmm(V, D), V.transpose(1, 2))                                      # [d, g, g]
-            g_tcol = (H.reshape(len(gs), -1) @ self._lag_matrix(gs[0]).t()).reshape(-1)
+        if max(gs) <= 64:
+            # the d congruences V_q D_q V_q^T and their lag sums in one launch
+            g_tcol = grid_ops.basis_lag_grad(self._grid_dev()[0], basis.Vtab, basis.kmax, D, kap)
+            g_kap = (Wt.diagonal() * basis.lam_kuu).sum()
+            return g_tcol, g_kap
         else:
             g_tcol = torch.zeros(sum(gs), dtype=torch.float64, device=self.device)
             off = 0
@@ -450,10 +441,9 @@ class SpectralQuery:
     def _solve(self):
         if self._Y is None:
             st = self.st
-            captured = (self.Fs * self.Fs).sum(1)                                # sum_j lam_j (b_j^T w)^2
-            self._tail = (self.prior * st["kscale"] - captured).clamp_min(0.0)
             self._Y = grid_ops.gemm(st["Linv"], self.Fs, tb=True)                # chol^-1 F^T  [r, n]
-            self._diag = (self._Y * self._Y).sum(0)
+            # |Y[:, j]|^2 and the left-out prior variance prior_j - sum_k lam_k (b_k^T w_j)^2, clamped
+            self._diag, self._tail = grid_ops.spectral_var(self._Y, self.Fs, self.prior, st["kscale"])
             self.fac._last = (self._tail, self._diag)
         return self._Y
 
