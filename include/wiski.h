@@ -420,6 +420,29 @@ int wiski_prof_enable(int32_t on);
  * floor contained in every kernel time measured this way */
 int wiski_prof_empty(int32_t n, double* avg_us, void* stream);
 
+/* ---- hyper-parameter step glue (hyper_columns.hip): what the framework spends ~10 tiny launches each on, as single launches ----
+ * wiski_stationary_columns      d_out [sum g] (fp64) = S * k(l h_q / ell_q): the Toeplitz columns of a Scale(RBF | Matern) kernel on the
+ *                               grid (gpytorch: kernel(x1, x2, last_dim_is_batch=True) on the grid points, GridKernel / GridInterpolationKernel).
+ *                               kind 0 RBF, 1 / 2 / 3 Matern-1/2, -3/2, -5/2; d_ell [nell] (nell = 1 isotropic or = d ARD), d_scale [1] or NULL,
+ *                               both DEVICE pointers in the model's dtype (no host read of a hyper-parameter).
+ * wiski_stationary_columns_grad d_gell [nell], d_gscale [1] (or NULL) = gradient of <d_gout, columns> w.r.t. lengthscales / outputscale.
+ * wiski_gaussian_metrics        d_out [2] = { sqrt(mean (mu - y)^2), mean 1/2 ((mu - y)^2 / v + log v + log 2 pi) }, v = var + d_add_var[0]
+ *                               (d_add_var may be NULL): the per-batch test metrics of the reference's regression loop
+ *                               (online_ski_regression.py:88-111), n points, one launch. */
+int wiski_stationary_columns_f32(const wiski_grid* grid, int32_t kind, const float* d_ell, int32_t nell, const float* d_scale, double* d_out, void* stream);
+int wiski_stationary_columns_f64(const wiski_grid* grid, int32_t kind, const double* d_ell, int32_t nell, const double* d_scale, double* d_out, void* stream);
+int wiski_stationary_columns_grad_f32(const wiski_grid* grid, int32_t kind, const float* d_ell, int32_t nell, const float* d_scale, const double* d_gout, float* d_gell, float* d_gscale, void* stream);
+int wiski_stationary_columns_grad_f64(const wiski_grid* grid, int32_t kind, const double* d_ell, int32_t nell, const double* d_scale, const double* d_gout, double* d_gell, double* d_gscale, void* stream);
+/* Scalar tail of the Woodbury MLL of one output (BWM:34-47), value and gradient, device scalars in and out:
+ *   d_val  = -1/2 ((c - bMb) / s2 + logdet + ld + n log(2 pi) + n log s2)  (d_logdet may be NULL), d_coef [3] = { d val / d bMb, d val / d logdet, c - bMb };
+ *   d_gs2  = g (1/2 coef[2] / s2^2 - 1/2 n / s2) - g_kap / s2^2   (d_gkap: gradient w.r.t. 1 / s2 through the factor, or NULL). */
+int wiski_mll_value_f32(const double* d_bMb, const double* d_logdet, const float* d_s2, const double* d_c, const double* d_ld, double n, double* d_val, double* d_coef, void* stream);
+int wiski_mll_value_f64(const double* d_bMb, const double* d_logdet, const double* d_s2, const double* d_c, const double* d_ld, double n, double* d_val, double* d_coef, void* stream);
+int wiski_mll_s2_grad_f32(const double* d_g, const double* d_coef, const float* d_s2, double n, const double* d_gkap, float* d_gs2, void* stream);
+int wiski_mll_s2_grad_f64(const double* d_g, const double* d_coef, const double* d_s2, double n, const double* d_gkap, double* d_gs2, void* stream);
+int wiski_gaussian_metrics_f32(int64_t n, const float* d_mu, const float* d_var, const float* d_y, const float* d_add_var, float* d_out, void* stream);
+int wiski_gaussian_metrics_f64(int64_t n, const double* d_mu, const double* d_var, const double* d_y, const double* d_add_var, double* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -657,6 +657,54 @@ def basis_project(grid, x, V, kmax, S, scale=None, colscale=None, tcol=None, wan
     return (F, prior) if want_prior else F
 
 
+def stationary_columns(grid, kind, ell, scale):
+    """``wiski_stationary_columns``: fp64 Toeplitz columns [sum g] of S * k(lag / ell) (kind 0 RBF, 1-3 Matern 1/2, 3/2, 5/2);
+    ell [1] or [d] and scale [1] / None are device tensors of one dtype (fp32 / fp64) -- no host read."""
+    out = torch.empty(sum(grid.g), dtype=torch.float64, device=ell.device)
+    rc = _hip.fn("wiski_stationary_columns", ell.dtype)(grid.ref, ctypes.c_int32(kind), _hip.dptr(ell), ctypes.c_int32(ell.numel()),
+                                                        None if scale is None else _hip.dptr(scale), _hip.dptr(out), _hip.stream_ptr(ell.device))
+    _hip.check(rc, "wiski_stationary_columns")
+    return out
+
+
+def stationary_columns_grad(grid, kind, ell, scale, gout):
+    g_ell = torch.empty_like(ell)
+    g_scale = None if scale is None else torch.empty_like(scale)
+    rc = _hip.fn("wiski_stationary_columns_grad", ell.dtype)(grid.ref, ctypes.c_int32(kind), _hip.dptr(ell), ctypes.c_int32(ell.numel()),
+                                                             None if scale is None else _hip.dptr(scale), _hip.dptr(gout),
+                                                             _hip.dptr(g_ell), None if g_scale is None else _hip.dptr(g_scale),
+                                                             _hip.stream_ptr(ell.device))
+    _hip.check(rc, "wiski_stationary_columns_grad")
+    return g_ell, g_scale
+
+
+def mll_value(bMb, logdet, s2, c, ld, n):
+    """``wiski_mll_value``: (val, coef [3]) fp64 device scalars of one output's Woodbury MLL tail; s2 a 1-element tensor (fp32 / fp64)."""
+    val = torch.empty((), dtype=torch.float64, device=bMb.device)
+    coef = torch.empty(3, dtype=torch.float64, device=bMb.device)
+    rc = _hip.fn("wiski_mll_value", s2.dtype)(_hip.dptr(bMb), None if logdet is None else _hip.dptr(logdet), _hip.dptr(s2), _hip.dptr(c), _hip.dptr(ld),
+                                              ctypes.c_double(float(n)), _hip.dptr(val), _hip.dptr(coef), _hip.stream_ptr(bMb.device))
+    _hip.check(rc, "wiski_mll_value")
+    return val, coef
+
+
+def mll_s2_grad(g, coef, s2, n, g_kap):
+    out = torch.empty_like(s2)
+    rc = _hip.fn("wiski_mll_s2_grad", s2.dtype)(_hip.dptr(g), _hip.dptr(coef), _hip.dptr(s2), ctypes.c_double(float(n)),
+                                                None if g_kap is None else _hip.dptr(g_kap), _hip.dptr(out), _hip.stream_ptr(s2.device))
+    _hip.check(rc, "wiski_mll_s2_grad")
+    return out
+
+
+def gaussian_metrics(mu, var, y, add_var=None):
+    """``wiski_gaussian_metrics``: device tensor [rmse, mean nll] of one batch (all arguments contiguous, one dtype)."""
+    out = torch.empty(2, dtype=mu.dtype, device=mu.device)
+    rc = _hip.fn("wiski_gaussian_metrics", mu.dtype)(ctypes.c_int64(mu.numel()), _hip.dptr(mu), _hip.dptr(var), _hip.dptr(y),
+                                                     None if add_var is None else _hip.dptr(add_var), _hip.dptr(out), _hip.stream_ptr(mu.device))
+    _hip.check(rc, "wiski_gaussian_metrics")
+    return out
+
+
 def basis_eig_update(g_dev, tcol64, Vin, kw, kuse):
     """``wiski_basis_eig_update``: the per-dim eigenvector tables Vin ([sum g_q * kw] fp64, row-major [g_q, kw] blocks) refined for the
     Toeplitz columns tcol64, all on the device.  Returns (Vout, ev [d, kw] descending, resid [d])."""

@@ -18,6 +18,7 @@ import torch
 
 from .constraints import Positive
 from .grid_ops import GridSpec
+from .settings import fused_hyper_columns
 
 
 def inv_softplus(x):
@@ -206,6 +207,54 @@ class ScaleKernel(Kernel):
         return s * self.base_kernel.lag_columns_cat(lags_cat, dim_index, batch_index)
 
 
+class _StationaryColumns(torch.autograd.Function):
+    """Toeplitz columns of S * k(lag / ell) on the grid and their gradient w.r.t. (ell, S), one launch each
+    (csrc/hyper_columns.hip) instead of ~10 broadcasting ops forward and ~12 autograd nodes backward."""
+
+    @staticmethod
+    def forward(ctx, ell, scale, grid_spec, kind):
+        from . import grid_ops
+
+        ell_c = ell.detach().reshape(-1).contiguous()
+        scale_c = None if scale is None else scale.detach().reshape(-1).to(ell_c.dtype).contiguous()
+        ctx.grid_spec, ctx.kind = grid_spec, kind
+        ctx.shapes = (ell.shape, None if scale is None else (scale.shape, scale.dtype))
+        ctx.save_for_backward(ell_c, scale_c)
+        return grid_ops.stationary_columns(grid_spec, kind, ell_c, scale_c)
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import grid_ops
+
+        ell_c, scale_c = ctx.saved_tensors
+        g_ell, g_scale = grid_ops.stationary_columns_grad(ctx.grid_spec, ctx.kind, ell_c, scale_c, gout.contiguous())
+        ell_shape, sc = ctx.shapes
+        return g_ell.reshape(ell_shape), (None if sc is None else g_scale.reshape(sc[0]).to(sc[1])), None, None
+
+
+def _fused_stationary(kernel, batch_index):
+    """(ell [1] or [d], scale [1] or None, kind) when `kernel` is (Scale of)* RBF | Matern of this module, else None."""
+    scale = None
+    while isinstance(kernel, ScaleKernel):
+        s = kernel.outputscale
+        if batch_index is not None and s.dim() > 0:
+            s = s[batch_index]
+        if s.numel() != 1:
+            return None
+        scale = s.reshape(1) if scale is None else scale * s.reshape(1)
+        kernel = kernel.base_kernel
+    if type(kernel) is RBFKernel:
+        kind = 0
+    elif type(kernel) is MaternKernel:
+        kind = {0.5: 1, 1.5: 2, 2.5: 3}[kernel.nu]
+    else:
+        return None
+    ls = kernel.lengthscale
+    if batch_index is not None and ls.dim() > 2:
+        ls = ls[batch_index]
+    return ls.reshape(-1), scale, kind
+
+
 def _native_stationary(kernel):
     """Scale(...(RBF | Matern)) chains of this module: their columns have the closed form used by lag_columns_cat."""
     while isinstance(kernel, ScaleKernel):
@@ -263,6 +312,11 @@ class GridInterpolationKernel(Kernel):
         p = next(self.base_kernel.parameters(), None)
         device = device if device is not None else (p.device if p is not None else "cpu")
         gs = self.grid_spec
+        if torch.device(device).type == "cuda" and fused_hyper_columns.on():
+            fs = _fused_stationary(self.base_kernel, batch_index)
+            if fs is not None and fs[0].is_cuda and fs[0].numel() in (1, gs.d) and fs[0].dtype in (torch.float32, torch.float64):
+                out = _StationaryColumns.apply(fs[0], fs[1], gs, fs[2])
+                return out if dtype is None else out.to(dtype)
         if _native_stationary(self.base_kernel):
             key = str(device)
             cached = self.__dict__.setdefault("_lag_cat", {}).get(key)

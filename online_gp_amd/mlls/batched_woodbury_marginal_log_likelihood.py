@@ -192,6 +192,32 @@ def _logdet_value(grid, A, eig, kap, E, exact, lanczos_steps=40):
     return torch.tensor(est / P * m, dtype=torch.float64, device=dev)
 
 
+class _SpectralMll(torch.autograd.Function):
+    """One output's MLL term  -1/2 ((c - b^T M b) / s2 + logdet + ld + n log 2 pi + n log s2)  (BWM:34-47) from the spectral
+    Woodbury factor, as a function of (Toeplitz columns, sigma2): the factor's two numbers and the scalar arithmetic around them in
+    one launch forward (wiski_mll_value), the factor's reduced-basis gradient + one launch backward -- instead of ~15
+    zero-dimensional framework ops and their ~20 autograd nodes per step."""
+
+    @staticmethod
+    def forward(ctx, tcol64, s2, model, o, want_logdet, sp):
+        fac, st, _ = sp
+        stats = model._kernel_cache["_stats"]
+        n = model.num_data
+        s2d = s2.detach()
+        val, coef = grid_ops.mll_value(st["bMb"], st["logdet"] if want_logdet else None, s2d, stats[o, 0], stats[o, 1], n)
+        ctx.fac, ctx.st, ctx.n = fac, st, n
+        ctx.save_for_backward(coef, s2d)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        coef, s2d = ctx.saved_tensors
+        gab = coef[:2] * g
+        g_tcol, g_kap = ctx.fac.mll_backward(ctx.st, gab[0], gab[1])
+        g_s2 = grid_ops.mll_s2_grad(g.contiguous(), coef, s2d, ctx.n, g_kap) if ctx.needs_input_grad[1] else None
+        return (g_tcol if ctx.needs_input_grad[0] else None), g_s2, None, None, None, None
+
+
 class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
     def __init__(self, likelihood, model, clear_caches_every_iteration=False):
         super().__init__()
@@ -215,9 +241,14 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
             tcol = model.covar_module.toeplitz_columns(batch_index=bi, device=model._device)          # float64, differentiable
             if self.has_learnable_noise:
                 s2 = self.likelihood.second_noise_covar.noise.reshape(-1)
-                s2 = (s2[o] if s2.numel() > 1 else s2[0]).double()
+                s2 = s2[o] if s2.numel() > 1 else s2[0]
             else:
                 s2 = torch.ones((), dtype=torch.float64, device=model._device)
+            sp = None if model._use_dense() else model._spectral_state(o)
+            if sp is not None:
+                out.append(_SpectralMll.apply(tcol, s2, model, o, want_logdet, sp))
+                continue
+            s2 = s2.double()
             bMb, logdet_q = _WoodburyTerms.apply(tcol, 1.0 / s2, model, o, want_logdet)
             c = cache["_stats"][o, 0]
             ld = cache["_stats"][o, 1]

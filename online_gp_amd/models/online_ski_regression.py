@@ -13,6 +13,7 @@ observation variance (latent + sigma^2), ``evaluate`` averages per-batch RMSE / 
 The streaming protocol itself lives in ``_streaming_wrapper.StreamingSKIWrapper``."""
 import torch
 
+from .. import grid_ops
 from ._streaming_wrapper import EVAL_CHUNK, StreamingSKIWrapper
 from .batched_fixed_noise_online_gp import FixedNoiseOnlineSKIGP
 
@@ -48,7 +49,7 @@ class OnlineSKIRegression(StreamingSKIWrapper):
 
     # ----- prediction
     def predict(self, inputs):
-        self.eval()
+        self._ensure_eval()
         post = self(inputs)
         mean, var = post.mean, post.variance
         if self.target_dim > 1:                                  # the GP lays several outputs out as [out, n]
@@ -60,10 +61,19 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         """(rmse, nll): means over batches of 1024 of the per-batch RMSE and mean Gaussian NLL; one host sync."""
         inputs = self._as_rows(inputs)
         targets = targets.reshape(-1, self.target_dim)
-        self.eval()
+        self._ensure_eval()
         per_batch = []
+        fused = self.target_dim == 1 and inputs.is_cuda
         for lo in range(0, inputs.shape[0], EVAL_CHUNK):
             y = targets[lo:lo + EVAL_CHUNK]
+            if fused:
+                # one output: both metrics of the batch from (mean, variance, sigma2) in one launch (wiski_gaussian_metrics)
+                post = self(inputs[lo:lo + EVAL_CHUNK])
+                mu = post.mean.reshape(-1).contiguous()
+                s2 = self.gp.likelihood.second_noise.detach().reshape(-1).to(mu.dtype)
+                per_batch.append(grid_ops.gaussian_metrics(mu, post.variance.reshape(-1).to(mu.dtype).contiguous(), y.reshape(-1).to(mu.dtype).contiguous(),
+                                                           s2))
+                continue
             mean, var = self.predict(inputs[lo:lo + EVAL_CHUNK])
             sq = (mean - y) ** 2
             nll = 0.5 * (sq / var + var.log() + _LOG_2PI)

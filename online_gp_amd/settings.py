@@ -229,6 +229,13 @@ class spectral_tail(_value_context):
     _global_value = None
 
 
+class fused_hyper_columns(_feature_flag):
+    """Toeplitz columns of (Scale of) RBF / Matern kernels and their gradient w.r.t. lengthscales and outputscale by one HIP launch
+    each (``wiski_stationary_columns``) instead of the broadcasting-op graph; off: the op graph (what foreign kernels always use)."""
+
+    _state = True
+
+
 class spectral_device_refresh(_feature_flag):
     """After a hyper-parameter step, refine the spectral factor's per-dim eigenvectors on the device (subspace iteration from the
     previous ones, ``wiski_basis_eig_update``) and keep the index set, instead of a host eigh + re-selection; the refinement's

@@ -506,3 +506,62 @@ def test_kron_toeplitz_grad_against_autograd(dtype, tol, gs, k):
     tcol = torch.cat([c.detach() for c in cols]).to("cuda", dtype)
     got = grid_ops.kron_toeplitz_grad(grid, tcol, X.to("cuda", dtype), Y.to("cuda", dtype)).cpu()
     assert (got - want).abs().max() < tol * want.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", ["rbf", "matern0.5", "matern1.5", "matern2.5"])
+@pytest.mark.parametrize("ard,scaled,d", [(True, True, 3), (False, True, 2), (True, False, 4), (False, False, 1)])
+def test_fused_hyper_columns_match_the_op_graph_and_the_oracle(dtype, kind, ard, scaled, d):
+    """wiski_stationary_columns / _grad (one launch each) against the broadcasting-op graph they replace (values and the
+    gradients autograd derives for lengthscales and outputscale) and against the oracle's closed-form columns (spec.py)."""
+    from online_gp_amd import kernels, settings
+
+    torch.manual_seed(d)
+    g = [9, 12, 7, 6][:d]
+    base = kernels.RBFKernel(ard_num_dims=d if ard else None) if kind == "rbf" else kernels.MaternKernel(nu=float(kind[6:]), ard_num_dims=d if ard else None)
+    cov = kernels.ScaleKernel(base) if scaled else base
+    gk = kernels.GridInterpolationKernel(cov, grid_size=g, num_dims=d, grid_bounds=[[-1.0, 1.0 + 0.3 * q] for q in range(d)]).to("cuda", dtype)
+    with torch.no_grad():
+        base.raw_lengthscale.add_(torch.randn_like(base.raw_lengthscale) * 0.3)
+        if scaled:
+            cov.raw_outputscale.add_(0.4)
+    w = torch.randn(sum(gk.grid_spec.g), dtype=torch.float64, device="cuda")
+    res = {}
+    for fused in (True, False):
+        for p in gk.parameters():
+            p.grad = None
+        with settings.fused_hyper_columns(fused):
+            cols = gk.toeplitz_columns(device="cuda")
+        assert cols.dtype == torch.float64
+        (cols * w).sum().backward()
+        res[fused] = (cols.detach().clone(), [p.grad.clone() for p in gk.parameters()])
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert (res[True][0] - res[False][0]).abs().max().item() < tol * max(1.0, res[False][0].abs().max().item())
+    for a, b in zip(res[True][1], res[False][1]):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert (a - b).abs().max().item() < (1e-10 if dtype == torch.float64 else 1e-4) * max(1.0, b.abs().max().item())
+    # oracle: closed-form columns at the same hyper-parameters
+    ell = base.lengthscale.detach().double().cpu().numpy().reshape(-1)
+    ell = np.broadcast_to(ell, (d,)) if ell.size == 1 else ell
+    s = float(cov.outputscale) if scaled else 1.0
+    g0, h, gs = spec.make_grid([[-1.0, 1.0 + 0.3 * q] for q in range(d)], g)
+    okind = {"rbf": "rbf", "matern0.5": "matern12", "matern1.5": "matern32", "matern2.5": "matern52"}[kind]
+    ref = np.concatenate(spec.toeplitz_columns(okind, h, gs, ell, s))
+    assert np.abs(res[True][0].cpu().numpy() - ref).max() < tol * 10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float64, 1e-12)])
+@pytest.mark.parametrize("n", [1, 7, 256, 1024])
+def test_gaussian_metrics_kernel(dtype, tol, n):
+    from online_gp_amd import grid_ops
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    mu = torch.randn(n, generator=g, dtype=torch.float64).to("cuda", dtype)
+    y = torch.randn(n, generator=g, dtype=torch.float64).to("cuda", dtype)
+    var = (torch.rand(n, generator=g, dtype=torch.float64) + 0.05).to("cuda", dtype)
+    s2 = torch.tensor([0.3], device="cuda", dtype=dtype)
+    out = grid_ops.gaussian_metrics(mu, var, y, s2)
+    sq = (mu.double() - y.double()) ** 2
+    v = var.double() + 0.3
+    ref = torch.stack([sq.mean().sqrt(), (0.5 * (sq / v + v.log() + 1.8378770664093453)).mean()])
+    assert (out.double() - ref).abs().max().item() < tol * 10 * max(1.0, ref.abs().max().item())
