@@ -371,12 +371,13 @@ int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_
  * (row-major, concatenated; kw even, <= 32; g_q <= 64; d_g [d] on the device), d_ev [d][kw] Ritz values (descending), d_resid [d]
  * the largest residual |K v - theta v|_inf / theta_1 over the first kuse vectors.  Two subspace-iteration steps + Rayleigh-Ritz
  * (parallel Jacobi), fp64, one workgroup per dim. */
-int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout, double* d_ev, double* d_resid, void* stream);
+int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout, double* d_ev, double* d_resid,
+                           const double* d_Vref, int32_t kref, double* d_Tq, void* stream);   /* d_Vref / d_Tq (both or neither): also T_q = Vref_q^T Vnew_q, [d][32][32] */
 /* Companion of wiski_basis_eig_update, one launch: the Kronecker-structured change of basis d_TS [r_ref, r] from the reference basis
- * (tables d_Vref [g_q][kref], index set d_Sref [d, r_ref]) to the refreshed one (d_Vnew [g_q][kw], d_S [d, r]), the eigenvalues d_lam [r]
+ * (index set d_Sref [d, r_ref]) to the refreshed one (d_S [d, r]) given d_Tq [d][32][32] = Vref_q^T Vnew_q from wiski_basis_eig_update, the eigenvalues d_lam [r]
  * of Kuu on the kept index set, and d_verdict [3] = { max eigen-residual, trace fraction the index set leaves out, eigenvalue-weighted
  * defect of the reference span }.  d_work: r + 1 doubles, ZERO on first use (the kernel leaves it zero). */
-int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, int32_t kw, int32_t r_ref, int32_t r, const double* d_Vref, const double* d_Vnew, const int32_t* d_Sref, const int32_t* d_S, const double* d_ev, const double* d_tcol, const double* d_resid, double* d_TS, double* d_lam, double* d_work, double* d_verdict, void* stream);
+int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, int32_t kw, int32_t r_ref, int32_t r, const double* d_Tq, const int32_t* d_Sref, const int32_t* d_S, const double* d_ev, const double* d_tcol, const double* d_resid, double* d_TS, double* d_lam, double* d_work, double* d_verdict, void* stream);
 /* d_out [sum g] = scale * lag sums of V_q D_q V_q^T (d_V tables [g_q][kw], d_D [d][kw][kw] from wiski_basis_pair_reduce): the gradient
  * w.r.t. the Toeplitz columns, one launch; g_q <= 64. */
 int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double* d_V, const double* d_D, double scale, double* d_out, void* stream);

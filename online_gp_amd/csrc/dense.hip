@@ -249,10 +249,75 @@ static int gemm128_min_blocks() {
   return v;
 }
 
+// 32 x 32 tiles, BK = 32, register prefetch: for products whose 64 x 64 tiling leaves most of the chip idle (the spectral factor's
+// T^T G_ref T: 540 x 327 outputs are 54 big tiles on 256 CUs -- and 187 small ones).  4 waves, one 16 x 16 MFMA tile each.
+template <typename real, bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm32(int M, int N, int K, real alpha, const real* __restrict__ A, int lda, const real* __restrict__ B, int ldb,
+                                                real beta, real* __restrict__ C, int ldc) {
+  __shared__ real sA[32][33];        // op(A) tile as sA[i][k]
+  __shared__ real sB[32][36];        // op(B) tile as sB[k][j]
+  using acc_t = typename Acc4<real>::type;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int qa = w >> 1, qb = w & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int r8 = tid >> 3, c4 = (tid & 7) * 4;
+  acc_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (real)0;
+  real pa[4], pb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if constexpr (!TA) { const int gi = m0 + r8, gk = k0 + c4 + u; pa[u] = (gi < M && gk < K) ? A[(int64_t)gi * lda + gk] : (real)0; }
+      else { const int gk = k0 + r8, gi = m0 + c4 + u; pa[u] = (gi < M && gk < K) ? A[(int64_t)gk * lda + gi] : (real)0; }
+      if constexpr (!TB) { const int gk = k0 + r8, gj = n0 + c4 + u; pb[u] = (gk < K && gj < N) ? B[(int64_t)gk * ldb + gj] : (real)0; }
+      else { const int gj = n0 + r8, gk = k0 + c4 + u; pb[u] = (gk < K && gj < N) ? B[(int64_t)gj * ldb + gk] : (real)0; }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if constexpr (!TA) sA[r8][c4 + u] = pa[u]; else sA[c4 + u][r8] = pa[u];
+      if constexpr (!TB) sB[r8][c4 + u] = pb[u]; else sB[c4 + u][r8] = pb[u];
+    }
+    __syncthreads();
+    if (k0 + 32 < K) fetch(k0 + 32);                // next tile's loads fly under this tile's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 4) {
+      const int kk = ks + (lane >> 4);
+      acc = mfma16(sA[qa * 16 + (lane & 15)][kk], sB[kk][qb * 16 + (lane & 15)], acc);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = m0 + qa * 16 + frag_row<real>(lane, r), gj = n0 + qb * 16 + (lane & 15);
+    if (gi < M && gj < N) {
+      const int64_t e = (int64_t)gi * ldc + gj;
+      const real v = alpha * acc[r];
+      C[e] = beta == (real)0 ? v : v + beta * C[e];
+    }
+  }
+}
+
 template <typename real>
 static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const real* A, int lda, const real* B, int ldb, real beta, real* C,
                        int ldc, hipStream_t s) {
   if (M <= 0 || N <= 0) return WISKI_OK;
+  {
+    // small tiles while the 64 x 64 grid would leave more than half of the 256 CUs without a tile (and there is enough K to matter)
+    const int64_t nb64 = (int64_t)((N + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
+    static const bool small_on = [] { const char* e = getenv("WISKI_GEMM32"); return !(e && e[0] == '0'); }();
+    if (small_on && nb64 < 128 && K >= 64 && (int64_t)M * N >= 32 * 32 * 8) {
+      dim3 g3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+      if (!ta && !tb) hipLaunchKernelGGL((k_gemm32<real, false, false>), g3, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else if (ta && !tb) hipLaunchKernelGGL((k_gemm32<real, true, false>), g3, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else if (!ta && tb) hipLaunchKernelGGL((k_gemm32<real, false, true>), g3, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else hipLaunchKernelGGL((k_gemm32<real, true, true>), g3, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
+  }
   {
     // the 128 x 128 kernel once its grid covers at least half the chip (n >= ~1500 square): below that the 64 x 64 tiles fill more CUs
     const int64_t nb = (int64_t)((N + G2N - 1) / G2N) * ((M + G2M - 1) / G2M);

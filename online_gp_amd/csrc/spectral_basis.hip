@@ -157,9 +157,16 @@ int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_
 // checked by the host one step later (a failed check falls back to the host eigh).  One workgroup per dim; g <= 64, kw <= 32.
 constexpr int EIG_G = 64, EIG_K = 32;
 
+#define WAVE_SYNC()                                   \
+  do {                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_wave_barrier();                  \
+  } while (0)
+
 __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict__ gs, const double* __restrict__ tcol, const double* __restrict__ Vin,
                                                     int kw, int kuse, double* __restrict__ Vout, double* __restrict__ ev_out,
-                                                    double* __restrict__ resid_out) {
+                                                    double* __restrict__ resid_out, const double* __restrict__ Vref, int kref,
+                                                    double* __restrict__ Tq_out) {
   __shared__ double sT[EIG_G], sV[EIG_G][EIG_K + 1], sZ[EIG_G][EIG_K + 1], sH[EIG_K][EIG_K + 1], sU[EIG_K][EIG_K + 1], sCS[EIG_K / 2][2], sTh[EIG_K];
   __shared__ int sPr[EIG_K / 2][2], sRank[EIG_K];
   __shared__ double sRed[4], sRed2[4];
@@ -213,62 +220,63 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     if (a < b) { const double s = 0.5 * (sH[a][b] + sH[b][a]); sH[a][b] = s; sH[b][a] = s; }
   }
   __syncthreads();
-  const int n = (kw + 1) & ~1, np = n / 2;            // Jacobi on an even size (kw is even by construction of the caller)
-  for (int sweep = 0; sweep < 12; ++sweep) {
-    // converged?  (the start is nearly diagonal -- the previous eigenvectors -- so two or three sweeps is the rule)
-    double off2 = 0, dg2 = 0;
-    for (int e = t; e < kw * kw; e += 256) {
-      const double v = sH[e / kw][e % kw];
-      if (e / kw == e % kw) dg2 += v * v; else off2 += v * v;
-    }
-    off2 = wave_reduce_sum<double>(off2);
-    dg2 = wave_reduce_sum<double>(dg2);
-    __syncthreads();                                  // sRed is reused below
-    if (lane == 0) { sRed[wv] = off2; sRed2[wv] = dg2; }
-    __syncthreads();
-    if ((sRed[0] + sRed[1] + sRed[2] + sRed[3]) <= 1e-30 * (sRed2[0] + sRed2[1] + sRed2[2] + sRed2[3])) break;
-    for (int step = 0; step < n - 1; ++step) {
-      if (t < np) {
-        int p_, q_;
-        if (t == 0) { p_ = n - 1; q_ = step; }
-        else { p_ = (step + t) % (n - 1); q_ = (step - t + (n - 1)) % (n - 1); }
-        if (p_ > q_) { const int x = p_; p_ = q_; q_ = x; }
-        sPr[t][0] = p_; sPr[t][1] = q_;
-        double c = 1.0, sn = 0.0;
-        if (q_ < kw) {
-          const double apq = sH[p_][q_];
-          if (apq != 0.0) {
-            const double theta = (sH[q_][q_] - sH[p_][p_]) / (2.0 * apq);
-            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(tt * tt + 1.0);
-            sn = tt * c;
+  // Rayleigh-Ritz by parallel cyclic Jacobi on ONE wave: the ~100 dependent phases of a few sweeps then cost their instructions, not
+  // a workgroup barrier each (which was most of this kernel's time)
+  const int n = (kw + 1) & ~1, np = n / 2;
+  if (wv == 0) {
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      double off2 = 0, dg2 = 0;
+      for (int e = lane; e < kw * kw; e += 64) {
+        const double v = sH[e / kw][e % kw];
+        if (e / kw == e % kw) dg2 += v * v; else off2 += v * v;
+      }
+      off2 = wave_reduce_sum<double>(off2);
+      dg2 = wave_reduce_sum<double>(dg2);
+      if (off2 <= 1e-30 * dg2) break;                 // (the start is nearly diagonal -- the previous eigenvectors: 3-4 sweeps)
+      for (int step = 0; step < n - 1; ++step) {
+        if (lane < np) {
+          int p_, q_;
+          if (lane == 0) { p_ = n - 1; q_ = step; }
+          else { p_ = (step + lane) % (n - 1); q_ = (step - lane + (n - 1)) % (n - 1); }
+          if (p_ > q_) { const int x = p_; p_ = q_; q_ = x; }
+          sPr[lane][0] = p_; sPr[lane][1] = q_;
+          double c = 1.0, sn = 0.0;
+          if (q_ < kw) {
+            const double apq = sH[p_][q_];
+            if (apq != 0.0) {
+              const double theta = (sH[q_][q_] - sH[p_][p_]) / (2.0 * apq);
+              const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+              c = 1.0 / sqrt(tt * tt + 1.0);
+              sn = tt * c;
+            }
           }
+          sCS[lane][0] = c; sCS[lane][1] = sn;
         }
-        sCS[t][0] = c; sCS[t][1] = sn;
+        WAVE_SYNC();
+        for (int e = lane; e < np * kw; e += 64) {
+          const int pi = e / kw, k = e % kw;
+          const int p_ = sPr[pi][0], q_ = sPr[pi][1];
+          if (q_ >= kw) continue;
+          const double c = sCS[pi][0], sn = sCS[pi][1];
+          const double akp = sH[k][p_], akq = sH[k][q_];
+          sH[k][p_] = c * akp - sn * akq; sH[k][q_] = sn * akp + c * akq;
+          const double ukp = sU[k][p_], ukq = sU[k][q_];
+          sU[k][p_] = c * ukp - sn * ukq; sU[k][q_] = sn * ukp + c * ukq;
+        }
+        WAVE_SYNC();
+        for (int e = lane; e < np * kw; e += 64) {
+          const int pi = e / kw, k = e % kw;
+          const int p_ = sPr[pi][0], q_ = sPr[pi][1];
+          if (q_ >= kw) continue;
+          const double c = sCS[pi][0], sn = sCS[pi][1];
+          const double apk = sH[p_][k], aqk = sH[q_][k];
+          sH[p_][k] = c * apk - sn * aqk; sH[q_][k] = sn * apk + c * aqk;
+        }
+        WAVE_SYNC();
       }
-      __syncthreads();
-      for (int e = t; e < np * kw; e += 256) {
-        const int pi = e / kw, k = e % kw;
-        const int p_ = sPr[pi][0], q_ = sPr[pi][1];
-        if (q_ >= kw) continue;
-        const double c = sCS[pi][0], sn = sCS[pi][1];
-        const double akp = sH[k][p_], akq = sH[k][q_];
-        sH[k][p_] = c * akp - sn * akq; sH[k][q_] = sn * akp + c * akq;
-        const double ukp = sU[k][p_], ukq = sU[k][q_];
-        sU[k][p_] = c * ukp - sn * ukq; sU[k][q_] = sn * ukp + c * ukq;
-      }
-      __syncthreads();
-      for (int e = t; e < np * kw; e += 256) {
-        const int pi = e / kw, k = e % kw;
-        const int p_ = sPr[pi][0], q_ = sPr[pi][1];
-        if (q_ >= kw) continue;
-        const double c = sCS[pi][0], sn = sCS[pi][1];
-        const double apk = sH[p_][k], aqk = sH[q_][k];
-        sH[p_][k] = c * apk - sn * aqk; sH[q_][k] = sn * apk + c * aqk;
-      }
-      __syncthreads();
     }
   }
+  __syncthreads();
   if (t < kw) sTh[t] = sH[t][t];
   __syncthreads();
   if (t < kw) {                                       // rank of each Ritz value (descending; ties by index)
@@ -290,6 +298,17 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
   }
   if (t < kw) ev_out[q * kw + sRank[t]] = sTh[t] > 0 ? sTh[t] : 0.0;
   __syncthreads();
+  // T_q = Vref_q^T Vnew_q for the change of basis (wiski_basis_change), while the new vectors sit in LDS
+  if (Vref && Tq_out) {
+    int roff = 0;
+    for (int p = 0; p < q; ++p) roff += gs[p] * kref;
+    for (int e = t; e < kref * kw; e += 256) {
+      const int a = e / kw, b = e % kw;
+      double acc = 0;
+      for (int i = 0; i < g; ++i) acc += Vref[roff + i * kref + a] * sV[i][b];
+      Tq_out[((int64_t)q * SPB_KMAX + a) * SPB_KMAX + b] = acc;
+    }
+  }
   // residual of the vectors that are used (the first kuse): max_i |K v - theta v|_i / theta_max
   applyK();
   double worst = 0;
@@ -317,17 +336,19 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
 }
 
 extern "C" int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout,
-                                      double* d_ev, double* d_resid, void* stream) {
+                                      double* d_ev, double* d_resid, const double* d_Vref, int32_t kref, double* d_Tq, void* stream) {
   if (d < 1 || d > WISKI_MAX_DIM || !d_g || !d_tcol || !d_Vin || !d_Vout || !d_ev || !d_resid || kw < 2 || kw > EIG_K || (kw & 1) || kuse < 1 || kuse > kw)
     return WISKI_E_BADARG;
-  hipLaunchKernelGGL(k_eig_update, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, d_tcol, d_Vin, (int)kw, (int)kuse, d_Vout, d_ev, d_resid);
+  if ((d_Vref || d_Tq) && (!d_Vref || !d_Tq || kref < 1 || kref > SPB_KMAX)) return WISKI_E_BADARG;
+  hipLaunchKernelGGL(k_eig_update, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, d_tcol, d_Vin, (int)kw, (int)kuse, d_Vout, d_ev, d_resid,
+                     d_Vref, (int)kref, d_Tq);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
 // ------------------------------------------------------------ change of basis ---
 // After wiski_basis_eig_update: everything that connects the refreshed eigenvectors to the factor's reference statistics, in
 // ONE launch (it was ~35 small torch launches):
-//   T_q = Vref_q^T Vnew_q  (kref x kw per dim, recomputed by every block in LDS: 3 x 32 x 32 x g FMAs)
+//   T_q = Vref_q^T Vnew_q  (d x 32 x 32, written by wiski_basis_eig_update while the new vectors sat in its LDS)
 //   TS[i, j] = prod_q T_q[Sref[q, i], S[q, j]]          the Kronecker-structured change of basis, r_ref x r
 //   lam[j]   = prod_q ev[q, S[q, j]]                    eigenvalues of Kuu on the kept index set
 //   verdict  = [ max_q resid_q,  1 - sum_j lam_j / trace(Kuu),  r * max_j lam_j (1 - |TS[:, j]|^2) / trace(Kuu) ]
@@ -336,8 +357,8 @@ extern "C" int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const doubl
 // work[0 .. r) (zero on entry, re-zeroed by the last block, which also writes lam and the verdict); work[r] is the block counter.
 constexpr int BC_ROWS = 8;
 
-__global__ __launch_bounds__(256) void k_basis_change(int d, const int* __restrict__ gs, int kref, int kw, int r_ref, int r, const double* __restrict__ Vref,
-                                                      const double* __restrict__ Vnew, const int32_t* __restrict__ Sref, const int32_t* __restrict__ S,
+__global__ __launch_bounds__(256) void k_basis_change(int d, const int* __restrict__ gs, int kref, int kw, int r_ref, int r, const double* __restrict__ Tq,
+                                                      const int32_t* __restrict__ Sref, const int32_t* __restrict__ S,
                                                       const double* __restrict__ ev, const double* __restrict__ tcol, const double* __restrict__ resid,
                                                       double* __restrict__ TS, double* __restrict__ lam, double* __restrict__ work,
                                                       double* __restrict__ verdict) {
@@ -348,14 +369,9 @@ __global__ __launch_bounds__(256) void k_basis_change(int d, const int* __restri
   int goff[WISKI_MAX_DIM + 1];
   goff[0] = 0;
   for (int q = 0; q < d; ++q) goff[q + 1] = goff[q] + gs[q];
-  for (int e = tid; e < d * kref * kw; e += 256) {
-    const int q = e / (kref * kw), a = (e / kw) % kref, b = e % kw;
-    const int g = goff[q + 1] - goff[q];
-    const double* __restrict__ vr = Vref + (int64_t)goff[q] * kref + a;
-    const double* __restrict__ vn = Vnew + (int64_t)goff[q] * kw + b;
-    double acc = 0;
-    for (int i = 0; i < g; ++i) acc += vr[(int64_t)i * kref] * vn[(int64_t)i * kw];
-    sT[q][a][b] = acc;
+  for (int e = tid; e < d * SPB_KMAX * SPB_KMAX; e += 256) {
+    const int q = e / (SPB_KMAX * SPB_KMAX), a = (e / SPB_KMAX) % SPB_KMAX, b = e % SPB_KMAX;
+    sT[q][a][b] = (a < kref && b < kw) ? Tq[e] : 0.0;      // T_q = Vref_q^T Vnew_q from wiski_basis_eig_update
   }
   __syncthreads();
   const int i0 = blockIdx.x * BC_ROWS;
@@ -429,14 +445,14 @@ __global__ __launch_bounds__(256) void k_woodbury_c(int r, const double* __restr
   if (j == 0) { lam[i] = li; sq[i] = sqrt(li); }
 }
 
-extern "C" int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, int32_t kw, int32_t r_ref, int32_t r, const double* d_Vref,
-                                  const double* d_Vnew, const int32_t* d_Sref, const int32_t* d_S, const double* d_ev, const double* d_tcol,
+extern "C" int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, int32_t kw, int32_t r_ref, int32_t r, const double* d_Tq,
+                                  const int32_t* d_Sref, const int32_t* d_S, const double* d_ev, const double* d_tcol,
                                   const double* d_resid, double* d_TS, double* d_lam, double* d_work, double* d_verdict, void* stream) {
-  if (d < 1 || d > WISKI_MAX_DIM || !d_g || kref < 1 || kref > SPB_KMAX || kw < 1 || kw > SPB_KMAX || r_ref < 1 || r < 1 || !d_Vref || !d_Vnew || !d_Sref ||
+  if (d < 1 || d > WISKI_MAX_DIM || !d_g || kref < 1 || kref > SPB_KMAX || kw < 1 || kw > SPB_KMAX || r_ref < 1 || r < 1 || !d_Tq || !d_Sref ||
       !d_S || !d_ev || !d_tcol || !d_resid || !d_TS || !d_lam || !d_work || !d_verdict)
     return WISKI_E_BADARG;
   const unsigned nb = (unsigned)((r_ref + BC_ROWS - 1) / BC_ROWS);
-  hipLaunchKernelGGL(k_basis_change, dim3(nb), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, (int)kref, (int)kw, (int)r_ref, (int)r, d_Vref, d_Vnew, d_Sref,
+  hipLaunchKernelGGL(k_basis_change, dim3(nb), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, (int)kref, (int)kw, (int)r_ref, (int)r, d_Tq, d_Sref,
                      d_S, d_ev, d_tcol, d_resid, d_TS, d_lam, d_work, d_verdict);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
@@ -497,23 +513,56 @@ extern "C" int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, c
 // reduced basis leaves out of query j): the two vectors a predictive variance is the sum of, in one launch.
 __global__ __launch_bounds__(256) void k_spectral_var(int n, int r, const double* __restrict__ Y, const double* __restrict__ F, const double* __restrict__ prior,
                                                       double kscale, double* __restrict__ diag, double* __restrict__ tail) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  // 64 queries per block (lanes: coalesced across the columns of Y), the r rows dealt to the 4 waves
+  __shared__ double s_d[4][64], s_c[4][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   double dsum = 0, cap = 0;
-  for (int i = 0; i < r; ++i) {
-    const double y = Y[(int64_t)i * n + j];
-    dsum += y * y;
+  if (j < n) {
+    for (int i = part; i < r; i += 4) {
+      const double y = Y[(int64_t)i * n + j];
+      dsum += y * y;
+    }
+    const double* __restrict__ f = F + (int64_t)j * r;
+    for (int k = part; k < r; k += 4) cap += f[k] * f[k];
   }
-  const double* __restrict__ f = F + (int64_t)j * r;
-  for (int k = 0; k < r; ++k) cap += f[k] * f[k];
-  diag[j] = dsum;
-  const double tl = prior[j] * kscale - cap;
-  tail[j] = tl > 0 ? tl : 0.0;
+  s_d[part][c] = dsum;
+  s_c[part][c] = cap;
+  __syncthreads();
+  if (part == 0 && j < n) {
+    diag[j] = s_d[0][c] + s_d[1][c] + s_d[2][c] + s_d[3][c];
+    const double tl = prior[j] * kscale - (s_c[0][c] + s_c[1][c] + s_c[2][c] + s_c[3][c]);
+    tail[j] = tl > 0 ? tl : 0.0;
+  }
+}
+
+// the same for a handful of queries (n < 16: the streaming loop asks for one): a block per query, 256 threads over the rows
+__global__ __launch_bounds__(256) void k_spectral_var_few(int n, int r, const double* __restrict__ Y, const double* __restrict__ F, const double* __restrict__ prior,
+                                                          double kscale, double* __restrict__ diag, double* __restrict__ tail) {
+  __shared__ double s_red[16];
+  const int j = blockIdx.x;
+  double dsum = 0, cap = 0;
+  for (int i = threadIdx.x; i < r; i += 256) {
+    const double y = Y[(int64_t)i * n + j], f = F[(int64_t)j * r + i];
+    dsum += y * y;
+    cap += f * f;
+  }
+  dsum = block_reduce_sum(dsum, s_red);
+  __syncthreads();
+  cap = block_reduce_sum(cap, s_red);
+  if (threadIdx.x == 0) {
+    diag[j] = dsum;
+    const double tl = prior[j] * kscale - cap;
+    tail[j] = tl > 0 ? tl : 0.0;
+  }
 }
 
 extern "C" int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, double kscale, double* d_diag,
                                   double* d_tail, void* stream) {
   if (n < 1 || r < 1 || !d_Y || !d_F || !d_prior || !d_diag || !d_tail) return WISKI_E_BADARG;
-  hipLaunchKernelGGL(k_spectral_var, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_Y, d_F, d_prior, kscale, d_diag, d_tail);
+  if (n < 16)
+    hipLaunchKernelGGL(k_spectral_var_few, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_Y, d_F, d_prior, kscale, d_diag, d_tail);
+  else
+    hipLaunchKernelGGL(k_spectral_var, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_Y, d_F, d_prior, kscale, d_diag, d_tail);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }

@@ -705,30 +705,33 @@ def gaussian_metrics(mu, var, y, add_var=None):
     return out
 
 
-def basis_eig_update(g_dev, tcol64, Vin, kw, kuse):
+def basis_eig_update(g_dev, tcol64, Vin, kw, kuse, ref_Vtab=None, kref=0):
     """``wiski_basis_eig_update``: the per-dim eigenvector tables Vin ([sum g_q * kw] fp64, row-major [g_q, kw] blocks) refined for the
     Toeplitz columns tcol64, all on the device.  Returns (Vout, ev [d, kw] descending, resid [d])."""
     d = g_dev.shape[0]
     Vout = torch.empty_like(Vin)
     ev = torch.empty((d, kw), dtype=torch.float64, device=Vin.device)
     resid = torch.empty(d, dtype=torch.float64, device=Vin.device)
+    Tq = None if ref_Vtab is None else torch.empty((d, 32, 32), dtype=torch.float64, device=Vin.device)
     rc = _hip.lib().wiski_basis_eig_update(ctypes.c_int32(d), _hip.dptr(g_dev), _hip.dptr(tcol64), _hip.dptr(Vin), ctypes.c_int32(kw),
-                                           ctypes.c_int32(kuse), _hip.dptr(Vout), _hip.dptr(ev), _hip.dptr(resid), _hip.stream_ptr(Vin.device))
+                                           ctypes.c_int32(kuse), _hip.dptr(Vout), _hip.dptr(ev), _hip.dptr(resid),
+                                           None if ref_Vtab is None else _hip.dptr(ref_Vtab), ctypes.c_int32(kref),
+                                           None if Tq is None else _hip.dptr(Tq), _hip.stream_ptr(Vin.device))
     _hip.check(rc, "wiski_basis_eig_update")
-    return Vout, ev, resid
+    return (Vout, ev, resid) if ref_Vtab is None else (Vout, ev, resid, Tq)
 
 
-def basis_change(g_dev, ref_Vtab, kref, ref_S, Vtab, kw, S, ev, tcol64, resid, work):
+def basis_change(g_dev, Tq, kref, ref_S, kw, S, ev, tcol64, resid, work):
     """``wiski_basis_change``: (TS [r_ref, r], lam [r], verdict [3]) for a device-refreshed basis; work: r + 1 zeroed doubles."""
     d, r_ref = ref_S.shape
     r = S.shape[1]
-    TS = torch.empty((r_ref, r), dtype=torch.float64, device=Vtab.device)
-    lam = torch.empty(r, dtype=torch.float64, device=Vtab.device)
-    verdict = torch.empty(3, dtype=torch.float64, device=Vtab.device)
+    TS = torch.empty((r_ref, r), dtype=torch.float64, device=Tq.device)
+    lam = torch.empty(r, dtype=torch.float64, device=Tq.device)
+    verdict = torch.empty(3, dtype=torch.float64, device=Tq.device)
     rc = _hip.lib().wiski_basis_change(ctypes.c_int32(d), _hip.dptr(g_dev), ctypes.c_int32(kref), ctypes.c_int32(kw), ctypes.c_int32(r_ref),
-                                       ctypes.c_int32(r), _hip.dptr(ref_Vtab), _hip.dptr(Vtab), _hip.dptr(ref_S), _hip.dptr(S), _hip.dptr(ev),
+                                       ctypes.c_int32(r), _hip.dptr(Tq), _hip.dptr(ref_S), _hip.dptr(S), _hip.dptr(ev),
                                        _hip.dptr(tcol64), _hip.dptr(resid), _hip.dptr(TS), _hip.dptr(lam), _hip.dptr(work), _hip.dptr(verdict),
-                                       _hip.stream_ptr(Vtab.device))
+                                       _hip.stream_ptr(Tq.device))
     _hip.check(rc, "wiski_basis_change")
     return TS, lam, verdict
 

@@ -314,12 +314,12 @@ class SpectralWoodburyFactor:
         d, g = self.grid.d, self.grid.g
         gd = self._grid_dev()
         # three launches: the eigenvector refresh, the change of basis with its verdict, the verdict's copy to pinned memory
-        Vtab, ev_tab, resid = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse)
         ref = self.ref
+        Vtab, ev_tab, resid, Tq = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax)
         work = self.__dict__.get("_bc_work")
         if work is None or work.shape[0] < old.r + 1:
             work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
-        TS, lam, verdict = grid_ops.basis_change(gd[0], ref.Vtab, ref.kmax, ref.S, Vtab, old.kmax, old.S, ev_tab, tcol64, resid, work[:old.r + 1])
+        TS, lam, verdict = grid_ops.basis_change(gd[0], Tq, ref.kmax, ref.S, old.kmax, old.S, ev_tab, tcol64, resid, work[:old.r + 1])
         basis = SpectralBasis.on_device(old, Vtab, ev_tab, None, lam=lam)
         host = self.__dict__.get("_chk_host")
         if host is None:
@@ -441,7 +441,10 @@ class SpectralQuery:
     def _solve(self):
         if self._Y is None:
             st = self.st
-            self._Y = grid_ops.gemm(st["Linv"], self.Fs, tb=True)                # chol^-1 F^T  [r, n]
+            if self.Fs.shape[0] == 1:                                            # one query: a matrix-vector product, not a 64-wide GEMM tile
+                self._Y = torch.mv(st["Linv"], self.Fs[0])[:, None]
+            else:
+                self._Y = grid_ops.gemm(st["Linv"], self.Fs, tb=True)            # chol^-1 F^T  [r, n]
             # |Y[:, j]|^2 and the left-out prior variance prior_j - sum_k lam_k (b_k^T w_j)^2, clamped
             self._diag, self._tail = grid_ops.spectral_var(self._Y, self.Fs, self.prior, st["kscale"])
             self.fac._last = (self._tail, self._diag)
