@@ -380,7 +380,7 @@ int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, 
 int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, int32_t kw, int32_t r_ref, int32_t r, const double* d_Tq, const int32_t* d_Sref, const int32_t* d_S, const double* d_ev, const double* d_tcol, const double* d_resid, double* d_TS, double* d_lam, double* d_work, double* d_verdict, void* stream);
 /* d_out [sum g] = scale * lag sums of V_q D_q V_q^T (d_V tables [g_q][kw], d_D [d][kw][kw] from wiski_basis_pair_reduce): the gradient
  * w.r.t. the Toeplitz columns, one launch; g_q <= 64. */
-int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double* d_V, const double* d_D, double scale, double* d_out, void* stream);
+int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double* d_V, const double* d_D, double scale, const double* d_scale, double* d_out, void* stream);   /* d_scale != NULL: the scale is read from the device (captured graphs) */
 /* d_diag[j] = |d_Y[:, j]|^2 (d_Y [r, n]), d_tail[j] = max(d_prior[j] * kscale - |d_F[j, :]|^2, 0) (d_F [n, r]): the two parts of the
  * predictive variances of n queries from the spectral factor, one launch. */
 int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, double kscale, double* d_diag, double* d_tail, void* stream);
@@ -436,11 +436,12 @@ int wiski_stationary_columns_grad_f32(const wiski_grid* grid, int32_t kind, cons
 int wiski_stationary_columns_grad_f64(const wiski_grid* grid, int32_t kind, const double* d_ell, int32_t nell, const double* d_scale, const double* d_gout, double* d_gell, double* d_gscale, void* stream);
 /* Scalar tail of the Woodbury MLL of one output (BWM:34-47), value and gradient, device scalars in and out:
  *   d_val  = -1/2 ((c - bMb) / s2 + logdet + ld + n log(2 pi) + n log s2)  (d_logdet may be NULL), d_coef [3] = { d val / d bMb, d val / d logdet, c - bMb };
- *   d_gs2  = g (1/2 coef[2] / s2^2 - 1/2 n / s2) - g_kap / s2^2   (d_gkap: gradient w.r.t. 1 / s2 through the factor, or NULL). */
-int wiski_mll_value_f32(const double* d_bMb, const double* d_logdet, const float* d_s2, const double* d_c, const double* d_ld, double n, double* d_val, double* d_coef, void* stream);
-int wiski_mll_value_f64(const double* d_bMb, const double* d_logdet, const double* d_s2, const double* d_c, const double* d_ld, double n, double* d_val, double* d_coef, void* stream);
-int wiski_mll_s2_grad_f32(const double* d_g, const double* d_coef, const float* d_s2, double n, const double* d_gkap, float* d_gs2, void* stream);
-int wiski_mll_s2_grad_f64(const double* d_g, const double* d_coef, const double* d_s2, double n, const double* d_gkap, double* d_gs2, void* stream);
+ *   d_gs2  = g (1/2 coef[2] / s2^2 - 1/2 n / s2) - g_kap / s2^2   (d_gkap: gradient w.r.t. 1 / s2 through the factor, or NULL).
+ * n: the data count by value, or from the device scalar d_n when that is not NULL (calls recorded into a hipGraph: the count moves on). */
+int wiski_mll_value_f32(const double* d_bMb, const double* d_logdet, const float* d_s2, const double* d_c, const double* d_ld, double n, const double* d_n, double* d_val, double* d_coef, void* stream);
+int wiski_mll_value_f64(const double* d_bMb, const double* d_logdet, const double* d_s2, const double* d_c, const double* d_ld, double n, const double* d_n, double* d_val, double* d_coef, void* stream);
+int wiski_mll_s2_grad_f32(const double* d_g, const double* d_coef, const float* d_s2, double n, const double* d_n, const double* d_gkap, float* d_gs2, void* stream);
+int wiski_mll_s2_grad_f64(const double* d_g, const double* d_coef, const double* d_s2, double n, const double* d_n, const double* d_gkap, double* d_gs2, void* stream);
 int wiski_gaussian_metrics_f32(int64_t n, const float* d_mu, const float* d_var, const float* d_y, const float* d_add_var, float* d_out, void* stream);
 int wiski_gaussian_metrics_f64(int64_t n, const double* d_mu, const double* d_var, const double* d_y, const double* d_add_var, double* d_out, void* stream);
 

@@ -117,9 +117,11 @@ __global__ __launch_bounds__(256) void k_gaussian_metrics(int64_t n, const real*
 //   g_s2 = g * ( 1/2 (c - bMb) / s2^2 - 1/2 n / s2 ) - g_kap / s2^2     (g_kap: gradient w.r.t. kappa = 1 / s2 from the factor)
 template <typename real>
 __global__ void k_mll_value(const double* __restrict__ bMb, const double* __restrict__ logdet, const real* __restrict__ s2p, const double* __restrict__ c,
-                            const double* __restrict__ ld, double n, double* __restrict__ val, double* __restrict__ coef) {
+                            const double* __restrict__ ld, double n_val, const double* __restrict__ n_dev, double* __restrict__ val,
+                            double* __restrict__ coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double s2 = (double)s2p[0];
+  const double n = n_dev ? n_dev[0] : n_val;       // (a device scalar when the call is part of a captured graph: the count moves on)
   val[0] = -0.5 * ((c[0] - bMb[0]) / s2 + (logdet ? logdet[0] : 0.0) + ld[0] + n * (1.8378770664093453 + log(s2)));
   coef[0] = 0.5 / s2;
   coef[1] = -0.5;
@@ -127,10 +129,11 @@ __global__ void k_mll_value(const double* __restrict__ bMb, const double* __rest
 }
 
 template <typename real>
-__global__ void k_mll_s2_grad(const double* __restrict__ g, const double* __restrict__ coef, const real* __restrict__ s2p, double n,
-                              const double* __restrict__ g_kap, real* __restrict__ g_s2) {
+__global__ void k_mll_s2_grad(const double* __restrict__ g, const double* __restrict__ coef, const real* __restrict__ s2p, double n_val,
+                              const double* __restrict__ n_dev, const double* __restrict__ g_kap, real* __restrict__ g_s2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double s2 = (double)s2p[0];
+  const double n = n_dev ? n_dev[0] : n_val;
   g_s2[0] = (real)(g[0] * (0.5 * coef[2] / (s2 * s2) - 0.5 * n / s2) - (g_kap ? g_kap[0] / (s2 * s2) : 0.0));
 }
 
@@ -188,26 +191,28 @@ int wiski_stationary_columns_grad_f64(const wiski_grid* grid, int32_t kind, cons
                                       double* d_gell, double* d_gscale, void* stream) {
   return columns_grad_impl<double>(grid, kind, d_ell, nell, d_scale, d_gout, d_gell, d_gscale, stream);
 }
-int wiski_mll_value_f32(const double* d_bMb, const double* d_logdet, const float* d_s2, const double* d_c, const double* d_ld, double n, double* d_val,
-                        double* d_coef, void* stream) {
+int wiski_mll_value_f32(const double* d_bMb, const double* d_logdet, const float* d_s2, const double* d_c, const double* d_ld, double n, const double* d_n,
+                        double* d_val, double* d_coef, void* stream) {
   if (!d_bMb || !d_s2 || !d_c || !d_ld || !d_val || !d_coef) return WISKI_E_BADARG;
-  hipLaunchKernelGGL((k_mll_value<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_bMb, d_logdet, d_s2, d_c, d_ld, n, d_val, d_coef);
+  hipLaunchKernelGGL((k_mll_value<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_bMb, d_logdet, d_s2, d_c, d_ld, n, d_n, d_val, d_coef);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
-int wiski_mll_value_f64(const double* d_bMb, const double* d_logdet, const double* d_s2, const double* d_c, const double* d_ld, double n, double* d_val,
-                        double* d_coef, void* stream) {
+int wiski_mll_value_f64(const double* d_bMb, const double* d_logdet, const double* d_s2, const double* d_c, const double* d_ld, double n, const double* d_n,
+                        double* d_val, double* d_coef, void* stream) {
   if (!d_bMb || !d_s2 || !d_c || !d_ld || !d_val || !d_coef) return WISKI_E_BADARG;
-  hipLaunchKernelGGL((k_mll_value<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_bMb, d_logdet, d_s2, d_c, d_ld, n, d_val, d_coef);
+  hipLaunchKernelGGL((k_mll_value<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_bMb, d_logdet, d_s2, d_c, d_ld, n, d_n, d_val, d_coef);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
-int wiski_mll_s2_grad_f32(const double* d_g, const double* d_coef, const float* d_s2, double n, const double* d_gkap, float* d_gs2, void* stream) {
+int wiski_mll_s2_grad_f32(const double* d_g, const double* d_coef, const float* d_s2, double n, const double* d_n, const double* d_gkap, float* d_gs2,
+                          void* stream) {
   if (!d_g || !d_coef || !d_s2 || !d_gs2) return WISKI_E_BADARG;
-  hipLaunchKernelGGL((k_mll_s2_grad<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_g, d_coef, d_s2, n, d_gkap, d_gs2);
+  hipLaunchKernelGGL((k_mll_s2_grad<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_g, d_coef, d_s2, n, d_n, d_gkap, d_gs2);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
-int wiski_mll_s2_grad_f64(const double* d_g, const double* d_coef, const double* d_s2, double n, const double* d_gkap, double* d_gs2, void* stream) {
+int wiski_mll_s2_grad_f64(const double* d_g, const double* d_coef, const double* d_s2, double n, const double* d_n, const double* d_gkap, double* d_gs2,
+                          void* stream) {
   if (!d_g || !d_coef || !d_s2 || !d_gs2) return WISKI_E_BADARG;
-  hipLaunchKernelGGL((k_mll_s2_grad<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_g, d_coef, d_s2, n, d_gkap, d_gs2);
+  hipLaunchKernelGGL((k_mll_s2_grad<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, d_g, d_coef, d_s2, n, d_n, d_gkap, d_gs2);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 int wiski_gaussian_metrics_f32(int64_t n, const float* d_mu, const float* d_var, const float* d_y, const float* d_add_var, float* d_out, void* stream) {

@@ -469,10 +469,11 @@ extern "C" int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_la
 //   g_tcol_q[l] = scale * sum_{|i - j| = l} (V_q D_q V_q^T)[i, j],
 // one workgroup per dim (it was two batched GEMMs and a [d, g^2] x [g^2, g] GEMM for which the BLAS picked a 139 us kernel).
 __global__ __launch_bounds__(256) void k_lag_grad(int d, const int* __restrict__ gs, int kw, const double* __restrict__ V, const double* __restrict__ D,
-                                                  double scale, double* __restrict__ out) {
+                                                  double scale_val, const double* __restrict__ scale_dev, double* __restrict__ out) {
   __shared__ double sV[EIG_G][SPB_KMAX + 1], sU[EIG_G][SPB_KMAX + 1], sD[SPB_KMAX][SPB_KMAX + 1], sAcc[4][EIG_G];
   const int q = blockIdx.x, t = threadIdx.x;
   const int g = gs[q];
+  const double scale = scale_dev ? scale_dev[0] : scale_val;      // (device scalar inside a captured graph)
   int toff = 0;
   for (int p = 0; p < q; ++p) toff += gs[p];
   for (int e = t; e < g * kw; e += 256) sV[e / kw][e % kw] = V[(int64_t)toff * kw + e];
@@ -502,9 +503,10 @@ __global__ __launch_bounds__(256) void k_lag_grad(int d, const int* __restrict__
   if (t < g) out[toff + t] = scale * (sAcc[0][t] + sAcc[1][t] + sAcc[2][t] + sAcc[3][t]);
 }
 
-extern "C" int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double* d_V, const double* d_D, double scale, double* d_out, void* stream) {
+extern "C" int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double* d_V, const double* d_D, double scale, const double* d_scale,
+                                    double* d_out, void* stream) {
   if (d < 1 || d > WISKI_MAX_DIM || !d_g || kw < 1 || kw > SPB_KMAX || !d_V || !d_D || !d_out) return WISKI_E_BADARG;
-  hipLaunchKernelGGL(k_lag_grad, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, (int)kw, d_V, d_D, scale, d_out);
+  hipLaunchKernelGGL(k_lag_grad, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, (int)kw, d_V, d_D, scale, d_scale, d_out);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 

@@ -682,16 +682,20 @@ def mll_value(bMb, logdet, s2, c, ld, n):
     """``wiski_mll_value``: (val, coef [3]) fp64 device scalars of one output's Woodbury MLL tail; s2 a 1-element tensor (fp32 / fp64)."""
     val = torch.empty((), dtype=torch.float64, device=bMb.device)
     coef = torch.empty(3, dtype=torch.float64, device=bMb.device)
+    nd = torch.is_tensor(n)                          # the count as a device scalar (fp64): calls recorded into a captured graph
     rc = _hip.fn("wiski_mll_value", s2.dtype)(_hip.dptr(bMb), None if logdet is None else _hip.dptr(logdet), _hip.dptr(s2), _hip.dptr(c), _hip.dptr(ld),
-                                              ctypes.c_double(float(n)), _hip.dptr(val), _hip.dptr(coef), _hip.stream_ptr(bMb.device))
+                                              ctypes.c_double(0.0 if nd else float(n)), _hip.dptr(n) if nd else None, _hip.dptr(val), _hip.dptr(coef),
+                                              _hip.stream_ptr(bMb.device))
     _hip.check(rc, "wiski_mll_value")
     return val, coef
 
 
 def mll_s2_grad(g, coef, s2, n, g_kap):
     out = torch.empty_like(s2)
-    rc = _hip.fn("wiski_mll_s2_grad", s2.dtype)(_hip.dptr(g), _hip.dptr(coef), _hip.dptr(s2), ctypes.c_double(float(n)),
-                                                None if g_kap is None else _hip.dptr(g_kap), _hip.dptr(out), _hip.stream_ptr(s2.device))
+    nd = torch.is_tensor(n)
+    rc = _hip.fn("wiski_mll_s2_grad", s2.dtype)(_hip.dptr(g), _hip.dptr(coef), _hip.dptr(s2), ctypes.c_double(0.0 if nd else float(n)),
+                                                _hip.dptr(n) if nd else None, None if g_kap is None else _hip.dptr(g_kap), _hip.dptr(out),
+                                                _hip.stream_ptr(s2.device))
     _hip.check(rc, "wiski_mll_s2_grad")
     return out
 
@@ -751,8 +755,10 @@ def woodbury_c(G, lam_kuu, kscale):
 def basis_lag_grad(g_dev, Vtab, kw, D, scale):
     """``wiski_basis_lag_grad``: [sum g] fp64 gradient w.r.t. the Toeplitz columns from the pair-reduced weights D [d, kw, kw]."""
     out = torch.empty(Vtab.shape[0] // kw, dtype=torch.float64, device=Vtab.device)
+    on_dev = torch.is_tensor(scale)                  # a device scalar (fp64): calls recorded into a captured graph
     rc = _hip.lib().wiski_basis_lag_grad(ctypes.c_int32(g_dev.shape[0]), _hip.dptr(g_dev), ctypes.c_int32(kw), _hip.dptr(Vtab), _hip.dptr(D.contiguous()),
-                                         ctypes.c_double(float(scale)), _hip.dptr(out), _hip.stream_ptr(Vtab.device))
+                                         ctypes.c_double(0.0 if on_dev else float(scale)), _hip.dptr(scale) if on_dev else None, _hip.dptr(out),
+                                         _hip.stream_ptr(Vtab.device))
     _hip.check(rc, "wiski_basis_lag_grad")
     return out
 

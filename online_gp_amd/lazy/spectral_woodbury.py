@@ -376,10 +376,12 @@ class SpectralWoodburyFactor:
         self.last_rel_bound = float((tailv / (diag + tailv).clamp_min(1e-300)).max())
         return self.last_rel_bound
 
-    def mll_backward(self, st, g_bMb, g_logdet):
+    def mll_backward(self, st, g_bMb, g_logdet, kap=None):
         """(d/d tcol [sum g] fp64, d/d kscale) of  g_bMb * b^T M b + g_logdet * logdet(I + Kt A)  in the reduced basis:
         d(b^T M b) = zeta^T (B^T dKt B) zeta,  d logdet = tr(S_B B^T dKt B),  S_B = G - G M_r G,  M_r = Lam^1/2 C^-1 Lam^1/2."""
-        basis, G, sq, chol, kap = st["basis"], st["G"], st["sq"], st["chol"], st["kscale"]
+        basis, G, sq = st["basis"], st["G"], st["sq"]
+        if kap is None:
+            kap = st["kscale"]                   # (a device scalar is handed in when the call is recorded into a captured graph)
         _, zeta = self.coefficients(st)
         # (the incoming gradients stay on the device: reading them would stall the host behind everything queued so far)
         Y2 = grid_ops.gemm(st["Linv"], (sq[:, None] * G).contiguous())           # chol^-1 Lam^1/2 G

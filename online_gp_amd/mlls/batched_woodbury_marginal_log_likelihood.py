@@ -199,13 +199,15 @@ class _SpectralMll(torch.autograd.Function):
     zero-dimensional framework ops and their ~20 autograd nodes per step."""
 
     @staticmethod
-    def forward(ctx, tcol64, s2, model, o, want_logdet, sp):
+    def forward(ctx, tcol64, s2, model, o, want_logdet, sp, n):
+        """n: the data count, a Python number -- or a device scalar when the step is recorded into a captured graph
+        (models/_streaming_wrapper.py), in which case 1 / sigma2 is taken from the device as well."""
         fac, st, _ = sp
         stats = model._kernel_cache["_stats"]
-        n = model.num_data
         s2d = s2.detach()
         val, coef = grid_ops.mll_value(st["bMb"], st["logdet"] if want_logdet else None, s2d, stats[o, 0], stats[o, 1], n)
         ctx.fac, ctx.st, ctx.n = fac, st, n
+        ctx.kap = (1.0 / s2d.double()).reshape(1) if torch.is_tensor(n) else None
         ctx.save_for_backward(coef, s2d)
         return val
 
@@ -213,9 +215,9 @@ class _SpectralMll(torch.autograd.Function):
     def backward(ctx, g):
         coef, s2d = ctx.saved_tensors
         gab = coef[:2] * g
-        g_tcol, g_kap = ctx.fac.mll_backward(ctx.st, gab[0], gab[1])
+        g_tcol, g_kap = ctx.fac.mll_backward(ctx.st, gab[0], gab[1], kap=ctx.kap)
         g_s2 = grid_ops.mll_s2_grad(g.contiguous(), coef, s2d, ctx.n, g_kap) if ctx.needs_input_grad[1] else None
-        return (g_tcol if ctx.needs_input_grad[0] else None), g_s2, None, None, None, None
+        return (g_tcol if ctx.needs_input_grad[0] else None), g_s2, None, None, None, None, None
 
 
 class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
@@ -228,12 +230,16 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
 
     def forward(self, distro=None, targets=None, *args):
         model = self.model
-        model._finish_pending()      # the solves below share the model's PCG workspace with a deferred refresh still in flight
-        if self.clear_caches_every_iteration:
-            model.zero_grad()
-        model.check_bounds()
+        # graph context (models/_streaming_wrapper.py): the call is being recorded into a captured graph -- the factor state comes
+        # from static staging buffers, the data count from a device scalar, and nothing here may touch the host-device boundary
+        gctx = model.__dict__.get("_graph_ctx")
+        if gctx is None:
+            model._finish_pending()  # the solves below share the model's PCG workspace with a deferred refresh still in flight
+            if self.clear_caches_every_iteration:
+                model.zero_grad()
+            model.check_bounds()
         cache = model._kernel_cache
-        n = model.num_data
+        n = model.num_data if gctx is None else gctx["n"]
         want_logdet = settings.skip_logdet_forward.off()
         out = []
         for o in range(model.num_outputs):
@@ -244,9 +250,9 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
                 s2 = s2[o] if s2.numel() > 1 else s2[0]
             else:
                 s2 = torch.ones((), dtype=torch.float64, device=model._device)
-            sp = None if model._use_dense() else model._spectral_state(o)
+            sp = gctx["sp"] if gctx is not None else (None if model._use_dense() else model._spectral_state(o))
             if sp is not None:
-                out.append(_SpectralMll.apply(tcol, s2, model, o, want_logdet, sp))
+                out.append(_SpectralMll.apply(tcol, s2, model, o, want_logdet, sp, n))
                 continue
             s2 = s2.double()
             bMb, logdet_q = _WoodburyTerms.apply(tcol, 1.0 / s2, model, o, want_logdet)

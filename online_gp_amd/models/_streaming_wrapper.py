@@ -78,12 +78,17 @@ class StreamingSKIWrapper(torch.nn.Module):
             params = list(params)
             fused = bool(params) and all(p.is_cuda and p.is_floating_point() for p in params)
             try:
+                if fused and capturable:              # step count on the device: the update can be recorded into a graph (_graphed_step.py)
+                    return torch.optim.Adam(params, lr=lr, fused=True, capturable=True)
                 return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
             except (RuntimeError, TypeError):
                 return torch.optim.Adam(params, lr=lr)
 
+        capturable = True
         self.gp_optimizer = adam(self.gp.parameters(), gp_lr)
+        capturable = False
         self.stem_optimizer = adam(self.stem.parameters(), stem_lr)
+        self.__dict__["_graphed"] = None              # a captured hyper step belongs to its optimiser
 
     def set_lr(self, gp_lr, stem_lr=None, bn_mom=None):
         self._make_optimizers(gp_lr, gp_lr if stem_lr is None else stem_lr)
@@ -136,6 +141,14 @@ class StreamingSKIWrapper(torch.nn.Module):
     def _hyper_step(self):
         """One Adam step on -MLL of the statistics absorbed so far (the reference scores the data seen *before*
         the new batch: BWM ignores its arguments and reads the kernel cache)."""
+        gs = self.__dict__.get("_graphed")
+        if gs is None:
+            from ._graphed_step import GraphedHyperStep
+
+            gs = self.__dict__["_graphed"] = GraphedHyperStep(self)
+        loss = gs.step()                             # forward + backward + Adam as one captured graph where that applies
+        if loss is not None:
+            return loss
         opt = self.gp_optimizer
         opt.zero_grad()
         # (the reference toggles gp.train() / mll.train() / gp.eval() around this, OSR:135-147; the Woodbury MLL here reads

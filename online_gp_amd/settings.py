@@ -229,6 +229,13 @@ class spectral_tail(_value_context):
     _global_value = None
 
 
+class graphed_hyper_step(_feature_flag):
+    """Streaming wrappers (OnlineSKIRegression ...): run the per-batch Adam step on the MLL as one captured HIP graph when the spectral
+    factor serves the MLL (models/_graphed_step.py); off: the op-by-op step."""
+
+    _state = True
+
+
 class fused_hyper_columns(_feature_flag):
     """Toeplitz columns of (Scale of) RBF / Matern kernels and their gradient w.r.t. lengthscales and outputscale by one HIP launch
     each (``wiski_stationary_columns``) instead of the broadcasting-op graph; off: the op graph (what foreign kernels always use)."""

@@ -809,3 +809,49 @@ def test_multi_output_absorb_in_one_launch_equals_the_per_output_loop(dtype, d, 
             assert torch.allclose(ma.mean, mb.mean, rtol=1e-4, atol=1e-6) and torch.allclose(ma.variance, mb.variance, rtol=1e-4, atol=1e-8)
     finally:
         grid_ops.scatter_stats_multi = orig
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 1e-9)])
+def test_graphed_hyper_step_equals_the_eager_step(dtype, tol):
+    """The per-batch Adam step on the MLL recorded into one HIP graph (models/_graphed_step.py) walks the same hyper-parameter
+    trajectory as the op-by-op step: same losses, same parameters, same predictions, step after step -- across the eager warm-up,
+    the capture, a re-capture forced by a re-selection of the factor's index set, and a learning-rate change."""
+    from online_gp_amd import settings
+    from online_gp_amd.lazy import spectral_woodbury as sw
+    from online_gp_amd.models import Identity, OnlineSKIRegression
+
+    rng = np.random.default_rng(5)
+    d, n0, steps = 3, 600, 16
+    X = rng.uniform(-1, 1, (n0 + steps * 4, d)); y = np.sin(2 * X[:, 0]) * X[:, 1] + 0.3 * X[:, 2] + 0.05 * rng.standard_normal(len(X))
+    Xt = torch.as_tensor(X, device=DEV, dtype=dtype); yt = torch.as_tensor(y, device=DEV, dtype=dtype)[:, None]
+    old_every = sw.RESELECT_EVERY
+    sw.RESELECT_EVERY = 6                      # the factor re-selects its index set every 6 device refreshes: forces one re-capture
+    try:
+        runs = {}
+        for graphed in (True, False):
+            with settings.graphed_hyper_step(graphed):
+                reg = OnlineSKIRegression(Identity(d), Xt[:n0], yt[:n0], 1e-2, 16, 1.0)
+                trace = []
+                for i in range(steps):
+                    lo = n0 + 4 * i
+                    if i == 11:
+                        if graphed:
+                            first = (reg._graphed.replays, reg._graphed.captures, reg._graphed.disabled)
+                        reg.set_lr(5e-3)             # a new optimiser: a new recorder, which warms up again
+                    rmse, nll = reg.evaluate(Xt[lo:lo + 4], yt[lo:lo + 4])
+                    _, loss = reg.update(Xt[lo:lo + 4], yt[lo:lo + 4])
+                    k = reg.gp.covar_module.base_kernel
+                    trace.append((rmse, nll, loss, k.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1).copy(),
+                                  float(k.outputscale.detach()), float(reg.gp.likelihood.second_noise.detach())))
+                runs[graphed] = (trace, reg)
+        gs = runs[True][1]._graphed
+        assert gs.disabled is None, gs.disabled
+        assert first[2] is None and first[0] == 11 - 3 and first[1] >= 2, first     # 3 eager warm-up steps, then replays; >= 1 re-capture
+        assert gs.replays == steps - 11 - 3 and gs.captures == 1
+        assert runs[False][1]._graphed.replays == 0
+        for i, (a, b) in enumerate(zip(runs[True][0], runs[False][0])):
+            for u, v in zip(a[:3], b[:3]):
+                assert abs(u - v) <= tol * 50 * max(1.0, abs(v)), (i, a[:3], b[:3])
+            assert np.abs(a[3] - b[3]).max() <= tol * 10 and abs(a[4] - b[4]) <= tol * 10 and abs(a[5] - b[5]) <= tol * 10, (i, a[3:], b[3:])
+    finally:
+        sw.RESELECT_EVERY = old_every
