@@ -384,6 +384,10 @@ int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double
 /* d_diag[j] = |d_Y[:, j]|^2 (d_Y [r, n]), d_tail[j] = max(d_prior[j] * kscale - |d_F[j, :]|^2, 0) (d_F [n, r]): the two parts of the
  * predictive variances of n queries from the spectral factor, one launch. */
 int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, double kscale, double* d_diag, double* d_tail, void* stream);
+/* After the factorisation, three launches: d_out (packed fp64, 6 r + 2) = hr [r] | c [r] | t [r] | coef [r] | zeta [r] | bMb | logdet | scratch [r]
+ * with hr = T^T h_ref (d_TS [r_ref, r]), c = chol^-1 (sq o hr) (d_Linv = chol^-1, [r, r]), bMb = |c|^2, t = chol^-T c, coef = sq o t,
+ * zeta = t / sq, logdet = 2 sum log diag d_chol. */
+int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, const double* d_href, const double* d_sq, const double* d_Linv, const double* d_chol, double* d_out, void* stream);
 /* C = I + Lam^1/2 G Lam^1/2, lam = lam_kuu * kscale, sq = sqrt(lam)  (r x r, contiguous): the matrix the spectral factor factorises. */
 int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_lam_kuu, double kscale, double* d_C, double* d_lam, double* d_sq, void* stream);
 

@@ -6,10 +6,11 @@
 // one-wave diagonal kernel alone 56 us, 0.57 ms for n = 327 although the arithmetic is 12 MFLOP.  Here ONE workgroup
 // (8 waves, one CU, the matrix resident in L2, the current panel in LDS) runs the whole right-looking factorisation with
 // 32-wide panels:
-//   A  load the diagonal block and the panel below it into LDS
-//   B  wave 0 factorises the 32 x 32 block (rows in registers) and inverts the factor (column per lane)
 //   C  panel  L21 = A21 L11^-T      32 x 32 MFMA tile products, one row tile per wave
-//   D  trailing update A22 -= L21 L21^T   lower tiles dealt to the waves, operands from the LDS panel
+//   D1 first block column of the trailing update A22 -= L21 L21^T: the next diagonal block (kept in LDS) and the next panel
+//   B  wave 0 factorises the next 32 x 32 block and inverts the factor (one instruction stream for both, see wave_potrf32) ...
+//   D2 ... while the other waves finish the trailing update (lower tiles, operands from the LDS panel)
+//   A  the next panel into LDS
 // and stores the inverses of the diagonal blocks.  k_tri_inv_small then builds the explicit inverse of the factor, one
 // workgroup per 32-column block (the block columns of a triangular inverse are independent):
 //   X_JJ = L_JJ^-1,   X_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK X_KJ.
@@ -18,6 +19,7 @@
 constexpr int SNB = 32;        // panel width
 constexpr int SLD = 34;        // LDS row stride (reals)
 constexpr int SMALL_N_MAX = 480;
+constexpr size_t SMALL_LDS_MAX = 160 * 1024;   // LDS of a CU
 constexpr int SWG = 512;       // threads of the factorisation workgroup (8 waves: 256 registers each -- the one-wave diagonal step wants them)
 constexpr int SNW = SWG / 64;
 
@@ -124,48 +126,54 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
   real(*sP)[SLD] = reinterpret_cast<real(*)[SLD]>(reinterpret_cast<real*>(sCol) + 4 * SNB);
   using acc_t = typename Acc4<real>::type;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int k0 = 0, blk = 0; k0 < n; k0 += SNB, ++blk) {
-    const int nb = n - k0 < SNB ? n - k0 : SNB;
-    const int mt = n - k0 - nb;                              // rows below the diagonal block
-    const int mtp = (mt + SNB - 1) / SNB * SNB;
-    // ---- A: diagonal block and panel into LDS
-    {
-      // (loads in batches of 8 per thread: issued back to back, one wait -- a load-store loop pays the L2 latency per row)
-      constexpr int RP = SWG / 32;                           // rows per pass
-      const int j = tid & 31, i0 = tid >> 5;
-      real v[8];
+  constexpr int RP = SWG / 32;                               // rows per pass of the cooperative loads (32 columns x RP rows)
+  const int lj = tid & 31, li0 = tid >> 5;
+  // panel below the diagonal block at k0 (rows k0 + nb .., columns k0 .. k0 + nb) -> sP, zero-padded to whole tiles.  Loads in
+  // batches of 8 per thread: issued back to back, one wait (a load-store loop pays the L2 latency per row).
+  auto load_panel = [&](int k0, int nb, int mt, int mtp) {
+    real v[8];
+    for (int rb = 0; rb < mtp; rb += 8 * RP) {
 #pragma unroll
-      for (int u = 0; u < SNB / RP; ++u) {
-        const int i = i0 + u * RP;
-        v[u] = (i < nb && j < nb) ? A[(int64_t)(k0 + i) * lda + k0 + j] : (i == j ? (real)1 : (real)0);
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + u * RP + li0;
+        v[u] = (r < mt && lj < nb) ? A[(int64_t)(k0 + nb + r) * lda + k0 + lj] : (real)0;
       }
 #pragma unroll
-      for (int u = 0; u < SNB / RP; ++u) sD[i0 + u * RP][j] = v[u];
-      for (int rb = 0; rb < mtp; rb += 8 * RP) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int r = rb + u * RP + i0;
-          v[u] = (r < mt && j < nb) ? A[(int64_t)(k0 + nb + r) * lda + k0 + j] : (real)0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int r = rb + u * RP + i0;
-          if (r < mtp) sP[r][j] = v[u];
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + u * RP + li0;
+        if (r < mtp) sP[r][lj] = v[u];
       }
     }
+  };
+  auto store_diag = [&](int k0, int nb, int blk) {           // factor block and its inverse (LDS) -> A, dinv
+    for (int i = li0; i < SNB; i += RP) {
+      if (i < nb && lj < nb) A[(int64_t)(k0 + i) * lda + k0 + lj] = sD[i][lj];
+      dinv[(int64_t)blk * SNB * SNB + i * SNB + lj] = sI[i][lj];
+    }
+  };
+  // ---- prologue: first diagonal block factorised, first panel loaded
+  {
+    const int nb = n < SNB ? n : SNB;
+    for (int i = li0; i < SNB; i += RP) sD[i][lj] = (i < nb && lj < nb) ? A[(int64_t)i * lda + lj] : (i == lj ? (real)1 : (real)0);
+    const int mt = n - nb;
+    load_panel(0, nb, mt, (mt + SNB - 1) / SNB * SNB);
     __syncthreads();
-    // ---- B: factor + inverse of the diagonal block (wave 0)
     if (w == 0) {
       const bool bad = wave_potrf32<real>(sD, sI, sCol, lane);
       if (bad && lane == 0) atomicOr(info, 1);
     }
     __syncthreads();
-    for (int i = tid >> 5; i < SNB; i += SWG / 32) {
-      const int j = tid & 31;
-      if (i < nb && j < nb) A[(int64_t)(k0 + i) * lda + k0 + j] = sD[i][j];
-      dinv[(int64_t)blk * SNB * SNB + i * SNB + j] = sI[i][j];
-    }
+    store_diag(0, nb, 0);
+  }
+  // Each round: panel of block k (C), then the first block column of the trailing update (D1: it yields the NEXT diagonal block,
+  // kept in LDS, and the next panel, to global), then -- concurrently -- wave 0 factorises that next diagonal block while the
+  // other waves do the rest of the trailing update (D2): the one-wave factorisation (~9 us) is the longest serial piece of a round
+  // and now hides behind the tile products.
+  for (int k0 = 0, blk = 0; k0 < n; k0 += SNB, ++blk) {
+    const int nb = n - k0 < SNB ? n - k0 : SNB;
+    const int mt = n - k0 - nb;                              // rows below the diagonal block
+    if (mt == 0) break;
+    const int mtp = (mt + SNB - 1) / SNB * SNB;
     // ---- C: panel L21 = A21 L11^-T, one 32-row tile per wave (in place in LDS, and to global)
     for (int rt = w; rt * SNB < mt; rt += SNW) {
       const int r0 = rt * SNB;
@@ -186,14 +194,10 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
           }
     }
     __syncthreads();
-    // ---- D: trailing update, lower tiles (ti >= tj) dealt to the waves
     const int nt = mtp / SNB;
-    const int ntile = nt * (nt + 1) / 2;
-    for (int tl = w; tl < ntile; tl += SNW) {
-      int ti = 0, rem = tl;                                  // tl -> (ti, tj), tj <= ti
-      while (rem > ti) { rem -= ti + 1; ++ti; }
-      const int tj = rem;
-      // the tile of A22 first (16 independent loads in flight under the MFMA loop), then the product, then the stores
+    const int nbn = mt < SNB ? mt : SNB;                     // size of the next diagonal block
+    // one lower tile (ti >= tj) of A22 -= L21 L21^T; the tile of A22 first (16 independent loads in flight under the MFMA loop)
+    auto update_tile = [&](int ti, int tj) {
       real cv[2][2][4];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -213,11 +217,37 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int i = ti * SNB + a * 16 + frag_row<real>(lane, r), j = tj * SNB + b * 16 + (lane & 15);
-            if (i < mt && j <= i) A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] = cv[a][b][r] - acc[a][b][r];
+            const int il = a * 16 + frag_row<real>(lane, r), jl = b * 16 + (lane & 15);
+            const int i = ti * SNB + il, j = tj * SNB + jl;
+            const real v = cv[a][b][r] - acc[a][b][r];
+            if (ti == 0 && tj == 0) sD[il][jl] = (il < nbn && jl < nbn) ? v : (il == jl ? (real)1 : (real)0);   // next diagonal block: stays in LDS
+            else if (i < mt && j <= i) A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] = v;
           }
+    };
+    // ---- D1: first block column of the update
+    for (int ti = w; ti < nt; ti += SNW) update_tile(ti, 0);
+    __threadfence_block();
+    __syncthreads();
+    // ---- B (wave 0: next diagonal block) alongside D2 (the other waves: tiles with tj >= 1)
+    if (w == 0) {
+      const bool bad = wave_potrf32<real>(sD, sI, sCol, lane);
+      if (bad && lane == 0) atomicOr(info, 1);
+    } else {
+      const int ntile2 = (nt - 1) * nt / 2;                  // lower triangle of the (nt - 1) x (nt - 1) tiles with ti >= tj >= 1
+      for (int tl = w - 1; tl < ntile2; tl += SNW - 1) {
+        int ti = 0, rem = tl;
+        while (rem > ti) { rem -= ti + 1; ++ti; }
+        update_tile(ti + 1, rem + 1);
+      }
     }
     __threadfence_block();
+    __syncthreads();
+    // ---- next round's inputs: factor block to global, panel below it into LDS
+    {
+      const int k1 = k0 + nb, mt1 = n - k1 - nbn;
+      store_diag(k1, nbn, blk + 1);
+      load_panel(k1, nbn, mt1, (mt1 + SNB - 1) / SNB * SNB);
+    }
     __syncthreads();
   }
   // strict upper triangle: zero
@@ -295,6 +325,101 @@ __global__ __launch_bounds__(256) void k_tri_inv_small(int n, const real* __rest
   }
 }
 
+// The same inverse with the sum over K dealt to the 4 waves: wave w stages the tiles L_IK, K = J + w, J + w + 4, ... in its OWN LDS
+// region and accumulates a full 32 x 32 partial product (no workgroup barrier inside the K loop: X_KJ is read-only by then), the
+// partials are summed through LDS, and X_IJ = -L_II^-1 S is one more tile product.  3 barriers per block row instead of 2 per
+// (row, K) pair, and a quarter of the tile products on the critical path: 88 -> ~40 us at n = 327.  Needs 6 tile regions of LDS
+// besides the block column, i.e. n <= 384 in fp64; larger matrices use k_tri_inv_small.
+template <typename real>
+__global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __restrict__ L, int ldl, const real* __restrict__ dinv, real* __restrict__ X, int ldx) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real(*sW)[SNB][SLD] = reinterpret_cast<real(*)[SNB][SLD]>(smem_raw);      // [4] wave-private: staged L tile, then the wave's partial
+  real(*sS)[SLD] = reinterpret_cast<real(*)[SLD]>(sW + 4);                  // summed partials
+  real(*sDI)[SLD] = sS + SNB;                                                // dinv[I]
+  real(*sX)[SLD] = sDI + SNB;                                                // block column J of X, rows from J * 32
+  using acc_t = typename Acc4<real>::type;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int J = blockIdx.x, j0 = J * SNB;
+  const int nblk = (n + SNB - 1) / SNB;
+  const int nbj = n - j0 < SNB ? n - j0 : SNB;
+  const int qa = w >> 1, qb = w & 1;
+  for (int e = tid; e < j0 * SNB; e += 256) {
+    const int i = e / SNB, j = e % SNB;
+    if (j < nbj) X[(int64_t)i * ldx + j0 + j] = (real)0;
+  }
+  for (int e = tid; e < SNB * SNB; e += 256) {
+    const int i = e / SNB, j = e % SNB;
+    const real v = dinv[(int64_t)J * SNB * SNB + e];
+    sX[i][j] = v;
+    if (i < nbj && j < nbj) X[(int64_t)(j0 + i) * ldx + j0 + j] = v;
+  }
+  __syncthreads();
+  for (int I = J + 1; I < nblk; ++I) {
+    const int i0 = I * SNB;
+    const int nbi = n - i0 < SNB ? n - i0 : SNB;
+    acc_t acc[2][2];
+    zero_acc<real>(acc);
+    for (int K = J + w; K < I; K += 4) {
+      // stage L[I][K] (32 x 32) into this wave's region: 16 elements per lane, rows of 256 B
+      real v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = u * 64 + lane, i = e >> 5, k = e & 31;
+        v[u] = i < nbi ? L[(int64_t)(i0 + i) * ldl + K * SNB + k] : (real)0;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();                       // the previous tile's operand reads are done
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = u * 64 + lane;
+        sW[w][e >> 5][e & 31] = v[u];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int xr = (K - J) * SNB;
+      wave_tile32<real>(lane, SNB, [&](int i, int k) { return sW[w][i][k]; }, [&](int k, int j) { return sX[xr + k][j]; }, acc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sW[w][a * 16 + frag_row<real>(lane, r)][b * 16 + (lane & 15)] = acc[a][b][r];
+    __syncthreads();
+    for (int e = tid; e < SNB * SNB; e += 256) {
+      const int i = e / SNB, j = e % SNB;
+      sS[i][j] = sW[0][i][j] + sW[1][i][j] + sW[2][i][j] + sW[3][i][j];
+      sDI[i][j] = dinv[(int64_t)I * SNB * SNB + e];
+    }
+    __syncthreads();
+    acc_t q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = (real)0;
+#pragma unroll
+    for (int ks = 0; ks < SNB; ks += 4) {
+      const int kk = ks + (lane >> 4);
+      q = mfma16(sDI[qa * 16 + (lane & 15)][kk], sS[kk][qb * 16 + (lane & 15)], q);
+    }
+    const int xr = (I - J) * SNB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = qa * 16 + frag_row<real>(lane, r), j = qb * 16 + (lane & 15);
+      const real v = -q[r];
+      sX[xr + i][j] = v;
+      if (i < nbi && j < nbj) X[(int64_t)(i0 + i) * ldx + j0 + j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename real>
+static inline size_t tri_inv_small4_lds(int n) {
+  const int mtp = (n + SNB - 1) / SNB * SNB;
+  return (size_t)((mtp + 6 * SNB) * SLD) * sizeof(real);
+}
+
 template <typename real>
 static inline size_t potrf_small_lds(int n) {
   const int mtp = (n + SNB - 1) / SNB * SNB;
@@ -312,7 +437,8 @@ static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int l
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) != hipSuccess) {
+        hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_tri_inv_small4<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX) != hipSuccess) {
       (void)hipGetLastError();
       return WISKI_E_LAUNCH;
     }
@@ -321,8 +447,12 @@ static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int l
   hipLaunchKernelGGL((k_potrf_small<real>), dim3(1), dim3(SWG), potrf_small_lds<real>(n), s, n, d_A, lda, d_dinv, d_info);
   if (d_X) {
     const int nblk = (n + SNB - 1) / SNB;
-    hipLaunchKernelGGL((k_tri_inv_small<real>), dim3((unsigned)nblk), dim3(256), tri_inv_small_lds<real>(n), s, n, (const real*)d_A, lda, (const real*)d_dinv, d_X,
-                       ldx);
+    if (tri_inv_small4_lds<real>(n) <= SMALL_LDS_MAX)
+      hipLaunchKernelGGL((k_tri_inv_small4<real>), dim3((unsigned)nblk), dim3(256), tri_inv_small4_lds<real>(n), s, n, (const real*)d_A, lda, (const real*)d_dinv,
+                         d_X, ldx);
+    else
+      hipLaunchKernelGGL((k_tri_inv_small<real>), dim3((unsigned)nblk), dim3(256), tri_inv_small_lds<real>(n), s, n, (const real*)d_A, lda, (const real*)d_dinv,
+                         d_X, ldx);
   }
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }

@@ -568,3 +568,95 @@ extern "C" int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const
     hipLaunchKernelGGL(k_spectral_var, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_Y, d_F, d_prior, kscale, d_diag, d_tail);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
+
+// ------------------------------------------------------------- factor tail ---
+// Everything the spectral factor derives from (T, h_ref, sqrt(lam), chol, chol^-1) once the factorisation is done -- it was ten
+// small framework launches (two GEMVs from the BLAS at 5-23 us each, products, reductions) on the critical path of every
+// hyper-parameter step -- as three launches of 1024-thread workgroups (a matrix-vector product wants many CUs' worth of L2
+// bandwidth and many loads in flight: one workgroup doing all three took 119 us):
+//   a  hr = T^T h_ref,  v = sqrt(lam) o hr                       64 columns per workgroup, the rows dealt to its 16 waves
+//   b  c = chol^-1 v                                              a wave per row
+//   c  t = chol^-T c,  coef = sqrt(lam) o t,  zeta = t / sqrt(lam),  bMb = |c|^2,  logdet = 2 sum log diag chol
+// out (packed, fp64): hr [r] | c [r] | t [r] | coef [r] | zeta [r] | bMb | logdet | v [r] (scratch).
+__global__ __launch_bounds__(1024) void k_tail_a(int r_ref, int r, const double* __restrict__ TS, const double* __restrict__ h_ref, const double* __restrict__ sq,
+                                                 double* __restrict__ out) {
+  __shared__ double s_p[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  double acc = 0;
+  if (j < r) {
+#pragma unroll 8
+    for (int i = wv; i < r_ref; i += 16) acc += TS[(int64_t)i * r + j] * h_ref[i];
+  }
+  s_p[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0 && j < r) {
+    double hr = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) hr += s_p[w][lane];
+    out[j] = hr;
+    out[5 * r + 2 + j] = sq[j] * hr;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_tail_b(int r, const double* __restrict__ Linv, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 16 + wv;
+  if (i >= r) return;
+  const double* __restrict__ row = Linv + (int64_t)i * r;
+  const double* __restrict__ v = out + 5 * r + 2;
+  double acc = 0;
+  for (int j = lane; j <= i; j += 64) acc += row[j] * v[j];
+  acc = wave_reduce_sum<double>(acc);
+  if (lane == 0) out[r + i] = acc;
+}
+
+__global__ __launch_bounds__(1024) void k_tail_c(int r, const double* __restrict__ Linv, const double* __restrict__ chol, const double* __restrict__ sq,
+                                                 double* __restrict__ out) {
+  __shared__ double s_p[16][64], s_red[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const double* __restrict__ c = out + r;
+  double acc = 0;
+  if (j < r) {
+    const int i0 = blockIdx.x * 64;                      // rows below the block's first column (the strict upper part is zero)
+#pragma unroll 8
+    for (int i = i0 + wv; i < r; i += 16) acc += Linv[(int64_t)i * r + j] * c[i];
+  }
+  s_p[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0 && j < r) {
+    double tv = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tv += s_p[w][lane];
+    const double s = sq[j];
+    out[2 * r + j] = tv;
+    out[3 * r + j] = s * tv;
+    out[4 * r + j] = tv / s;
+  }
+  if (blockIdx.x == 0) {
+    double c2 = 0, ld = 0;
+    for (int i = threadIdx.x; i < r; i += 1024) {
+      c2 += c[i] * c[i];
+      ld += log(chol[(int64_t)i * r + i]);
+    }
+    __syncthreads();
+    c2 = block_reduce_sum(c2, s_red);
+    __syncthreads();
+    ld = block_reduce_sum(ld, s_red);
+    if (threadIdx.x == 0) {
+      out[5 * r] = c2;
+      out[5 * r + 1] = 2.0 * ld;
+    }
+  }
+}
+
+extern "C" int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, const double* d_href, const double* d_sq, const double* d_Linv,
+                                 const double* d_chol, double* d_out, void* stream) {
+  if (r_ref < 1 || r < 1 || !d_TS || !d_href || !d_sq || !d_Linv || !d_chol || !d_out) return WISKI_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tail_a, dim3((unsigned)((r + 63) / 64)), dim3(1024), 0, s, (int)r_ref, (int)r, d_TS, d_href, d_sq, d_out);
+  hipLaunchKernelGGL(k_tail_b, dim3((unsigned)((r + 15) / 16)), dim3(1024), 0, s, (int)r, d_Linv, d_out);
+  hipLaunchKernelGGL(k_tail_c, dim3((unsigned)((r + 63) / 64)), dim3(1024), 0, s, (int)r, d_Linv, d_chol, d_sq, d_out);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}

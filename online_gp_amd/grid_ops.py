@@ -740,6 +740,16 @@ def basis_change(g_dev, Tq, kref, ref_S, kw, S, ev, tcol64, resid, work):
     return TS, lam, verdict
 
 
+def factor_tail(TS, h_ref, sq, Linv, chol):
+    """``wiski_factor_tail``: (hr, c_half, t, coef, zeta, bMb, logdet) -- views of one packed fp64 tensor -- in three launches."""
+    r_ref, r = TS.shape
+    out = torch.empty(6 * r + 2, dtype=torch.float64, device=TS.device)
+    rc = _hip.lib().wiski_factor_tail(ctypes.c_int32(r_ref), ctypes.c_int32(r), _hip.dptr(TS), _hip.dptr(h_ref), _hip.dptr(sq), _hip.dptr(Linv),
+                                      _hip.dptr(chol), _hip.dptr(out), _hip.stream_ptr(TS.device))
+    _hip.check(rc, "wiski_factor_tail")
+    return out[:r], out[r:2 * r], out[2 * r:3 * r], out[3 * r:4 * r], out[4 * r:5 * r], out[5 * r], out[5 * r + 1]
+
+
 def woodbury_c(G, lam_kuu, kscale):
     """``wiski_woodbury_c``: (C = I + Lam^1/2 G Lam^1/2, lam = lam_kuu * kscale, sqrt(lam)) in one launch."""
     r = G.shape[0]

@@ -266,16 +266,16 @@ class SpectralWoodburyFactor:
                 return {"need_reference": True, "basis": basis, "tail": tail}
         GT = grid_ops.gemm(self.G_ref, TS)                                    # [r_ref, r]
         G = grid_ops.gemm(TS, GT, ta=True)                                    # T^T G_ref T
-        hr = torch.mv(TS.t(), self.h_ref)
         C, lam, sq = grid_ops.woodbury_c(G, basis.lam_kuu, kscale)            # I + Lam^1/2 G Lam^1/2
         # C = I + PSD: cannot fail on finite input.  With the factor its explicit inverse (r^3 / 3 flop more): every later solve
         # against it -- mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64
         # launches.  Two launches in all for r <= 480 (dense_small.h).
         Linv, info = grid_ops.potrf_inverse_(C)
-        ch = torch.mv(Linv, sq * hr)                                          # chol^-1 Lam^1/2 h
         cur = {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": TS, "lam": lam, "sq": sq, "G": G,
-               "hr": hr, "chol": C, "Linv": Linv, "info": info, "c_half": ch, "bMb": (ch * ch).sum(), "logdet": grid_ops.chol_logdet(C),
-               "tail": tail}
+               "chol": C, "Linv": Linv, "info": info, "tail": tail}
+        # hr = T^T h_ref, c = chol^-1 Lam^1/2 hr, b^T M b = |c|^2, t = chol^-T c, the mean coefficients and logdet (wiski_factor_tail)
+        hr, ch, t, coef, zeta, bMb, logdet = grid_ops.factor_tail(TS, self.h_ref, sq, Linv, C)
+        cur.update(hr=hr, c_half=ch, t=t, coef=coef, zeta=zeta, bMb=bMb, logdet=logdet)
         if self._chk is not None and not self._verdict():
             # the device-refreshed basis failed its check (eigen-residual, trace left out by the kept index set, defect of the
             # reference span): nothing built on it is used -- the host path selects afresh.  The verdict was copied back right

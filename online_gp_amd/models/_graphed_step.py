@@ -67,7 +67,7 @@ class GraphedHyperStep:
         basis = sp[1]["basis"]
         # (priors registered after a capture are not seen by it: call ``set_lr`` -- a new optimiser -- or toggle the setting to re-capture)
         key = (basis.S.data_ptr(), basis.r, basis.kmax, str(gp._dtype), tuple(float(g["lr"]) for g in opt.param_groups), id(opt),
-               settings.fused_hyper_columns.on())
+               settings.fused_hyper_columns.on(), tuple(p.requires_grad for g in opt.param_groups for p in g["params"]))
         if key != self.key:
             # a capture costs ~2 ms: worth it only if it is then replayed.  If the factor keeps re-selecting its index set (host-side
             # refresh, a kernel whose spectrum moves fast), stop re-capturing for a while and let the eager path run.
