@@ -446,3 +446,88 @@ def default_tail_of(dtype):
     from online_gp_amd.lazy.spectral_woodbury import default_tail
 
     return default_tail(dtype)
+
+
+def test_factor_glue_kernels_against_their_torch_forms():
+    """The single-launch pieces of the factor refresh (wiski_woodbury_c, wiski_potrf_inverse, wiski_factor_tail, wiski_spectral_var,
+    wiski_basis_lag_grad, wiski_basis_change) against the framework expressions they replaced, on random inputs."""
+    from online_gp_amd import grid_ops
+
+    torch.manual_seed(3)
+    f64 = dict(dtype=torch.float64, device=DEV)
+    for r_ref, r in [(61, 37), (540, 327), (700, 520)]:
+        R = torch.randn(r, r, **f64)
+        G = R @ R.t() / r
+        lam_kuu = torch.rand(r, **f64) + 0.1
+        kscale = 1.7
+        C, lam, sq = grid_ops.woodbury_c(G, lam_kuu, kscale)
+        lam_t = lam_kuu * kscale
+        assert torch.allclose(lam, lam_t, rtol=1e-14) and torch.allclose(sq, lam_t.sqrt(), rtol=1e-14)
+        C_t = lam_t.sqrt()[:, None] * G * lam_t.sqrt()[None, :] + torch.eye(r, **f64)
+        assert (C - C_t).abs().max().item() < 1e-12 * C_t.abs().max().item()
+        chol = C.clone()
+        Linv, info = grid_ops.potrf_inverse_(chol)
+        assert int(info.item()) == 0
+        L_t = torch.linalg.cholesky(C_t)
+        assert (chol - L_t).abs().max().item() < 1e-10
+        TS = torch.randn(r_ref, r, **f64) / r_ref ** 0.5
+        h_ref = torch.randn(r_ref, **f64)
+        hr, ch, t, coef, zeta, bMb, logdet = grid_ops.factor_tail(TS, h_ref, sq, Linv, chol)
+        hr_t = TS.t() @ h_ref
+        ch_t = torch.linalg.solve_triangular(L_t, (sq * hr_t)[:, None], upper=False)[:, 0]
+        t_t = torch.linalg.solve_triangular(L_t.t(), ch_t[:, None], upper=True)[:, 0]
+        for a, b in [(hr, hr_t), (ch, ch_t), (t, t_t), (coef, sq * t_t), (zeta, t_t / sq)]:
+            assert (a - b).abs().max().item() < 1e-9 * max(1.0, b.abs().max().item())
+        assert abs(float(bMb) - float((ch_t * ch_t).sum())) < 1e-9 * float((ch_t * ch_t).sum())
+        assert abs(float(logdet) - float(2 * L_t.diagonal().log().sum())) < 1e-9 * r
+        for n in (1, 7, 64, 300):
+            F = torch.randn(n, r, **f64)
+            Y = (Linv @ F.t()).contiguous()
+            prior = (F * F).sum(1) / kscale * torch.linspace(0.5, 1.5, n, **f64)     # some above, some below the captured part
+            diag, tail = grid_ops.spectral_var(Y, F, prior, kscale)
+            assert torch.allclose(diag, (Y * Y).sum(0), rtol=1e-12)
+            assert torch.allclose(tail, (prior * kscale - (F * F).sum(1)).clamp_min(0.0), rtol=1e-10, atol=1e-10)
+    # lag gradient: sum over |i - j| = l of V D V^T, per dim
+    d, kw = 3, 12
+    gs = [50, 33, 64]
+    g_dev = torch.tensor(gs, dtype=torch.int32, device=DEV)
+    Vs = [torch.randn(g, kw, **f64) for g in gs]
+    D = torch.randn(d, kw, kw, **f64)
+    out = grid_ops.basis_lag_grad(g_dev, torch.cat([v.reshape(-1) for v in Vs]), kw, D, 0.37)
+    off = 0
+    for q, g in enumerate(gs):
+        H = Vs[q] @ D[q] @ Vs[q].t()
+        idx = (torch.arange(g, device=DEV)[:, None] - torch.arange(g, device=DEV)[None, :]).abs()
+        ref = torch.zeros(g, **f64).index_add_(0, idx.reshape(-1), H.reshape(-1)) * 0.37
+        assert (out[off:off + g] - ref).abs().max().item() < 1e-10 * max(1.0, ref.abs().max().item())
+        off += g
+    # the same with the scale read from the device (what a captured graph does)
+    out2 = grid_ops.basis_lag_grad(g_dev, torch.cat([v.reshape(-1) for v in Vs]), kw, D, torch.tensor([0.37], **f64))
+    assert torch.equal(out, out2)
+    # change of basis: TS[i, j] = prod_q T_q[Sref[q, i], S[q, j]], lam, verdict
+    kref, r_ref, r = 14, 203, 151
+    Tq = torch.zeros(d, 32, 32, **f64)
+    Tq[:, :kref, :kw] = torch.randn(d, kref, kw, **f64) * 0.3
+    Sref = torch.randint(0, kref, (d, r_ref), device=DEV, dtype=torch.int32)
+    S = torch.randint(0, kw, (d, r), device=DEV, dtype=torch.int32)
+    ev = torch.rand(d, kw, **f64) + 0.05
+    tcol = torch.rand(sum(gs), **f64) + 0.5
+    resid = torch.tensor([1e-14, 3e-13, 2e-15], **f64)
+    work = torch.zeros(r + 1, **f64)
+    for rep in range(2):                                       # the workspace is left clean: a second call gives the same
+        TS, lam, verdict = grid_ops.basis_change(g_dev, Tq, kref, Sref, kw, S, ev, tcol, resid, work)
+        TS_t = torch.ones(r_ref, r, **f64)
+        lam_t = torch.ones(r, **f64)
+        for q in range(d):
+            TS_t = TS_t * Tq[q][Sref[q].long()][:, S[q].long()]
+            lam_t = lam_t * ev[q][S[q].long()]
+        assert (TS - TS_t).abs().max().item() < 1e-14 and torch.allclose(lam, lam_t, rtol=1e-14)
+        total = 1.0
+        o = 0
+        for g in gs:
+            total *= g * float(tcol[o]); o += g
+        defect = (1.0 - (TS_t * TS_t).sum(0)).clamp_min(0.0)
+        ref_v = [3e-13, 1.0 - float(lam_t.sum()) / total, float((lam_t * defect).max()) / total * r]
+        for a, b in zip(verdict.tolist(), ref_v):
+            assert abs(a - b) < 1e-10 * max(1.0, abs(b)), (rep, verdict.tolist(), ref_v)
+        assert float(work.abs().max()) == 0.0
