@@ -569,34 +569,42 @@ def main():
             # the reference's timed step at full fidelity (experiments/regression.py:48-54, OSR:56-146): evaluate = predictive
             # mean AND variance (rmse, nll) of the incoming batch, update = one Adam step on the Woodbury MLL + condition
             X0, y0 = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
-            Xr, yr = synth_stream(16384, d, 31337, dev, dtype, args.stream)
+            Xr, yr = synth_stream(49152, d, 31337, dev, dtype, args.stream)
             with settings.cg_tolerance(tol), settings.variance_cg_tolerance(3e-3):
                 reg = OnlineSKIRegression(Identity(d), X0, y0, 1e-3, args.grid, 1.0)
 
                 def ref_steps(tag, lo0):
-                    for qs, nst in ((1, 8), (64, 6), (1024, 5)):
+                    # (the first steps of a fresh wrapper run eagerly and then record the hyper step into a graph,
+                    # models/_graphed_step.py: the median below is over the steady steps after them)
+                    for qs, nst in ((1, 24), (64, 16), (1024, 12)):
                         ts = []
                         for i in range(nst):
                             lo = lo0 + i * qs
+                            if qs > 1:
+                                lo += 64 if qs == 64 else 2048         # past the points the smaller batch sizes used
                             xb, yb = Xr[lo:lo + qs], yr[lo:lo + qs]
                             torch.cuda.synchronize(); t0 = time.perf_counter()
                             reg.evaluate(xb, yb)
                             reg.update(xb, yb)
                             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-                        extra[f"reference_step_ms_q{qs}{tag}"] = float(np.median(ts[2:])) * 1e3
-                        extra[f"reference_step_updates_per_s_q{qs}{tag}"] = qs / float(np.median(ts[2:]))
+                        extra[f"reference_step_ms_q{qs}{tag}"] = float(np.median(ts[5:])) * 1e3
+                        extra[f"reference_step_updates_per_s_q{qs}{tag}"] = qs / float(np.median(ts[5:]))
 
                 # default path: mean, variance and the MLL with its exact gradient from the spectral factor where it applies
                 ref_steps("", 0)
                 fac = reg.gp.__dict__.get("_spectral", {}).get(0)
-                extra["reference_step_path"] = ("spectral Woodbury factor for mean / variance / MLL (rank %d, %d reference builds)" % (fac.cur["basis"].r, fac.rebuilds)
+                gs_ = reg.__dict__.get("_graphed")
+                extra["reference_step_path"] = ("spectral Woodbury factor for mean / variance / MLL (rank %d, %d reference builds, %d eigenvector refreshes on the device); "
+                                                "Adam step on the MLL as a captured HIP graph: %d captures, %d replays%s"
+                                                % (fac.cur["basis"].r, fac.rebuilds, fac.device_refreshes, 0 if gs_ is None else gs_.captures,
+                                                   0 if gs_ is None else gs_.replays, "" if gs_ is None or gs_.disabled is None else " (disabled: %s)" % gs_.disabled)
                                                 if fac is not None and fac.cur is not None else "wiski_pcg (mean, 64-column variance solves, Hutchinson MLL gradient)")
                 # the PCG path of the same step (what every kernel / grid falls back to): 64-column variance solves, 10 Hutchinson probes
                 with settings.spectral_factor(False):
-                    ref_steps("_pcg", 5120)
+                    ref_steps("_pcg", 16384)
                     # ... and under the reference's own solver setting (config/regression.yaml:24-27: cg_tolerance 1e-2 for every solve)
                     with settings.cg_tolerance(1e-2):
-                        ref_steps("_pcg_at_cg_tolerance_1e-2", 2048)
+                        ref_steps("_pcg_at_cg_tolerance_1e-2", 32768)
                 gc_settle()
                 # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
                 gp = reg.gp
