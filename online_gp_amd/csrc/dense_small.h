@@ -18,6 +18,7 @@
 
 constexpr int SNB = 32;        // panel width
 constexpr int SLD = 34;        // LDS row stride (reals)
+constexpr int SLDX = 33;       // row stride of the inverse's block column in k_tri_inv_small4
 constexpr int SMALL_N_MAX = 480;
 constexpr size_t SMALL_LDS_MAX = 160 * 1024;   // LDS of a CU
 constexpr int SWG = 512;       // threads of the factorisation workgroup (8 waves: 256 registers each -- the one-wave diagonal step wants them)
@@ -328,15 +329,15 @@ __global__ __launch_bounds__(256) void k_tri_inv_small(int n, const real* __rest
 // The same inverse with the sum over K dealt to the 4 waves: wave w stages the tiles L_IK, K = J + w, J + w + 4, ... in its OWN LDS
 // region and accumulates a full 32 x 32 partial product (no workgroup barrier inside the K loop: X_KJ is read-only by then), the
 // partials are summed through LDS, and X_IJ = -L_II^-1 S is one more tile product.  3 barriers per block row instead of 2 per
-// (row, K) pair, and a quarter of the tile products on the critical path: 88 -> ~40 us at n = 327.  Needs 6 tile regions of LDS
-// besides the block column, i.e. n <= 384 in fp64; larger matrices use k_tri_inv_small.
+// (row, K) pair, and a quarter of the tile products on the critical path: 88 -> ~40 us at n = 327.  Needs 4 tile regions of LDS
+// besides the block column (161.5 KB at n = 480 in fp64).
 template <typename real>
 __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __restrict__ L, int ldl, const real* __restrict__ dinv, real* __restrict__ X, int ldx) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real(*sW)[SNB][SLD] = reinterpret_cast<real(*)[SNB][SLD]>(smem_raw);      // [4] wave-private: staged L tile, then the wave's partial
-  real(*sS)[SLD] = reinterpret_cast<real(*)[SLD]>(sW + 4);                  // summed partials
-  real(*sDI)[SLD] = sS + SNB;                                                // dinv[I]
-  real(*sX)[SLD] = sDI + SNB;                                                // block column J of X, rows from J * 32
+  real(*sS)[SLD] = sW[0];                                                    // summed partials  (take over regions 0 and 1 once the partials
+  real(*sDI)[SLD] = sW[1];                                                   // dinv[I]           have been read: same element, same thread)
+  real(*sX)[SLDX] = reinterpret_cast<real(*)[SLDX]>(sW + 4);                // block column J of X, rows from J * 32 (stride 33: n = 480 fits in fp64)
   using acc_t = typename Acc4<real>::type;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int J = blockIdx.x, j0 = J * SNB;
@@ -390,8 +391,10 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
     __syncthreads();
     for (int e = tid; e < SNB * SNB; e += 256) {
       const int i = e / SNB, j = e % SNB;
-      sS[i][j] = sW[0][i][j] + sW[1][i][j] + sW[2][i][j] + sW[3][i][j];
-      sDI[i][j] = dinv[(int64_t)I * SNB * SNB + e];
+      const real sum = sW[0][i][j] + sW[1][i][j] + sW[2][i][j] + sW[3][i][j];
+      const real di = dinv[(int64_t)I * SNB * SNB + e];
+      sS[i][j] = sum;                                        // (= sW[0][i][j], sW[1][i][j]: this thread's own elements)
+      sDI[i][j] = di;
     }
     __syncthreads();
     acc_t q;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
 template <typename real>
 static inline size_t tri_inv_small4_lds(int n) {
   const int mtp = (n + SNB - 1) / SNB * SNB;
-  return (size_t)((mtp + 6 * SNB) * SLD) * sizeof(real);
+  return (size_t)(mtp * SLDX + 4 * SNB * SLD) * sizeof(real);
 }
 
 template <typename real>
