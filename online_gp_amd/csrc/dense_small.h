@@ -198,8 +198,7 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
     const int nt = mtp / SNB;
     const int nbn = mt < SNB ? mt : SNB;                     // size of the next diagonal block
     // one lower tile (ti >= tj) of A22 -= L21 L21^T; the tile of A22 first (16 independent loads in flight under the MFMA loop)
-    auto update_tile = [&](int ti, int tj) {
-      real cv[2][2][4];
+    auto load_tile = [&](int ti, int tj, real (&cv)[2][2][4]) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -209,6 +208,8 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
             const int i = ti * SNB + a * 16 + frag_row<real>(lane, r), j = tj * SNB + b * 16 + (lane & 15);
             cv[a][b][r] = (i < mt && j <= i) ? A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] : (real)0;
           }
+    };
+    auto finish_tile = [&](int ti, int tj, const real (&cv)[2][2][4]) {
       acc_t acc[2][2];
       zero_acc<real>(acc);
       wave_tile32<real>(lane, SNB, [&](int i, int k) { return sP[ti * SNB + i][k]; }, [&](int k, int j) { return sP[tj * SNB + j][k]; }, acc);
@@ -225,6 +226,11 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
             else if (i < mt && j <= i) A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] = v;
           }
     };
+    auto update_tile = [&](int ti, int tj) {
+      real cv[2][2][4];
+      load_tile(ti, tj, cv);
+      finish_tile(ti, tj, cv);
+    };
     // ---- D1: first block column of the update
     for (int ti = w; ti < nt; ti += SNW) update_tile(ti, 0);
     __threadfence_block();
@@ -235,10 +241,35 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
       if (bad && lane == 0) atomicOr(info, 1);
     } else {
       const int ntile2 = (nt - 1) * nt / 2;                  // lower triangle of the (nt - 1) x (nt - 1) tiles with ti >= tj >= 1
-      for (int tl = w - 1; tl < ntile2; tl += SNW - 1) {
-        int ti = 0, rem = tl;
-        while (rem > ti) { rem -= ti + 1; ++ti; }
-        update_tile(ti + 1, rem + 1);
+      // (the next tile's 16 loads are issued before this tile's products: with two waves per SIMD little else hides the L2 latency)
+      auto decode = [&](int tl, int& ti, int& tj) {
+        int t = 0, rem = tl;
+        while (rem > t) { rem -= t + 1; ++t; }
+        ti = t + 1; tj = rem + 1;
+      };
+      int tl = w - 1, ti = 0, tj = 0;
+      if constexpr (sizeof(real) == 8) {                     // (fp64: two tiles of C in registers beside the diagonal step's spill: plain loop)
+        for (; tl < ntile2; tl += SNW - 1) {
+          decode(tl, ti, tj);
+          update_tile(ti, tj);
+        }
+      } else {
+      real cva[2][2][4], cvb[2][2][4];
+      if (tl < ntile2) { decode(tl, ti, tj); load_tile(ti, tj, cva); }
+      while (tl < ntile2) {
+        const int tn = tl + SNW - 1;
+        int ti2 = 0, tj2 = 0;
+        if (tn < ntile2) { decode(tn, ti2, tj2); load_tile(ti2, tj2, cvb); }
+        finish_tile(ti, tj, cva);
+        tl = tn;
+        if (tl < ntile2) {
+          const int tn2 = tl + SNW - 1;
+          int ti3 = 0, tj3 = 0;
+          if (tn2 < ntile2) { decode(tn2, ti3, tj3); load_tile(ti3, tj3, cva); }
+          finish_tile(ti2, tj2, cvb);
+          tl = tn2; ti = ti3; tj = tj3;
+        }
+      }
       }
     }
     __threadfence_block();
