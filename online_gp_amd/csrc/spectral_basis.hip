@@ -157,6 +157,11 @@ int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_
 // checked by the host one step later (a failed check falls back to the host eigh).  One workgroup per dim; g <= 64, kw <= 32.
 constexpr int EIG_G = 64, EIG_K = 32;
 
+#ifdef WISKI_EIG_TIMING                               // phase stamps of block 0 (tools: a -DWISKI_EIG_TIMING build; resid_out must hold 8 + 16 doubles)
+#define EIG_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) resid_out[8 + (k)] = (double)wall_clock64(); } while (0)
+#else
+#define EIG_STAMP(k) do { } while (0)
+#endif
 #define WAVE_SYNC()                                   \
   do {                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     }
     __syncthreads();
   };
+  EIG_STAMP(0);
   for (int iter = 0; iter < 2; ++iter) {
     applyK();
     // modified Gram-Schmidt on the columns of sZ (rows = lanes of a wave, g <= 64); column c is normalised by wave 0, the
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     for (int e = t; e < g * kw; e += 256) sV[e / kw][e % kw] = sZ[e / kw][e % kw];
     __syncthreads();
   }
+  EIG_STAMP(1);
   applyK();                                           // sZ = K V
   for (int e = t; e < kw * kw; e += 256) {            // H = V^T K V (symmetrised)
     const int a = e / kw, b = e % kw;
@@ -220,6 +227,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     if (a < b) { const double s = 0.5 * (sH[a][b] + sH[b][a]); sH[a][b] = s; sH[b][a] = s; }
   }
   __syncthreads();
+  EIG_STAMP(2);
   // Rayleigh-Ritz by parallel cyclic Jacobi on ONE wave: the ~100 dependent phases of a few sweeps then cost their instructions, not
   // a workgroup barrier each (which was most of this kernel's time)
   const int n = (kw + 1) & ~1, np = n / 2;
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     }
   }
   __syncthreads();
+  EIG_STAMP(3);
   if (t < kw) sTh[t] = sH[t][t];
   __syncthreads();
   if (t < kw) {                                       // rank of each Ritz value (descending; ties by index)
@@ -298,6 +307,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
   }
   if (t < kw) ev_out[q * kw + sRank[t]] = sTh[t] > 0 ? sTh[t] : 0.0;
   __syncthreads();
+  EIG_STAMP(4);
   // T_q = Vref_q^T Vnew_q for the change of basis (wiski_basis_change), while the new vectors sit in LDS
   if (Vref && Tq_out) {
     int roff = 0;
@@ -309,6 +319,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
       Tq_out[((int64_t)q * SPB_KMAX + a) * SPB_KMAX + b] = acc;
     }
   }
+  EIG_STAMP(5);
   // residual of the vectors that are used (the first kuse): max_i |K v - theta v|_i / theta_max
   applyK();
   double worst = 0;
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     const double o = __shfl_xor(worst, off, 64);
     worst = o > worst ? o : worst;
   }
+  EIG_STAMP(6);
   __syncthreads();
   if (lane == 0) sRed[wv] = worst;
   __syncthreads();
