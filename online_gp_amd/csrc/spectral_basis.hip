@@ -5,7 +5,10 @@
 // fraction of trace(Kt) (r ~ 400 at the default RBF hyper-parameters on a 50^3 grid).  In that basis the reference's
 // Woodbury algebra (BFN:343-404: Q = I + L^T Kt L, pred_mean, pred_cov) is a dense r x r problem,
 //     G = B^T A B,   C = I + Lam^(1/2) G Lam^(1/2) = chol chol^T,   M ~= B Lam^(1/2) C^-1 Lam^(1/2) B^T,
-// which lives on the MFMA GEMM / Cholesky / TRSM kernels of dense.hip.  The two kernels here are what is not a GEMM:
+// which lives on the MFMA GEMM / Cholesky / TRSM kernels of dense.hip.  The kernels here are what is not a GEMM -- the first two
+// below, and (further down, each with its own header) the device-side refresh after a hyper-parameter step: k_eig_update
+// (eigenvectors of the Toeplitz factors refined from the previous ones), k_basis_change (change of basis + verdict),
+// k_woodbury_c, k_tail_a / b / c (everything derived from the factor), k_spectral_var (query variances), k_lag_grad (MLL backward).
 //
 //   k_basis_project   F[p, j] = scale_p * colscale_j * prod_q (w_q(x_p) . V_q[j0_q(x_p) .. +3, S_q[j]])      (= (W B)[p, j])
 //                     (+ the prior variance prod_q w_q^T K_q w_q of each point, for the truncation bound)

@@ -27,6 +27,13 @@ GEMM), and re-expresses it in the current eigenbasis by the Kronecker-structured
 T[i, j] = prod_q (V_ref,q^T V_q)[S_ref[q, i], S[q, j]]:  G = T^T G_ref T.  The part of a current basis vector outside
 the reference span ("defect") is monitored, weighted by its eigenvalue; when it exceeds the tail budget the reference
 is rebuilt from the stencil (r_ref SpMV columns).  Everything dense runs in fp64 on wiski_gemm / potrf / trsm.
+
+Per-batch hyper-parameter steps (the reference's online loop) never leave the device: the eigenvectors are REFINED from the
+previous ones by wiski_basis_eig_update (subspace iteration + Rayleigh-Ritz, one workgroup per dim), the index set is kept,
+wiski_basis_change builds T together with a three-number verdict (eigen-residual, trace left out, reference-span defect) that
+is read back before the state is handed out; a failed verdict -- or every 64th step -- takes the host path (eigh + selection).
+Then wiski_woodbury_c, wiski_potrf_inverse (one-workgroup Cholesky + explicit inverse for r <= 480) and wiski_factor_tail
+(DESIGN 3.9).
 """
 import numpy as np
 import torch
