@@ -556,6 +556,15 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 return None
         return fac, st, tcol64
 
+    def _spectral_in_use(self):
+        """Every output has a spectral factor that follows the stream and has been asked for a state recently."""
+        if settings.spectral_factor.off() or self._use_dense():
+            return False
+        facs = self.__dict__.get("_spectral", {})
+        dirty = self.__dict__.get("_spectral_dirty", {})
+        return all((f := facs.get(o)) is not None and f.ref is not None and f.cur is not None and not dirty.get(o, False) and f.idle_absorbs < 8
+                   for o in range(self.num_outputs))
+
     def _spectral_absorb(self, o, X, wa, wby, init=False, bypass=False):
         """Keep the spectral factor of output o (if one exists) in step with the statistics."""
         fac = self.__dict__.get("_spectral", {}).get(o)
@@ -762,7 +771,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         # smooth kernel on a large grid, variances wanted: mean AND variance of the batch from the spectral factor (one
         # projection kernel shared by both; its truncation error is far below the CG tolerance) -- no solve at all
         sq = None
-        if settings.skip_posterior_variances.off():
+        # ... and means only, when the hyper-parameters have moved since the last solve and a factor is being kept current anyway
+        # (a streaming wrapper that takes an MLL step per batch, e.g. the classifier's predict -> update loop): the factor's
+        # refresh is needed by that step in any case, a PCG mean solve would first re-solve the preconditioner's eigenproblems
+        ms = self._mean_state
+        hypers_moved = self._memo.get("prediction_cache") is None and ms is not None and ms.get("ver") != self._hyper_version()
+        if settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use()):
             sps = [self._spectral_state(o) for o in range(out)]
             if all(sp is not None for sp in sps):
                 sq = [sp[0].query(sp[1], Xf, sp[2]) for sp in sps]

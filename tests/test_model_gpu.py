@@ -855,3 +855,32 @@ def test_graphed_hyper_step_equals_the_eager_step(dtype, tol):
             assert np.abs(a[3] - b[3]).max() <= tol * 10 and abs(a[4] - b[4]) <= tol * 10 and abs(a[5] - b[5]) <= tol * 10, (i, a[3:], b[3:])
     finally:
         sw.RESELECT_EVERY = old_every
+
+
+def test_classifier_means_after_an_mll_step_come_from_the_factor_and_match_pcg():
+    """predict -> update loops with an MLL step per batch (the Dirichlet classifier, two outputs with per-point noise): once the
+    hyper-parameters have moved since the last mean solve and the spectral factors are being kept current for the MLL, a
+    means-only request is answered from them -- same means as the PCG solve it replaces."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import Identity, OnlineSKIClassifier
+
+    rng = np.random.default_rng(9)
+    d, n0 = 3, 900
+    X = rng.uniform(-1, 1, (n0 + 80, d)); lab = (np.sin(2 * X[:, 0]) + X[:, 1] * X[:, 2] > 0).astype(np.int64)
+    Xt = torch.as_tensor(X, device=DEV, dtype=torch.float64); lt = torch.as_tensor(lab, device=DEV)
+    with settings.cg_tolerance(1e-10):
+        clf = OnlineSKIClassifier(Identity(d), Xt[:n0], lt[:n0], 0.01, 1e-2, 14, 1.1)
+        for i in range(6):
+            lo = n0 + 8 * i
+            clf.predict(Xt[lo:lo + 8]); clf.update(Xt[lo:lo + 8], lt[lo:lo + 8])
+        gp = clf.gp
+        assert gp._spectral_in_use() and gp._memo.get("prediction_cache") is None
+        Xq = Xt[n0 + 60:n0 + 80]
+        clf.eval()
+        with settings.skip_posterior_variances(True):
+            m_fac = clf(Xq).mean
+            assert gp._memo.get("prediction_cache") is None               # no PCG solve was made for it
+            with settings.spectral_factor(False):
+                m_pcg = clf(Xq).mean
+        assert m_fac.shape == m_pcg.shape == (2, 20)
+        assert (m_fac - m_pcg).abs().max().item() < 1e-5 * m_pcg.abs().max().item()
