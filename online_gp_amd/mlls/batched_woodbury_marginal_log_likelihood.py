@@ -250,7 +250,7 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
                 s2 = s2[o] if s2.numel() > 1 else s2[0]
             else:
                 s2 = torch.ones((), dtype=torch.float64, device=model._device)
-            sp = gctx["sp"] if gctx is not None else (None if model._use_dense() else model._spectral_state(o))
+            sp = gctx["sp"][o] if gctx is not None else (None if model._use_dense() else model._spectral_state(o))
             if sp is not None:
                 out.append(_SpectralMll.apply(tcol, s2, model, o, want_logdet, sp, n))
                 continue

@@ -15,7 +15,8 @@ What a replay needs is that every address the recorded kernels read is still the
   * the index set S of the basis is used in place: the graph is re-captured when the factor re-selects it (or when the learning
     rate, the optimiser, the dtype or the set of priors changes).
 The first steps run eagerly (they also serve as the warm-up the allocator wants before a capture); whenever the spectral path does
-not apply -- dense regime, rough kernel, several outputs, a foreign optimiser -- the caller's eager path runs instead.
+not apply -- dense regime, rough kernel, a foreign optimiser -- the caller's eager path runs instead.  Several outputs (the Dirichlet
+classifier's two) are one graph: one factor, one set of staging buffers per output.
 """
 import torch
 
@@ -44,7 +45,7 @@ class GraphedHyperStep:
         gp, opt = w.gp, w.gp_optimizer
         if self.disabled is not None or settings.graphed_hyper_step.off() or settings.spectral_factor.off():
             return None
-        if gp.num_outputs != 1 or torch.device(gp._device).type != "cuda" or gp._use_dense() or w.mll.clear_caches_every_iteration:
+        if torch.device(gp._device).type != "cuda" or gp._use_dense() or w.mll.clear_caches_every_iteration:
             return None
         if not isinstance(opt, torch.optim.Adam) or not all(g.get("capturable") and g.get("fused") for g in opt.param_groups):
             return None
@@ -52,21 +53,22 @@ class GraphedHyperStep:
             return None
         gp._finish_pending()
         gp.check_bounds()                             # the eager MLL does both first; neither may happen inside a capture
-        return gp._spectral_state(0)
+        sps = [gp._spectral_state(o) for o in range(gp.num_outputs)]      # one factor per output (own statistics, own hyper-parameters)
+        return sps if all(sp is not None for sp in sps) else None
 
     def step(self):
         """One Adam step on -MLL; returns the loss, or None when the caller has to take the eager path."""
-        sp = self._applicable()
-        if sp is None:
+        sps = self._applicable()
+        if sps is None:
             return None
         if self.eager_calls < WARMUP_STEPS:
             self.eager_calls += 1
             return None
         w = self.w
         gp, opt = w.gp, w.gp_optimizer
-        basis = sp[1]["basis"]
         # (priors registered after a capture are not seen by it: call ``set_lr`` -- a new optimiser -- or toggle the setting to re-capture)
-        key = (basis.S.data_ptr(), basis.r, basis.kmax, str(gp._dtype), tuple(float(g["lr"]) for g in opt.param_groups), id(opt),
+        key = (tuple((sp[1]["basis"].S.data_ptr(), sp[1]["basis"].r, sp[1]["basis"].kmax) for sp in sps), str(gp._dtype),
+               tuple(float(g["lr"]) for g in opt.param_groups), id(opt),
                settings.fused_hyper_columns.on(), tuple(p.requires_grad for g in opt.param_groups for p in g["params"]))
         if key != self.key:
             # a capture costs ~2 ms: worth it only if it is then replayed.  If the factor keeps re-selecting its index set (host-side
@@ -82,51 +84,53 @@ class GraphedHyperStep:
             else:
                 self.churn = 0
             try:
-                self._capture(sp, key)
+                self._capture(sps, key)
             except Exception as exc:                  # a capture that cannot be made is not an error of the step: run eagerly from now on
                 self.disabled = f"{type(exc).__name__}: {exc}"
                 self.graph = self.key = None
                 gp.__dict__.pop("_graph_ctx", None)
                 return None
-        self._stage(sp)
+        self._stage(sps)
         self.graph.replay()
         self.replays += 1
         gp.zero_grad()                                # (as the eager step: drops the gradients and moves the hyper-parameter epoch on)
         return float(self.loss)
 
     # ---------------------------------------------------------------------------------------------------------------------
-    def _stage(self, sp):
-        fac, st, _ = sp
-        basis = st["basis"]
-        fac.coefficients(st)
-        self.G.copy_(st["G"])
-        self.Linv.copy_(st["Linv"])
-        torch.cat([st["sq"], st["zeta"], basis.lam_kuu, basis.ev_tab.reshape(-1), basis.Vtab, st["bMb"].reshape(1), st["logdet"].reshape(1)], out=self.packed)
+    def _stage(self, sps):
+        for (fac, st, _), buf in zip(sps, self.bufs):
+            basis = st["basis"]
+            fac.coefficients(st)
+            buf["G"].copy_(st["G"])
+            buf["Linv"].copy_(st["Linv"])
+            torch.cat([st["sq"], st["zeta"], basis.lam_kuu, basis.ev_tab.reshape(-1), basis.Vtab, st["bMb"].reshape(1), st["logdet"].reshape(1)],
+                      out=buf["packed"])
         self.n_pin[0] = float(self.w.gp.num_data)
         self.n_dev.copy_(self.n_pin, non_blocking=True)
 
-    def _capture(self, sp, key):
+    def _capture(self, sps, key):
         w = self.w
         gp, opt = w.gp, w.gp_optimizer
-        fac, st, _ = sp
-        basis = st["basis"]
-        dev, r = st["G"].device, basis.r
+        dev = sps[0][1]["G"].device
         f64 = dict(dtype=torch.float64, device=dev)
-        self.G = torch.empty((r, r), **f64)
-        self.Linv = torch.empty((r, r), **f64)
-        sizes = [r, r, r, basis.ev_tab.numel(), basis.Vtab.numel(), 1, 1]
-        self.packed = torch.empty(sum(sizes), **f64)
-        v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = torch.split(self.packed, sizes)
+        self.bufs, static = [], []
+        for fac, st, _ in sps:
+            basis = st["basis"]
+            r = basis.r
+            sizes = [r, r, r, basis.ev_tab.numel(), basis.Vtab.numel(), 1, 1]
+            buf = {"G": torch.empty((r, r), **f64), "Linv": torch.empty((r, r), **f64), "packed": torch.empty(sum(sizes), **f64)}
+            v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = torch.split(buf["packed"], sizes)
+            sbasis = SpectralBasis.on_device(basis, v_V, v_ev.view(basis.ev_tab.shape), None, lam=v_lam)
+            static.append((fac, {"basis": sbasis, "G": buf["G"], "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": buf["Linv"], "bMb": v_bMb.reshape(()),
+                                 "logdet": v_logdet, "kscale": None}, None))
+            self.bufs.append(buf)
+            fac._grid_dev()                           # (an upload: must exist before the capture)
         self.n_dev = torch.zeros(1, **f64)
         self.n_pin = torch.zeros(1, dtype=torch.float64).pin_memory()
-        sbasis = SpectralBasis.on_device(basis, v_V, v_ev.view(basis.ev_tab.shape), None, lam=v_lam)
-        static_state = {"basis": sbasis, "G": self.G, "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": self.Linv, "bMb": v_bMb.reshape(()),
-                        "logdet": v_logdet, "kscale": None}
-        fac._grid_dev()                               # (an upload: must exist before the capture)
-        self._stage(sp)
+        self._stage(sps)
         opt.zero_grad(set_to_none=True)               # the capture allocates the gradients in its own pool; replays rewrite them
         graph = torch.cuda.CUDAGraph()
-        gp._graph_ctx = {"sp": (fac, static_state, None), "n": self.n_dev}
+        gp._graph_ctx = {"sp": static, "n": self.n_dev}
         try:
             with torch.cuda.graph(graph):
                 with settings.skip_logdet_forward(True):

@@ -884,3 +884,35 @@ def test_classifier_means_after_an_mll_step_come_from_the_factor_and_match_pcg()
                 m_pcg = clf(Xq).mean
         assert m_fac.shape == m_pcg.shape == (2, 20)
         assert (m_fac - m_pcg).abs().max().item() < 1e-5 * m_pcg.abs().max().item()
+
+
+def test_graphed_hyper_step_with_two_outputs_equals_the_eager_step():
+    """The Dirichlet classifier's per-batch Adam step (two outputs: two factors, per-point noise, no learnable sigma2) as one graph."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import Identity, OnlineSKIClassifier
+
+    rng = np.random.default_rng(11)
+    d, n0, steps = 3, 900, 10
+    X = rng.uniform(-1, 1, (n0 + 8 * steps, d)); lab = (np.sin(2 * X[:, 0]) + X[:, 1] * X[:, 2] > 0).astype(np.int64)
+    Xt = torch.as_tensor(X, device=DEV, dtype=torch.float64); lt = torch.as_tensor(lab, device=DEV)
+    runs = {}
+    for graphed in (True, False):
+        with settings.graphed_hyper_step(graphed), settings.cg_tolerance(1e-10):
+            clf = OnlineSKIClassifier(Identity(d), Xt[:n0], lt[:n0], 0.01, 1e-2, 14, 1.1)
+            trace = []
+            for i in range(steps):
+                lo = n0 + 8 * i
+                clf.predict(Xt[lo:lo + 8])
+                _, loss = clf.update(Xt[lo:lo + 8], lt[lo:lo + 8])
+                k = clf.gp.covar_module.base_kernel
+                trace.append((loss, k.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1).copy(), k.outputscale.detach().cpu().numpy().reshape(-1).copy()))
+            clf.eval()
+            with settings.skip_posterior_variances(True):
+                runs[graphed] = (trace, clf(Xt[:40]).mean.cpu().numpy(), clf._graphed)
+    gs = runs[True][2]
+    assert gs.disabled is None and gs.captures >= 1 and gs.replays == steps - 3, (gs.disabled, gs.captures, gs.replays)
+    assert runs[False][2].replays == 0
+    for i, (a, b) in enumerate(zip(runs[True][0], runs[False][0])):
+        assert abs(a[0] - b[0]) <= 1e-8 * max(1.0, abs(b[0])), (i, a[0], b[0])
+        assert np.abs(a[1] - b[1]).max() <= 1e-9 and np.abs(a[2] - b[2]).max() <= 1e-9, (i, a, b)
+    assert np.abs(runs[True][1] - runs[False][1]).max() <= 1e-7 * np.abs(runs[False][1]).max()
