@@ -606,6 +606,28 @@ def main():
                     with settings.cg_tolerance(1e-2):
                         ref_steps("_pcg_at_cg_tolerance_1e-2", 32768)
                 gc_settle()
+                # the two-output counterpart (online_ski_classifier.py: Dirichlet classifier, per-point noise, predict -> update per batch)
+                try:
+                    from online_gp_amd.models import OnlineSKIClassifier
+
+                    lab0, labr = (y0 > 0).long().reshape(-1), (yr > 0).long().reshape(-1)
+                    clf = OnlineSKIClassifier(Identity(d), X0, lab0, 0.01, 1e-3, args.grid, 1.1)
+                    tsc = []
+                    for i in range(24):
+                        xb, lb = Xr[40000 + 8 * i:40000 + 8 * (i + 1)], labr[40000 + 8 * i:40000 + 8 * (i + 1)]
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        clf.predict(xb)
+                        clf.update(xb, lb)
+                        torch.cuda.synchronize(); tsc.append(time.perf_counter() - t0)
+                    extra["classifier_step_ms_q8"] = float(np.median(tsc[5:])) * 1e3
+                    gsc = clf.__dict__.get("_graphed")
+                    extra["classifier_step_path"] = "two outputs: %d graph captures, %d replays%s" % (
+                        0 if gsc is None else gsc.captures, 0 if gsc is None else gsc.replays,
+                        "" if gsc is None or gsc.disabled is None else " (disabled: %s)" % gsc.disabled)
+                    del clf
+                except Exception as exc:                                     # an extra, never the bench line
+                    extra["classifier_step_error"] = repr(exc)[:200]
+                gc_settle()
                 # small-batch latencies of the headline step (the reference driver streams with batch_size 1, config/regression.yaml:22)
                 gp = reg.gp
                 with settings.skip_posterior_variances(True), settings.deferred_bounds_check(True), torch.no_grad():
