@@ -318,7 +318,6 @@ class SpectralWoodburyFactor:
 
     def _device_refresh(self, cur, tcol64, tail):
         old = cur["basis"]
-        d, g = self.grid.d, self.grid.g
         gd = self._grid_dev()
         # three launches: the eigenvector refresh, the change of basis with its verdict, the verdict's copy to pinned memory
         ref = self.ref
