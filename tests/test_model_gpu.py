@@ -916,3 +916,35 @@ def test_graphed_hyper_step_with_two_outputs_equals_the_eager_step():
         assert abs(a[0] - b[0]) <= 1e-8 * max(1.0, abs(b[0])), (i, a[0], b[0])
         assert np.abs(a[1] - b[1]).max() <= 1e-9 and np.abs(a[2] - b[2]).max() <= 1e-9, (i, a, b)
     assert np.abs(runs[True][1] - runs[False][1]).max() <= 1e-7 * np.abs(runs[False][1]).max()
+
+
+def test_reference_step_pipeline_at_the_bench_size_matches_the_plain_path():
+    """BASELINE's configuration (d = 3, 50^3 grid, fp32, 21 743 initial points): 30 evaluate -> Adam-on-MLL -> condition steps with the
+    device pipeline (graphed Adam step, eigenvectors refined on the device, fused kernel columns, factor means) against the same steps
+    op by op with host-side eigen-decompositions -- per-step metrics, losses, the hyper-parameter trajectory and final predictions."""
+    import bench
+    from online_gp_amd import settings
+    from online_gp_amd.models import Identity, OnlineSKIRegression
+
+    dev = torch.device(DEV)
+    X0, y0 = bench.synth_stream(21743, 3, 0, dev, torch.float32, "uniform")
+    Xr, yr = bench.synth_stream(4096, 3, 31337, dev, torch.float32, "uniform")
+    runs = {}
+    for fast in (True, False):
+        with settings.cg_tolerance(1e-4), settings.graphed_hyper_step(fast), settings.spectral_device_refresh(fast), settings.fused_hyper_columns(fast):
+            reg = OnlineSKIRegression(Identity(3), X0, y0, 1e-3, 50, 1.0)
+            tr = []
+            for i in range(30):
+                xb, yb = Xr[16 * i:16 * (i + 1)], yr[16 * i:16 * (i + 1)]
+                rmse, nll = reg.evaluate(xb, yb)
+                _, loss = reg.update(xb, yb)
+                k = reg.gp.covar_module.base_kernel
+                tr.append([rmse, nll, loss] + k.base_kernel.lengthscale.detach().reshape(-1).tolist() + [float(k.outputscale.detach()), float(reg.gp.likelihood.second_noise.detach())])
+            m, v = reg.predict(Xr[2048:2112])
+            runs[fast] = (np.array(tr), m.double().cpu().numpy(), v.double().cpu().numpy(), reg)
+    gs, fac = runs[True][3]._graphed, runs[True][3].gp._spectral[0]
+    assert gs.disabled is None and gs.replays == 27 and fac.device_refreshes >= 29 and fac.rebuilds == 1
+    a, b = runs[True], runs[False]
+    assert np.abs(a[0] - b[0]).max() < 2e-3 * max(1.0, np.abs(b[0]).max()), np.abs(a[0] - b[0]).max(0)
+    assert np.abs(a[0][:, 3:] - b[0][:, 3:]).max() < 1e-5                       # the hyper-parameters themselves: fp32 rounding of a 1e-3 Adam step
+    assert np.abs(a[1] - b[1]).max() < 1e-3 * np.abs(b[1]).max() and (np.abs(a[2] - b[2]) / b[2]).max() < 1e-2
