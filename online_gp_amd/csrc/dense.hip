@@ -129,22 +129,25 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, real alpha, c
 constexpr int G2M = 128, G2N = 128, G2LD = 144;
 template <typename real> struct G2K { static constexpr int value = sizeof(real) == 4 ? 32 : 16; };
 
-template <typename real, bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm128(int M, int N, int K, real alpha, const real* __restrict__ A, int lda, const real* __restrict__ B,
+template <typename real, bool TA, bool TB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm128(int M, int N, int K, real alpha, const real* __restrict__ A, int lda, const real* __restrict__ B,
                                                  int ldb, real beta, real* __restrict__ C, int ldc) {
-  constexpr int BK = G2K<real>::value, EPT = BK / 2;      // elements per thread and operand tile
+  constexpr int NT = 64 * NW;                             // 4 waves (64 x 64 each) or 8 waves (64 x 32 each: twice the waves per CU when the grid is one block per CU)
+  constexpr int BK = G2K<real>::value, EPT = BK * 128 / NT;   // elements per thread and operand tile
+  constexpr int TPL = NT / 128;                           // threads per row of an operand tile stored along k
+  constexpr int BT = 8 / NW * 2;                          // 16-column MFMA tiles per wave along N (4 | 2)
   constexpr int VW = 16 / (int)sizeof(real);              // reals per 16-byte vector
-  __shared__ real sA[BK][G2LD];
-  __shared__ real sB[BK][G2LD];
+  __shared__ real sA2[2][BK][G2LD];                       // two stages: the next tile is written while this one is read (one barrier per K tile)
+  __shared__ real sB2[2][BK][G2LD];
   using acc_t = typename Acc4<real>::type;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = NW == 4 ? w >> 1 : w >> 2, wc = NW == 4 ? w & 1 : w & 3;
   const int m0 = blockIdx.y * G2M, n0 = blockIdx.x * G2N;
-  acc_t acc[4][4];
+  acc_t acc[4][BT];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < BT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = (real)0;
 
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void k_gemm128(int M, int N, int K, real alpha
   auto fetch = [&](auto along_k_tag, const real* __restrict__ P, int ld, int l0, int L, int k0, real (&reg)[EPT]) {
     constexpr bool ALONG_K = decltype(along_k_tag)::value;
     if constexpr (ALONG_K) {
-      const int l = tid >> 1, kb = (tid & 1) * EPT;
+      const int l = tid / TPL, kb = (tid % TPL) * EPT;
       const int gl = l0 + l, gk = k0 + kb;
       const real* __restrict__ src = P + (int64_t)gl * ld + gk;
       if (gl < L && gk + EPT <= K && (ld % VW) == 0 && ((uintptr_t)P % 16) == 0) {
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gemm128(int M, int N, int K, real alpha
         for (int u = 0; u < EPT; ++u) reg[u] = (gl < L && gk + u < K) ? src[u] : (real)0;
       }
     } else {
-      constexpr int TPR = 256 / BK;
+      constexpr int TPR = NT / BK;
       const int k = tid / TPR, lb = (tid % TPR) * EPT;
       const int gk = k0 + k, gl = l0 + lb;
       const real* __restrict__ src = P + (int64_t)gk * ld + gl;
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256) void k_gemm128(int M, int N, int K, real alpha
   auto stash = [&](auto along_k_tag, real (*S)[G2LD], const real (&reg)[EPT]) {
     constexpr bool ALONG_K = decltype(along_k_tag)::value;
     if constexpr (ALONG_K) {
-      const int l = tid >> 1, kb = (tid & 1) * EPT;
+      const int l = tid / TPL, kb = (tid % TPL) * EPT;
 #pragma unroll
       for (int u = 0; u < EPT; ++u) S[kb + u][l] = reg[u];
     } else {
-      constexpr int TPR = 256 / BK;
+      constexpr int TPR = NT / BK;
       const int k = tid / TPR, lb = (tid % TPR) * EPT;
 #pragma unroll
       for (int u = 0; u < EPT; ++u) S[k][lb + u] = reg[u];
@@ -202,36 +205,45 @@ __global__ __launch_bounds__(256) void k_gemm128(int M, int N, int K, real alpha
   real ra[EPT], rb[EPT];
   fetch(AK{}, A, lda, m0, M, 0, ra);
   fetch(BKt{}, B, ldb, n0, N, 0, rb);
+  stash(AK{}, sA2[0], ra);
+  stash(BKt{}, sB2[0], rb);
+  __syncthreads();
+  int cur = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();                                      // everybody is done reading the previous tile
-    stash(AK{}, sA, ra);
-    stash(BKt{}, sB, rb);
-    __syncthreads();
-    if (k0 + BK < K) {                                    // the next tile's loads fly while this one is in the matrix cores
+    const bool more = k0 + BK < K;
+    if (more) {                                           // the next tile's loads fly while this one is in the matrix cores
       fetch(AK{}, A, lda, m0, M, k0 + BK, ra);
       fetch(BKt{}, B, ldb, n0, N, k0 + BK, rb);
     }
+    real(*sA)[G2LD] = sA2[cur];
+    real(*sB)[G2LD] = sB2[cur];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      real af[4], bf[4];
+      real af[4], bf[BT];
 #pragma unroll
       for (int a = 0; a < 4; ++a) af[a] = sA[ks + (lane >> 4)][wr * 64 + a * 16 + (lane & 15)];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = sB[ks + (lane >> 4)][wc * 64 + b * 16 + (lane & 15)];
+      for (int b = 0; b < BT; ++b) bf[b] = sB[ks + (lane >> 4)][wc * (16 * BT) + b * 16 + (lane & 15)];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+        for (int b = 0; b < BT; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
     }
+    if (more) {                                           // into the other stage: its readers passed the barrier of the previous tile
+      stash(AK{}, sA2[cur ^ 1], ra);
+      stash(BKt{}, sB2[cur ^ 1], rb);
+    }
+    __syncthreads();
+    cur ^= 1;
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < BT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = m0 + wr * 64 + a * 16 + frag_row<real>(lane, r);
-        const int gj = n0 + wc * 64 + b * 16 + (lane & 15);
+        const int gj = n0 + wc * (16 * BT) + b * 16 + (lane & 15);
         if (gi < M && gj < N) {
           const int64_t e = (int64_t)gi * ldc + gj;
           const real v = alpha * acc[a][b][r];
@@ -244,7 +256,7 @@ static int gemm128_min_blocks() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("WISKI_GEMM128_MIN_BLOCKS");    // 0 disables the large-tile kernel (A/B hook for tools/bench_dense.py)
-    v = e ? atoi(e) : 128;
+    v = e ? atoi(e) : 32;
   }
   return v;
 }
@@ -324,12 +336,23 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
     const int minb = gemm128_min_blocks();
     // (K >= 256: the rank-64 trailing updates of wiski_potrf / wiski_trsm are 4 K tiles of fp64 -- prologue-bound here, faster on the
     // small kernel; fp64 needs twice the grid before the large tile wins: 24 vs 27 TF at n = 1536, 42 vs 39 at 2048)
-    if (minb > 0 && nb >= (sizeof(real) == 8 ? 2 * minb : minb) && K >= 256) {
+    // (round 3, 8-wave form: fp32 wins from 32 blocks -- 24 vs 21 TF at n = 1024 --, fp64 from 128 -- 31 vs 27 TF at n = 1536, but 14 vs 18 at 1024)
+    if (minb > 0 && nb >= (sizeof(real) == 8 ? 4 * minb : minb) && K >= 256) {
       dim3 g2((unsigned)((N + G2N - 1) / G2N), (unsigned)((M + G2M - 1) / G2M));
-      if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      else hipLaunchKernelGGL((k_gemm128<real, true, true>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      // 8 waves per 128 x 128 tile (64 x 32 per wave) beat 4 at every size measured: twice the waves per CU hide the LDS and
+      // barrier latency of the K loop (fp32 n = 2048: 89 -> 100 TF, fp64 n = 4096: 45 -> 61 TF); the 4-wave form stays as an A/B hook
+      static const int nw8_max = [] { const char* e = getenv("WISKI_GEMM128_NW8_MAX_BLOCKS"); return e ? atoi(e) : (1 << 30); }();
+      if (nb <= nw8_max) {
+        if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+        else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+        else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+        else hipLaunchKernelGGL((k_gemm128<real, true, true, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+        return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+      }
+      if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+      else hipLaunchKernelGGL((k_gemm128<real, true, true, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
       return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
     }
   }
