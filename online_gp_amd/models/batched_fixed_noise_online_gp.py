@@ -426,6 +426,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         st = self._memo.setdefault("precond", {}).get(o)
         wsum = float(self._wsum[o])
         stale = st is None or st["ver"] != ver
+        if stale and st is not None and st.get("tcol") is not None and settings.precond_hyper_drift.value() > 0 and st["tcol"].shape == tcol.shape:
+            # new hyper-parameters, but close to the ones the eigenbasis was solved for: keep it (still SPD, still close to the inverse)
+            drift = float((tcol - st["tcol"]).abs().max() / st["tcol"].abs().max())
+            if drift <= settings.precond_hyper_drift.value():
+                st["ver"] = ver
+                stale = False
         its = (getattr(self, "_last_iters", None) or [0] * (o + 1))[o]
         if not stale:
             if st.get("it0") is None and its > 0:
@@ -452,7 +458,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 st["it0"] = None
             else:
                 eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles)
-                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles, "it0": None}
+                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles, "it0": None, "tcol": tcol.detach().clone()}
                 self._memo["precond"][o] = st
         return st["eig"], wsum / st["norm"]
 
