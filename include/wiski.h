@@ -389,7 +389,9 @@ int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const double* d_
  * zeta = t / sq, logdet = 2 sum log diag d_chol. */
 int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, const double* d_href, const double* d_sq, const double* d_Linv, const double* d_chol, double* d_out, void* stream);
 /* C = I + Lam^1/2 G Lam^1/2, lam = lam_kuu * kscale, sq = sqrt(lam)  (r x r, contiguous): the matrix the spectral factor factorises. */
-int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_lam_kuu, double kscale, double* d_C, double* d_lam, double* d_sq, void* stream);
+int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_lam_kuu, double kscale, double* d_C, double* d_lam, double* d_sq, double* d_sqG, void* stream);   /* d_sqG (may be NULL): Lam^1/2 G */
+/* MLL backward: d_Wt = g_ld (G - P) + g_b zeta zeta^T (r x r), d_gkap = sum_i Wt[i,i] lam_kuu[i]; d_gb, d_gld device scalars.  One launch. */
+int wiski_mll_weights(int32_t r, const double* d_G, const double* d_P, const double* d_zeta, const double* d_lam_kuu, const double* d_gb, const double* d_gld, double* d_Wt, double* d_gkap, void* stream);
 
 /* (e) -- the one collective of the path: in-place RCCL all-reduce(SUM), grouped into one launch, of the
  * statistics that are sums over data points: the half-stencil delta of W^T D^-1 W (n_half reals), W^T D^-1 y (n_b), the

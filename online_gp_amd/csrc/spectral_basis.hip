@@ -451,12 +451,13 @@ __global__ __launch_bounds__(256) void k_basis_change(int d, const int* __restri
 // C = I + Lam^1/2 G Lam^1/2 with lam = lam_kuu * kscale (also written out, with its square root): the matrix the spectral
 // Woodbury factor factorises, in one launch.
 __global__ __launch_bounds__(256) void k_woodbury_c(int r, const double* __restrict__ G, const double* __restrict__ lam_kuu, double kscale,
-                                                    double* __restrict__ C, double* __restrict__ lam, double* __restrict__ sq) {
+                                                    double* __restrict__ C, double* __restrict__ lam, double* __restrict__ sq, double* __restrict__ sqG) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)r * r) return;
   const int i = (int)(e / r), j = (int)(e % r);
   const double li = lam_kuu[i] * kscale, lj = lam_kuu[j] * kscale;
   C[e] = sqrt(li) * G[e] * sqrt(lj) + (i == j ? 1.0 : 0.0);
+  if (sqG) sqG[e] = sqrt(li) * G[e];                 // Lam^1/2 G: the MLL backward's right-hand side (chol^-1 Lam^1/2 G)
   if (j == 0) { lam[i] = li; sq[i] = sqrt(li); }
 }
 
@@ -472,10 +473,42 @@ extern "C" int wiski_basis_change(int32_t d, const int32_t* d_g, int32_t kref, i
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
-extern "C" int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_lam_kuu, double kscale, double* d_C, double* d_lam, double* d_sq, void* stream) {
+// MLL backward, weights of the reduced-basis gradient in one launch:  Wt = g_ld (G - P) + g_b zeta zeta^T  (P = Y2^T Y2 from the GEMM),
+// g_kap = sum_i Wt[i, i] lam_kuu[i]  (block 0).  g_b, g_ld: device scalars (the incoming gradients are never read by the host).
+__global__ __launch_bounds__(256) void k_mll_weights(int r, const double* __restrict__ G, const double* __restrict__ P, const double* __restrict__ zeta,
+                                                     const double* __restrict__ lam_kuu, const double* __restrict__ g_b, const double* __restrict__ g_ld,
+                                                     double* __restrict__ Wt, double* __restrict__ g_kap) {
+  __shared__ double s_red[16];
+  const double gb = g_b[0], gl = g_ld[0];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)r * r; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / r), j = (int)(e % r);
+    Wt[e] = gl * (G[e] - P[e]) + gb * zeta[i] * zeta[j];
+  }
+  if (blockIdx.x == 0) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < r; i += 256) {
+      const int64_t e = (int64_t)i * r + i;
+      acc += (gl * (G[e] - P[e]) + gb * zeta[i] * zeta[i]) * lam_kuu[i];
+    }
+    acc = block_reduce_sum(acc, s_red);
+    if (threadIdx.x == 0) g_kap[0] = acc;
+  }
+}
+
+extern "C" int wiski_mll_weights(int32_t r, const double* d_G, const double* d_P, const double* d_zeta, const double* d_lam_kuu, const double* d_gb,
+                                 const double* d_gld, double* d_Wt, double* d_gkap, void* stream) {
+  if (r < 1 || !d_G || !d_P || !d_zeta || !d_lam_kuu || !d_gb || !d_gld || !d_Wt || !d_gkap) return WISKI_E_BADARG;
+  int64_t nb = ((int64_t)r * r + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_mll_weights, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (int)r, d_G, d_P, d_zeta, d_lam_kuu, d_gb, d_gld, d_Wt, d_gkap);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+extern "C" int wiski_woodbury_c(int32_t r, const double* d_G, const double* d_lam_kuu, double kscale, double* d_C, double* d_lam, double* d_sq, double* d_sqG,
+                                void* stream) {
   if (r < 1 || !d_G || !d_lam_kuu || !d_C || !d_lam || !d_sq) return WISKI_E_BADARG;
   const int64_t tot = (int64_t)r * r;
-  hipLaunchKernelGGL(k_woodbury_c, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)r, d_G, d_lam_kuu, kscale, d_C, d_lam, d_sq);
+  hipLaunchKernelGGL(k_woodbury_c, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)r, d_G, d_lam_kuu, kscale, d_C, d_lam, d_sq, d_sqG);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 

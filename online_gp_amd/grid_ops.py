@@ -751,15 +751,27 @@ def factor_tail(TS, h_ref, sq, Linv, chol):
 
 
 def woodbury_c(G, lam_kuu, kscale):
-    """``wiski_woodbury_c``: (C = I + Lam^1/2 G Lam^1/2, lam = lam_kuu * kscale, sqrt(lam)) in one launch."""
+    """``wiski_woodbury_c``: (C = I + Lam^1/2 G Lam^1/2, lam = lam_kuu * kscale, sqrt(lam), Lam^1/2 G) in one launch."""
     r = G.shape[0]
     C = torch.empty_like(G)
+    sqG = torch.empty_like(G)
     lam = torch.empty(r, dtype=torch.float64, device=G.device)
     sq = torch.empty(r, dtype=torch.float64, device=G.device)
     rc = _hip.lib().wiski_woodbury_c(ctypes.c_int32(r), _hip.dptr(G), _hip.dptr(lam_kuu), ctypes.c_double(float(kscale)), _hip.dptr(C), _hip.dptr(lam),
-                                     _hip.dptr(sq), _hip.stream_ptr(G.device))
+                                     _hip.dptr(sq), _hip.dptr(sqG), _hip.stream_ptr(G.device))
     _hip.check(rc, "wiski_woodbury_c")
-    return C, lam, sq
+    return C, lam, sq, sqG
+
+
+def mll_weights(G, P, zeta, lam_kuu, g_b, g_ld):
+    """``wiski_mll_weights``: (Wt = g_ld (G - P) + g_b zeta zeta^T, g_kap = sum_i Wt_ii lam_kuu_i); g_b, g_ld fp64 device scalars."""
+    r = G.shape[0]
+    Wt = torch.empty_like(G)
+    g_kap = torch.empty((), dtype=torch.float64, device=G.device)
+    rc = _hip.lib().wiski_mll_weights(ctypes.c_int32(r), _hip.dptr(G), _hip.dptr(P), _hip.dptr(zeta), _hip.dptr(lam_kuu), _hip.dptr(g_b), _hip.dptr(g_ld),
+                                      _hip.dptr(Wt), _hip.dptr(g_kap), _hip.stream_ptr(G.device))
+    _hip.check(rc, "wiski_mll_weights")
+    return Wt, g_kap
 
 
 def basis_lag_grad(g_dev, Vtab, kw, D, scale):

@@ -273,13 +273,13 @@ class SpectralWoodburyFactor:
                 return {"need_reference": True, "basis": basis, "tail": tail}
         GT = grid_ops.gemm(self.G_ref, TS)                                    # [r_ref, r]
         G = grid_ops.gemm(TS, GT, ta=True)                                    # T^T G_ref T
-        C, lam, sq = grid_ops.woodbury_c(G, basis.lam_kuu, kscale)            # I + Lam^1/2 G Lam^1/2
+        C, lam, sq, sqG = grid_ops.woodbury_c(G, basis.lam_kuu, kscale)       # I + Lam^1/2 G Lam^1/2 (and Lam^1/2 G for the MLL backward)
         # C = I + PSD: cannot fail on finite input.  With the factor its explicit inverse (r^3 / 3 flop more): every later solve
         # against it -- mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64
         # launches.  Two launches in all for r <= 480 (dense_small.h).
         Linv, info = grid_ops.potrf_inverse_(C)
         cur = {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": TS, "lam": lam, "sq": sq, "G": G,
-               "chol": C, "Linv": Linv, "info": info, "tail": tail}
+               "chol": C, "Linv": Linv, "info": info, "tail": tail, "sqG": sqG}
         # hr = T^T h_ref, c = chol^-1 Lam^1/2 hr, b^T M b = |c|^2, t = chol^-T c, the mean coefficients and logdet (wiski_factor_tail)
         hr, ch, t, coef, zeta, bMb, logdet = grid_ops.factor_tail(TS, self.h_ref, sq, Linv, C)
         cur.update(hr=hr, c_half=ch, t=t, coef=coef, zeta=zeta, bMb=bMb, logdet=logdet)
@@ -390,19 +390,20 @@ class SpectralWoodburyFactor:
             kap = st["kscale"]                   # (a device scalar is handed in when the call is recorded into a captured graph)
         _, zeta = self.coefficients(st)
         # (the incoming gradients stay on the device: reading them would stall the host behind everything queued so far)
-        Y2 = grid_ops.gemm(st["Linv"], (sq[:, None] * G).contiguous())           # chol^-1 Lam^1/2 G
-        SB = G - grid_ops.gemm(Y2, Y2, ta=True)
+        sqG = st.get("sqG")
+        Y2 = grid_ops.gemm(st["Linv"], sqG if sqG is not None else (sq[:, None] * G).contiguous())   # chol^-1 Lam^1/2 G
+        P = grid_ops.gemm(Y2, Y2, ta=True)                                        # G M_r G
         if not torch.is_tensor(g_bMb):
             g_bMb = torch.tensor(float(g_bMb), dtype=torch.float64, device=self.device)
         if not torch.is_tensor(g_logdet):
             g_logdet = torch.tensor(float(g_logdet), dtype=torch.float64, device=self.device)
-        Wt = torch.addcmul(g_logdet.double() * SB, zeta[:, None] * g_bMb.double(), zeta[None, :]).contiguous()
+        # Wt = g_logdet S_B + g_bMb zeta zeta^T and its trace against lam in one launch (wiski_mll_weights)
+        Wt, g_kap = grid_ops.mll_weights(G, P, zeta.contiguous(), basis.lam_kuu, g_bMb.double().contiguous(), g_logdet.double().contiguous())
         D = grid_ops.basis_pair_reduce(Wt, basis.S, basis.ev_tab, basis.kmax)
         gs = self.grid.g
         if max(gs) <= 64:
             # the d congruences V_q D_q V_q^T and their lag sums in one launch
             g_tcol = grid_ops.basis_lag_grad(self._grid_dev()[0], basis.Vtab, basis.kmax, D, kap)
-            g_kap = (Wt.diagonal() * basis.lam_kuu).sum()
             return g_tcol, g_kap
         else:
             g_tcol = torch.zeros(sum(gs), dtype=torch.float64, device=self.device)
@@ -411,7 +412,6 @@ class SpectralWoodburyFactor:
                 H = basis.Vq[q] @ D[q, :basis.kmax, :basis.kmax] @ basis.Vq[q].t()                 # [g_q, g_q]
                 g_tcol[off:off + gq] = torch.mv(self._lag_matrix(gq), H.reshape(-1))               # sums along the lag diagonals
                 off += gq
-        g_kap = (Wt.diagonal() * basis.lam_kuu).sum()
         return g_tcol * kap, g_kap
 
     def _lag_matrix(self, g):

@@ -103,6 +103,7 @@ class GraphedHyperStep:
             fac.coefficients(st)
             buf["G"].copy_(st["G"])
             buf["Linv"].copy_(st["Linv"])
+            buf["sqG"].copy_(st["sqG"])
             torch.cat([st["sq"], st["zeta"], basis.lam_kuu, basis.ev_tab.reshape(-1), basis.Vtab, st["bMb"].reshape(1), st["logdet"].reshape(1)],
                       out=buf["packed"])
         self.n_pin[0] = float(self.w.gp.num_data)
@@ -118,10 +119,11 @@ class GraphedHyperStep:
             basis = st["basis"]
             r = basis.r
             sizes = [r, r, r, basis.ev_tab.numel(), basis.Vtab.numel(), 1, 1]
-            buf = {"G": torch.empty((r, r), **f64), "Linv": torch.empty((r, r), **f64), "packed": torch.empty(sum(sizes), **f64)}
+            buf = {"G": torch.empty((r, r), **f64), "Linv": torch.empty((r, r), **f64), "sqG": torch.empty((r, r), **f64),
+                   "packed": torch.empty(sum(sizes), **f64)}
             v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = torch.split(buf["packed"], sizes)
             sbasis = SpectralBasis.on_device(basis, v_V, v_ev.view(basis.ev_tab.shape), None, lam=v_lam)
-            static.append((fac, {"basis": sbasis, "G": buf["G"], "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": buf["Linv"], "bMb": v_bMb.reshape(()),
+            static.append((fac, {"basis": sbasis, "G": buf["G"], "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": buf["Linv"], "sqG": buf["sqG"], "bMb": v_bMb.reshape(()),
                                  "logdet": v_logdet, "kscale": None}, None))
             self.bufs.append(buf)
             fac._grid_dev()                           # (an upload: must exist before the capture)

@@ -460,8 +460,15 @@ def test_factor_glue_kernels_against_their_torch_forms():
         G = R @ R.t() / r
         lam_kuu = torch.rand(r, **f64) + 0.1
         kscale = 1.7
-        C, lam, sq = grid_ops.woodbury_c(G, lam_kuu, kscale)
+        C, lam, sq, sqG = grid_ops.woodbury_c(G, lam_kuu, kscale)
         lam_t = lam_kuu * kscale
+        assert torch.allclose(sqG, lam_t.sqrt()[:, None] * G, rtol=1e-14, atol=0)
+        P = torch.randn(r, r, **f64); zeta = torch.randn(r, **f64)
+        gb, gl = torch.tensor(0.37, **f64), torch.tensor(-0.5, **f64)
+        Wt, g_kap = grid_ops.mll_weights(G, P, zeta, lam_kuu, gb, gl)
+        Wt_t = gl * (G - P) + gb * torch.outer(zeta, zeta)
+        assert (Wt - Wt_t).abs().max().item() < 1e-13 * Wt_t.abs().max().item()
+        assert abs(float(g_kap) - float((Wt_t.diagonal() * lam_kuu).sum())) < 1e-11 * float((Wt_t.diagonal().abs() * lam_kuu).sum())
         assert torch.allclose(lam, lam_t, rtol=1e-14) and torch.allclose(sq, lam_t.sqrt(), rtol=1e-14)
         C_t = lam_t.sqrt()[:, None] * G * lam_t.sqrt()[None, :] + torch.eye(r, **f64)
         assert (C - C_t).abs().max().item() < 1e-12 * C_t.abs().max().item()
