@@ -204,15 +204,6 @@ class precond_profile_drift(_value_context):
     _global_value = 0.2
 
 
-class precond_hyper_drift(_value_context):
-    """Largest relative change (max-norm) of the kernel's Toeplitz columns the CG preconditioner tolerates before its generalized
-    eigenbasis is recomputed for new hyper-parameters.  A preconditioner built for slightly different hyper-parameters is still a
-    symmetric positive definite operator close to the inverse: the solve converges to the same solution, the host eigen-decompositions
-    (~0.6 ms on three 50-node axes) are paid once per ~30 optimiser steps of 1e-3 instead of every step.  0: re-solve on every change."""
-
-    _global_value = 0.03
-
-
 class density_profile_preconditioner(_feature_flag):
     """Model W^T D^-1 W in the CG preconditioner as a kron_q diag(t_q) with t_q the per-dim
     data-density profile (instead of a I): the inducing nodes outside the data box carry no
