@@ -681,6 +681,12 @@ def main():
         # algorithmic bytes of one k=1 stencil SpMV launch: the symmetric half stencil A_h once
         # (the model's native storage; every entry serves A[i,j] and A[j,i]) + v in + out (+ add)
         spmv_bytes = (grid.R + 1) // 2 * grid.m * es + 3 * grid.m * es
+        if world > 1 and exchange_used == "stencil":
+            # stencil-sharded step: this rank's launch streams only ITS groups of the half stencil (+ the vectors)
+            from online_gp_amd.grid_ops import half_stencil_group_slices, shard_groups
+
+            g_lo, g_hi = shard_groups(d, 0, world)
+            spmv_bytes = sum(b - a for a, b in half_stencil_group_slices(grid, g_lo, g_hi)) * es + 3 * grid.m * es
         avg_ms = spmv_ms / max(spmv_n, 1)
         achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
         dma = dtype == torch.float32 and d == 3 and grid.m % 4 == 0 and os.environ.get("WISKI_SYM_DMA", "1") != "0"
