@@ -1,4 +1,4 @@
-// Cholesky factorisation and triangular inverse of SMALL matrices (n <= 480) in one launch each.
+// Cholesky factorisation (n <= 512) and triangular inverse (n <= 480) of SMALL matrices in one launch each.
 // Included by dense.hip (uses its MFMA helpers mfma16 / Acc4 / frag_row).
 //
 // The spectral Woodbury factor (lazy/spectral_woodbury.py) refactorises an r x r fp64 matrix, r ~ 300-500, after every
@@ -19,7 +19,8 @@
 constexpr int SNB = 32;        // panel width
 constexpr int SLD = 34;        // LDS row stride (reals)
 constexpr int SLDX = 33;       // row stride of the inverse's block column in k_tri_inv_small4
-constexpr int SMALL_N_MAX = 480;
+constexpr int SMALL_N_MAX = 480;        // factor + explicit inverse in two launches
+constexpr int SMALL_N_MAX_POTRF = 512;  // the factorisation alone still fits its panel in LDS (157.7 KB in fp64)
 constexpr size_t SMALL_LDS_MAX = 160 * 1024;   // LDS of a CU
 constexpr int SWG = 512;       // threads of the factorisation workgroup (8 waves: 256 registers each -- the one-wave diagonal step wants them)
 constexpr int SNW = SWG / 64;
@@ -470,7 +471,7 @@ template <typename real>
 static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int ldx, int32_t* d_info, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX)) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX_POTRF)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_tri_inv_small4<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX) != hipSuccess) {
       (void)hipGetLastError();

@@ -78,10 +78,11 @@ def test_cholesky_trsm_logdet(dtype, tol, n):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
-@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 65, 100, 327, 449, 480, 481, 700])
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 65, 100, 327, 449, 480, 481, 500, 512, 513, 700])
 def test_cholesky_with_explicit_inverse(dtype, tol, n):
     """wiski_potrf_inverse: factor in place + X = L^-1.  n <= 480 is the one-workgroup path (dense_small.h: every panel
-    boundary case -- partial last block, exactly full blocks, one block), beyond it the blocked path + a triangular solve."""
+    boundary case -- partial last block, exactly full blocks, one block); up to 512 the factor still is, with a blocked triangular solve for
+    the inverse; beyond that the blocked factorisation."""
     from online_gp_amd import grid_ops
 
     g = torch.Generator(device="cpu").manual_seed(1000 + n)
