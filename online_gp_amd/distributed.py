@@ -164,6 +164,27 @@ class ShardedStatsUpdater:
         stencil_bytes = 2 * ((grid.R + 1) // 2) * grid.m * m.num_outputs * (4 if m._dtype == torch.float32 else 8)
         return atomics < stencil_bytes
 
+    def _gather_rows(self, packed, world):
+        """All-gather the rows of ``packed`` [q_r, c] over the ranks -> (all rows in rank order, offset of this rank's rows).
+        With ``equal_shards=True`` one collective; otherwise the shard lengths travel first (one tiny all-gather + host read)
+        and shorter shards are padded to the longest for the collective, the padding dropped afterwards."""
+        rank = dist.get_rank(self.group)
+        q = packed.shape[0]
+        if self.equal_shards:
+            parts = [torch.empty_like(packed) for _ in range(world)]
+            dist.all_gather(parts, packed, group=self.group)
+            return torch.cat(parts, dim=0), rank * q
+        mine = torch.tensor([q], dtype=torch.int64, device=packed.device)
+        lens = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(lens, mine, group=self.group)
+        lens = [int(t.item()) for t in lens]
+        qmax = max(lens)
+        if qmax != q:
+            packed = torch.cat([packed, packed.new_zeros(qmax - q, packed.shape[1])], dim=0)
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(parts, packed, group=self.group)
+        return torch.cat([p_[:n_] for p_, n_ in zip(parts, lens)], dim=0), sum(lens[:rank])
+
     def _update_points(self, X, Y, noise, world):
         m = self.model
         dev = m._device
@@ -171,9 +192,7 @@ class ShardedStatsUpdater:
         X2 = X.reshape(-1, d).to(dev, m._dtype)
         cols = [X2, Y.to(dev, m._dtype)] + ([noise.to(dev, m._dtype)] if noise is not None else [])
         packed = torch.cat(cols, dim=1).contiguous()
-        parts = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(parts, packed, group=self.group)
-        allp = torch.cat(parts, dim=0)
+        allp, _ = self._gather_rows(packed, world)
         out = Y.shape[1]
         Xa, Ya = allp[:, :d].contiguous(), allp[:, d:d + out].contiguous()
         Na = allp[:, d + out:].contiguous() if noise is not None else None
@@ -193,16 +212,18 @@ class ShardedStatsUpdater:
             Y = Y[:, None]
         d = m._grid.d
         q = X.reshape(-1, d).shape[0]
-        stencil = self.exchange == "stencil" and self.comm is None and self._enter_stencil_shard(world)
-        if stencil or (self.comm is None and m.num_outputs == 1 and (self.exchange == "stencil" or self._use_points(q, world, m._device))):
+        # the gathered routes ("points" / "stencil") take shards of any length: unless equal shards were promised the lengths are
+        # exchanged first and the gather is padded (a hard-wired torch.empty_like(packed) receive buffer hangs or corrupts the
+        # collective when the ranks disagree); the cost-model route keeps its own decision
+        gathered = self.comm is None and m.num_outputs == 1 and (
+            self.exchange in ("stencil", "points") or self._use_points(q, world, m._device))
+        stencil = gathered and self.exchange == "stencil" and self._enter_stencil_shard(world)
+        if gathered:
             self.last_exchange = "stencil" if stencil else "points"
             packed = torch.cat([X.reshape(-1, d).to(m._device, m._dtype), Y.to(m._device, m._dtype)], dim=1).contiguous()
-            parts = [torch.empty_like(packed) for _ in range(world)]
-            dist.all_gather(parts, packed, group=self.group)
-            allp = torch.cat(parts, dim=0)
+            allp, lo = self._gather_rows(packed, world)
             mean = m.stream_step(allp[:, :d].contiguous(), allp[:, d:d + 1].contiguous(), want_mean)
-            r = dist.get_rank(self.group)
-            return mean.reshape(-1)[r * q:(r + 1) * q] if mean is not None else None
+            return mean.reshape(-1)[lo:lo + q] if mean is not None else None
         from . import settings
 
         m._finish_pending()

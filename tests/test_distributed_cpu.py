@@ -82,6 +82,22 @@ class StubModel:
     def _dump_caches(self):
         self.dumped += 1
 
+    # the one-call step of the gathered routes: absorb + "mean" = first coordinate, so a rank's slice can be recognised
+    def stream_step(self, X, Y, want_mean=True):
+        self.condition_on_observations(X, Y, torch.ones_like(Y))
+        self.last_batch = X.clone()
+        return X[:, 0].clone() if want_mean else None
+
+    def enter_stencil_shard(self, rank, world, allreduce, comm=None):
+        self._stencil_shard = (rank, world)
+        return True
+
+
+def ref1_stencil(gb, g, X, Y):
+    one = StubModel(gb, g)
+    one.condition_on_observations(X, Y, torch.ones_like(Y))
+    return one._kernel_cache["WtW"].stencil
+
 
 def _worker(rank, world, port, tmpdir):
     sys.path.insert(0, ROOT)
@@ -154,6 +170,20 @@ def _worker(rank, world, port, tmpdir):
     one.condition_on_observations(X[0], Y[0], N[0])
     ok = ok and upd.last_exchange == "stats" and torch.allclose(model._kernel_cache["WtW"].stencil, one._kernel_cache["WtW"].stencil, atol=1e-12) \
         and model.num_data == 40 and cut > 0
+    # stream_step on the gathered routes with UNEQUAL shards (15 / 25 points): lengths travel first, the gather is padded, every
+    # rank steps on all 40 points in rank order and gets back the means of its own rows (used to hang / mis-slice)
+    for mode in ("points", "stencil"):
+        model = StubModel(gb, g)
+        upd = ShardedStatsUpdater(model, exchange=mode)
+        mean = upd.stream_step(X[0, sl], Y[0, sl])
+        ok = ok and upd.last_exchange == mode and model.num_data == 40 and torch.equal(model.last_batch, X[0]) \
+            and torch.equal(mean, X[0, sl, 0]) and torch.allclose(model._kernel_cache["WtW"].stencil, ref1_stencil(gb, g, X[0], Y[0]), atol=1e-12)
+        # equal shards promised: one collective, same slices
+        model = StubModel(gb, g)
+        upd = ShardedStatsUpdater(model, exchange=mode, equal_shards=True)
+        sl2 = slice(rank * 20, (rank + 1) * 20)
+        mean = upd.stream_step(X[1, sl2], Y[1, sl2])
+        ok = ok and torch.equal(model.last_batch, X[1]) and torch.equal(mean, X[1, sl2, 0])
     open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
