@@ -1876,7 +1876,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   // atomically accumulated transposed term: zero here, re-zeroed by every consumer (zl)
   int zl = 0;
   const int nch = wide ? (sym ? sym_partials<real>(G, k, &zl) : spmv_nch(G.d)) : 0;
-  const bool sharded = shard && shard->nranks > 1;
+  const bool sharded = wiski_shard_active(shard);
   SymDmaParts stab{};
   if (sharded) {
     if (!sym || !wide || G.d != 3 || k != 1 || sizeof(real) != 4 || shard->rank < 0 || shard->rank >= shard->nranks) return WISKI_E_BADARG;

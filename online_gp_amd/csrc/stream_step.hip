@@ -28,7 +28,7 @@ static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f32* a, co
   int64_t n1 = 0, n2 = 0;
   if (zero)
     if (int rc = wiski_pcg_zero_regions_f32(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
-  if (a->shard && a->shard->nranks > 1) {
+  if (wiski_shard_active(a->shard)) {
     int32_t glo = 0, ghi = 0;
     if (int rc = wiski_shard_groups(g->d, a->shard->rank, a->shard->nranks, &glo, &ghi)) return rc;
     return wiski_scatter_stats_step_sharded_f32(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, glo, ghi, s);
@@ -40,7 +40,7 @@ static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f64* a, co
   int64_t n1 = 0, n2 = 0;
   if (zero)
     if (int rc = wiski_pcg_zero_regions_f64(g, 1, a->max_iter, a->d_work, 1, &p1, &n1, &p2, &n2)) return rc;
-  if (a->shard && a->shard->nranks > 1) {
+  if (wiski_shard_active(a->shard)) {
     int32_t glo = 0, ghi = 0;
     if (int rc = wiski_shard_groups(g->d, a->shard->rank, a->shard->nranks, &glo, &ghi)) return rc;
     return wiski_scatter_stats_step_sharded_f64(g, x, y, wa, wb, nz, n, a->d_b, a->d_A_half, a->d_cnt, a->d_U, carry ? a->d_R : nullptr, mean_out, a->d_stats, a->d_err, p1, n1, p2, n2, guard, expect, glo, ghi, s);
@@ -64,7 +64,7 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
                             double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* as, int32_t defer, int32_t* h_resumed) {
   if (!grid || !a || q < 0 || !a->d_A_half || !a->d_b || !a->d_U || !a->d_Z || !a->d_R) return WISKI_E_BADARG;
   if (q > 0 && (!d_x || !d_y || !d_wa || !d_wb || !d_noise)) return WISKI_E_BADARG;
-  if (a->shard && a->shard->nranks > 1 && q > 0 && !d_mean_out) return WISKI_E_BADARG;   // the sharded absorb is the mean-emitting kernel
+  if (wiski_shard_active(a->shard) && q > 0 && !d_mean_out) return WISKI_E_BADARG;   // the sharded absorb is the mean-emitting kernel
   int rc = WISKI_OK;
   if (h_resumed) *h_resumed = 0;
   bool absorbed = false;                     // the speculative absorb below has run

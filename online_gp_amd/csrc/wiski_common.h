@@ -196,6 +196,11 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
 constexpr int PCG_DOT_SLOTS = 16;
 constexpr int PCG_DOT_STRIDE = 16;
 constexpr int PCG_DOT_COL = PCG_DOT_SLOTS * PCG_DOT_STRIDE;   // doubles per column in one ring entry
+// A replica is stencil-sharded when it shares the half stencil with other ranks -- or when it is the only rank of a real
+// communicator (it then owns every group and its all-reduces are identities: the in-C RCCL branch of the sharded solve can be
+// exercised on one device, tests/test_distributed_gpu.py).
+static inline bool wiski_shard_active(const wiski_shard* s) { return s && (s->nranks > 1 || (s->nranks == 1 && s->comm)); }
+
 struct PcgScal {
   double* base;
   int k;

@@ -256,16 +256,19 @@ class ShardedStatsUpdater:
             if dots is not None:
                 dist.all_reduce(dots, op=dist.ReduceOp.SUM, group=group)
 
-        # WISKI_SHARD_TRANSPORT=rccl: the all-reduce of a product is issued from C (wiski_allreduce_stats on an ncclComm_t of
-        # our own: vector + p.Ap slots in ONE grouped launch on the solve's stream, no re-entry into Python).  Default: the
-        # callback above through torch.distributed's communicator (the path the two-rank test exercises).
+        # Transport of the per-product all-reduce.  On the nccl (= RCCL) backend the default is the C route: wiski_allreduce_stats
+        # on an ncclComm_t of our own -- vector + p.Ap slots in ONE grouped launch on the solve's stream, no re-entry into Python
+        # per CG iteration.  WISKI_SHARD_TRANSPORT=torch forces the callback above through torch.distributed's communicator
+        # (the only route on gloo: the path the two-rank single-GPU test exercises); =rccl forces the C route.
         comm = None
         import os
 
-        if os.environ.get("WISKI_SHARD_TRANSPORT") == "rccl" and not gloo_cuda:
+        want = os.environ.get("WISKI_SHARD_TRANSPORT", "rccl" if dist.get_backend(group) == "nccl" else "torch")
+        if want == "rccl" and not gloo_cuda:
             if getattr(self, "_shard_comm", None) is None:
                 self._shard_comm = RcclCommunicator(group)
             comm = self._shard_comm.handle
+        self.shard_transport = "rccl" if comm is not None else "torch"
         return m.enter_stencil_shard(dist.get_rank(group), world, allreduce, comm=comm)
 
     def _delta_cache(self):

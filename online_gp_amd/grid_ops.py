@@ -384,7 +384,7 @@ class StreamStep:
         """Stencil-sharded step (wiski_shard): this replica owns the groups shard_groups(d, rank, nranks) of the half stencil.
         comm: an ncclComm_t handle (int) for the RCCL route; allreduce(vec, dots): a Python callable that all-reduces (SUM, in
         place) the two torch views it is given -- the views alias the solver's workspace."""
-        if nranks <= 1:
+        if nranks < 1 or (nranks == 1 and not comm):   # (a single rank WITH a communicator runs the sharded path: it owns every group)
             self.args.shard = None
             self._shard = None
             return

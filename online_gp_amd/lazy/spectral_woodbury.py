@@ -43,6 +43,7 @@ from .. import grid_ops, settings
 KMAX = 32
 GUARD = 6          # extra eigenvectors per dim carried for the device-side subspace iteration
 RESELECT_EVERY = 64
+MEAN_CHECK_EVERY = 8   # factor states between two evaluations of the mean-truncation bound
 
 
 def default_tail(dtype):
@@ -191,6 +192,49 @@ class SpectralWoodburyFactor:
         self._dev_refreshes = 0
         self.device_refreshes = 0  # diagnostics / tests
         self.last_verdict = None
+        # monitor of the truncated MEAN (the variance has its own per-query bound): see mean_bound()
+        self.mean_ok = True
+        self.last_mean_bound = None
+        self._mean_chk = None
+        self._mean_countdown = 0
+
+    # ---------------------------------------------------------------------- mean-truncation monitor --
+    def mean_monitor(self, st, query, b, tcol_dev, scale):
+        """Bound on what the truncation does to the predictive MEAN, evaluated every MEAN_CHECK_EVERY-th call and read one call late.
+
+        With Delta = M(Kt) - M(Kt_B), 0 <= Delta <= Kt - Kt_B (module docstring), Cauchy-Schwarz in the PSD form Delta gives for
+        every query   |w^T M b - w^T M_B b| <= sqrt(w^T Delta w  b^T Delta b) <= sqrt(tail(w) * btail),
+            btail = b^T Kt b - sum_j lam_j (b_j^T b)^2       (one Kronecker-Toeplitz product + two dots, fp64),
+        and tail(w) is the left-out prior variance of the query that the variance path adds back anyway.  The variance bound says
+        nothing about the mean: btail grows with the data (b = W^T D^-1 y) while tail(w) does not, so a long stream / small noise can
+        move the factor's mean although its variances stay inside their bound.  ``scale`` = max |mean| of the batch (device
+        scalar).  The ratio bound / scale is copied to pinned memory asynchronously; the NEXT call reads it (long since arrived)
+        and sets ``mean_ok`` -- the model then serves means from its PCG state until a later check passes again."""
+        lim = settings.spectral_mean_tolerance.value()
+        if lim is None:
+            lim = 1e-3 if self.dtype == torch.float32 else 1e-5
+        if self._mean_chk is not None:
+            host, ev = self._mean_chk
+            ev.synchronize()
+            self.last_mean_bound = float(host[0])
+            self.mean_ok = self.last_mean_bound <= lim
+            self._mean_chk = None
+        self._mean_countdown -= 1
+        if self._mean_countdown > 0:
+            return
+        self._mean_countdown = MEAN_CHECK_EVERY
+        b64 = b.reshape(-1).double()
+        Kb = grid_ops.kron_toeplitz_mm(self.grid, tcol_dev.double() if tcol_dev.dtype != torch.float64 else tcol_dev, b64, scale=float(st["kscale"]))
+        btail = (torch.dot(b64, Kb) - torch.dot(st["lam"], st["hr"] * st["hr"])).clamp_min(0.0)
+        tailw = (query.prior * float(st["kscale"]) - (query.Fs * query.Fs).sum(1)).clamp_min(0.0).max()
+        ratio = (torch.sqrt(tailw * btail) / scale.double().clamp_min(1e-300)).reshape(1)
+        host = self.__dict__.get("_mean_host")
+        if host is None:
+            host = self._mean_host = torch.empty(1, dtype=torch.float64).pin_memory()
+        host.copy_(ratio, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._mean_chk = (host, ev)
 
     # ------------------------------------------------------------------ reference statistics --
     def _project_grid_vectors(self, basis, Vm):

@@ -476,10 +476,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         computes 1 / world of A p, one all-reduce of an m-vector per CG iteration makes the product whole.  Every rank must
         see every point (the caller all-gathers the shards) and must make the same calls.  `allreduce(vec, dots)`: in-place
         SUM over the ranks of the two tensors (dots may be None); `allreduce_full(t)`: the same for one large tensor, used
-        when a consumer needs the whole stencil again (leave_stencil_shard).  Returns False where the sharded step does not
+        when a consumer needs the whole stencil again (leave_stencil_shard).  `comm`: an ncclComm_t (wiski_comm_*) -- the per-product
+        all-reduce is then issued from C on the solve's stream (one grouped RCCL launch, no re-entry into Python); a single rank
+        with a communicator owns every group and still takes that path.  Returns False where the sharded step does not
         apply (then nothing changes): d = 3, fp32, one output, native half stencil only."""
         op = _wtw_ops(self._kernel_cache["WtW"])[0]
-        if (world <= 1 or self.num_outputs != 1 or self._grid.d != 3 or self._dtype != torch.float32 or self._use_dense() or not op.is_half
+        if ((world <= 1 and not comm) or self.num_outputs != 1 or self._grid.d != 3 or self._dtype != torch.float32 or self._use_dense() or not op.is_half
                 or self._grid.m % 4 or op.root is not None):
             return False
         if self.__dict__.get("_stencil_shard") is not None:
@@ -771,23 +773,31 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             block = X.shape[-2]
         Xf = X.reshape(-1, grid.d).contiguous()
         n = Xf.shape[0]
-        # smooth kernel on a large grid, variances wanted: mean AND variance of the batch from the spectral factor (one
-        # projection kernel shared by both; at 50^3 fp32 its mean is within 1-4e-5 of max |mean| of a 1e-7 PCG solve, which is where a PCG
-        # solve at the streaming tolerance 1e-4 lands too: 3e-6 - 2e-5) -- no solve at all
+        # smooth kernel on a large grid, variances wanted: the variance of the batch comes from the spectral factor (no solve at
+        # all, with a per-query truncation bound).  The MEAN comes from the factor too only when the hyper-parameters have moved
+        # since the last solve and a factor is being kept current anyway (a streaming wrapper that takes an MLL step per batch:
+        # the factor's refresh is needed by that step in any case, a PCG mean solve would first re-solve the preconditioner's
+        # eigenproblems) -- and only while the factor's mean monitor is green (sqrt(tail(w) b^T (Kt - Kt_B) b), evaluated every
+        # few states: the variance bound does not control the mean).  In every other case the mean is the warm-started PCG
+        # state's, which carries its own tolerance.
         sq = None
-        # ... and means only, when the hyper-parameters have moved since the last solve and a factor is being kept current anyway
-        # (a streaming wrapper that takes an MLL step per batch, e.g. the classifier's predict -> update loop): the factor's
-        # refresh is needed by that step in any case, a PCG mean solve would first re-solve the preconditioner's eigenproblems
         ms = self._mean_state
         hypers_moved = self._memo.get("prediction_cache") is None and ms is not None and ms.get("ver") != self._hyper_version()
+        factor_mean = False
         if settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use()):
             sps = [self._spectral_state(o) for o in range(out)]
             if all(sp is not None for sp in sps):
                 sq = [sp[0].query(sp[1], Xf, sp[2]) for sp in sps]
-        if sq is not None:
-            pc = None
-            mean = torch.stack([s_.mean() for s_ in sq], dim=1).to(self._dtype)   # [n, out]
-        else:
+                factor_mean = hypers_moved and all(sp[0].mean_ok for sp in sps)
+        pc = None
+        if factor_mean:
+            mean = torch.stack([s_.mean() for s_ in sq], dim=1)                   # [n, out] fp64
+            scale = mean.abs().amax(0)
+            for o, sp in enumerate(sps):
+                sp[0].mean_monitor(sp[1], sq[o], self._kernel_cache["interpolation_cache"][o, :, 0], sp[2], scale[o])
+            factor_mean = all(sp[0].mean_ok for sp in sps)                         # (a verdict read just now may have turned it off)
+            mean = mean.to(self._dtype)
+        if not factor_mean:
             pc = self.prediction_cache
             mean = grid_ops.gather(grid, Xf, pc["pred_mean"][..., 0], self._err)  # [n, out]   left_interp, :206-210
         if settings.deferred_bounds_check.off():

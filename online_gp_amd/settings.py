@@ -229,6 +229,15 @@ class spectral_tail(_value_context):
     _global_value = None
 
 
+class spectral_mean_tolerance(_value_context):
+    """Largest admissible bound on the truncation error of a predictive MEAN taken from the spectral factor, relative to the
+    largest mean of the batch (None: 1e-3 in fp32, 1e-5 in fp64 -- a tenth of the parity bars).  The factor evaluates
+    sqrt(tail(w) * b^T (Kt - Kt_B) b) every few states (``SpectralWoodburyFactor.mean_monitor``); above the limit the model
+    answers means from its PCG state instead."""
+
+    _global_value = None
+
+
 class graphed_hyper_step(_feature_flag):
     """Streaming wrappers (OnlineSKIRegression ...): run the per-batch Adam step on the MLL as one captured HIP graph when the spectral
     factor serves the MLL (models/_graphed_step.py); off: the op-by-op step."""

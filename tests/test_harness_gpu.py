@@ -128,15 +128,24 @@ def test_c5_qnipv_active_learning_on_malaria_geometry():
                                               outputscale_prior=GammaPrior(2.0, 0.15)), grid_size=30, num_dims=2, grid_bounds=gb)
     gen = torch.Generator(device="cpu").manual_seed(1)
     obs = lambda X: f(X) + nvar(X).sqrt() * torch.randn(X.shape[0], generator=gen, dtype=torch.float64).to(X)
-    model = OnlineSKIBotorchModel(x0, obs(x0).reshape(-1, 1), nvar(x0).reshape(-1, 1), covar_module=cov, learn_additional_noise=True)
-    model.eval()
-    ipv0 = float(model.posterior(mc).variance.mean())
     seen = {}
 
     def on_step(step, m):
         seen[step] = m.num_data
 
-    rows, model, chosen = harness.qnipv_active_learning(model, pool, obs, mc, batch_size=6, num_steps=500, num_candidate_sets=16, num_fantasies=3,
+    absorbed = [(x0.cpu().numpy(), None)]          # every (X, y) the loop hands to the model, in order (y of the init set: below)
+
+    def obs_rec(X):
+        yv = obs(X)
+        absorbed.append((X.detach().cpu().numpy().reshape(-1, 2), yv.detach().cpu().numpy().reshape(-1)))
+        return yv
+
+    y0 = obs(x0)
+    absorbed[0] = (absorbed[0][0], y0.cpu().numpy().reshape(-1))
+    model = OnlineSKIBotorchModel(x0, y0.reshape(-1, 1), nvar(x0).reshape(-1, 1), covar_module=cov, learn_additional_noise=True)
+    model.eval()
+    ipv0 = float(model.posterior(mc).variance.mean())
+    rows, model, chosen = harness.qnipv_active_learning(model, pool, obs_rec, mc, batch_size=6, num_steps=500, num_candidate_sets=16, num_fantasies=3,
                                                         noise_fn=nvar, on_step=on_step)
     ipv = [ipv0] + [r["integrated_posterior_variance"] for r in rows]
     assert all(b < a for a, b in zip(ipv, ipv[1:])) and ipv[-1] < 0.8 * ipv0
@@ -148,3 +157,14 @@ def test_c5_qnipv_active_learning_on_malaria_geometry():
     assert torch.isfinite(post.mean).all() and (post.variance > 0).all()
     cache = model._kernel_cache
     assert cache["interpolation_cache"].shape == (1, 900, 1) and model.num_data == 3010          # the reference's full run: batch_size 6 x 500 steps
+    # ... and the conditioned model equals the data-space oracle (exact GP on W Kuu W^T + sigma2 D, n x n Cholesky) on everything it
+    # has absorbed: all 3 010 points with their heteroscedastic noise, mean and variance at 64 held-out points, rtol 1e-4
+    from oracle import dataspace
+
+    Xall = np.concatenate([a for a, _ in absorbed]); yall = np.concatenate([b for _, b in absorbed])
+    assert Xall.shape == (3010, 2) and np.array_equal(Xall[10:], pool.cpu().numpy()[chosen.cpu().numpy().reshape(-1)])
+    nz = nvar(torch.as_tensor(Xall)).numpy()
+    mo, vo = dataspace.DataSpaceGP(gb.numpy(), 30, "matern12", ell, osc, s2).fit(Xall, yall, nz).predict(mc[:64].cpu().numpy())
+    post = model.posterior(mc[:64])
+    assert np.abs(post.mean.reshape(-1).cpu().numpy() - mo).max() < 1e-4 * np.abs(mo).max()
+    assert np.abs(post.variance.reshape(-1).cpu().numpy() - vo).max() < 1e-4 * vo.max()

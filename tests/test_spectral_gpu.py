@@ -442,6 +442,57 @@ def test_hyperparameter_steps_refresh_the_factor_on_the_device():
         assert fac.last_verdict[1] > 1.5 * default_tail_of(dtype) or fac.device_refreshes == before   # caught by the verdict (or never tried)
 
 
+def test_mean_monitor_bounds_the_truncated_mean_and_falls_back_to_pcg():
+    """The factor's variance bound says nothing about its MEAN.  The monitor sqrt(tail(w) b^T (Kt - Kt_B) b) (a) really bounds
+    the deviation of the factor's mean from the exact one, (b) stays green at the default tail, (c) turns the factor's mean off --
+    the model then answers from its PCG state and meets the oracle -- when a coarse basis moves the mean beyond the tolerance."""
+    from online_gp_amd import settings
+    from online_gp_amd.lazy import spectral_woodbury as sw
+
+    rng = np.random.default_rng(33)
+    d, g, n = 3, 14, 900
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + 0.3 * X[:, 2] + 0.05 * rng.standard_normal(n)
+    Xs = rng.uniform(-1, 1, (40, d))
+    dtype = torch.float64
+    Xst = torch.as_tensor(Xs, device=DEV, dtype=dtype)
+
+    def nudge(m, f):
+        k = m.covar_module.base_kernel
+        with torch.no_grad():
+            k.base_kernel.lengthscale = k.base_kernel.lengthscale * f
+        m._dump_caches()
+
+    old_every = sw.MEAN_CHECK_EVERY
+    sw.MEAN_CHECK_EVERY = 1
+    try:
+        for tail, expect_ok in ((None, True), (3e-3, False)):
+            with settings.spectral_tail(tail), settings.cg_tolerance(1e-9):
+                m = _model(X, y, g, dtype)
+                m.eval()
+                m(Xst).variance                               # builds the factor; the mean of this call is the PCG state's
+                fac = m._spectral[0]
+                devs, bounds = [], []
+                for step in range(3):
+                    nudge(m, 1.01 if step % 2 == 0 else 1 / 1.01)
+                    served_by_factor = fac.mean_ok
+                    mu = m(Xst).mean.cpu().numpy()
+                    ell, s, s2 = _hypers(m)
+                    mo, _ = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, np.ones(n)).predict(Xs)
+                    dev = np.abs(mu - mo).max() / np.abs(mo).max()
+                    if step > 0 and fac.last_mean_bound is not None and served_by_factor and fac.mean_ok:
+                        devs.append(dev); bounds.append(fac.last_mean_bound)
+                    if not fac.mean_ok:
+                        assert dev < 1e-4, (tail, step, dev)       # PCG mean: the fp64 parity bar
+                assert fac.last_mean_bound is not None
+                assert fac.mean_ok == expect_ok, (tail, fac.last_mean_bound)
+                for dv, bd in zip(devs, bounds):
+                    assert dv <= bd * 1.5 + 1e-9, (tail, dv, bd)   # (a): a bound (the check is one call late: small drift allowed)
+                if expect_ok:
+                    assert max(devs) < 1e-4
+    finally:
+        sw.MEAN_CHECK_EVERY = old_every
+
+
 def default_tail_of(dtype):
     from online_gp_amd.lazy.spectral_woodbury import default_tail
 
