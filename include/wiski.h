@@ -215,6 +215,28 @@ typedef struct wiski_shard {
 } wiski_shard;
 int wiski_shard_groups(int32_t d, int32_t rank, int32_t nranks, int32_t* g_lo, int32_t* g_hi);
 
+/* Two-level preconditioner of the fused fp32 solve (d = 3, one right-hand side).  The separable model
+ * P = (Kt^-1 + a kron_q diag(t_q))^-1 is exact only for a separable data density; on road-like (line-clustered) streams
+ * W^T D^-1 W is far from that and a warm CG step needs 6 iterations instead of 2.5.  In the generalized eigenbasis X of the
+ * separable model (the tables wiski_pcg already transforms with: X^T (kron diag t) X = I, Kt = X^-T D X^-1) the system
+ * matrix is D^-1 + X^T A X; the two-level form keeps the EXACT block N = (D_S^-1 + X_S^T A X_S)^-1 on the r modes of largest
+ * prior eigenvalue D (the directions the data inform) and the diagonal model D / (1 + a D) on all others -- block Jacobi in
+ * spectral coordinates, SPD.  The caller owns N (r x r, fp32) and refreshes it as the stream grows (projection of the new
+ * points on X_S + a GEMM + an r x r Cholesky, off the critical path: a stale block only costs iterations, never accuracy).
+ * The coupling crosses the dim-0 slabs of the fused slab kernel: the blocks that hold selected modes exchange their r
+ * coefficients through d_cs (self-validating 64-bit words stamped with a per-launch number drawn on the host: a launch sequence
+ * that uses a wiski_twolevel must not be captured into a graph and replayed), every block then forms the rows of N c it needs.
+ * Modes are identified by their eigen-indices (i0, x, y) in the order of the eigen tables handed to the solve. */
+typedef struct wiski_twolevel {
+  int32_t r;                 /* modes in the exact block, 1 <= r <= 512 */
+  int32_t nslab;             /* number of dim-0 eigen-indices i0 that hold at least one selected mode */
+  const uint64_t* d_mask;    /* [g0][64]: bit y of d_mask[i0 * 64 + x] set <=> mode (i0, x, y) is selected */
+  const int32_t* d_off;      /* [g0 + 1]: the selected modes of slab i0 are d_off[i0] .. d_off[i0 + 1] - 1 in block order */
+  const uint16_t* d_pos;     /* [r]: x << 8 | y of every selected mode, block order (sorted by i0) */
+  const float* d_N;          /* [r][r] row-major, symmetric positive definite, block order */
+  uint64_t* d_cs;            /* [r] exchange words {application number << 32 | fp32 bits}, zeroed ONCE by the caller */
+} wiski_twolevel;
+
 /* Deferred convergence poll.  wiski_pcg_async_* = wiski_pcg_* plus a host-side handle (zero-initialised by the caller,
  * released with wiski_pcg_async_free) and a mode: 0 = as wiski_pcg; 1 = START: queue the iterations up to the first poll
  * (first_check), queue the poll, return WISKI_PENDING without waiting -- the host gets its time back while the GPU iterates;
@@ -286,6 +308,7 @@ typedef struct wiski_stream_args_f32 {
   double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
   void* d_bin; int64_t bin_bytes;                 /* optional binning workspace of the absorb (wiski_scatter_bin_bytes), or NULL / 0 */
   const wiski_shard* shard;                      /* NULL, or: this replica owns a share of the half stencil (see wiski_shard) */
+  const wiski_twolevel* two_level;               /* NULL, or: exact block on the dominant modes in the preconditioner (see wiski_twolevel) */
 } wiski_stream_args_f32;
 typedef struct wiski_stream_args_f64 {
   double* d_A_half; double* d_b; double* d_cnt; double* d_stats; int32_t* d_err;
@@ -294,6 +317,7 @@ typedef struct wiski_stream_args_f64 {
   double tol; int32_t max_iter; int32_t check_every; void* d_work; int64_t work_bytes;
   void* d_bin; int64_t bin_bytes;
   const wiski_shard* shard;
+  const wiski_twolevel* two_level;               /* must be NULL (the two-level block exists for the fused fp32 path only) */
 } wiski_stream_args_f64;
 int wiski_stream_step_f32(const wiski_grid* grid, const wiski_stream_args_f32* args, const float* d_x, const float* d_y, const float* d_wa, const float* d_wb, const float* d_noise, int64_t q, float* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
 int wiski_stream_step_f64(const wiski_grid* grid, const wiski_stream_args_f64* args, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t q, double* d_mean_out, int32_t carry, int32_t first_check, int32_t* h_iters, double* h_relres, int32_t* h_err, void* stream, wiski_pcg_async* handle, int32_t defer, int32_t* h_resumed);
@@ -312,6 +336,23 @@ int wiski_scatter_stats_step_sharded_f32(const wiski_grid* grid, const float* d_
 int wiski_scatter_stats_step_sharded_f64(const wiski_grid* grid, const double* d_x, const double* d_y, const double* d_wa, const double* d_wb, const double* d_noise, int64_t n, double* d_b, double* d_A_half, double* d_cnt, const double* d_u, double* d_res, double* d_mean_out, double* d_stats, int32_t* d_err, void* z1, int64_t n1_bytes, void* z2, int64_t n2_bytes, const void* d_guard, int64_t guard_expect, int32_t g_lo, int32_t g_hi, void* stream);
 int wiski_pcg_sharded_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard);
 int wiski_pcg_sharded_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard);
+/* wiski_pcg_async / wiski_pcg_sharded with the two-level block (two_level may be NULL: then exactly wiski_pcg_sharded).
+ * two_level != NULL needs the fused path: d = 3, every g_q <= 64, k = 1, eigen tables given; f64: WISKI_E_BADARG. */
+int wiski_pcg_twolevel_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard, const wiski_twolevel* two_level);
+/* Refresh of the block in ONE call, everything queued on `stream`: G (r x r fp64, caller-owned, running sum) += F^T F with
+ * F = diag(d_scale) W(d_x) X_S for the n points absorbed since the last refresh (d_scale [n] = sqrt of the per-point weights, or
+ * NULL for unit weights; d_V / kw / d_S: the per-dim eigenvector tables [g_q][kw] and index set [3][r] of X_S as for
+ * wiski_basis_project), then d_N (r x r fp32) = (D_S^-1 + gscale G)^-1 with D_S = kscale * d_lam_unit, through the Cholesky factor
+ * and inverse of C = I + (gscale D_S)^1/2 G (gscale D_S)^1/2.  gscale = 1: the block for the statistics as they are; > 1: for a
+ * stream expected to have grown by that factor while the block is in use (the block is applied some steps after it was computed
+ * and until the next one arrives; for a stationary stream G grows in proportion to the absorbed weight).  n = 0 just re-derives
+ * N from G.  d_work: scratch of wiski_twolevel_refresh_workspace_bytes(r) bytes. */
+int64_t wiski_twolevel_refresh_workspace_bytes(int32_t r);
+int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_scale, const double* d_V, int32_t kw, const int32_t* d_S, int32_t r, const double* d_lam_unit, double kscale, double gscale, double* d_G, void* d_work, int64_t work_bytes, float* d_N, void* stream);
+/* One application of the fused preconditioner on its own (what a CG iteration does to its residual; test and tooling entry):
+ * d_y = P r, d_t = Kt^-1 P r, *d_rho (device double) += r . P r, for one m-vector d_r; d_w0 (m reals) and d_w1 (2 m reals)
+ * are scratch.  two_level as above or NULL.  d = 3, every g_q <= 64, g_1 g_2 % 4 == 0. */
+int wiski_precond_apply_f32(const wiski_grid* grid, const float* d_evec, const float* d_evec2, const float* d_eval, float kscale, float shift, const float* d_r, float* d_w0, float* d_w1, float* d_y, float* d_t, double* d_rho, const wiski_twolevel* two_level, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libwiski_hip.so")
-_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip", "spectral_basis.hip", "hyper_columns.hip"]
+_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip", "spectral_basis.hip", "hyper_columns.hip", "two_level.hip"]
 _HEADERS = ["wiski_common.h", "spmv_sym_dma.h", "spmv_sym_dma_mc.h", "spmm_sym_cols.h", "scatter_owner.h", os.path.join("..", "..", "include", "wiski.h")]
 MAX_DIM = 4
 
@@ -94,6 +94,7 @@ def lib():
             )
         _lib = ctypes.CDLL(_SO)
         _lib.wiski_pcg_workspace_bytes.restype = ctypes.c_int64
+        _lib.wiski_twolevel_refresh_workspace_bytes.restype = ctypes.c_int64
     if hasattr(_lib, "wiski_root_update_workspace_elems"):
         _lib.wiski_root_update_workspace_elems.restype = ctypes.c_int64
     return _lib

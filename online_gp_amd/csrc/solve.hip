@@ -1836,7 +1836,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
                     real shift, const real* d_RHS, int32_t k, real* d_U, real* d_Z, int32_t warm, double tol, int32_t max_iter,
                     int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres,
                     const int32_t* d_err, int32_t* h_err, int32_t a_sym, real* d_R, void* stream, wiski_pcg_async* as = nullptr,
-                    int32_t amode = 0, const wiski_shard* shard = nullptr) {
+                    int32_t amode = 0, const wiski_shard* shard = nullptr, const wiski_twolevel* two_level = nullptr) {
   // shard (wiski_shard, nranks > 1): d_A holds only this rank's groups of the half stencil; every A . v product is this rank's
   // share, summed over the ranks by ONE all-reduce of an m-vector (+ the p . Ap slots) per product on the solve's stream.
   // Everything else -- preconditioner, vector updates, scalars -- is replicated, so all ranks take identical iterations.
@@ -2025,6 +2025,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   // host convergence polls: after `first_check` iterations, then every `check_every`
   auto due = [&](int i) { return i == max_iter || i == first_check || (i > first_check && (i - first_check) % check_every == 0); };
   const bool fused_cg = spectral && wide && spectral_fused_ok<real>(G);
+  if (two_level && !(fused_cg && sizeof(real) == 4 && k == 1)) return WISKI_E_BADARG;   // the exact block lives in the fused fp32 slab kernel
   bool pending = false;   // fused path: update_x of iteration it-1 not applied yet
   // publish: fold the convergence poll of iteration `it` into this update; returns its sequence number (0: nothing launched)
   auto flush_update = [&](bool publish = false) -> long long {
@@ -2045,7 +2046,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
       if (!fuse_upd) flush_update();
       const bool init_now = init_in_fwd && it == 0;
       rc = launch_spectral_fused_cg<real>(G, d_evec, d_evec2, d_eval, kscale, shift, r, k, sa, sb, it, pending ? 1 : 0, tol2, p, pt, cpart, cnch, czl,
-                                          d_U, d_Z, S, s, init_now ? d_RHS : (const real*)nullptr);
+                                          d_U, d_Z, S, s, init_now ? d_RHS : (const real*)nullptr, two_level);
       pending = false;
       if (rc) return rc;
       rc = spmv_wide(p, pt, (real)1, S.php(it));
@@ -2226,6 +2227,19 @@ int wiski_pcg_async_f64(const wiski_grid* g, const double* A, const double* tcol
 }
 int wiski_pcg_sharded_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s, wiski_pcg_async* as, int32_t amode, const wiski_shard* shard) {
   return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode, shard);
+}
+int wiski_pcg_twolevel_f32(const wiski_grid* g, const float* A, const float* tcol, float kscale, const float* evec, const float* evec2, const float* eval, float shift, const float* RHS, int32_t k, float* U, float* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* R, void* s, wiski_pcg_async* as, int32_t amode, const wiski_shard* shard, const wiski_twolevel* two_level) {
+  return pcg_impl<float>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode, shard, two_level);
+}
+// One application of the fused preconditioner (iteration 0 of the CG front end without an update to fold in): p = y = P r,
+// pt = t = Kt^-1 y, rho += r . y.
+int wiski_precond_apply_f32(const wiski_grid* grid, const float* evec, const float* evec2, const float* eval, float kscale, float shift, const float* d_r, float* w0, float* w1, float* d_y, float* d_t, double* d_rho, const wiski_twolevel* two_level, void* stream) {
+  GridDev<float> G;
+  if (int rc = make_grid_dev<float>(grid, &G)) return rc;
+  if (!evec || !eval || !d_r || !w0 || !w1 || !d_y || !d_t || !d_rho || !spectral_fused_ok<float>(G) || G.m % 4) return WISKI_E_BADARG;
+  PcgScal S{d_rho - 1, 1, nullptr};          // rho(0) = base + k (1 + 2 * 0) = d_rho; nothing else of S is touched at it = 0, apply = 0
+  return launch_spectral_fused_cg<float>(G, evec, evec2, eval, kscale, shift, const_cast<float*>(d_r), 1, w0, w1, 0, 0, 0.0, d_y, d_t, (float*)nullptr, 0, 0,
+                                         (float*)nullptr, (float*)nullptr, S, (hipStream_t)stream, (const float*)nullptr, two_level);
 }
 int wiski_pcg_sharded_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* R, void* s, wiski_pcg_async* as, int32_t amode, const wiski_shard* shard) {
   return pcg_impl<double>(g, A, tcol, kscale, evec, evec2, eval, shift, RHS, k, U, Z, warm, tol, max_iter, check_every, first_check, work, wb, iters, relres, d_err, h_err, a_sym, R, s, as, amode, shard);

@@ -17,6 +17,8 @@
 // broadcast).
 #include "wiski_common.h"
 
+#include <atomic>
+
 #ifdef SPEC_TIMING
 __device__ long long g_spec_dbg[16];
 #define SPEC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_spec_dbg[i] = clock64(); } while (0)
@@ -463,15 +465,38 @@ struct SpecTile {
   }
 };
 
+// Two-level block (wiski_twolevel, include/wiski.h) as the kernel sees it.
+struct TwoLevelDev {
+  int r, nslab;
+  const unsigned long long* mask;
+  const int* off;
+  const unsigned short* pos;
+  const float* N;
+  unsigned long long* cs;      // [r] {application epoch << 32 | coefficient bits}
+  unsigned epoch;              // unique per application (never 0)
+};
+constexpr int SPEC_TL_MAXR = 512;
+
 // NW = 4: the waves own 32 x 32 quadrants; NW = 8: 16 x 32 strips (half the MFMA chain per wave, two waves per SIMD)
-template <int KS, int VW, int NW>
+// TL: the r selected modes (largest prior eigenvalues) are not scaled by the diagonal model: the blocks that hold them
+// exchange their coefficients c_S through tl.cs, every block forms the rows of N c_S that belong to its slab (y-half:
+// N c_S, t-half: D_S^-1 N c_S) and rho takes c_S^T N c_S for them.  The exchange needs no counter and no fence: every
+// coefficient travels as ONE 64-bit word {epoch of this application, fp32 bits}, written and read with device-scope atomics
+// (around the per-XCD L2s), and a reader spins on each word it wants until it carries the current epoch -- one store-to-load
+// latency in all (a release / acquire arrival counter with its L2 write-back and invalidate cost 10 us per application).
+// Blocks of slabs without selected modes never wait.  All g0 x 2 blocks are co-resident (one per CU), so the wait cannot
+// deadlock; a bounded spin turns a scheduling accident into a failed solve (reported as non-convergence), not a hung device.
+template <int KS, int VW, int NW, bool TL>
 __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
                                                         const float* __restrict__ Z1, const float* __restrict__ Z2,
                                                         const float* __restrict__ evals, float kscale, float shift,
-                                                        const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho) {
+                                                        const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho,
+                                                        TwoLevelDev tl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
   __shared__ float sE[128];                       // eigenvalues of dims 1 | 2, zero padded to 64 each
+  __shared__ float sC[TL ? SPEC_TL_MAXR : 1];     // the exchanged coefficients c_S
+  __shared__ float sCp[TL ? SPEC_TL_MAXR : 1];    // this slab's rows of N c_S
   float* bufA = reinterpret_cast<float*>(smem);   // [64][80]: X, later C3 (stride LDN)
   float* bufB = bufA + 64 * SPEC_LDT;             // [64][80]: C2 (stride LDN), later C5 (stride LDT)
   float* sV1 = bufB + 64 * SPEC_LDT;              // [b][x], stride LDT
@@ -497,6 +522,17 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
     sE[t] = ev;
   }
   const float l0 = kscale * evals[i0];
+  // two-level: the selection masks of the rows this lane holds C3 entries of (bit y of row x), issued with the other loads
+  int tl_o0 = 0, tl_ns = 0;
+  unsigned long long mrow[RT][4];
+  if constexpr (TL) {
+    tl_o0 = tl.off[i0];
+    tl_ns = tl.off[i0 + 1] - tl_o0;              // block-uniform
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mrow[a][r] = tl_ns > 0 ? tl.mask[i0 * 64 + wr * 16 * RT + a * 16 + (lane >> 4) * 4 + r] : 0ull;
+  }
   SPEC_STAMP(6);
   tX.commit(bufA, SPEC_LDT);           // every image is written in full (padding = zeros); bufB is first written by P2
   tV1.commit(sV1, SPEC_LDT);
@@ -534,8 +570,12 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
         const float lam = l0 * sE[wr * 16 * RT + a * 16 + l4 * 4 + r] * e2;
         const float f1 = __frcp_rn(1.f + shift * lam);
         const float v = acc[a][cc][r];
-        rho_lane += (lam * f1) * v * v;   // r^T P r in the eigenbasis (padding: lam = 0)
-        acc[a][cc][r] = v * (h == 0 ? f1 : lam * f1);
+        bool sel = false;
+        if constexpr (TL) sel = (mrow[a][r] >> (wc * 32 + cc * 16 + l15)) & 1ull;
+        if (!sel) {
+          rho_lane += (lam * f1) * v * v;   // r^T P r in the eigenbasis (padding: lam = 0)
+          acc[a][cc][r] = v * (h == 0 ? f1 : lam * f1);
+        }                                   // selected modes stay unscaled: the exact block below replaces them
       }
     }
   store_tiles(bufA, SPEC_LDN);
@@ -544,6 +584,54 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
     if (t == 0) unsafeAtomicAdd(rho + c, tot);
   }
   __syncthreads();
+  if constexpr (TL) {
+    if (tl_ns > 0) {                // block-uniform
+      constexpr int NT = 64 * NW;
+      // (1) this slab's raw coefficients -> the exchange buffer (the y-half blocks write; the t-half computed the same numbers)
+      if (h == 1)
+        for (int e = t; e < tl_ns; e += NT) {
+          const unsigned pp = tl.pos[tl_o0 + e];
+          const unsigned long long wv = ((unsigned long long)tl.epoch << 32) | (unsigned long long)__float_as_uint(bufA[(pp >> 8) * SPEC_LDN + (pp & 255u)]);
+          __hip_atomic_store(tl.cs + tl_o0 + e, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      // (2) all r coefficients -> LDS, each as soon as its word carries this application's epoch
+      for (int e = t; e < tl.r; e += NT) {
+        unsigned long long wv = __hip_atomic_load(tl.cs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spins = 0; (unsigned)(wv >> 32) != tl.epoch && spins < (1 << 20); ++spins) {
+          __builtin_amdgcn_s_sleep(1);
+          wv = __hip_atomic_load(tl.cs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sC[e] = __uint_as_float((unsigned)wv);
+      }
+      __syncthreads();
+      // (3) the rows of N c_S of this slab: one wave per row, lanes stride the columns
+      float rsel = 0.f;
+      for (int e = w; e < tl_ns; e += NW) {
+        const float* __restrict__ nrow = tl.N + (int64_t)(tl_o0 + e) * tl.r;
+        float d = 0.f;
+        for (int q = lane; q < tl.r; q += 64) d += nrow[q] * sC[q];
+        d = wave_reduce_sum<float>(d);
+        if (lane == 0) {
+          sCp[e] = d;
+          rsel += sC[tl_o0 + e] * d;
+        }
+      }
+      if (rho != nullptr && h == 1) {
+        const double tot = block_reduce_sum((double)rsel, s_red);     // (contains the barrier that publishes sCp)
+        if (t == 0) unsafeAtomicAdd(rho + c, tot);
+      } else {
+        __syncthreads();
+      }
+      // (4) back into the C3 image: N c_S for the y-half, D_S^-1 N c_S for the t-half
+      for (int e = t; e < tl_ns; e += NT) {
+        const unsigned pp = tl.pos[tl_o0 + e];
+        const int x = pp >> 8, y = pp & 255u;
+        const float lam = l0 * sE[x] * sE[64 + y];
+        bufA[x * SPEC_LDN + y] = h == 1 ? sCp[e] : sCp[e] / lam;
+      }
+      __syncthreads();
+    }
+  }
   SPEC_STAMP(3);
   // P5: A = C3 (bufA natural), B = bV2^T (sB2 [y][b]) -> C5 [b = i1'][y = i2] (bufB, stride LDT)
   spec_mfma_product<true, true, KS, RT>(bufA, sB2, wr, wc, lane, acc);
@@ -966,28 +1054,44 @@ constexpr size_t SPEC_SLAB_MFMA_LDS = (size_t)(4 * 64 * SPEC_LDT + 2 * 64 * SPEC
 // slab launch: fp32 on the matrix cores, fp64 on the register-tile kernel
 template <typename real>
 static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, const real* Z1, const real* Z2, const real* evals, real kscale,
-                       real shift, const real* src, real* dst, int k, double* rho, hipStream_t s) {
+                       real shift, const real* src, real* dst, int k, double* rho, hipStream_t s, const wiski_twolevel* two_level = nullptr) {
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
+  if (two_level && (sizeof(real) != 4 || k != 1 || two_level->r < 1 || two_level->r > SPEC_TL_MAXR || two_level->nslab < 1 || two_level->nslab > g0 ||
+                    !two_level->d_mask || !two_level->d_off || !two_level->d_pos || !two_level->d_N || !two_level->d_cs))
+    return WISKI_E_BADARG;
   if constexpr (sizeof(real) == 4) {
     const int gm = g1 > g2 ? g1 : g2;
     const bool even = g1 % 2 == 0 && g2 % 2 == 0;      // 8-byte loads need 8-byte aligned rows
+    TwoLevelDev tl{};
+    if (two_level) {
+      static std::atomic<unsigned> tl_epoch{0};            // one number per application, process-wide, never 0
+      unsigned ep = ++tl_epoch;
+      if (ep == 0) ep = ++tl_epoch;
+      tl = TwoLevelDev{two_level->r, two_level->nslab, (const unsigned long long*)two_level->d_mask, two_level->d_off, two_level->d_pos,
+                       two_level->d_N, (unsigned long long*)two_level->d_cs, ep};
+    }
 #define SLAB_MFMA2(KS, VW)                                                                                                                     \
   do {                                                                                                                                         \
     static bool lds_set = false;   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                      \
     if (!lds_set) {                                                                                                                            \
-      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma<KS, VW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,                            \
-                              (int)SPEC_SLAB_MFMA_LDS) != hipSuccess ||                                                                        \
-          hipFuncSetAttribute((const void*)k_spec_slab_mfma<KS, VW, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,                            \
-                              (int)SPEC_SLAB_MFMA_LDS) != hipSuccess)                                                                          \
-        return WISKI_E_LAUNCH;                                                                                                                 \
+      for (const void* fp : {(const void*)k_spec_slab_mfma<KS, VW, 4, false>, (const void*)k_spec_slab_mfma<KS, VW, 8, false>,                \
+                             (const void*)k_spec_slab_mfma<KS, VW, 4, true>, (const void*)k_spec_slab_mfma<KS, VW, 8, true>})                  \
+        if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPEC_SLAB_MFMA_LDS) != hipSuccess)                        \
+          return WISKI_E_LAUNCH;                                                                                                               \
       lds_set = true;                                                                                                                          \
     }                                                                                                                                          \
-    if (slab_waves == 8)                                                                                                                       \
-      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 8>), dim3((unsigned)g0, 2, (unsigned)k), dim3(512), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1,   \
-                         Z2, evals, kscale, shift, src, dst, k, rho);                                                                          \
+    if (two_level && slab_waves == 8)                                                                                                          \
+      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 8, true>), dim3((unsigned)g0, 2, 1), dim3(512), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1,       \
+                         Z2, evals, kscale, shift, src, dst, k, rho, tl);                                                                      \
+    else if (two_level)                                                                                                                        \
+      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 4, true>), dim3((unsigned)g0, 2, 1), dim3(256), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1,       \
+                         Z2, evals, kscale, shift, src, dst, k, rho, tl);                                                                      \
+    else if (slab_waves == 8)                                                                                                                  \
+      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 8, false>), dim3((unsigned)g0, 2, (unsigned)k), dim3(512), SPEC_SLAB_MFMA_LDS, s, G, V1,    \
+                         V2, Z1, Z2, evals, kscale, shift, src, dst, k, rho, tl);                                                              \
     else                                                                                                                                       \
-      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 4>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), SPEC_SLAB_MFMA_LDS, s, G, V1, V2, Z1,   \
-                         Z2, evals, kscale, shift, src, dst, k, rho);                                                                          \
+      hipLaunchKernelGGL((k_spec_slab_mfma<KS, VW, 4, false>), dim3((unsigned)g0, 2, (unsigned)k), dim3(256), SPEC_SLAB_MFMA_LDS, s, G, V1,    \
+                         V2, Z1, Z2, evals, kscale, shift, src, dst, k, rho, tl);                                                              \
   } while (0)
 #define SLAB_MFMA(KS)              \
   do {                             \
@@ -1179,7 +1283,7 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 template <typename real>
 int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
                              int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
-                             real* z, PcgScal S, hipStream_t s, const real* rhs0) {
+                             real* z, PcgScal S, hipStream_t s, const real* rhs0, const wiski_twolevel* two_level) {
   const int g0 = G.g[0], g1 = G.g[1];
   if (!evec2) evec2 = evec;
   const real* V0 = evec;
@@ -1198,17 +1302,17 @@ int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const rea
     if (apply || rhs0) return WISKI_E_BADARG;
     if (int rc = launch_mode0<real, false>(G, V0, V0, 0, 0, (const real*)r, w0, k, (const real*)nullptr, 0, (double*)nullptr, s)) return rc;
   }
-  if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, S.rho(it), s)) return rc;
+  if (int rc = launch_slab<real>(G, V1, V2, Z1, Z2, evals, kscale, shift, (const real*)w0, w1, k, S.rho(it), s, two_level)) return rc;
   return launch_mode0_bwd_updp<real>(G, V0, Z0, (const real*)w1, k, it, p, pt, S, s);
 }
 
 template bool spectral_fused_ok<float>(const GridDev<float>&);
 template int launch_spectral_fused_cg<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, float*, int, float*,
                                              float*, int, int, double, float*, float*, float*, int, int, float*, float*, PcgScal, hipStream_t,
-                                             const float*);
+                                             const float*, const wiski_twolevel*);
 template int launch_spectral_fused_cg<double>(const GridDev<double>&, const double*, const double*, const double*, double, double, double*, int,
                                               double*, double*, int, int, double, double*, double*, double*, int, int, double*, double*, PcgScal,
-                                              hipStream_t, const double*);
+                                              hipStream_t, const double*, const wiski_twolevel*);
 template bool spectral_fused_ok<double>(const GridDev<double>&);
 template int launch_spectral_fused<float>(const GridDev<float>&, const float*, const float*, const float*, float, float, const float*, int, float*,
                                           float*, float*, double*, hipStream_t);

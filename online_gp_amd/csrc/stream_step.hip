@@ -49,11 +49,13 @@ static int scatter_step1(const wiski_grid* g, const wiski_stream_args_f64* a, co
 }
 static int pcg1(const wiski_grid* g, const wiski_stream_args_f32* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
                 wiski_pcg_async* as, int mode) {
-  return wiski_pcg_sharded_f32(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol,
-                               a->max_iter, a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s, as, mode, a->shard);
+  return wiski_pcg_twolevel_f32(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol,
+                                a->max_iter, a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s, as, mode, a->shard,
+                                a->two_level);
 }
 static int pcg1(const wiski_grid* g, const wiski_stream_args_f64* a, int warm, int first_check, int32_t* it, double* rr, int32_t* herr, void* s,
                 wiski_pcg_async* as, int mode) {
+  if (a->two_level) return WISKI_E_BADARG;
   return wiski_pcg_sharded_f64(g, a->d_A_half, a->d_tcol, a->kscale, a->d_evec, a->d_evec2, a->d_eval, a->shift, a->d_b, 1, a->d_U, a->d_Z, warm, a->tol,
                                a->max_iter, a->check_every, first_check, a->d_work, a->work_bytes, it, rr, a->d_err, herr, 1, a->d_R, s, as, mode, a->shard);
 }

@@ -249,4 +249,4 @@ int launch_spectral_fused(const GridDev<real>& G, const real* evec, const real* 
 template <typename real>
 int launch_spectral_fused_cg(const GridDev<real>& G, const real* evec, const real* evec2, const real* evals, real kscale, real shift, real* r,
                              int k, real* w0, real* w1, int it, int apply, double tol2, real* p, real* pt, real* part, int nch, int zl, real* u,
-                             real* z, PcgScal S, hipStream_t s, const real* rhs0 = nullptr);
+                             real* z, PcgScal S, hipStream_t s, const real* rhs0 = nullptr, const wiski_twolevel* two_level = nullptr);

@@ -308,7 +308,7 @@ class _StreamArgs32(ctypes.Structure):
                 ("d_tcol", ctypes.c_void_p), ("kscale", ctypes.c_float), ("d_evec", ctypes.c_void_p), ("d_evec2", ctypes.c_void_p),
                 ("d_eval", ctypes.c_void_p), ("shift", ctypes.c_float), ("tol", ctypes.c_double), ("max_iter", ctypes.c_int32),
                 ("check_every", ctypes.c_int32), ("d_work", ctypes.c_void_p), ("work_bytes", ctypes.c_int64),
-                ("d_bin", ctypes.c_void_p), ("bin_bytes", ctypes.c_int64), ("shard", ctypes.c_void_p)]
+                ("d_bin", ctypes.c_void_p), ("bin_bytes", ctypes.c_int64), ("shard", ctypes.c_void_p), ("two_level", ctypes.c_void_p)]
 
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
@@ -318,6 +318,12 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 class _Shard(ctypes.Structure):
     """include/wiski.h: wiski_shard"""
     _fields_ = [("rank", ctypes.c_int32), ("nranks", ctypes.c_int32), ("comm", ctypes.c_void_p), ("allreduce", ALLREDUCE_FN), ("ctx", ctypes.c_void_p)]
+
+
+class TwoLevelStruct(ctypes.Structure):
+    """include/wiski.h: wiski_twolevel"""
+    _fields_ = [("r", ctypes.c_int32), ("nslab", ctypes.c_int32), ("d_mask", ctypes.c_void_p), ("d_off", ctypes.c_void_p), ("d_pos", ctypes.c_void_p),
+                ("d_N", ctypes.c_void_p), ("d_cs", ctypes.c_void_p)]
 
 
 def shard_groups(d, rank, nranks):
@@ -408,6 +414,11 @@ class StreamStep:
         self._shard = _Shard(rank, nranks, comm, self._shard_cb, None)
         self.args.shard = ctypes.addressof(self._shard)
 
+    def set_two_level(self, tl):
+        """tl: a TwoLevelStruct kept alive by the caller (its d_N may be re-pointed between steps), or None."""
+        self._two_level = tl
+        self.args.two_level = ctypes.addressof(tl) if tl is not None else None
+
     def set_solver(self, kscale, eig, shift, tol, check_every):
         a = self.args
         evec, evals, evec2 = (tuple(eig) + (None,))[:3]
@@ -445,7 +456,23 @@ class StreamStep:
         return (res if self.resumed.value == 1 else None), self.pending
 
 
-def kron_eigen(grid, tcol, profiles=None):
+def precond_apply(grid, eig, kscale, shift, r, two_level=None):
+    """One application of the fused fp32 preconditioner to the grid vector r (``wiski_precond_apply``): (y = P r, t = Kt^-1 y, r . y)."""
+    evec, evals, evec2 = (tuple(eig) + (None,))[:3]
+    r = r.contiguous()
+    m = grid.m
+    w0 = torch.empty(m, dtype=r.dtype, device=r.device)
+    w1 = torch.empty(2 * m, dtype=r.dtype, device=r.device)
+    y, t = torch.empty_like(r), torch.empty_like(r)
+    rho = torch.zeros(2, dtype=torch.float64, device=r.device)
+    rc = _hip.lib().wiski_precond_apply_f32(grid.ref, _hip.dptr(evec), _hip.dptr(evec2), _hip.dptr(evals), ctypes.c_float(kscale), ctypes.c_float(shift),
+                                            _hip.dptr(r), _hip.dptr(w0), _hip.dptr(w1), _hip.dptr(y), _hip.dptr(t), ctypes.c_void_p(rho.data_ptr() + 8),
+                                            ctypes.byref(two_level) if two_level is not None else None, _hip.stream_ptr(r.device))
+    _hip.check(rc, "wiski_precond_apply")
+    return y, t, rho[1]
+
+
+def kron_eigen(grid, tcol, profiles=None, host_out=None):
     """Per-dim (generalized) eigen-decomposition of the d small symmetric-Toeplitz Kronecker
     factors (host side, fp64, O(d g^3) -- done when the hyper-parameters or the data-density
     profile change, not per streaming update).
@@ -473,6 +500,9 @@ def kron_eigen(grid, tcol, profiles=None):
         vals.append(np.clip(w, 0.0, None))
         off += g
     mk = lambda parts: torch.as_tensor(np.concatenate(parts)).to(tcol.device, tcol.dtype)
+    if host_out is not None:              # fp64 host copies (per dim: eigenvectors [g, g] column = mode, eigenvalues ascending)
+        host_out["X"] = [x.reshape(g, g) for x, g in zip(X, grid.g)]
+        host_out["D"] = [v.copy() for v in vals]
     if profiles is None:
         return mk(X), mk(vals)
     return mk(X), mk(vals), mk(Z)

@@ -259,6 +259,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         # keeps R exact under the increment, and the next refresh starts without an A U product
         ms = self._mean_state
         mine = cache is self._kernel_cache
+        if mine and self.num_outputs == 1:
+            if half_delta is not None:
+                self._two_level_lose()               # the increment arrives by all-reduce: other ranks' points never pass here
+            else:
+                self._two_level_note(X, None if unit else (1.0 / noise[:, 0] if init else 1.0 / noise[:, 0].clamp_min(1e-7)), init=init)
         carry = (mine and half_delta is None and not init and ms is not None and ms.get("R_ok", False)
                  and settings.residual_carry_over.on())
         carry_delta = (half_delta is not None and res_delta is not None and not init and ms is not None and ms.get("R_ok", False)
@@ -454,8 +459,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 st["wsum"] = wsum                      # same density shape: keep the eigenbasis, only the scale moves
                 st["it0"] = None
             else:
-                eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles)
-                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles, "it0": None}
+                host = {}
+                eig = grid_ops.kron_eigen(self._grid, tcol, profiles=profiles, host_out=host)
+                st = {"ver": ver, "wsum": wsum, "eig": eig, "norm": norm, "profiles": profiles, "it0": None, "eig_host": host}
                 self._memo["precond"][o] = st
         return st["eig"], wsum / st["norm"]
 
@@ -903,6 +909,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self._wsum_host[0] += float(q)
         self.num_data = self.num_data + q
         self._refresh_count = getattr(self, "_refresh_count", 0) + 1
+        self._two_level_step(step, pst, X, q)            # (may set the poll hint: before _first_poll)
         last = (getattr(self, "_last_iters", None) or [0])[0]
         fc, probe = self._first_poll(last)
         carry = ms.get("R_ok", False) and self._refresh_count % 16 != 0
@@ -927,6 +934,48 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         self._note_solve(ms, step(X, y1, ones, ones, ones, mean, carry, fc), fc, probe)
         return mean
 
+    # ------------------------------------------------- two-level preconditioner --
+    def _two_level_applies(self):
+        return (settings.two_level_preconditioner.on() and self.num_outputs == 1 and self._grid.d == 3 and self._dtype == torch.float32
+                and max(self._grid.g) <= 64 and not self._use_dense())
+
+    def _two_level_note(self, X, wa, init=False):
+        """Every point the statistics absorb is either pending for, or part of, the exact block of the two-level preconditioner
+        (lazy/two_level.py); points absorbed without passing here make the tracker give up until the statistics are rebuilt."""
+        if not self._two_level_applies():
+            self.__dict__.pop("_two_level", None)
+            return
+        from ..lazy.two_level import TwoLevelTracker
+
+        tr = self.__dict__.get("_two_level")
+        if tr is None or init:
+            if tr is None and not init:
+                return                                 # statistics older than the tracker: never covered
+            tr = self.__dict__["_two_level"] = TwoLevelTracker()
+        tr.note(X.reshape(-1, self._grid.d), wa)
+
+    def _two_level_lose(self):
+        tr = self.__dict__.get("_two_level")
+        if tr is not None:
+            tr.lose()
+
+    def _two_level_step(self, step, pst, X, q):
+        """Before a one-call streaming step: note its batch, keep the block's refresh pipeline going, point the solve at the block."""
+        tr = self.__dict__.get("_two_level") if self._two_level_applies() else None
+        tl = None
+        if tr is not None:
+            tr.note(X, None)
+            _, s2, _ = self._hyper()[0]
+            tl = tr.for_step(self._grid, self._device, pst, 1.0 / s2, float(self._wsum[0]), self._err,
+                             lockstep=self.__dict__.get("_stencil_shard") is not None,
+                             last_iters=(getattr(self, "_last_iters", None) or [0])[0])
+            if tr.switched:
+                # a new block: the iteration count of the previous solves says little about the next one -- poll after 2 iterations,
+                # then after every one (the poll placement would otherwise walk down one iteration per probe)
+                self._poll_hint_sticky = 2
+        if getattr(step, "_two_level", None) is not tl:
+            step.set_two_level(tl)
+
     def _first_poll(self, last):
         """Where a warm refresh polls convergence first: (iteration count, is this a probe?).  Streaming steps are alike (at
         50^3 the uniform bench stream needs 3 iterations for its first ~40 steps and 2 ever after; the clustered one 6, now and
@@ -939,6 +988,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         against 0.216 with this placement, tools/policy_probe.py.)"""
         if not last:
             return 0, False
+        sticky = getattr(self, "_poll_hint_sticky", 0)
+        if sticky:
+            # a new block of the two-level preconditioner went in: for this step and the next (whose `last` still predates the
+            # switch: deferred refreshes report one step late) poll after 2 iterations, then after every one
+            self._poll_hint_sticky = sticky - 1
+            return min(last, 2), False
         hint = getattr(self, "_poll_hint", 0)
         if hint:
             # the previous solve was a cold one: its count (8 at 50^3) says nothing about a warm, residual-carrying refresh

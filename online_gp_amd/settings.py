@@ -212,6 +212,52 @@ class density_profile_preconditioner(_feature_flag):
     _state = True
 
 
+class two_level_preconditioner(_feature_flag):
+    """One-call streaming steps on large 3-D fp32 grids (``FixedNoiseOnlineSKIGP.stream_step``): keep the EXACT block
+    (D_S^-1 + X_S^T W^T D^-1 W X_S)^-1 of the system matrix on the ``two_level_rank`` dominant modes of the preconditioner's
+    generalized eigenbasis and the separable density model on the rest (``lazy/two_level.py``, include/wiski.h: wiski_twolevel).
+    The separable model alone needs 6 CG iterations per step on road-like (line-clustered) streams, 2.5 on uniform ones.
+    The block follows the stream on a side stream; its age costs iterations, never accuracy."""
+
+    _state = True
+
+
+class two_level_rank(_value_context):
+    """Modes in the exact block of the two-level preconditioner (<= 480).  50^3, road-like stream: 128 / 192 / 256 / 384 modes
+    need 3.28 / 3.02 / 3.02 / 3.02 iterations per step (2.0 late in the stream); the refresh costs grow with the square."""
+
+    _global_value = 192
+
+
+class two_level_min_iters(_value_context):
+    """The two-level block is built only for streams whose first warm steps need at least this many CG iterations under the
+    separable density model alone (uniform-like streams converge in 2-3 and never pay for it)."""
+
+    _global_value = 4.0
+
+
+class two_level_predictive(_feature_flag):
+    """Compute each block for the absorbed weight expected in the middle of its service life (G scaled accordingly) rather than
+    for the weight at the time of the refresh: a block is always somewhat old when it is used."""
+
+    _state = True
+
+
+class two_level_growth(_value_context):
+    """A refresh of the two-level block is started when the absorbed weight has grown by this factor since the last one
+    (50^3 road-like stream: 1.1 -> 22 refreshes per 3droad-sized pass, 2.57 iterations per step; 1.2 -> 13 and 2.62)."""
+
+    _global_value = 1.2
+
+
+class two_level_lag(_value_context):
+    """Stencil-sharded multi-GPU steps (replicas must take identical iterations): streaming steps between the start of a block
+    refresh (side stream) and the step that switches it in -- fixed, so that every rank switches at the same step.  One GPU: a
+    finished refresh is switched in by the first step that finds it complete (at the latest 4 x this many steps on)."""
+
+    _global_value = 2
+
+
 class spectral_factor(_feature_flag):
     """Large grids, smooth kernels: serve predictive variances and the marginal log-likelihood from a dense Woodbury
     factor in the dominant Kronecker eigenspace of Kuu (``lazy/spectral_woodbury.py``) whenever that space is small

@@ -1,0 +1,160 @@
+"""GPU: the two-level preconditioner of the fused fp32 solve (include/wiski.h: wiski_twolevel, online_gp_amd/lazy/two_level.py):
+the exact block on the dominant generalized eigenmodes inside the slab kernel against numpy, the block the refresh pipeline
+builds against the stencil it models, and the streaming loop with and without it (same posterior, fewer CG iterations on the
+road-like stream of SURVEY 8d)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _toeplitz_cols(g, h, ell):
+    return [np.exp(-0.5 * (np.arange(gq) * hq / ell) ** 2) * 0.7 for gq, hq in zip(g, h)]
+
+
+@pytest.mark.parametrize("g,rank,profiled", [((12, 8, 16), 40, True), ((20, 20, 20), 96, False), ((50, 50, 50), 256, True)])
+def test_slab_kernel_block_against_numpy(g, rank, profiled):
+    """wiski_precond_apply with a wiski_twolevel: y = X [N c_S | f2 c_rest], t = Z [D_S^-1 N c_S | f1 c_rest], rho = r . y for a
+    random SPD block N on the `rank` dominant modes, application after application."""
+    from online_gp_amd import grid_ops
+    from online_gp_amd.lazy import two_level as tlm
+
+    rng = np.random.default_rng(5)
+    gb = [[-1.1, 1.1]] * 3
+    grid = grid_ops.GridSpec(gb, list(g))
+    cols = _toeplitz_cols(g, grid.h, 0.5)
+    tcol = torch.as_tensor(np.concatenate(cols), device=DEV, dtype=torch.float32)
+    profiles = [np.clip(0.2 + rng.uniform(0, 1, gq), 1e-2, None) for gq in g] if profiled else None
+    host = {}
+    eig = grid_ops.kron_eigen(grid, tcol, profiles=profiles, host_out=host)
+    kscale, shift = 1.3, 2.5
+    blk = tlm.TwoLevelBlock(grid, torch.device(DEV), host, kscale, rank, None)
+    r_ = blk.r
+    A = rng.standard_normal((r_, r_))
+    N = (A @ A.T / r_ + np.diag(rng.uniform(0.5, 2.0, r_))) * 0.3
+    blk.N[0].copy_(torch.as_tensor(N, dtype=torch.float32))
+    X = [h.astype(np.float32).astype(np.float64) for h in host["X"]]          # what the kernel transforms with (fp32 tables)
+    Dq = [d.astype(np.float32).astype(np.float64) for d in host["D"]]
+    Z = X if profiles is None else [np.asarray(p)[:, None] * x for p, x in zip(profiles, host["X"])]
+    Z = [z.astype(np.float32).astype(np.float64) for z in Z]
+    m = int(np.prod(g))
+    for trial in range(3):
+        r = rng.standard_normal(m)
+        c = np.einsum("ai,bj,ck,abc->ijk", X[0], X[1], X[2], r.reshape(g), optimize=True)
+        lam = kscale * np.einsum("i,j,k->ijk", *Dq)
+        f1 = 1.0 / (1.0 + shift * lam)
+        cy, ct = c * lam * f1, c * f1
+        i0, i1, i2 = blk.idx_host
+        cs = c[i0, i1, i2]
+        ns = N @ cs
+        cy[i0, i1, i2] = ns
+        ct[i0, i1, i2] = ns / lam[i0, i1, i2]
+        y_ref = np.einsum("ai,bj,ck,ijk->abc", X[0], X[1], X[2], cy, optimize=True).reshape(-1)
+        t_ref = np.einsum("ai,bj,ck,ijk->abc", Z[0], Z[1], Z[2], ct, optimize=True).reshape(-1)
+        rho_ref = float((c * cy).sum())
+        y, t, rho = grid_ops.precond_apply(grid, eig, kscale, shift, torch.as_tensor(r, device=DEV, dtype=torch.float32), two_level=blk.struct)
+        torch.cuda.synchronize()
+        assert np.abs(y.cpu().numpy() - y_ref).max() < 2e-4 * np.abs(y_ref).max(), trial
+        assert np.abs(t.cpu().numpy() - t_ref).max() < 2e-4 * np.abs(t_ref).max(), trial
+        assert abs(float(rho) - rho_ref) < 1e-4 * abs(rho_ref)
+    # without the block the same entry point is the separable preconditioner
+    y0, t0, _ = grid_ops.precond_apply(grid, eig, kscale, shift, torch.as_tensor(r, device=DEV, dtype=torch.float32))
+    y_sep = np.einsum("ai,bj,ck,ijk->abc", X[0], X[1], X[2], c * lam * f1, optimize=True).reshape(-1)
+    assert np.abs(y0.cpu().numpy() - y_sep).max() < 2e-4 * np.abs(y_sep).max()
+
+
+def _clustered(n, seed):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    return bench.synth_stream(n, 3, seed, torch.device(DEV), torch.float32, "clustered")
+
+
+def test_block_follows_the_stream_and_cuts_the_iterations():
+    """Streaming loop on the road-like stream (24^3, proportions of the 50^3 bench): with the two-level block the posterior mean
+    is the same (both solves converge to the same tolerance), the CG iteration count per step falls well below the separable
+    preconditioner's, and the block's G equals X_S^T A X_S of the stencil the model holds (every absorbed point is in it)."""
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    g, q, steps = 24, 452, 40
+    n0 = 2400
+    X, y = _clustered(n0 + steps * q, 0)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    res = {}
+    for on in (False, True):
+        with settings.two_level_preconditioner(on), settings.two_level_rank(128), settings.skip_posterior_variances(True), settings.cg_tolerance(1e-4), \
+                settings.deferred_refresh(True), settings.deferred_bounds_check(True), torch.no_grad():
+            m = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+            m.prediction_cache
+            its = []
+            for s in range(steps):
+                sl = slice(n0 + s * q, n0 + (s + 1) * q)
+                m.stream_step(X[sl], y[sl])
+                if getattr(m, "_last_iters", None):
+                    its.append(m._last_iters[0])
+            m._finish_pending()
+            mean = grid_ops.gather(m._grid, X[:256], m._mean_state["U"], m._err)[:, 0].clone()
+            res[on] = (np.mean(its[8:]), mean, m)
+    (it_off, mean_off, _), (it_on, mean_on, m) = res[False], res[True]
+    assert (mean_on - mean_off).abs().max().item() < 2e-3 * mean_off.abs().max().item()
+    assert it_on <= it_off - 0.8, (it_on, it_off)
+    tr = m.__dict__["_two_level"]
+    blk = tr.block
+    assert blk is not None and blk.active >= 0 and blk.refreshes >= 3 and tr.covered
+    # G (+ what is still pending) against the stencil: a few columns of X_S^T A X_S
+    blk.finish()
+    if tr.pending:
+        blk.launch_refresh(tr.pending, 10 ** 6, 0.0)
+        tr.pending = []
+        blk.finish()
+    torch.cuda.synchronize()
+    host = m._memo["precond"][0]["eig_host"]
+    Xh = host["X"]
+    i0, i1, i2 = blk.idx_host
+    js = [0, 1, blk.r // 2, blk.r - 1]
+    cols = np.stack([np.einsum("a,b,c->abc", Xh[0][:, i0[j]], Xh[1][:, i1[j]], Xh[2][:, i2[j]]).reshape(-1) for j in js])
+    AB = grid_ops.stencil_spmv(m._grid, m._kernel_cache["WtW"].stencil, torch.as_tensor(cols, device=DEV, dtype=torch.float32)).double().cpu().numpy()
+    Gcol = np.stack([np.einsum("abc,ar,br,cr->r", ab.reshape(g, g, g), Xh[0][:, i0], Xh[1][:, i1], Xh[2][:, i2], optimize=True) for ab in AB])
+    Gdev = blk.G.cpu().numpy()
+    for k_, j in enumerate(js):
+        assert np.abs(Gdev[j] - Gcol[k_]).max() < 2e-4 * np.abs(Gdev).max(), j
+
+
+def test_tracker_gives_up_when_points_bypass_it_and_after_a_hyper_step():
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    X, y = _clustered(6000, 1)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    with settings.skip_posterior_variances(True), settings.two_level_rank(64), settings.two_level_min_iters(0.0), torch.no_grad():
+        m = FixedNoiseOnlineSKIGP(X[:2000], y[:2000], None, grid_bounds=gb, grid_size=16, learn_additional_noise=True).eval()
+        m.prediction_cache
+        for s in range(8):
+            m.stream_step(X[2000 + 250 * s:2250 + 250 * s], y[2000 + 250 * s:2250 + 250 * s])
+        tr = m.__dict__["_two_level"]
+        assert tr.covered and tr.block is not None
+        ref = FixedNoiseOnlineSKIGP(X[:4000], y[:4000], None, grid_bounds=gb, grid_size=16, learn_additional_noise=True).eval()
+        assert torch.allclose(m(X[:64]).mean, ref(X[:64]).mean, rtol=1e-2, atol=2e-3)
+        # a hyper-parameter change re-solves the eigenbasis: the block is dropped, the solves go on with the separable model
+        k = m.covar_module.base_kernel
+        k.base_kernel.lengthscale = k.base_kernel.lengthscale * 1.05
+        m._dump_caches()
+        m.prediction_cache
+        m.stream_step(X[4000:4500], y[4000:4500])
+        m.stream_step(X[4500:5000], y[4500:5000])
+        m._finish_pending()
+        assert not m.__dict__["_two_level"].covered and m.__dict__["_two_level"].block is None
+        k2 = ref.covar_module.base_kernel
+        k2.base_kernel.lengthscale = k2.base_kernel.lengthscale * 1.05
+        ref._dump_caches()
+        ref.condition_on_observations(X[4000:5000], y[4000:5000], None, inplace=True)
+        assert torch.allclose(m(X[:64]).mean, ref(X[:64]).mean, rtol=1e-2, atol=2e-3)
