@@ -129,8 +129,9 @@ def cpu_baseline(args, tol, budget_s=20.0, max_steps=100):
     return {"value": steps * q / dt, "unit": "updates/s", "cores": baseline.num_threads(), "kind": "port",
             "sample": f"{steps} steps of q={q} after the {args.n_init}-point init (same grid / dtype / tolerance / warm starts as the GPU leg), "
                       f"OpenMP C port on {baseline.num_threads()} threads (= the CPUs the container's quota allows; {os.cpu_count()} logical CPUs are "
-                      f"visible, and 128 threads run 5x slower under that quota), CG with the same density-profile preconditioner as the "
-                      f"GPU leg ({np.mean(iters):.1f} iterations per step; with the plain Kt preconditioner it was 155 and 1.6e4 updates/s), {dt:.1f} s"}
+                      f"visible, and 128 threads run 5x slower under that quota), {args.stream} stream, CG with the separable density-profile "
+                      f"preconditioner of the GPU library ({np.mean(iters):.1f} iterations per step; the GPU leg adds the two-level block on "
+                      f"road-like streams, which the port does not have; with the plain Kt preconditioner the port needed 155), {dt:.1f} s"}
 
 
 def dense_reference_timings(dev):
@@ -187,7 +188,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--n-init", type=int, default=21743, help="5%% of 434874 (init_ratio of the reference config)")
     ap.add_argument("--tol", type=float, default=None, help="CG relative-residual tolerance")
-    ap.add_argument("--stream", default="uniform", choices=["uniform", "clustered"], help="synthetic stream of SURVEY.md 8d")
+    ap.add_argument("--stream", default="clustered", choices=["uniform", "clustered"],
+                    help="synthetic stream of SURVEY.md 8d; default: the road-like variant (BASELINE config 3 is 3droad), the uniform one goes to extra")
     ap.add_argument("--blocks", type=int, default=0, help="number of timed K-step blocks (0 = enough for ~0.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extras (profiling runs)")
@@ -355,6 +357,10 @@ def main():
                  "stream_points_per_pass": int(model.num_data), "note": "each pass re-starts from the init data and streams at most a 3droad-sized "
                  "stream (434 874 points) of fresh synthetic points"}
         exchange_used = upd.last_exchange
+        tr = model.__dict__.get("_two_level")
+        extra["two_level_preconditioner"] = ({"rank": tr.block.r, "refreshes_in_last_pass": tr.block.refreshes, "growth": settings.two_level_growth.value(),
+                                              "slabs_exchanging": tr.block.nslab} if tr is not None and tr.block is not None
+                                             else "not built (the separable density model converges in < %g iterations on this stream)" % settings.two_level_min_iters.value())
         if headline_note:
             extra["headline_note"] = headline_note
 
@@ -389,7 +395,7 @@ def main():
             try:                                   # an extra that fails must not cost the JSON line: the error is recorded instead
                 # second value: the road-like clustered stream of SURVEY 8d (3droad IS road-like)
                 other = "clustered" if args.stream == "uniform" else "uniform"
-                _, _, bs, its, _, _ = run_stream(other, "auto", max(3, R // 3), 7, profile=False)
+                _, _, bs, its, _, _ = run_stream(other, "auto", R, 7, profile=False)          # as many blocks as the headline: whole passes
                 extra[f"{other}_stream_updates_per_s"] = K * q / block_seconds(bs)[0]
                 extra[f"{other}_stream_cg_iters_per_step_mean"] = float(np.mean(its))
 
@@ -745,7 +751,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": ("road-like CLUSTERED (64 poly-lines, sigma 0.02) " if args.stream == "clustered" else "UNIFORM ") + f"3droad-sized synthetic stream d={d} (the road-like clustered variant of SURVEY 8d: extra.clustered_stream_*), {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
+            "config": {"workload": ("road-like CLUSTERED (points along 64 poly-lines, sigma 0.02: SURVEY 8d's stand-in for UCI 3droad; the uniform variant: extra.uniform_stream_*) " if args.stream == "clustered" else "UNIFORM (the road-like clustered variant of SURVEY 8d: extra.clustered_stream_*) ") + f"3droad-sized synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}; {R} timed blocks of {K} steps (all steps / summed block time)",
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -212,7 +212,7 @@ class SpectralWoodburyFactor:
         and sets ``mean_ok`` -- the model then serves means from its PCG state until a later check passes again."""
         lim = settings.spectral_mean_tolerance.value()
         if lim is None:
-            lim = 1e-3 if self.dtype == torch.float32 else 1e-5
+            lim = 1e-2 if self.dtype == torch.float32 else 1e-4
         if self._mean_chk is not None:
             host, ev = self._mean_chk
             ev.synchronize()

@@ -780,21 +780,22 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         Xf = X.reshape(-1, grid.d).contiguous()
         n = Xf.shape[0]
         # smooth kernel on a large grid, variances wanted: the variance of the batch comes from the spectral factor (no solve at
-        # all, with a per-query truncation bound).  The MEAN comes from the factor too only when the hyper-parameters have moved
-        # since the last solve and a factor is being kept current anyway (a streaming wrapper that takes an MLL step per batch:
-        # the factor's refresh is needed by that step in any case, a PCG mean solve would first re-solve the preconditioner's
-        # eigenproblems) -- and only while the factor's mean monitor is green (sqrt(tail(w) b^T (Kt - Kt_B) b), evaluated every
-        # few states: the variance bound does not control the mean).  In every other case the mean is the warm-started PCG
-        # state's, which carries its own tolerance.
+        # all, with a per-query truncation bound).  The MEAN comes from the warm-started PCG state whenever that is current
+        # (it carries its own tolerance and costs one gather).  Where it is not -- the hyper-parameters have moved since the
+        # last solve, or no solve has run yet: a streaming wrapper that takes an MLL step per batch keeps a factor current for
+        # that step anyway, while a PCG mean would first re-solve the preconditioner's eigenproblems and then iterate -- the
+        # factor serves the mean too, but only while its mean monitor is green (sqrt(tail(w) b^T (Kt - Kt_B) b), evaluated every
+        # few states: the variance bound does not control the mean).
         sq = None
         ms = self._mean_state
-        hypers_moved = self._memo.get("prediction_cache") is None and ms is not None and ms.get("ver") != self._hyper_version()
+        pcg_current = self._memo.get("prediction_cache") is not None or (ms is not None and ms.get("ver") == self._hyper_version())
+        hypers_moved = not pcg_current and ms is not None          # (means only, no PCG state at all: a cold solve, then warm ones)
         factor_mean = False
         if settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use()):
             sps = [self._spectral_state(o) for o in range(out)]
             if all(sp is not None for sp in sps):
                 sq = [sp[0].query(sp[1], Xf, sp[2]) for sp in sps]
-                factor_mean = hypers_moved and all(sp[0].mean_ok for sp in sps)
+                factor_mean = not pcg_current and all(sp[0].mean_ok for sp in sps)
         pc = None
         if factor_mean:
             mean = torch.stack([s_.mean() for s_ in sq], dim=1)                   # [n, out] fp64

@@ -466,7 +466,7 @@ def test_mean_monitor_bounds_the_truncated_mean_and_falls_back_to_pcg():
     sw.MEAN_CHECK_EVERY = 1
     try:
         for tail, expect_ok in ((None, True), (3e-3, False)):
-            with settings.spectral_tail(tail), settings.cg_tolerance(1e-9):
+            with settings.spectral_tail(tail), settings.cg_tolerance(1e-9), settings.spectral_mean_tolerance(1e-5):
                 m = _model(X, y, g, dtype)
                 m.eval()
                 m(Xst).variance                               # builds the factor; the mean of this call is the PCG state's
