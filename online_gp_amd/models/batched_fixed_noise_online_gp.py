@@ -968,7 +968,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             tr.note(X, None)
             _, s2, _ = self._hyper()[0]
             tl = tr.for_step(self._grid, self._device, pst, 1.0 / s2, float(self._wsum[0]), self._err,
-                             lockstep=self.__dict__.get("_stencil_shard") is not None,
+                             lockstep=self.__dict__.get("_stencil_shard") is not None or settings.two_level_lockstep.on(),
                              last_iters=(getattr(self, "_last_iters", None) or [0])[0])
             if tr.switched:
                 # a new block: the iteration count of the previous solves says little about the next one -- poll after 2 iterations,

@@ -243,6 +243,13 @@ class two_level_predictive(_feature_flag):
     _state = True
 
 
+class two_level_lockstep(_feature_flag):
+    """Switch a refreshed two-level block in exactly ``two_level_lag`` steps after its refresh was started even on one GPU (what
+    stencil-sharded replicas always do): iteration counts then do not depend on how fast the side stream ran (tests)."""
+
+    _state = False
+
+
 class two_level_growth(_value_context):
     """A refresh of the two-level block is started when the absorbed weight has grown by this factor since the last one
     (50^3 road-like stream: 1.1 -> 22 refreshes per 3droad-sized pass, 2.57 iterations per step; 1.2 -> 13 and 2.62)."""

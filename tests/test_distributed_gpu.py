@@ -169,6 +169,31 @@ def _worker_stencil_shard(rank, world, port, tmpdir):
         got = upd.stream_step(X[lo + rank * q:lo + (rank + 1) * q], y[lo + rank * q:lo + (rank + 1) * q])
         want = ref.stream_step(X[lo:lo + world * q], y[lo:lo + world * q])
         ok = ok and torch.allclose(got, want[rank * q:(rank + 1) * q], rtol=1e-3, atol=2e-4) and model.__dict__.get("_stencil_shard") is not None
+    # the two-level preconditioner inside the sharded step: replicas must switch a refreshed block in at the SAME step (lock-step
+    # activation) or their iteration counts -- and with them their collectives -- diverge.  Forced on (min_iters 0) on a
+    # road-like stream; the single-process reference runs the same lock-step schedule.
+    sys.path.insert(0, ROOT)
+    import bench
+
+    Xc, yc = bench.synth_stream(n0 + 10 * world * q, 3, 3, dev, torch.float32, "clustered")
+    with settings.cg_tolerance(1e-5), settings.skip_posterior_variances(True), settings.deferred_refresh(True), settings.deferred_bounds_check(True), \
+            settings.two_level_min_iters(0.0), settings.two_level_rank(96), settings.two_level_lockstep(True), torch.no_grad():
+        ref = FixedNoiseOnlineSKIGP(Xc[:n0], yc[:n0], torch.ones_like(yc[:n0]), grid_bounds=gb, grid_size=24, learn_additional_noise=True).eval()
+        model = FixedNoiseOnlineSKIGP(Xc[:n0], yc[:n0], torch.ones_like(yc[:n0]), grid_bounds=gb, grid_size=24, learn_additional_noise=True).eval()
+        ref.prediction_cache; model.prediction_cache
+        upd = ShardedStatsUpdater(model, equal_shards=True, exchange="stencil")
+        hist_ref, hist_got = [], []
+        for s in range(10):
+            lo = n0 + s * world * q
+            want = ref.stream_step(Xc[lo:lo + world * q], yc[lo:lo + world * q])
+            got = upd.stream_step(Xc[lo + rank * q:lo + (rank + 1) * q], yc[lo + rank * q:lo + (rank + 1) * q])
+            ok = ok and torch.allclose(got, want[rank * q:(rank + 1) * q], rtol=1e-3, atol=3e-4)
+            hist_ref.append(ref._last_iters[0]); hist_got.append(model._last_iters[0])
+        ref._finish_pending(); model._finish_pending()
+        trm, trr = model.__dict__["_two_level"], ref.__dict__["_two_level"]
+        ok = ok and trm.block is not None and trm.block.active >= 0 and trm.block.refreshes == trr.block.refreshes
+        ok = ok and hist_ref == hist_got and model.__dict__.get("_stencil_shard") is not None
+        msgs.append(f"two-level iters ref {hist_ref} got {hist_got} refreshes {trm.block.refreshes if trm.block else None}")
     open(os.path.join(tmpdir, f"st_{rank}"), "w").write(("1" if ok else "0") + " " + "; ".join(msgs))
     dist.barrier()
     dist.destroy_process_group()
