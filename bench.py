@@ -268,10 +268,10 @@ def main():
             gc_settle()                                    # the previous pass's model (reference cycles) goes before the new one allocates
             model = FixedNoiseOnlineSKIGP(X0, y0, torch.ones_like(y0), grid_bounds=gb, grid_size=args.grid, learn_additional_noise=True)
             model.eval()
-            # N > 1, "auto": the stencil-sharded step (the one exchange that divides the step's work; distributed.py) where it
-            # applies -- d = 3, fp32 -- else the cheaper of the point / statistics exchanges
+            # N > 1, "auto": the stencil-sharded step (the one exchange that divides the step's work; distributed.py; any d, both
+            # precisions since round 4); where it does not apply the updater falls back to the point exchange
             ex = exchange
-            if ex == "auto" and world > 1 and d == 3 and dtype == torch.float32 and os.environ.get("WISKI_BENCH_NO_STENCIL_SHARD") != "1":
+            if ex == "auto" and world > 1 and os.environ.get("WISKI_BENCH_NO_STENCIL_SHARD") != "1":
                 ex = "stencil"
             upd = ShardedStatsUpdater(model, equal_shards=True, exchange=ex)   # every rank streams q points per step
 

@@ -618,14 +618,16 @@ extern "C" int wiski_sym_dbg(long long* out) { return hipMemcpyFromSymbol(out, H
 template <typename real, int KC, bool DOT>
 __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ V, int k,
                                                            int ng, int nch, int span, int W4, real* __restrict__ part,
-                                                           const real* __restrict__ add, real beta, double* __restrict__ dots) {
+                                                           const real* __restrict__ add, real beta, double* __restrict__ dots, int g_lo, int g_hi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_off[176];
   __shared__ double s_red[16];
   const int m = G.m, d = G.d;
   const int ch = blockIdx.y;
   const int c0 = blockIdx.z * KC;
-  const int gA = (int)((int64_t)ch * ng / nch), gB = (int)((int64_t)(ch + 1) * ng / nch);
+  // the groups of this launch, [g_lo, g_hi) -- all ng of them, or the share of a stencil-sharded replica (wiski_shard) --
+  // dealt to the nch chunks (a chunk may be empty: it then writes a zero partial)
+  const int gA = g_lo + (int)((int64_t)ch * (g_hi - g_lo) / nch), gB = g_lo + (int)((int64_t)(ch + 1) * (g_hi - g_lo) / nch);
   const int cP = ng - 1;                        // prefix code of the centre: (7^(d-1) - 1) / 2
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int STAGE = 7 * 256;                // reals of one group tile of a wave
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
     }
   };
   GroupData cur;
-  int wb = s_off[0];
+  int wb = gB > gA ? s_off[0] : 0;
   for (int g = gA; g < gB; ++g) {
     const int f = s_off[g - gA];
     if (f < wb || f - wb > span) {          // uniform: the window moves on
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
       if (DOT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pd += (double)xo[c][r] * (2.0 * (double)acc[c][r] - (double)dg[c][r]);
-        if (ch == 0 && add) {
+        if (gA == 0 && gB > 0 && add) {        // the chunk that holds the centre group (sharded: on exactly one rank)
           const Vec4<real> ad = load4<real>(add + e);
           pd += (double)beta * ((double)xo[c][0] * ad.x + (double)xo[c][1] * ad.y + (double)xo[c][2] * ad.z + (double)xo[c][3] * ad.w);
         }
@@ -930,9 +932,12 @@ static inline int shard_parts_d3(int lo, int hi, SymDmaParts* tab) {
 
 template <typename real>
 static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real* V, int k, real* part, const real* add, real beta, double* dots,
-                            hipStream_t s, const SymDmaParts* shard_tab = nullptr) {
-  if (shard_tab && !(sizeof(real) == 4 && sym_use_dma<real>(G, k))) return WISKI_E_BADARG;   // sharded products: d = 3, fp32, k = 1 only
-  if (sym_use_cols(k)) {
+                            hipStream_t s, const SymDmaParts* shard_tab = nullptr, int g_lo = 0, int g_hi = -1) {
+  // a stencil shard is given as a part table (the LDS-DMA kernel: d = 3, fp32, k = 1) or as a group range (the LDS-window kernel)
+  if (shard_tab && !(sizeof(real) == 4 && sym_use_dma<real>(G, k))) return WISKI_E_BADARG;
+  const bool ranged = g_hi >= 0;
+  if (ranged && (shard_tab || k != 1 || g_lo < 0 || g_hi < g_lo || g_hi > sym_groups(G.d))) return WISKI_E_BADARG;
+  if (sym_use_cols(k) && !ranged) {
     // part[0] <- A V (column-major, written by the product itself); the row-major copy of V lives behind it
     const int m = G.m, kp = spmmc_kp(k);
     const int64_t km = (int64_t)k * m;
@@ -956,7 +961,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
   }
   if constexpr (sizeof(real) == 4) {
-    if (sym_use_dma<real>(G, k)) {
+    if (sym_use_dma<real>(G, k) && !ranged) {
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
       const size_t sh = symdma_lds_bytes(G.g[2], g_sym_dma_nst);
       SymDmaParts tab{};
@@ -988,7 +993,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     }
   }
   if constexpr (sizeof(real) == 4) {
-    if (sym_use_dma_mc<real>(G, k)) {
+    if (sym_use_dma_mc<real>(G, k) && !ranged) {
       const int kc = k >= 4 ? 4 : 2;
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
       const size_t sh = symdma_mc_lds_bytes(G.g[2], kc);
@@ -1032,8 +1037,10 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return WISKI_E_LAUNCH;                   \
       lds_set[di] = sh;                                                                                                                         \
     }                                                                                                                                           \
-    if (dots) launch_timed(k_stencil_spmv4_sym<real, KC, true>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);  \
-    else launch_timed(k_stencil_spmv4_sym<real, KC, false>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots);      \
+    if (dots) launch_timed(k_stencil_spmv4_sym<real, KC, true>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots,   \
+                           ranged ? g_lo : 0, ranged ? g_hi : ng);                                                                              \
+    else launch_timed(k_stencil_spmv4_sym<real, KC, false>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots,       \
+                      ranged ? g_lo : 0, ranged ? g_hi : ng);                                                                                   \
   } while (0)
   if (kc == 4) SPMV4S(4);
   else if (kc == 2) SPMV4S(2);
@@ -1878,12 +1885,15 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   const int nch = wide ? (sym ? sym_partials<real>(G, k, &zl) : spmv_nch(G.d)) : 0;
   const bool sharded = wiski_shard_active(shard);
   SymDmaParts stab{};
+  int sh_lo = 0, sh_hi = 0;                      // this replica's groups (stencil-sharded solves)
+  bool sh_dma = false;                           // its products run on the LDS-DMA kernel (part table) / on the LDS-window kernel (group range)
   if (sharded) {
-    if (!sym || !wide || G.d != 3 || k != 1 || sizeof(real) != 4 || shard->rank < 0 || shard->rank >= shard->nranks) return WISKI_E_BADARG;
+    if (!sym || !wide || k != 1 || shard->rank < 0 || shard->rank >= shard->nranks) return WISKI_E_BADARG;
     if (!shard->comm && !shard->allreduce) return WISKI_E_BADARG;
-    int glo, ghi;
-    shard_group_range(sym_groups(G.d), shard->rank, shard->nranks, &glo, &ghi);
-    shard_parts_d3(glo, ghi, &stab);           // may be empty (more ranks than groups): that rank contributes zeros
+    if (shard->comm && sizeof(real) != 4) return WISKI_E_BADARG;      // (the in-C RCCL route sums fp32 vectors; fp64 shards use the callback)
+    shard_group_range(sym_groups(G.d), shard->rank, shard->nranks, &sh_lo, &sh_hi);   // may be empty (more ranks than groups): zeros
+    sh_dma = sym_use_dma<real>(G, k);
+    if (sh_dma) shard_parts_d3(sh_lo, sh_hi, &stab);
   }
   // what the consumers of a product read: the partial vectors of the local launch, or the all-reduced sum
   real* cpart = sharded ? hp : part;
@@ -1891,11 +1901,18 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   auto spmv_wide = [&](const real* v, const real* add, real beta, double* dots) -> int {
     if (!sharded)
       return sym ? launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s) : launch_spmv4<real>(G, d_A, v, k, part, add, beta, dots, s);
-    if (stab.n) {
-      if (int r1 = launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s, &stab)) return r1;
+    int np = 0;                                   // partial vectors this rank's launch wrote
+    if (sh_dma) {
+      if (stab.n) {
+        if (int r1 = launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s, &stab)) return r1;
+      }
+      np = stab.n;
+    } else if (sh_hi > sh_lo) {
+      if (int r1 = launch_spmv4_sym<real>(G, d_A, v, k, part, add, beta, dots, s, nullptr, sh_lo, sh_hi)) return r1;
+      np = nch - 1;
     }
     const int m4 = m / 4;
-    hipLaunchKernelGGL((k_shard_reduce<real>), dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, s, m4, m, (const real*)part, stab.n,
+    hipLaunchKernelGGL((k_shard_reduce<real>), dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, s, m4, m, (const real*)part, np,
                        part + (int64_t)(nch - 1) * k * m, hp);
     if (hipGetLastError() != hipSuccess) return WISKI_E_LAUNCH;
     const int64_t nd = dots ? (int64_t)k * PCG_DOT_COL : 0;

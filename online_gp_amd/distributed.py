@@ -129,7 +129,7 @@ class ShardedStatsUpdater:
         """exchange: "stats" (all-reduce the statistics deltas), "points" (all-gather the shards, scatter them all
         on every rank), "stencil" (``stream_step`` only: all-gather the shards, then every rank scatters and multiplies
         only ITS groups of the half stencil and one m-vector all-reduce per CG iteration completes the product -- the one
-        exchange that divides the step's work; d = 3, fp32, one output, else it behaves like "points") or "auto" (the
+        exchange that divides the step's work; one output, grids beyond the dense regime with m % 4 == 0, else it behaves like "points") or "auto" (the
         cheaper of the first two by a simple cost model).  The point exchange needs the same
         shard length on every rank; ``equal_shards=True`` promises that (no size check), otherwise the sizes are
         compared first (one tiny all-reduce + host read) and unequal shards fall back to the statistics exchange."""
@@ -264,7 +264,7 @@ class ShardedStatsUpdater:
         import os
 
         want = os.environ.get("WISKI_SHARD_TRANSPORT", "rccl" if dist.get_backend(group) == "nccl" else "torch")
-        if want == "rccl" and not gloo_cuda:
+        if want == "rccl" and not gloo_cuda and m._dtype == torch.float32:      # (the C route sums fp32 vectors)
             if getattr(self, "_shard_comm", None) is None:
                 self._shard_comm = RcclCommunicator(group)
             comm = self._shard_comm.handle

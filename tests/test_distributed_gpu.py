@@ -199,6 +199,73 @@ def _worker_stencil_shard(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
+def _worker_stencil_shard_any_d(rank, world, port, tmpdir):
+    """The stencil-sharded step outside d = 3 / fp32 (round 4): the LDS-window SpMV restricted to the replica's group range.
+    BASELINE config 2's geometry scaled down (d = 4, fp64, 12^4) and a 2-D fp32 grid beyond the dense regime (64^2): same means,
+    iteration counts and (re-summed) statistics as a single-process model fed the concatenated batches."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.distributed import ShardedStatsUpdater
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    dev = torch.device("cuda:0")
+    ok, msgs = True, []
+
+    def chk(ok_, tag, val):
+        if not val:
+            msgs.append(f'check {tag} failed')
+        return ok_ and bool(val)
+
+    for d, g, dtype, n0, q, tol, cgt in ((4, 12, torch.float64, 6000, 256, 1e-7, 1e-9), (2, 64, torch.float32, 6000, 256, 2e-4, 1e-5)):
+        rng = np.random.default_rng(11 + d)
+        steps = 4
+        X = torch.as_tensor(rng.uniform(-1, 1, (n0 + steps * world * q, d)), device=dev, dtype=dtype)
+        y = torch.sin(2 * X[:, :1]) * torch.cos(X[:, 1:2]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=dtype)
+        gb = torch.tensor([[-1.1, 1.1]] * d)
+        with settings.cg_tolerance(cgt), settings.skip_posterior_variances(True), settings.deferred_refresh(True), settings.deferred_bounds_check(True), torch.no_grad():
+            ref = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], torch.ones_like(y[:n0]), grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+            model = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], torch.ones_like(y[:n0]), grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+            ref.prediction_cache; model.prediction_cache
+            upd = ShardedStatsUpdater(model, equal_shards=True, exchange="stencil")
+            for s in range(steps):
+                lo = n0 + s * world * q
+                want = ref.stream_step(X[lo:lo + world * q], y[lo:lo + world * q])
+                got = upd.stream_step(X[lo + rank * q:lo + (rank + 1) * q], y[lo + rank * q:lo + (rank + 1) * q])
+                ok = chk(ok, 1, torch.allclose(got, want[rank * q:(rank + 1) * q], rtol=10 * tol, atol=10 * tol))
+            ref._finish_pending(); model._finish_pending()
+            ok = chk(ok, 2, upd.last_exchange == "stencil" and model.__dict__.get("_stencil_shard") is not None)
+            ok = chk(ok, 3, ref._last_iters == model._last_iters)
+            msgs.append(f"d={d}: iters ref {ref._last_iters} got {model._last_iters}")
+            ng = (model._grid.R // 7 + 1) // 2
+            lo_g, hi_g = grid_ops.shard_groups(d, rank, world)
+            flat = model._kernel_cache["WtW"].stencil.reshape(-1)
+            reff = ref._kernel_cache["WtW"].stencil.reshape(-1)
+            for a, b in grid_ops.half_stencil_group_slices(model._grid, 0, lo_g) + grid_ops.half_stencil_group_slices(model._grid, hi_g, ng):
+                ok = chk(ok, 4, float(flat[a:b].abs().max()) == 0.0)
+            for a, b in grid_ops.half_stencil_group_slices(model._grid, lo_g, hi_g):
+                ok = chk(ok, 5, (flat[a:b] - reff[a:b]).abs().max().item() <= tol * float(reff.abs().max()))
+            m1 = grid_ops.gather(model._grid, X[:64], model._mean_state["U"], model._err)[:, 0]
+            m2 = grid_ops.gather(ref._grid, X[:64], ref._mean_state["U"], ref._err)[:, 0]
+            ok = chk(ok, 6, torch.allclose(m1, m2, rtol=10 * tol, atol=10 * tol))
+            msgs.append(f"d={d}: mean dev {(m1 - m2).abs().max().item():.2e}")
+            model.leave_stencil_shard()
+            ok = chk(ok, 7, (model._kernel_cache["WtW"].stencil - ref._kernel_cache["WtW"].stencil).abs().max().item() <= tol * float(reff.abs().max()))
+    open(os.path.join(tmpdir, f"sd_{rank}"), "w").write(("1" if ok else "0") + " " + "; ".join(msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stencil_sharded_stream_step_any_dimension_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_stencil_shard_any_d, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = open(tmp_path / f"sd_{r}").read()
+        assert res.startswith("1"), res
+
+
 def test_stencil_sharded_stream_step_world2(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker_stencil_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
