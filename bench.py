@@ -395,7 +395,7 @@ def main():
             try:                                   # an extra that fails must not cost the JSON line: the error is recorded instead
                 # second value: the road-like clustered stream of SURVEY 8d (3droad IS road-like)
                 other = "clustered" if args.stream == "uniform" else "uniform"
-                _, _, bs, its, _, _ = run_stream(other, "auto", R, 7, profile=False)          # as many blocks as the headline: whole passes
+                _, _, bs, its, _, _ = run_stream(other, "auto", R, 0, profile=False)          # as many blocks as the headline, same seeds
                 extra[f"{other}_stream_updates_per_s"] = K * q / block_seconds(bs)[0]
                 extra[f"{other}_stream_cg_iters_per_step_mean"] = float(np.mean(its))
 
@@ -700,7 +700,7 @@ def main():
         # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (tools/pmc_traffic.py),
         # NOT in this run -- read back from the committed profile and labelled with its source
         traffic, traffic_source = None, None
-        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if args.grid == 50 and d == 3 and kname in pmc["kernels"]:
@@ -714,7 +714,7 @@ def main():
         try:
             import csv
 
-            for fn in ("r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
+            for fn in ("r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
                 if not os.path.exists(os.path.join(ROOT, "profiles", fn)):
                     continue
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:

@@ -647,7 +647,10 @@ __global__ __launch_bounds__(256) void k_set_identity(int n, real* __restrict__ 
 template <typename real>
 static int potrf_full(int n, real* d_A, int lda, int32_t* d_info, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (n <= SMALL_N_MAX_POTRF && small_path_enabled()) return potrf_small_entry<real>(n, d_A, lda, (real*)nullptr, 0, d_info, s);
+  if (n <= SMALL_N_MAX_POTRF && small_path_enabled()) {
+    const int rs = potrf_small_entry<real>(n, d_A, lda, (real*)nullptr, 0, d_info, s);
+    if (rs != WISKI_SMALL_UNAVAILABLE) return rs;
+  }
   int rc = potrf_impl<real>(n, d_A, lda, d_info, s);
   if (rc) return rc;
   const int64_t tot = (int64_t)n * n;
@@ -660,7 +663,10 @@ template <typename real>
 static int potrf_inverse(int n, real* d_A, int lda, real* d_X, int ldx, int32_t* d_info, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!d_X || ldx < n) return WISKI_E_BADARG;
-  if (n <= SMALL_N_MAX && small_path_enabled()) return potrf_small_entry<real>(n, d_A, lda, d_X, ldx, d_info, s);
+  if (n <= SMALL_N_MAX && small_path_enabled()) {
+    const int rs = potrf_small_entry<real>(n, d_A, lda, d_X, ldx, d_info, s);
+    if (rs != WISKI_SMALL_UNAVAILABLE) return rs;
+  }
   int rc = potrf_full<real>(n, d_A, lda, d_info, stream);
   if (rc) return rc;
   const int64_t tot = (int64_t)n * n;

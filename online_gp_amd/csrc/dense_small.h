@@ -15,6 +15,7 @@
 // workgroup per 32-column block (the block columns of a triangular inverse are independent):
 //   X_JJ = L_JJ^-1,   X_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK X_KJ.
 #pragma once
+#include <mutex>
 
 constexpr int SNB = 32;        // panel width
 constexpr int SLD = 34;        // LDS row stride (reals)
@@ -466,18 +467,26 @@ static inline size_t tri_inv_small_lds(int n) {
   return (size_t)((mtp + 3 * SNB) * SLD) * sizeof(real);
 }
 
+constexpr int WISKI_SMALL_UNAVAILABLE = 1;   // (internal) the one-workgroup path cannot run on this device: use the blocked one
 // Factor (and optionally invert: d_X != nullptr) a small matrix.  d_dinv: scratch [nblk][32][32].
 template <typename real>
 static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int ldx, int32_t* d_info, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX_POTRF)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_tri_inv_small4<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX) != hipSuccess) {
-      (void)hipGetLastError();
-      return WISKI_E_LAUNCH;
+  // the ~160 KB dynamic-LDS opt-in is a per-device function attribute: tracked per device, set once under a lock; a device that
+  // refuses it (less LDS) answers WISKI_SMALL_UNAVAILABLE and the callers take the blocked path
+  static std::mutex mu;
+  static int state[64] = {0};                     // 0 unknown, 1 granted, -1 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return WISKI_SMALL_UNAVAILABLE;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (state[dev] == 0) {
+      const bool ok = hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX_POTRF)) == hipSuccess &&
+                      hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) == hipSuccess &&
+                      hipFuncSetAttribute((const void*)k_tri_inv_small4<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX) == hipSuccess;
+      if (!ok) (void)hipGetLastError();
+      state[dev] = ok ? 1 : -1;
     }
-    attr_done = true;
+    if (state[dev] < 0) return WISKI_SMALL_UNAVAILABLE;
   }
   hipLaunchKernelGGL((k_potrf_small<real>), dim3(1), dim3(SWG), potrf_small_lds<real>(n), s, n, d_A, lda, d_dinv, d_info);
   if (d_X) {

@@ -49,6 +49,9 @@ class Kernel(torch.nn.Module):
         """`closure()` -> the constrained value `prior` scores; the MLL adds prior.log_prob(closure()).sum() (BWM:48-49)."""
         self.add_module(name, prior)
         self._wiski_priors[name] = (prior, closure)
+        from .priors import note_registration
+
+        note_registration()
 
     @property
     def lengthscale(self):

@@ -121,6 +121,12 @@ class TwoLevelBlock:
                 wa = None if all(p_[1] is None for p_ in points) else torch.cat(
                     [p_[1] if p_[1] is not None else torch.ones(p_[0].shape[0], dtype=p_[0].dtype, device=self.device) for p_ in points])
             sc = None if wa is None else wa.to(X.dtype).sqrt().contiguous()
+            sub = settings.two_level_subsample.value()
+            if sub > 1 and X.shape[0] >= 64 * sub:
+                # G is a sum of one rank-one term per point: every sub-th point with weight `sub` estimates it without bias, and a
+                # preconditioner needs no more (the projection + Gram product are the refresh's only O(points) work)
+                X = X[::sub]
+                sc = (sc[::sub] * (sub ** 0.5)).contiguous() if sc is not None else torch.full((X.shape[0],), float(sub) ** 0.5, dtype=X.dtype, device=self.device)
             X = X.contiguous()
             rc = _hip.lib().wiski_twolevel_refresh_f32(self.grid.ref, _hip.dptr(X), ctypes.c_int64(X.shape[0]), _hip.dptr(sc), _hip.dptr(self.Vtab),
                                                         ctypes.c_int32(self.kw), _hip.dptr(self.S), ctypes.c_int32(self.r), _hip.dptr(self.lam_unit),

@@ -31,9 +31,17 @@ class fixed_trace_probes(settings._feature_flag):
     """Matrix-free MLL: keep the Rademacher probe vectors of the trace estimator fixed from step to step (a sample-average
     objective: the same probes score every hyper-parameter setting) and warm-start their solves from the previous step's
     solutions -- streaming steps change (A, hyper-parameters) a little at a time, so the probe solves then cost 2-3 CG
-    iterations instead of a cold solve each.  Off: fresh probes seeded by the data count, cold solves (gpytorch's habit)."""
+    iterations instead of a cold solve each.  A fixed probe set is a sample-average objective whose Hutchinson error does not
+    average out over steps, so the set is redrawn every ``trace_probe_refresh_every`` steps (one cold multi-column solve then).
+    Off: fresh probes seeded by the data count at every step, cold solves (gpytorch's habit)."""
 
     _state = True
+
+
+class trace_probe_refresh_every(settings._value_context):
+    """Steps a fixed set of trace probes is kept before it is redrawn (``fixed_trace_probes``)."""
+
+    _global_value = 16
 
 
 class _WoodburyTerms(torch.autograd.Function):
@@ -94,11 +102,14 @@ class _WoodburyTerms(torch.autograd.Function):
             # columns 1..P the trace probes (rhs A e_j, FIXED e_j, warm-started from the previous step's solutions: keep
             # the pre-images z, re-derive u = Kt_new z).  The k = P + 1 products read A_h once per 4 columns.
             ps = model.__dict__.get("_mll_probes", {}).get(o)
-            if ps is None or ps["E"].shape != (P, m) or ps["E"].dtype != dt or ps["E"].device != dev:
-                gen = torch.Generator(device=dev).manual_seed(0x5EED + o)
+            if (ps is None or ps["E"].shape != (P, m) or ps["E"].dtype != dt or ps["E"].device != dev
+                    or ps["age"] >= trace_probe_refresh_every.value()):
+                draw = 0 if ps is None else ps["draw"] + 1
+                gen = torch.Generator(device=dev).manual_seed(0x5EED + o + 7919 * draw)
                 E = torch.randint(0, 2, (P, m), generator=gen, device=dev).to(dt) * 2 - 1
-                ps = {"E": E, "Z": None}
+                ps = {"E": E, "Z": None, "age": 0, "draw": draw}
                 model.__dict__.setdefault("_mll_probes", {})[o] = ps
+            ps["age"] += 1
             E = ps["E"]
             RHS = torch.cat([b[None], grid_ops.stencil_spmv(grid, A.stencil, E)])
             warm = ms is not None and ps["Z"] is not None

@@ -66,10 +66,18 @@ class GraphedHyperStep:
             return None
         w = self.w
         gp, opt = w.gp, w.gp_optimizer
-        # (priors registered after a capture are not seen by it: call ``set_lr`` -- a new optimiser -- or toggle the setting to re-capture)
+        # everything the captured graph bakes in: the index sets, the optimiser's hyper-parameters (lr, betas, eps, weight decay ...),
+        # the set of registered priors, the statistics buffer the MLL reads, which parameters are trainable
+        from ..priors import REGISTRY_EPOCH
+
+        def _hp(g):
+            return tuple((k_, (tuple(v) if isinstance(v, (tuple, list)) else v)) for k_, v in sorted(g.items())
+                         if k_ != "params" and isinstance(v, (int, float, bool, tuple, list, type(None))))
+
         key = (tuple((sp[1]["basis"].S.data_ptr(), sp[1]["basis"].r, sp[1]["basis"].kmax) for sp in sps), str(gp._dtype),
-               tuple(float(g["lr"]) for g in opt.param_groups), id(opt),
-               settings.fused_hyper_columns.on(), tuple(p.requires_grad for g in opt.param_groups for p in g["params"]))
+               tuple(_hp(g) for g in opt.param_groups), id(opt),
+               settings.fused_hyper_columns.on(), tuple(p.requires_grad for g in opt.param_groups for p in g["params"]),
+               REGISTRY_EPOCH[0], gp._kernel_cache["_stats"].data_ptr())
         if key != self.key:
             # a capture costs ~2 ms: worth it only if it is then replayed.  If the factor keeps re-selecting its index set (host-side
             # refresh, a kernel whose spectrum moves fast), stop re-capturing for a while and let the eager path run.

@@ -49,6 +49,13 @@ class UniformPrior(Prior):
         return torch.distributions.Uniform(self.a.to(like), self.b.to(like), validate_args=False)
 
 
+REGISTRY_EPOCH = [0]      # bumped by every register_prior call anywhere: a cheap "did the set of priors change" for cached consumers
+
+
+def note_registration():
+    REGISTRY_EPOCH[0] += 1
+
+
 def named_priors(module):
     """(name, prior, closure) for every prior registered (``register_prior``) on `module` or a sub-module;
     ``closure()`` returns the constrained parameter value the prior scores."""

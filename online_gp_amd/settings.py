@@ -243,6 +243,13 @@ class two_level_predictive(_feature_flag):
     _state = True
 
 
+class two_level_subsample(_value_context):
+    """The two-level block's Gram matrix is accumulated from every `n`-th absorbed point (weighted by n): an unbiased estimate
+    of X_S^T W^T D^-1 W X_S at 1/n of the refresh work; 1 = every point."""
+
+    _global_value = 1
+
+
 class two_level_lockstep(_feature_flag):
     """Switch a refreshed two-level block in exactly ``two_level_lag`` steps after its refresh was started even on one GPU (what
     stencil-sharded replicas always do): iteration counts then do not depend on how fast the side stream ran (tests)."""

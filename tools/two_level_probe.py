@@ -26,7 +26,7 @@ def one(kind, on, rank, lag, growth, reps=2):
     X, y = bench.synth_stream(n0 + steps * q, 3, 0, dev, torch.float32, kind)
     best = None
     for rep in range(reps):
-        with settings.two_level_preconditioner(on), settings.two_level_rank(rank), settings.two_level_lag(lag), settings.two_level_growth(growth), \
+        with settings.two_level_subsample(int(os.environ.get('SUB', '1'))), settings.two_level_preconditioner(on), settings.two_level_rank(rank), settings.two_level_lag(lag), settings.two_level_growth(growth), \
                 settings.cg_tolerance(TOL), settings.skip_posterior_variances(True), settings.deferred_refresh(True), settings.deferred_bounds_check(True), torch.no_grad():
             m = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], torch.ones_like(y[:n0]), grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
             m.prediction_cache
