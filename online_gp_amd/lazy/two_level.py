@@ -104,7 +104,7 @@ class TwoLevelBlock:
         self.refreshes = 0
 
     # ------------------------------------------------------------------------------------------------- refresh --
-    def launch_refresh(self, points, step, weight, gscale=1.0):
+    def launch_refresh(self, points, step, weight, gscale=1.0, subsample=None):
         """Queue, on the side stream: G += sum F^T diag(wa) F over `points` [(X, wa or None), ...], then N -> the spare buffer."""
         tgt = 1 - self.active if self.active >= 0 else 0
         main = torch.cuda.current_stream(self.device)
@@ -121,7 +121,7 @@ class TwoLevelBlock:
                 wa = None if all(p_[1] is None for p_ in points) else torch.cat(
                     [p_[1] if p_[1] is not None else torch.ones(p_[0].shape[0], dtype=p_[0].dtype, device=self.device) for p_ in points])
             sc = None if wa is None else wa.to(X.dtype).sqrt().contiguous()
-            sub = settings.two_level_subsample.value()
+            sub = subsample if subsample else settings.two_level_subsample.value()
             if sub > 1 and X.shape[0] >= 64 * sub:
                 # G is a sum of one rank-one term per point: every sub-th point with weight `sub` estimates it without bias, and a
                 # preconditioner needs no more (the projection + Gram product are the refresh's only O(points) work)
@@ -195,7 +195,7 @@ class TwoLevelTracker:
     def lose(self):
         self.pending, self.pending_n, self.covered, self.block, self.block_key = [], 0, False, None, None
 
-    def for_step(self, grid, device, pst, kscale, weight, err, lockstep=False, last_iters=0):
+    def for_step(self, grid, device, pst, kscale, weight, err, lockstep=False, last_iters=0, subsample=None):
         """Called once per fast streaming step, after its batch was noted: returns the TwoLevelStruct to solve with (or None)
         and keeps the refresh pipeline going.  `weight`: absorbed weight (sum of wa) including this step's batch; `last_iters`:
         CG iterations of the most recent finished solve."""
@@ -233,5 +233,5 @@ class TwoLevelTracker:
             lo, hi = weight + lag * dq, max(growth * weight, weight + dq) + lag * dq
             gscale = 0.5 * (lo + hi) / max(weight, 1.0) if settings.two_level_predictive.on() else 1.0
             pts, self.pending, self.pending_n = self.pending, [], 0
-            blk.launch_refresh(pts, self.step, weight, gscale)
+            blk.launch_refresh(pts, self.step, weight, gscale, subsample)
         return blk.struct if blk.active >= 0 else None

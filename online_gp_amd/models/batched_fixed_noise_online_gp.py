@@ -969,9 +969,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if tr is not None:
             tr.note(X, None)
             _, s2, _ = self._hyper()[0]
+            sh = self.__dict__.get("_stencil_shard")
+            # stencil-sharded replicas see the gathered batch of ALL ranks and each keeps its own copy of the block: every world-th
+            # point (weighted) keeps a replica's refresh work at what one GPU's stream costs (the side stream must keep pace with
+            # the steps, or the lock-step switch would stall them)
+            sub = max(settings.two_level_subsample.value(), sh["world"]) if sh is not None and sh["world"] > 1 else None
             tl = tr.for_step(self._grid, self._device, pst, 1.0 / s2, float(self._wsum[0]), self._err,
-                             lockstep=self.__dict__.get("_stencil_shard") is not None or settings.two_level_lockstep.on(),
-                             last_iters=(getattr(self, "_last_iters", None) or [0])[0])
+                             lockstep=sh is not None or settings.two_level_lockstep.on(),
+                             last_iters=(getattr(self, "_last_iters", None) or [0])[0], subsample=sub)
             if tr.switched:
                 # a new block: the iteration count of the previous solves says little about the next one -- poll after 2 iterations,
                 # then after every one (the poll placement would otherwise walk down one iteration per probe)

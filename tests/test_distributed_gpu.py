@@ -171,13 +171,14 @@ def _worker_stencil_shard(rank, world, port, tmpdir):
         ok = ok and torch.allclose(got, want[rank * q:(rank + 1) * q], rtol=1e-3, atol=2e-4) and model.__dict__.get("_stencil_shard") is not None
     # the two-level preconditioner inside the sharded step: replicas must switch a refreshed block in at the SAME step (lock-step
     # activation) or their iteration counts -- and with them their collectives -- diverge.  Forced on (min_iters 0) on a
-    # road-like stream; the single-process reference runs the same lock-step schedule.
+    # road-like stream; the single-process reference runs the same lock-step schedule and the same subsampling of the Gram
+    # accumulation (a sharded replica takes every world-th point of the gathered batch).
     sys.path.insert(0, ROOT)
     import bench
 
     Xc, yc = bench.synth_stream(n0 + 10 * world * q, 3, 3, dev, torch.float32, "clustered")
     with settings.cg_tolerance(1e-5), settings.skip_posterior_variances(True), settings.deferred_refresh(True), settings.deferred_bounds_check(True), \
-            settings.two_level_min_iters(0.0), settings.two_level_rank(96), settings.two_level_lockstep(True), torch.no_grad():
+            settings.two_level_min_iters(0.0), settings.two_level_rank(96), settings.two_level_lockstep(True), settings.two_level_subsample(2), torch.no_grad():
         ref = FixedNoiseOnlineSKIGP(Xc[:n0], yc[:n0], torch.ones_like(yc[:n0]), grid_bounds=gb, grid_size=24, learn_additional_noise=True).eval()
         model = FixedNoiseOnlineSKIGP(Xc[:n0], yc[:n0], torch.ones_like(yc[:n0]), grid_bounds=gb, grid_size=24, learn_additional_noise=True).eval()
         ref.prediction_cache; model.prediction_cache
