@@ -56,8 +56,10 @@ class GraphedHyperStep:
         sps = [gp._spectral_state(o) for o in range(gp.num_outputs)]      # one factor per output (own statistics, own hyper-parameters)
         return sps if all(sp is not None for sp in sps) else None
 
-    def step(self):
-        """One Adam step on -MLL; returns the loss, or None when the caller has to take the eager path."""
+    def step(self, lazy=False):
+        """One Adam step on -MLL; returns the loss, or None when the caller has to take the eager path.  lazy: return the device
+        scalar instead of reading it (the read is a synchronisation: a caller with more launches to queue -- the absorb of the
+        batch -- reads it after those; valid until the next replay)."""
         sps = self._applicable()
         if sps is None:
             return None
@@ -102,7 +104,7 @@ class GraphedHyperStep:
         self.graph.replay()
         self.replays += 1
         gp.zero_grad()                                # (as the eager step: drops the gradients and moves the hyper-parameter epoch on)
-        return float(self.loss)
+        return self.loss if lazy else float(self.loss)
 
     # ---------------------------------------------------------------------------------------------------------------------
     def _stage(self, sps):

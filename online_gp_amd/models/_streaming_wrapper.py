@@ -130,6 +130,8 @@ class StreamingSKIWrapper(torch.nn.Module):
                 if update_stem:                      # running statistics see the new points and a replay sample
                     self.stem(torch.cat([inputs, self._replay.sample(_REPLAY)]))
         self._ensure_eval()
+        if torch.is_tensor(gp_loss):                 # the captured step's loss, read only now: the absorb above was queued behind the
+            gp_loss = float(gp_loss)                 # graph without waiting for it (one GPU idle gap less per step)
         return stem_loss, gp_loss
 
     def _ensure_eval(self):
@@ -146,7 +148,7 @@ class StreamingSKIWrapper(torch.nn.Module):
             from ._graphed_step import GraphedHyperStep
 
             gs = self.__dict__["_graphed"] = GraphedHyperStep(self)
-        loss = gs.step()                             # forward + backward + Adam as one captured graph where that applies
+        loss = gs.step(lazy=True)                    # forward + backward + Adam as one captured graph where that applies
         if loss is not None:
             return loss
         opt = self.gp_optimizer

@@ -13,7 +13,7 @@ observation variance (latent + sigma^2), ``evaluate`` averages per-batch RMSE / 
 The streaming protocol itself lives in ``_streaming_wrapper.StreamingSKIWrapper``."""
 import torch
 
-from .. import grid_ops
+from .. import grid_ops, settings
 from ._streaming_wrapper import EVAL_CHUNK, StreamingSKIWrapper
 from .batched_fixed_noise_online_gp import FixedNoiseOnlineSKIGP
 
@@ -64,11 +64,15 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         self._ensure_eval()
         per_batch = []
         fused = self.target_dim == 1 and inputs.is_cuda
+        # the out-of-grid check of the queries is read together with the metrics (ONE host sync at the end instead of one inside
+        # every posterior call plus one for the metrics: each sync leaves the GPU idle until the host has queued the next launch)
+        late_check = fused and settings.deferred_bounds_check.off()
         for lo in range(0, inputs.shape[0], EVAL_CHUNK):
             y = targets[lo:lo + EVAL_CHUNK]
             if fused:
                 # one output: both metrics of the batch from (mean, variance, sigma2) in one launch (wiski_gaussian_metrics)
-                post = self(inputs[lo:lo + EVAL_CHUNK])
+                with settings.deferred_bounds_check(True):
+                    post = self(inputs[lo:lo + EVAL_CHUNK])
                 mu = post.mean.reshape(-1).contiguous()
                 s2 = self.gp.likelihood.second_noise.detach().reshape(-1).to(mu.dtype)
                 per_batch.append(grid_ops.gaussian_metrics(mu, post.variance.reshape(-1).to(mu.dtype).contiguous(), y.reshape(-1).to(mu.dtype).contiguous(),
@@ -78,6 +82,11 @@ class OnlineSKIRegression(StreamingSKIWrapper):
             sq = (mean - y) ** 2
             nll = 0.5 * (sq / var + var.log() + _LOG_2PI)
             per_batch.append(torch.stack([sq.mean().sqrt(), nll.mean()]))
+        if late_check:
+            vals = torch.cat([torch.stack(per_batch).mean(0).double(), self.gp._err.double()]).tolist()
+            if int(vals[2]):
+                self.gp._raise_out_of_bounds(int(vals[2]))      # as the posterior call would have (gpytorch raises inside it)
+            return vals[0], vals[1]
         rmse, nll = torch.stack(per_batch).mean(0).tolist()
         return rmse, nll
 
