@@ -64,12 +64,14 @@ __global__ __launch_bounds__(256) void k_gram_acc(int n, int r, int chunk, const
   }
 }
 
-// N32[i][j] = sq[i] sq[j] T[i][j] / gscale
-__global__ void k_tl_scale_cast(int r, const double* __restrict__ T, const double* __restrict__ sq, double inv_gscale, float* __restrict__ N) {
+// N32[i][j] = sq[i] sq[j] T[i][j] / gscale; a failed factorisation (*info != 0: G was corrupted) poisons N with NaNs so that the
+// caller's finiteness check keeps the block from ever being switched in
+__global__ void k_tl_scale_cast(int r, const double* __restrict__ T, const double* __restrict__ sq, double inv_gscale, const int32_t* __restrict__ info,
+                                float* __restrict__ N) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < r * r) {
     const int i = e / r, j = e - i * r;
-    N[e] = (float)(sq[i] * sq[j] * T[e] * inv_gscale);
+    N[e] = *info ? __builtin_nanf("") : (float)(sq[i] * sq[j] * T[e] * inv_gscale);
   }
 }
 
@@ -118,7 +120,7 @@ int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t
   if (int rc = wiski_potrf_inverse_f64(r, C, r, Li, r, info, stream)) return rc;
   if (int rc = wiski_gemm_f64(1, 0, r, r, r, 1.0, Li, r, Li, r, 0.0, T, r, stream)) return rc;
   hipLaunchKernelGGL(k_tl_scale_cast, dim3((unsigned)((r * r + 255) / 256)), dim3(256), 0, s, (int)r, (const double*)T, (const double*)sq, 1.0 / gscale,
-                     d_N);
+                     (const int32_t*)info, d_N);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 }

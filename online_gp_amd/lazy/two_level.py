@@ -100,6 +100,7 @@ class TwoLevelBlock:
             _SIDE[str(device)] = torch.cuda.Stream(device=device)
         self.side = _SIDE[str(device)]
         self.in_flight = None                  # (event, step it was launched at, buffer index)
+        self.failed = False
         self.weight_at_launch = 0.0
         self.refreshes = 0
 
@@ -134,6 +135,10 @@ class TwoLevelBlock:
                                                         ctypes.c_int64(self.work.numel()), _hip.dptr(self.N[tgt]), _hip.stream_ptr(self.device))
             _hip.check(rc, "wiski_twolevel_refresh")
             self._keep = (X, sc)                     # alive until the side stream has read them (replaced by the next refresh)
+            # verdict of the refresh (a failed factorisation poisons N): lands in pinned memory before `done`, read without a sync
+            if getattr(self, "_ok_host", None) is None:
+                self._ok_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._ok_host.copy_(torch.isfinite(self.N[tgt]).all().to(torch.int32).reshape(1), non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.side)
         self.in_flight = (done, step, tgt)
@@ -157,6 +162,9 @@ class TwoLevelBlock:
                 return False
             done.synchronize()
         self.in_flight = None
+        if not int(self._ok_host[0]):
+            self.failed = True                  # G is corrupt (non-finite points reached it): the tracker drops the block
+            return False
         self.active = tgt
         self.struct.d_N = self.N[tgt].data_ptr()
         return True
@@ -224,6 +232,9 @@ class TwoLevelTracker:
         blk = self.block
         self.step += 1
         self.switched = blk.tick(self.step, settings.two_level_lag.value(), lockstep)
+        if blk.failed:
+            self.lose()
+            return None
         growth = settings.two_level_growth.value()
         if blk.in_flight is None and self.pending and weight >= growth * blk.weight_at_launch:
             # the block will serve from ~`lag` steps on until the next one arrives (~`lag` steps after the weight has grown by

@@ -158,3 +158,32 @@ def test_tracker_gives_up_when_points_bypass_it_and_after_a_hyper_step():
         ref._dump_caches()
         ref.condition_on_observations(X[4000:5000], y[4000:5000], None, inplace=True)
         assert torch.allclose(m(X[:64]).mean, ref(X[:64]).mean, rtol=1e-2, atol=2e-3)
+
+
+def test_a_corrupt_block_is_never_switched_in():
+    """A refresh whose factorisation fails (here: NaNs planted in G, as garbage points would) poisons its N; the tracker sees the
+    verdict before the switch, drops the block for good and the stream carries on with the separable preconditioner -- same mean."""
+    from online_gp_amd import settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    X, y = _clustered(8000, 2)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    with settings.skip_posterior_variances(True), settings.two_level_rank(64), settings.two_level_min_iters(0.0), settings.two_level_growth(1.0), \
+            settings.two_level_lockstep(True), torch.no_grad():
+        m = FixedNoiseOnlineSKIGP(X[:2000], y[:2000], None, grid_bounds=gb, grid_size=16, learn_additional_noise=True).eval()
+        m.prediction_cache
+        for s in range(8):
+            m.stream_step(X[2000 + 250 * s:2250 + 250 * s], y[2000 + 250 * s:2250 + 250 * s])
+        tr = m.__dict__["_two_level"]
+        blk = tr.block
+        assert blk is not None and blk.active >= 0
+        blk.finish()
+        torch.cuda.synchronize()
+        blk.G.fill_(float("nan"))
+        for s in range(8, 16):
+            m.stream_step(X[2000 + 250 * s:2250 + 250 * s], y[2000 + 250 * s:2250 + 250 * s])
+        m._finish_pending()
+        assert blk.failed and tr.block is None and not tr.covered
+        ref = FixedNoiseOnlineSKIGP(X[:6000], y[:6000], None, grid_bounds=gb, grid_size=16, learn_additional_noise=True).eval()
+        got, want = m(X[:64]).mean, ref(X[:64]).mean
+        assert torch.isfinite(got).all() and torch.allclose(got, want, rtol=1e-2, atol=2e-3)
