@@ -910,3 +910,9 @@ int64_t wiski_root_update_workspace_elems(int32_t m, int32_t r, int32_t q) { ret
 int wiski_root_update_f32(int32_t m, int32_t r, int32_t q, float* L, int32_t ldl, float* R, int32_t ldr, const float* V, int32_t ldv, float* ws, int64_t ws_elems, void* s) { return root_update_impl<float>(m, r, q, L, ldl, R, ldr, V, ldv, ws, ws_elems, s); }
 int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* L, int32_t ldl, double* R, int32_t ldr, const double* V, int32_t ldv, double* ws, int64_t ws_elems, void* s) { return root_update_impl<double>(m, r, q, L, ldl, R, ldr, V, ldv, ws, ws_elems, s); }
 }
+
+#ifdef WISKI_POTRF_TIMING
+extern "C" int wiski_potrf_stamps(long long* host_out) {   // tools only: the phase stamps of the last one-workgroup factorisation
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_potrf_stamp), sizeof(long long) * 17 * 8) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -65,14 +65,18 @@ __device__ __forceinline__ double read_lane(double v, int src) {
 // One wave: sD (32 x 32, LDS, identity-padded beyond nb) -> its Cholesky factor in place (strict upper zeroed) and the
 // inverse of the factor in sI.  The two halves of the wave run the SAME instruction stream on different data: lane t < 32
 // holds row t of the matrix, lane 32 + t holds e_t, the right-hand side whose forward substitution gives column t of the
-// inverse.  Step k: the pivot by a lane read, a_k = v[k] / sqrt(pivot) in every lane (the factor's column entry l_tk in the
-// lower half, the inverse's entry x_kt in the upper half), column k of the factor published through LDS, and
-// v[j] -= a_k l_jk for j > k -- which is the rank-1 update of the factorisation in the lower half and the substitution step in
-// the upper half.  The inverse costs no extra instructions.  Returns true if a pivot was not positive.
+// inverse.  Step k: a_k = v[k] / sqrt(pivot) in every lane (the factor's column entry l_tk in the lower half, the inverse's
+// entry x_kt in the upper half) and v[j] -= a_k l_jk for j > k -- the rank-1 update of the factorisation in the lower half and
+// the substitution step in the upper half.  The inverse costs no extra instructions.
+//
+// The serial chain of a step is pivot -> rsqrt (+ 2 Newton steps) -> a_k -> the next pivot, and nothing else: the update of
+// the next TWO columns takes l_{k+1,k}, l_{k+2,k} by lane reads (v_readlane: no LDS round trip), the rest of the rank-1 update
+// (columns >= k + 3) goes through LDS one iteration LATER -- its broadcast reads are issued at the top of the next iteration
+// and land while that iteration's rsqrt chain runs (updates of a column commute; column j only has to be complete when step j
+// starts, and steps j - 1 / j - 2 reach it by the lane-read path).  One wave's LDS operations execute in order, so the reads
+// need no wait on the write before them.  ~9 -> ~3 us per 32 x 32 block in fp64.  Returns true if a pivot was not positive.
 template <typename real>
 __device__ __forceinline__ bool wave_potrf32(real (*sD)[SLD], real (*sI)[SLD], real (*sCol)[2 * SNB], int lane) {
-  const int t = lane & 31;
-  const bool fac = lane < SNB;
   // (an opaque zero added to the LDS bases: the ~600 constant addresses of the unrolled loop below then stay immediate offsets of
   // one base register instead of being materialised and hoisted out of the caller's loop, which spilled ~500 registers)
   int opaque = 0;
@@ -80,13 +84,27 @@ __device__ __forceinline__ bool wave_potrf32(real (*sD)[SLD], real (*sI)[SLD], r
   sCol += opaque;
   sD += opaque;
   sI += opaque;
+  const int t = lane & 31;
+  const bool fac = lane < SNB;
   real v[SNB];
 #pragma unroll
-  for (int j = 0; j < SNB; ++j) v[j] = fac ? sD[t][j] : (j == t ? (real)1 : (real)0);
+  for (int j = 0; j < SNB; ++j) {
+    const real ld = sD[t][j];                    // (every lane reads: a select, not a branch -- with branches in this function the
+    v[j] = fac ? ld : (j == t ? (real)1 : (real)0);   //  compiler sinks the deferred updates to their uses and spills)
+  }
   bool bad = false;
+  real piv0 = read_lane(v[0], 0);
+  real aprev = (real)0;
 #pragma unroll
   for (int k = 0; k < SNB; ++k) {
-    const real piv0 = read_lane(v[k], k);
+    // broadcast reads for the deferred part of step k - 1 (columns >= k + 2)
+    real lc[SNB];
+    if (k >= 1) {
+#pragma unroll
+      for (int j = k + 2; j < SNB; ++j) lc[j] = sCol[(k - 1) & 1][j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the chain
     if (!(piv0 > (real)0)) bad = true;
     const real piv = piv0 > (real)0 ? piv0 : (real)1;
     real ri;
@@ -98,14 +116,23 @@ __device__ __forceinline__ bool wave_potrf32(real (*sD)[SLD], real (*sI)[SLD], r
       ri = ri * (1.5 - 0.5 * piv * ri * ri);
       ri = ri * (1.5 - 0.5 * piv * ri * ri);
     }
-    const real ak = (fac && t < k) ? (real)0 : v[k] * ri;      // rows above the pivot take no part (their v[k] is upper-triangle data)
+    // (rows t < k of the factor half carry upper-triangle leftovers in v[k]: they scale and update them like everybody else --
+    //  nobody reads those slots, the store below writes zeros there -- which keeps the loop free of branches)
+    const real ak = v[k] * ri;
     v[k] = ak;
-    sCol[k & 1][lane] = ak;                      // (unconditional: slots 32..63 take the upper half's values and are never read; a branch here
-                                                 //  splits the block and the compiler then sinks the updates below to their distant uses -- spills)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    if (k + 1 < SNB) {
+      v[k + 1] -= ak * read_lane(ak, k + 1);
+      piv0 = read_lane(v[k + 1], k + 1);
+    }
+    if (k + 2 < SNB) v[k + 2] -= ak * read_lane(ak, k + 2);
+    sCol[k & 1][lane] = ak;                      // (unconditional: slots 32..63 take the upper half's values and are never read)
+    __builtin_amdgcn_sched_barrier(0);
+    // deferred part of step k - 1
+    if (k >= 1) {
 #pragma unroll
-    for (int j = k + 1; j < SNB; ++j) v[j] -= ak * sCol[k & 1][j];
+      for (int j = k + 2; j < SNB; ++j) v[j] -= aprev * lc[j];
+    }
+    aprev = ak;
     __builtin_amdgcn_sched_barrier(0);           // finish this step's updates here: deferring them keeps the loaded columns live (spills)
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -118,65 +145,148 @@ __device__ __forceinline__ bool wave_potrf32(real (*sD)[SLD], real (*sI)[SLD], r
   return bad;
 }
 
+#ifdef WISKI_POTRF_TIMING                             // phase stamps of the factorisation workgroup (tools/potrf_phases.py: a -DWISKI_POTRF_TIMING build)
+__device__ long long g_potrf_stamp[17 * 8];
+#define POTRF_STAMP(round, k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (round) < 17) g_potrf_stamp[(round) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define POTRF_STAMP(round, k) do { } while (0)
+#endif
+
 // A (n x n, lda) -> lower Cholesky factor in place (strict upper zeroed), inverses of the 32 x 32 diagonal blocks of the
-// factor in dinv [nblk][32][32] (identity-padded).  One workgroup of SWG threads.  Dynamic LDS: (nrow_pad + 64) * SLD + 128 reals.
+// factor in dinv [nblk][32][32] (identity-padded).  One workgroup of SWG threads.  Dynamic LDS: potrf_small_lds(n).
+//
+// The loop is written so that every piece of code exists ONCE (the unrolled diagonal step alone is 13 KB in fp64; the kernel
+// has to stay well inside the 64 KB instruction cache it shares with the neighbouring CU -- a round executes each phase once,
+// so a kernel that does not fit re-fetches every instruction of every round from L2: measured 8.7 vs 5.3 us for the diagonal
+// step, and the 60 KB version of this kernel lost 3 us per round to it).  A round of block k:
+//   X   wave 0 factorises + inverts the diagonal block (LDS -> LDS) WHILE the other 7 waves finish the trailing update of the
+//       previous round (D2: tiles with tj >= 1, operands = the previous panel in LDS) and then -- once all 7 are through,
+//       counted in LDS, no workgroup barrier -- bring this round's panel (written by the previous D1) into LDS
+//   --  factor block and its inverse to global
+//   C   panel L21 = A21 L11^-T, one 32-row MFMA tile per wave (in place in LDS, and to global)
+//   D1  first block column of A22 -= L21 L21^T: the NEXT diagonal block (stays in LDS) and the next panel (to global)
 template <typename real>
 __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A, int lda, real* __restrict__ dinv, int32_t* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real(*sD)[SLD] = reinterpret_cast<real(*)[SLD]>(smem_raw);
   real(*sI)[SLD] = sD + SNB;
   real(*sCol)[2 * SNB] = reinterpret_cast<real(*)[2 * SNB]>(sI + SNB);
-  real(*sP)[SLD] = reinterpret_cast<real(*)[SLD]>(reinterpret_cast<real*>(sCol) + 4 * SNB);
+  int* sCnt = reinterpret_cast<int*>(reinterpret_cast<real*>(sCol) + 4 * SNB);      // arrivals of the 7 update waves (monotone)
+  real(*sP)[SLD] = reinterpret_cast<real(*)[SLD]>(reinterpret_cast<real*>(sCol) + 4 * SNB + 2);
   using acc_t = typename Acc4<real>::type;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  constexpr int RP = SWG / 32;                               // rows per pass of the cooperative loads (32 columns x RP rows)
-  const int lj = tid & 31, li0 = tid >> 5;
-  // panel below the diagonal block at k0 (rows k0 + nb .., columns k0 .. k0 + nb) -> sP, zero-padded to whole tiles.  Loads in
-  // batches of 8 per thread: issued back to back, one wait (a load-store loop pays the L2 latency per row).
-  auto load_panel = [&](int k0, int nb, int mt, int mtp) {
+  const int lj = tid & 31;
+  // panel below the diagonal block at k0 (rows k0 + nb .., columns k0 .. k0 + nb) -> sP, zero-padded to whole tiles, by the
+  // threads t0 .. t0 + 32 * rp.  Loads in batches of 8 per thread: issued back to back, one wait.
+  auto load_panel = [&](int k0, int nb, int mt, int mtp, int t0, int rp) {
+    const int li0 = (tid - t0) >> 5;
     real v[8];
-    for (int rb = 0; rb < mtp; rb += 8 * RP) {
+    for (int rb = 0; rb < mtp; rb += 8 * rp) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int r = rb + u * RP + li0;
+        const int r = rb + u * rp + li0;
         v[u] = (r < mt && lj < nb) ? A[(int64_t)(k0 + nb + r) * lda + k0 + lj] : (real)0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int r = rb + u * RP + li0;
+        const int r = rb + u * rp + li0;
         if (r < mtp) sP[r][lj] = v[u];
       }
     }
   };
-  auto store_diag = [&](int k0, int nb, int blk) {           // factor block and its inverse (LDS) -> A, dinv
-    for (int i = li0; i < SNB; i += RP) {
+  // one lower tile (ti >= tj) of the trailing matrix at `base`:  A22 -= P_ti P_tj^T with the panel rows in sP; lim = its rows.
+  // load_tile requests the tile of A22 (16 independent loads), finish_tile does the products and writes it back.  Tile (0, 0)
+  // of D1 is the next diagonal block: it stays in LDS (identity-padded to 32 x 32).
+  auto load_tile = [&](int ti, int tj, int base, int lim, real (&cv)[2][2][4]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ti * SNB + a * 16 + frag_row<real>(lane, r), j = tj * SNB + b * 16 + (lane & 15);
+          cv[a][b][r] = (i < lim && j <= i) ? A[(int64_t)(base + i) * lda + base + j] : (real)0;
+        }
+  };
+  auto finish_tile = [&](int ti, int tj, int base, int lim, bool diag_to_lds, int nbn, const real (&cv)[2][2][4]) {
+    acc_t acc[2][2];
+    zero_acc<real>(acc);
+    wave_tile32<real>(lane, SNB, [&](int i, int k) { return sP[ti * SNB + i][k]; }, [&](int k, int j) { return sP[tj * SNB + j][k]; }, acc);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int il = a * 16 + frag_row<real>(lane, r), jl = b * 16 + (lane & 15);
+          const int i = ti * SNB + il, j = tj * SNB + jl;
+          const real v = cv[a][b][r] - acc[a][b][r];
+          if (diag_to_lds && ti == 0) sD[il][jl] = (il < nbn && jl < nbn) ? v : (il == jl ? (real)1 : (real)0);
+          else if (i < lim && j <= i) A[(int64_t)(base + i) * lda + base + j] = v;
+        }
+  };
+  // ---- prologue: first diagonal block and first panel into LDS
+  {
+    const int nb = n < SNB ? n : SNB;
+    for (int i = tid >> 5; i < SNB; i += SWG / 32) sD[i][lj] = (i < nb && lj < nb) ? A[(int64_t)i * lda + lj] : (i == lj ? (real)1 : (real)0);
+    const int mt = n - nb;
+    load_panel(0, nb, mt, (mt + SNB - 1) / SNB * SNB, 0, SWG / 32);
+    if (tid == 0) *sCnt = 0;
+  }
+  __syncthreads();
+  int pmt = 0;                                               // rows of the previous round's trailing matrix (it starts at k0)
+  int narr = 0;                                              // arrivals the update waves have waited for so far
+  for (int k0 = 0, blk = 0;; ++blk) {
+    const int nb = n - k0 < SNB ? n - k0 : SNB;
+    const int mt = n - k0 - nb;                              // rows below the diagonal block
+    const int mtp = (mt + SNB - 1) / SNB * SNB;
+    POTRF_STAMP(blk, 0);
+    // ---- X: wave 0 on the diagonal block; the others on the previous round's trailing tiles, then this round's panel
+    if (w == 0) {
+      __builtin_amdgcn_s_setprio(3);                          // the serial chain of the round: ahead of the tile waves on this SIMD
+      const bool bad = wave_potrf32<real>(sD, sI, sCol, lane);
+      __builtin_amdgcn_s_setprio(0);
+      if (bad && lane == 0) atomicOr(info, 1);
+      POTRF_STAMP(blk, 1);
+    } else {
+      const int pnt = (pmt + SNB - 1) / SNB;
+      const int ntile2 = (pnt - 1) * pnt / 2;                // lower triangle of the (pnt - 1) x (pnt - 1) tiles with ti >= tj >= 1
+      // wave w takes the tiles tl = w - 1, w - 1 + 7, ... of the triangle (row by row).  (Requesting the next tile before this
+      // tile's products was measured: no gain -- at 64 cycles per fp64 MFMA the CU's matrix pipes, not the L2 latency, bound
+      // this phase -- and its 6 KB of code pushed the kernel out of the instruction cache)
+      int ti = 1, tj = 1;
+      for (int tl = 0; tl < ntile2; ++tl) {
+        if (tl % (SNW - 1) == w - 1) {
+          real cv[2][2][4];
+          load_tile(ti, tj, k0, pmt, cv);
+          finish_tile(ti, tj, k0, pmt, false, 0, cv);
+        }
+        if (++tj > ti) { ++ti; tj = 1; }
+      }
+      if (blk > 0 && mt > 0) {
+        // all 7 waves have read their last operands from the previous panel -> it may be overwritten
+        __threadfence_block();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        narr += SNW - 1;
+        if (lane == 0) {
+          __hip_atomic_fetch_add(sCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          while (__hip_atomic_load(sCnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < narr) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_panel(k0, nb, mt, mtp, 64, (SWG - 64) / 32);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    POTRF_STAMP(blk, 2);
+    // ---- factor block and its inverse (LDS) -> A, dinv
+    for (int i = tid >> 5; i < SNB; i += SWG / 32) {
       if (i < nb && lj < nb) A[(int64_t)(k0 + i) * lda + k0 + lj] = sD[i][lj];
       dinv[(int64_t)blk * SNB * SNB + i * SNB + lj] = sI[i][lj];
     }
-  };
-  // ---- prologue: first diagonal block factorised, first panel loaded
-  {
-    const int nb = n < SNB ? n : SNB;
-    for (int i = li0; i < SNB; i += RP) sD[i][lj] = (i < nb && lj < nb) ? A[(int64_t)i * lda + lj] : (i == lj ? (real)1 : (real)0);
-    const int mt = n - nb;
-    load_panel(0, nb, mt, (mt + SNB - 1) / SNB * SNB);
-    __syncthreads();
-    if (w == 0) {
-      const bool bad = wave_potrf32<real>(sD, sI, sCol, lane);
-      if (bad && lane == 0) atomicOr(info, 1);
-    }
-    __syncthreads();
-    store_diag(0, nb, 0);
-  }
-  // Each round: panel of block k (C), then the first block column of the trailing update (D1: it yields the NEXT diagonal block,
-  // kept in LDS, and the next panel, to global), then -- concurrently -- wave 0 factorises that next diagonal block while the
-  // other waves do the rest of the trailing update (D2): the one-wave factorisation (~9 us) is the longest serial piece of a round
-  // and now hides behind the tile products.
-  for (int k0 = 0, blk = 0; k0 < n; k0 += SNB, ++blk) {
-    const int nb = n - k0 < SNB ? n - k0 : SNB;
-    const int mt = n - k0 - nb;                              // rows below the diagonal block
     if (mt == 0) break;
-    const int mtp = (mt + SNB - 1) / SNB * SNB;
+    const int nt = mtp / SNB;
+    const int nbn = mt < SNB ? mt : SNB;                     // size of the next diagonal block
     // ---- C: panel L21 = A21 L11^-T, one 32-row tile per wave (in place in LDS, and to global)
     for (int rt = w; rt * SNB < mt; rt += SNW) {
       const int r0 = rt * SNB;
@@ -197,92 +307,18 @@ __global__ __launch_bounds__(SWG) void k_potrf_small(int n, real* __restrict__ A
           }
     }
     __syncthreads();
-    const int nt = mtp / SNB;
-    const int nbn = mt < SNB ? mt : SNB;                     // size of the next diagonal block
-    // one lower tile (ti >= tj) of A22 -= L21 L21^T; the tile of A22 first (16 independent loads in flight under the MFMA loop)
-    auto load_tile = [&](int ti, int tj, real (&cv)[2][2][4]) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = ti * SNB + a * 16 + frag_row<real>(lane, r), j = tj * SNB + b * 16 + (lane & 15);
-            cv[a][b][r] = (i < mt && j <= i) ? A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] : (real)0;
-          }
-    };
-    auto finish_tile = [&](int ti, int tj, const real (&cv)[2][2][4]) {
-      acc_t acc[2][2];
-      zero_acc<real>(acc);
-      wave_tile32<real>(lane, SNB, [&](int i, int k) { return sP[ti * SNB + i][k]; }, [&](int k, int j) { return sP[tj * SNB + j][k]; }, acc);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int il = a * 16 + frag_row<real>(lane, r), jl = b * 16 + (lane & 15);
-            const int i = ti * SNB + il, j = tj * SNB + jl;
-            const real v = cv[a][b][r] - acc[a][b][r];
-            if (ti == 0 && tj == 0) sD[il][jl] = (il < nbn && jl < nbn) ? v : (il == jl ? (real)1 : (real)0);   // next diagonal block: stays in LDS
-            else if (i < mt && j <= i) A[(int64_t)(k0 + nb + i) * lda + k0 + nb + j] = v;
-          }
-    };
-    auto update_tile = [&](int ti, int tj) {
+    POTRF_STAMP(blk, 3);
+    // ---- D1: first block column of the update (the next diagonal block -> sD, the next panel -> global)
+    for (int ti = w; ti < nt; ti += SNW) {
       real cv[2][2][4];
-      load_tile(ti, tj, cv);
-      finish_tile(ti, tj, cv);
-    };
-    // ---- D1: first block column of the update
-    for (int ti = w; ti < nt; ti += SNW) update_tile(ti, 0);
-    __threadfence_block();
-    __syncthreads();
-    // ---- B (wave 0: next diagonal block) alongside D2 (the other waves: tiles with tj >= 1)
-    if (w == 0) {
-      const bool bad = wave_potrf32<real>(sD, sI, sCol, lane);
-      if (bad && lane == 0) atomicOr(info, 1);
-    } else {
-      const int ntile2 = (nt - 1) * nt / 2;                  // lower triangle of the (nt - 1) x (nt - 1) tiles with ti >= tj >= 1
-      // (the next tile's 16 loads are issued before this tile's products: with two waves per SIMD little else hides the L2 latency)
-      auto decode = [&](int tl, int& ti, int& tj) {
-        int t = 0, rem = tl;
-        while (rem > t) { rem -= t + 1; ++t; }
-        ti = t + 1; tj = rem + 1;
-      };
-      int tl = w - 1, ti = 0, tj = 0;
-      if constexpr (sizeof(real) == 8) {                     // (fp64: two tiles of C in registers beside the diagonal step's spill: plain loop)
-        for (; tl < ntile2; tl += SNW - 1) {
-          decode(tl, ti, tj);
-          update_tile(ti, tj);
-        }
-      } else {
-      real cva[2][2][4], cvb[2][2][4];
-      if (tl < ntile2) { decode(tl, ti, tj); load_tile(ti, tj, cva); }
-      while (tl < ntile2) {
-        const int tn = tl + SNW - 1;
-        int ti2 = 0, tj2 = 0;
-        if (tn < ntile2) { decode(tn, ti2, tj2); load_tile(ti2, tj2, cvb); }
-        finish_tile(ti, tj, cva);
-        tl = tn;
-        if (tl < ntile2) {
-          const int tn2 = tl + SNW - 1;
-          int ti3 = 0, tj3 = 0;
-          if (tn2 < ntile2) { decode(tn2, ti3, tj3); load_tile(ti3, tj3, cva); }
-          finish_tile(ti2, tj2, cvb);
-          tl = tn2; ti = ti3; tj = tj3;
-        }
-      }
-      }
+      load_tile(ti, 0, k0 + nb, mt, cv);
+      finish_tile(ti, 0, k0 + nb, mt, true, nbn, cv);
     }
     __threadfence_block();
     __syncthreads();
-    // ---- next round's inputs: factor block to global, panel below it into LDS
-    {
-      const int k1 = k0 + nb, mt1 = n - k1 - nbn;
-      store_diag(k1, nbn, blk + 1);
-      load_panel(k1, nbn, mt1, (mt1 + SNB - 1) / SNB * SNB);
-    }
-    __syncthreads();
+    POTRF_STAMP(blk, 4);
+    k0 += nb;
+    pmt = mt;
   }
   // strict upper triangle: zero
   for (int i = tid >> 6; i < n; i += SNW)
@@ -459,7 +495,7 @@ static inline size_t tri_inv_small4_lds(int n) {
 template <typename real>
 static inline size_t potrf_small_lds(int n) {
   const int mtp = (n + SNB - 1) / SNB * SNB;
-  return (size_t)((mtp + 2 * SNB) * SLD + 4 * SNB) * sizeof(real);
+  return (size_t)((mtp + 2 * SNB) * SLD + 4 * SNB + 2) * sizeof(real);
 }
 template <typename real>
 static inline size_t tri_inv_small_lds(int n) {
