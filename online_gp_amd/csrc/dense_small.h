@@ -16,6 +16,8 @@
 //   X_JJ = L_JJ^-1,   X_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK X_KJ.
 #pragma once
 #include <mutex>
+#include <tuple>
+#include <vector>
 
 constexpr int SNB = 32;        // panel width
 constexpr int SLD = 34;        // LDS row stride (reals)
@@ -400,8 +402,32 @@ __global__ __launch_bounds__(256) void k_tri_inv_small(int n, const real* __rest
 // partials are summed through LDS, and X_IJ = -L_II^-1 S is one more tile product.  3 barriers per block row instead of 2 per
 // (row, K) pair, and a quarter of the tile products on the critical path: 88 -> ~40 us at n = 327.  Needs 4 tile regions of LDS
 // besides the block column (161.5 KB at n = 480 in fp64).
+// Cross-workgroup flags of the cooperative factorisation (dense_coop.h): lane 0 polls until *p >= need.  What the flag guards is
+// read with agent-scope atomic loads afterwards (coop_load), so no cache invalidate is needed -- only that those loads are
+// issued after the poll has returned, which in-order issue gives once the compiler keeps them below the loop.
+__device__ __forceinline__ void coop_wait_ge(const int* p, int need) {
+  if ((threadIdx.x & 63) == 0)
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ bool coop_poll_ge(const int* p, int need) {        // one look, wave-uniform answer
+  int v = 0;
+  if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" ::: "memory");
+  return v >= need;
+}
 template <typename real>
-__global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __restrict__ L, int ldl, const real* __restrict__ dinv, real* __restrict__ X, int ldx) {
+__device__ __forceinline__ real coop_load(const real* p, bool coherent) {
+  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+// Block column J of X = L^-1 by the first 4 waves of the calling workgroup.  ready != nullptr: block row I of L (and dinv[I])
+// may only be read once ready[I] >= 1 -- the column then TRAILS a factorisation that is still running in another workgroup.
+template <typename real>
+__device__ __forceinline__ void tri_inv_column4(int n, const real* L, int ldl, const real* dinv, real* __restrict__ X, int ldx, int J,
+                                                const int* ready) {      // (L, dinv not __restrict__: another workgroup may still be writing them)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real(*sW)[SNB][SLD] = reinterpret_cast<real(*)[SNB][SLD]>(smem_raw);      // [4] wave-private: staged L tile, then the wave's partial
   real(*sS)[SLD] = sW[0];                                                    // summed partials  (take over regions 0 and 1 once the partials
@@ -409,7 +435,7 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
   real(*sX)[SLDX] = reinterpret_cast<real(*)[SLDX]>(sW + 4);                // block column J of X, rows from J * 32 (stride 33: n = 480 fits in fp64)
   using acc_t = typename Acc4<real>::type;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int J = blockIdx.x, j0 = J * SNB;
+  const int j0 = J * SNB;
   const int nblk = (n + SNB - 1) / SNB;
   const int nbj = n - j0 < SNB ? n - j0 : SNB;
   const int qa = w >> 1, qb = w & 1;
@@ -417,9 +443,10 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
     const int i = e / SNB, j = e % SNB;
     if (j < nbj) X[(int64_t)i * ldx + j0 + j] = (real)0;
   }
+  if (ready) coop_wait_ge(ready + J, 1);
   for (int e = tid; e < SNB * SNB; e += 256) {
     const int i = e / SNB, j = e % SNB;
-    const real v = dinv[(int64_t)J * SNB * SNB + e];
+    const real v = coop_load(&dinv[(int64_t)J * SNB * SNB + e], ready != nullptr);
     sX[i][j] = v;
     if (i < nbj && j < nbj) X[(int64_t)(j0 + i) * ldx + j0 + j] = v;
   }
@@ -429,13 +456,14 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
     const int nbi = n - i0 < SNB ? n - i0 : SNB;
     acc_t acc[2][2];
     zero_acc<real>(acc);
+    if (ready) coop_wait_ge(ready + I, 1);
     for (int K = J + w; K < I; K += 4) {
       // stage L[I][K] (32 x 32) into this wave's region: 16 elements per lane, rows of 256 B
       real v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int e = u * 64 + lane, i = e >> 5, k = e & 31;
-        v[u] = i < nbi ? L[(int64_t)(i0 + i) * ldl + K * SNB + k] : (real)0;
+        v[u] = i < nbi ? coop_load(&L[(int64_t)(i0 + i) * ldl + K * SNB + k], ready != nullptr) : (real)0;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();                       // the previous tile's operand reads are done
@@ -461,7 +489,7 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
     for (int e = tid; e < SNB * SNB; e += 256) {
       const int i = e / SNB, j = e % SNB;
       const real sum = sW[0][i][j] + sW[1][i][j] + sW[2][i][j] + sW[3][i][j];
-      const real di = dinv[(int64_t)I * SNB * SNB + e];
+      const real di = coop_load(&dinv[(int64_t)I * SNB * SNB + e], ready != nullptr);
       sS[i][j] = sum;                                        // (= sW[0][i][j], sW[1][i][j]: this thread's own elements)
       sDI[i][j] = di;
     }
@@ -487,6 +515,11 @@ __global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __res
 }
 
 template <typename real>
+__global__ __launch_bounds__(256) void k_tri_inv_small4(int n, const real* __restrict__ L, int ldl, const real* __restrict__ dinv, real* __restrict__ X, int ldx) {
+  tri_inv_column4<real>(n, L, ldl, dinv, X, ldx, (int)blockIdx.x, nullptr);
+}
+
+template <typename real>
 static inline size_t tri_inv_small4_lds(int n) {
   const int mtp = (n + SNB - 1) / SNB * SNB;
   return (size_t)(mtp * SLDX + 4 * SNB * SLD) * sizeof(real);
@@ -503,7 +536,33 @@ static inline size_t tri_inv_small_lds(int n) {
   return (size_t)((mtp + 3 * SNB) * SLD) * sizeof(real);
 }
 
-constexpr int WISKI_SMALL_UNAVAILABLE = 1;   // (internal) the one-workgroup path cannot run on this device: use the blocked one
+constexpr int WISKI_SMALL_UNAVAILABLE = 1;   // (internal) the small-matrix path cannot run on this device: use the blocked one
+
+#include "dense_coop.h"
+
+// Persistent flag block of the cooperative kernel, one per (device, stream): calls on one stream are ordered, calls on different
+// streams must not share flags.  Zeroed once at allocation; every launch leaves it zeroed (dense_coop.h).
+static CoopSync* coop_sync_for(int dev, hipStream_t s) {
+  static std::mutex mu;
+  static std::vector<std::tuple<int, hipStream_t, CoopSync*>> pool;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : pool)
+    if (std::get<0>(e) == dev && std::get<1>(e) == s) return std::get<2>(e);
+  CoopSync* p = nullptr;
+  if (hipMalloc((void**)&p, sizeof(CoopSync)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemset(p, 0, sizeof(CoopSync)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  pool.emplace_back(dev, s, p);
+  return p;
+}
+
+static bool coop_path_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("WISKI_POTRF_COOP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // Factor (and optionally invert: d_X != nullptr) a small matrix.  d_dinv: scratch [nblk][32][32].
 template <typename real>
 static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int ldx, int32_t* d_info, hipStream_t s) {
@@ -517,6 +576,7 @@ static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int l
     std::lock_guard<std::mutex> lk(mu);
     if (state[dev] == 0) {
       const bool ok = hipFuncSetAttribute((const void*)k_potrf_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_small_lds<real>(SMALL_N_MAX_POTRF)) == hipSuccess &&
+                      hipFuncSetAttribute((const void*)k_potrf_coop<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX) == hipSuccess &&
                       hipFuncSetAttribute((const void*)k_tri_inv_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_inv_small_lds<real>(SMALL_N_MAX)) == hipSuccess &&
                       hipFuncSetAttribute((const void*)k_tri_inv_small4<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX) == hipSuccess;
       if (!ok) (void)hipGetLastError();
@@ -524,10 +584,26 @@ static int potrf_small(int n, real* d_A, int lda, real* d_dinv, real* d_X, int l
     }
     if (state[dev] < 0) return WISKI_SMALL_UNAVAILABLE;
   }
+  const int nblk = (n + SNB - 1) / SNB;
+  // The cooperating-workgroups kernel (one launch for factor + inverse) unless the stream is being captured into a graph (its
+  // flag block is allocated on first use) or its LDS does not fit; then the one-workgroup factorisation and the separate inverse.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+  const bool inv4 = d_X && tri_inv_small4_lds<real>(n) <= SMALL_LDS_MAX;
+  if (coop_path_enabled() && nblk <= 16 && (!d_X || inv4) && potrf_coop_lds<real>(n, d_X != nullptr) <= SMALL_LDS_MAX) {
+    CoopSync* sy = cap == hipStreamCaptureStatusNone ? coop_sync_for(dev, s) : nullptr;
+    if (sy) {
+      const int ntiles = nblk >= 3 ? (nblk - 2) * (nblk - 1) / 2 : 0;
+      const int n_owner_wg = (ntiles + SNW - 1) / SNW;
+      const unsigned grid = 1u + (unsigned)n_owner_wg + (d_X ? (unsigned)nblk : 0u);
+      hipLaunchKernelGGL((k_potrf_coop<real>), dim3(grid), dim3(SWG), potrf_coop_lds<real>(n, d_X != nullptr), s, n, d_A, lda, d_dinv, d_X, ldx, d_info, sy,
+                         n_owner_wg);
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
+  }
   hipLaunchKernelGGL((k_potrf_small<real>), dim3(1), dim3(SWG), potrf_small_lds<real>(n), s, n, d_A, lda, d_dinv, d_info);
   if (d_X) {
-    const int nblk = (n + SNB - 1) / SNB;
-    if (tri_inv_small4_lds<real>(n) <= SMALL_LDS_MAX)
+    if (inv4)
       hipLaunchKernelGGL((k_tri_inv_small4<real>), dim3((unsigned)nblk), dim3(256), tri_inv_small4_lds<real>(n), s, n, (const real*)d_A, lda, (const real*)d_dinv,
                          d_X, ldx);
     else

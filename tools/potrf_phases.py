@@ -10,7 +10,7 @@ R = torch.randn(n, n, dtype=torch.float64, device="cuda")
 A = (R @ R.t() / n + torch.eye(n, dtype=torch.float64, device="cuda")).to(dt)
 buf = A.clone()
 for _ in range(5):
-    buf.copy_(A); grid_ops.potrf_(buf)
+    buf.copy_(A); (grid_ops.potrf_inverse_(buf) if 'inv' in sys.argv else grid_ops.potrf_(buf))
 torch.cuda.synchronize()
 st = (ctypes.c_longlong * (17 * 8))()
 assert _hip.lib().wiski_potrf_stamps(st) == 0
