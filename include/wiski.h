@@ -427,6 +427,45 @@ int wiski_basis_lag_grad(int32_t d, const int32_t* d_g, int32_t kw, const double
 /* d_diag[j] = |d_Y[:, j]|^2 (d_Y [r, n]), d_tail[j] = max(d_prior[j] * kscale - |d_F[j, :]|^2, 0) (d_F [n, r]): the two parts of the
  * predictive variances of n queries from the spectral factor, one launch. */
 int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, double kscale, double* d_diag, double* d_tail, void* stream);
+/* ---- the Adam step on the MLL for the standard parameterisation, without the framework's autograd (csrc/hyper_step.hip; recorded into a
+ * HIP graph by models/_graphed_step.py).  Replaces, for (Scale of)* RBF | Matern kernels with a homoskedastic second noise, what
+ * /root/reference/online_gp/models/online_ski_regression.py:135-147 does through torch autograd + torch.optim.Adam. */
+#define WISKI_HYPER_MAX_PARAMS 6
+typedef struct {
+  void* raw;          /* the raw (unconstrained) parameter, numel elements of the parameter dtype */
+  void* exp_avg;      /* Adam's first / second moments (parameter dtype) and step counter(s) (fp32; step_numel = 1 or numel) */
+  void* exp_avg_sq;
+  void* step;
+  int32_t numel;
+  int32_t step_numel;
+  int32_t role;       /* 0 lengthscale (numel 1 or d), 1 a factor of the output scale, 2 the second noise sigma2 */
+  int32_t kind;       /* 0: value = lower + softplus(raw); 1: value = lower + (upper - lower) sigmoid(raw) */
+  double lower, upper;
+} wiski_hyper_param;
+typedef struct {
+  int32_t count;
+  int32_t reserved;
+  wiski_hyper_param p[WISKI_HYPER_MAX_PARAMS];
+} wiski_hyper_plan;
+/* d_ell [1 or d], d_scale [1] (NULL without output scales), d_s2 [1] (and d_s2_f64, may be NULL) from the raw parameters; with d_tcol64 != NULL also
+ * the Toeplitz columns [sum g] (kind 0 RBF, 1-3 Matern 1/2, 3/2, 5/2) in fp64 and, if d_tcol != NULL, in the parameter dtype. */
+int wiski_hyper_columns_f32(const wiski_hyper_plan* plan, const wiski_grid* grid, int32_t kind, float* d_ell, float* d_scale, float* d_s2, double* d_s2_f64, double* d_tcol64, float* d_tcol, void* stream);
+int wiski_hyper_columns_f64(const wiski_hyper_plan* plan, const wiski_grid* grid, int32_t kind, double* d_ell, double* d_scale, double* d_s2, double* d_s2_f64, double* d_tcol64, double* d_tcol, void* stream);
+/* d_out [9] = { val, coef0, coef1, coef2, g = -1/n, g coef0, g coef1, loss = -val/n, 1/s2 } (wiski_mll_value's arithmetic; d_n the data count on the
+ * device); d_loss (may be NULL) receives the loss as well. */
+int wiski_hyper_mid_f32(const double* d_bMb, const double* d_logdet, const float* d_s2, const double* d_c, const double* d_ld, const double* d_n, double* d_out, double* d_loss, void* stream);
+int wiski_hyper_mid_f64(const double* d_bMb, const double* d_logdet, const double* d_s2, const double* d_c, const double* d_ld, const double* d_n, double* d_out, double* d_loss, void* stream);
+/* Chain rule to the raw parameters (d_gell, d_gscale from wiski_stationary_columns_grad, sigma2's from d_mid / d_gkap) and torch.optim.Adam's update
+ * (no weight decay, no amsgrad) of every parameter of the plan, its moments and step counters. */
+int wiski_hyper_adam_f32(const wiski_hyper_plan* plan, const float* d_scale, const float* d_s2, const float* d_gell, const float* d_gscale, const double* d_mid, const double* d_gkap, const double* d_n, double lr, double beta1, double beta2, double eps, void* stream);
+int wiski_hyper_adam_f64(const wiski_hyper_plan* plan, const double* d_scale, const double* d_s2, const double* d_gell, const double* d_gscale, const double* d_mid, const double* d_gkap, const double* d_n, double lr, double beta1, double beta2, double eps, void* stream);
+/* evaluate() of n <= 64 queries from the spectral factor in one launch (the reference loop scores every batch before absorbing it,
+ * /root/reference/online_gp/models/online_ski_regression.py:56-78): d_F [n, r] = W B Lam^1/2 and d_prior [n] from wiski_basis_project,
+ * d_Linv = chol^-1 [r, r] (ld ldl), d_t [r] = chol^-T chol^-1 Lam^1/2 h, d_s2 [1] the observation noise, d_y [n] the targets, d_err the
+ * out-of-grid flag (may be NULL).  d_out (fp64 [4]) = { rmse, mean Gaussian nll, flag, max |mean| }; d_mean / d_var (may be NULL): the
+ * means and LATENT variances in the data dtype.  d_ws: 200 doubles, zero on first use (left zero). */
+int wiski_spectral_evaluate_f32(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t, double kscale, const float* d_s2, const float* d_y, const int32_t* d_err, double* d_ws, double* d_out, float* d_mean, float* d_var, void* stream);
+int wiski_spectral_evaluate_f64(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t, double kscale, const double* d_s2, const double* d_y, const int32_t* d_err, double* d_ws, double* d_out, double* d_mean, double* d_var, void* stream);
 /* After the factorisation, three launches: d_out (packed fp64, 6 r + 2) = hr [r] | c [r] | t [r] | coef [r] | zeta [r] | bMb | logdet | scratch [r]
  * with hr = T^T h_ref (d_TS [r_ref, r]), c = chol^-1 (sq o hr) (d_Linv = chol^-1, [r, r]), bMb = |c|^2, t = chol^-T c, coef = sq o t,
  * zeta = t / sq, logdet = 2 sum log diag d_chol. */

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libwiski_hip.so")
-_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip", "spectral_basis.hip", "hyper_columns.hip", "two_level.hip"]
+_SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip", "spectral_basis.hip", "hyper_columns.hip", "two_level.hip", "hyper_step.hip"]
 _HEADERS = ["wiski_common.h", "spmv_sym_dma.h", "spmv_sym_dma_mc.h", "spmm_sym_cols.h", "scatter_owner.h", os.path.join("..", "..", "include", "wiski.h")]
 MAX_DIM = 4
 
@@ -34,6 +34,21 @@ class wiski_grid(ctypes.Structure):
         ("g0", ctypes.c_double * MAX_DIM),
         ("h", ctypes.c_double * MAX_DIM),
     ]
+
+
+HYPER_MAX_PARAMS = 6
+
+
+class wiski_hyper_param(ctypes.Structure):
+    _fields_ = [
+        ("raw", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("step", ctypes.c_void_p),
+        ("numel", ctypes.c_int32), ("step_numel", ctypes.c_int32), ("role", ctypes.c_int32), ("kind", ctypes.c_int32),
+        ("lower", ctypes.c_double), ("upper", ctypes.c_double),
+    ]
+
+
+class wiski_hyper_plan(ctypes.Structure):
+    _fields_ = [("count", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", wiski_hyper_param * HYPER_MAX_PARAMS)]
 
 
 def sources():

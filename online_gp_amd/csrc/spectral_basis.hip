@@ -708,3 +708,156 @@ extern "C" int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, c
   hipLaunchKernelGGL(k_tail_c, dim3((unsigned)((r + 63) / 64)), dim3(1024), 0, s, (int)r, d_Linv, d_chol, d_sq, d_out);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
+
+// ------------------------------------------------- evaluate() of a small batch ---
+// The reference loop scores every incoming batch before it absorbs it (OSR:56-78: predictive mean and variance of the batch -> rmse,
+// nll).  From the factor that is  mean_j = F_j . t,  var_j = (|chol^-1 F_j|^2 + max(prior_j kscale - |F_j|^2, 0)) sigma2  and two
+// reductions -- it used to be 18 launches (two BLAS GEMVs, the variance kernel, a dozen framework element-wise ops and reductions,
+// the metrics kernel, the packing of the three numbers the host reads).  Here it is ONE launch for n <= 64 queries: workgroup
+// (bx, by) takes 8 rows of chol^-1 and 8 queries (rows and query vectors in registers, lane-strided), adds its share of the squared
+// norms to the accumulators in d_ws; the workgroups with bx = 0 also form the means and |F_j|^2; the last workgroup to finish (a
+// ticket) turns the accumulators into variances and the batch metrics, writes
+//     d_out = { rmse, mean nll, out-of-grid flag (d_err), max_j |mean_j| }           (fp64: one host read)
+// (and, if asked, the means / latent variances in the data dtype), and zeroes d_ws again.  d_ws: 200 doubles, ZERO on first use.
+template <typename real>
+__global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const double* __restrict__ F, const double* __restrict__ prior, const double* __restrict__ Linv,
+                                                       int ldl, const double* __restrict__ t, double kscale, const real* __restrict__ s2p,
+                                                       const real* __restrict__ y, const int32_t* __restrict__ err, double* ws, double* __restrict__ out,
+                                                       real* __restrict__ mean_out, real* __restrict__ var_out) {
+  __shared__ double s_acc[4][8];
+  __shared__ double s_red[16];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q0 = blockIdx.y * 8, nq = n - q0 < 8 ? n - q0 : 8;
+  double f[8][8];
+#pragma unroll
+  for (int qq = 0; qq < 8; ++qq)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int k = lane + 64 * m;
+      f[qq][m] = (qq < nq && k < r) ? F[(int64_t)(q0 + qq) * r + k] : 0.0;
+    }
+  double acc[8];
+#pragma unroll
+  for (int qq = 0; qq < 8; ++qq) acc[qq] = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int i = blockIdx.x * 8 + w * 2 + rr;
+    double li[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int k = lane + 64 * m;
+      li[m] = (i < r && k <= i) ? Linv[(int64_t)i * ldl + k] : 0.0;      // (chol^-1 is lower triangular)
+    }
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      double d = 0.0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) d += li[m] * f[qq][m];
+      d = wave_reduce_sum<double>(d);
+      acc[qq] += d * d;
+    }
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) s_acc[w][qq] = acc[qq];
+  __syncthreads();
+  if (threadIdx.x < nq) unsafeAtomicAdd(ws + q0 + threadIdx.x, s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+  if (blockIdx.x == 0) {
+    // means and |F_j|^2 of this workgroup's queries: wave w takes queries w and w + 4
+    double tv[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int k = lane + 64 * m;
+      tv[m] = k < r ? t[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qq = w + 4 * u;
+      double mu = 0.0, cap = 0.0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        // (f is indexed by the compile-time unrolled u, w is wave-uniform: select instead of a dynamic register index)
+        const double fv = w == 0 ? f[4 * u][m] : w == 1 ? f[4 * u + 1][m] : w == 2 ? f[4 * u + 2][m] : f[4 * u + 3][m];
+        mu += fv * tv[m];
+        cap += fv * fv;
+      }
+      mu = wave_reduce_sum<double>(mu);
+      cap = wave_reduce_sum<double>(cap);
+      if (lane == 0 && qq < nq) {
+        __hip_atomic_store(ws + 64 + q0 + qq, mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + 128 + q0 + qq, cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // ticket: this workgroup's contributions are out (vmcnt: the atomics and stores above have been acknowledged)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = (int)(gridDim.x * gridDim.y);
+    const int tk = __hip_atomic_fetch_add(reinterpret_cast<int*>(ws + 192), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = tk == total - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: variances, metrics, reset
+  const double s2 = (double)s2p[0];
+  double sq = 0.0, nl = 0.0, amax = 0.0;
+  if (threadIdx.x < n) {
+    const int j = threadIdx.x;
+    const double dg = __hip_atomic_load(ws + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mu = __hip_atomic_load(ws + 64 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double cap = __hip_atomic_load(ws + 128 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double tl = prior[j] * kscale - cap;
+    tl = tl > 0 ? tl : 0.0;
+    // (rounded to the data dtype where the op-by-op path rounds: the latent variance, the mean, their use in the metrics)
+    real var = (real)((dg + tl) * s2);
+    var = var > (real)0 ? var : (real)0;
+    const real mur = (real)mu;
+    if (mean_out) mean_out[j] = mur;
+    if (var_out) var_out[j] = var;
+    const real df = mur - y[j];
+    const real v = (real)((double)var + s2);
+    const real s = df * df;
+    sq = (double)s;
+    nl = (double)((real)0.5 * (s / v + (real)log((double)v) + (real)1.8378770664093453));
+    amax = fabs(mu);
+    __hip_atomic_store(ws + j, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(ws + 192), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sq = block_reduce_sum(sq, s_red);
+  nl = block_reduce_sum(nl, s_red);
+  // max |mean|: n <= 64 values sit in wave 0
+  double mx = amax;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(mx, o);
+    mx = other > mx ? other : mx;
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sqrt(sq / (double)n);
+    out[1] = nl / (double)n;
+    out[2] = err ? (double)err[0] : 0.0;
+    out[3] = mx;
+  }
+}
+
+template <typename real>
+static int spectral_evaluate_impl(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t,
+                                  double kscale, const real* d_s2, const real* d_y, const int32_t* d_err, double* d_ws, double* d_out, real* d_mean,
+                                  real* d_var, void* stream) {
+  if (n < 1 || n > 64 || r < 1 || r > 512 || ldl < r || !d_F || !d_prior || !d_Linv || !d_t || !d_s2 || !d_y || !d_ws || !d_out) return WISKI_E_BADARG;
+  hipLaunchKernelGGL((k_spectral_eval<real>), dim3((unsigned)((r + 7) / 8), (unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_F,
+                     d_prior, d_Linv, (int)ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+extern "C" int wiski_spectral_evaluate_f32(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t,
+                                           double kscale, const float* d_s2, const float* d_y, const int32_t* d_err, double* d_ws, double* d_out,
+                                           float* d_mean, float* d_var, void* stream) {
+  return spectral_evaluate_impl<float>(n, r, d_F, d_prior, d_Linv, ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var, stream);
+}
+extern "C" int wiski_spectral_evaluate_f64(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t,
+                                           double kscale, const double* d_s2, const double* d_y, const int32_t* d_err, double* d_ws, double* d_out,
+                                           double* d_mean, double* d_var, void* stream) {
+  return spectral_evaluate_impl<double>(n, r, d_F, d_prior, d_Linv, ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var, stream);
+}

@@ -708,6 +708,29 @@ def stationary_columns_grad(grid, kind, ell, scale, gout):
     return g_ell, g_scale
 
 
+def hyper_columns(plan, grid, kind, ell, scale, s2, s2_f64=None, tcol64=None, tcol=None):
+    """``wiski_hyper_columns``: constrained values (ell, scale, s2: pre-allocated, parameter dtype) of the plan's raw parameters and, with
+    `tcol64`, the Toeplitz columns (fp64 and, with `tcol`, the parameter dtype) -- one launch, no host read."""
+    rc = _hip.fn("wiski_hyper_columns", ell.dtype)(ctypes.byref(plan), grid.ref, ctypes.c_int32(kind), _hip.dptr(ell), _hip.dptr(scale), _hip.dptr(s2),
+                                                   _hip.dptr(s2_f64), _hip.dptr(tcol64), _hip.dptr(tcol), _hip.stream_ptr(ell.device))
+    _hip.check(rc, "wiski_hyper_columns")
+
+
+def hyper_mid(bMb, logdet, s2, c, ld, n_dev, out, loss_out=None):
+    """``wiski_hyper_mid``: out [9] fp64 = {val, coef0..2, g = -1/n, g coef0, g coef1, loss, 1/s2}."""
+    rc = _hip.fn("wiski_hyper_mid", s2.dtype)(_hip.dptr(bMb), None if logdet is None else _hip.dptr(logdet), _hip.dptr(s2), _hip.dptr(c), _hip.dptr(ld),
+                                              _hip.dptr(n_dev), _hip.dptr(out), _hip.dptr(loss_out), _hip.stream_ptr(s2.device))
+    _hip.check(rc, "wiski_hyper_mid")
+
+
+def hyper_adam(plan, scale, s2, g_ell, g_scale, mid, g_kap, n_dev, lr, beta1, beta2, eps):
+    """``wiski_hyper_adam``: chain rule to the raw parameters + torch.optim.Adam's update of the plan's parameters, in place."""
+    rc = _hip.fn("wiski_hyper_adam", s2.dtype)(ctypes.byref(plan), _hip.dptr(scale), _hip.dptr(s2), _hip.dptr(g_ell), _hip.dptr(g_scale), _hip.dptr(mid),
+                                               _hip.dptr(g_kap), _hip.dptr(n_dev), ctypes.c_double(lr), ctypes.c_double(beta1), ctypes.c_double(beta2),
+                                               ctypes.c_double(eps), _hip.stream_ptr(s2.device))
+    _hip.check(rc, "wiski_hyper_adam")
+
+
 def mll_value(bMb, logdet, s2, c, ld, n):
     """``wiski_mll_value``: (val, coef [3]) fp64 device scalars of one output's Woodbury MLL tail; s2 a 1-element tensor (fp32 / fp64)."""
     val = torch.empty((), dtype=torch.float64, device=bMb.device)
@@ -826,6 +849,20 @@ def spectral_var(Y, F, prior, kscale):
                                        _hip.dptr(diag), _hip.dptr(tail), _hip.stream_ptr(Y.device))
     _hip.check(rc, "wiski_spectral_var")
     return diag, tail
+
+
+def spectral_evaluate(F, prior, Linv, t, kscale, s2, y, err, ws, want_moments=False):
+    """``wiski_spectral_evaluate``: rmse / nll / out-of-grid flag / max |mean| (fp64 [4], on the device) of n <= 64 queries from the
+    spectral factor in one launch; with `want_moments` also (mean, latent variance) in y's dtype.  ws: 200 zeroed doubles, reused."""
+    n, r = F.shape
+    out = torch.empty(4, dtype=torch.float64, device=F.device)
+    mean = torch.empty(n, dtype=y.dtype, device=F.device) if want_moments else None
+    var = torch.empty(n, dtype=y.dtype, device=F.device) if want_moments else None
+    rc = _hip.fn("wiski_spectral_evaluate", y.dtype)(ctypes.c_int32(n), ctypes.c_int32(r), _hip.dptr(F), _hip.dptr(prior), _hip.dptr(Linv),
+                                                     ctypes.c_int32(Linv.shape[1]), _hip.dptr(t), ctypes.c_double(float(kscale)), _hip.dptr(s2), _hip.dptr(y),
+                                                     _hip.dptr(err), _hip.dptr(ws), _hip.dptr(out), _hip.dptr(mean), _hip.dptr(var), _hip.stream_ptr(F.device))
+    _hip.check(rc, "wiski_spectral_evaluate")
+    return (out, mean, var) if want_moments else out
 
 
 def basis_pair_reduce(Wt, S, ev, kmax):

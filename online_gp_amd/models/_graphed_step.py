@@ -20,7 +20,7 @@ classifier's two) are one graph: one factor, one set of staging buffers per outp
 """
 import torch
 
-from .. import settings
+from .. import _hip, grid_ops, settings
 from ..lazy.spectral_woodbury import SpectralBasis
 
 WARMUP_STEPS = 3
@@ -37,6 +37,9 @@ class GraphedHyperStep:
         self.replays = 0
         self.disabled = None       # reason, once a capture has failed
         self.churn = self.cooldown = self.replays_at_capture = 0
+        self.fused = False         # the current graph was recorded without autograd (csrc/hyper_step.hip)
+        self.fused_captures = 0
+        self._seed = None
 
     # ---------------------------------------------------------------------------------------------------------------------
     def _applicable(self):
@@ -79,7 +82,7 @@ class GraphedHyperStep:
         key = (tuple((sp[1]["basis"].S.data_ptr(), sp[1]["basis"].r, sp[1]["basis"].kmax) for sp in sps), str(gp._dtype),
                tuple(_hp(g) for g in opt.param_groups), id(opt),
                settings.fused_hyper_columns.on(), tuple(p.requires_grad for g in opt.param_groups for p in g["params"]),
-               REGISTRY_EPOCH[0], gp._kernel_cache["_stats"].data_ptr())
+               REGISTRY_EPOCH[0], gp._kernel_cache["_stats"].data_ptr(), settings.fused_hyper_step.on())
         if key != self.key:
             # a capture costs ~2 ms: worth it only if it is then replayed.  If the factor keeps re-selecting its index set (host-side
             # refresh, a kernel whose spectrum moves fast), stop re-capturing for a while and let the eager path run.
@@ -104,7 +107,21 @@ class GraphedHyperStep:
         self.graph.replay()
         self.replays += 1
         gp.zero_grad()                                # (as the eager step: drops the gradients and moves the hyper-parameter epoch on)
-        return self.loss if lazy else float(self.loss)
+        self._seed = gp._hyper_version() if self.fused else None
+        return self.loss if lazy else self.read_loss()
+
+    def read_loss(self):
+        """The loss of the last replay (a host read: everything queued so far completes).  The fused graph also left the Toeplitz
+        columns and sigma2 of the UPDATED hyper-parameters behind: they are handed to the model's memo, so the next factor refresh
+        neither re-evaluates the kernel nor reads sigma2 back (one synchronisation and ~8 launches less per step)."""
+        if not self.fused:
+            return float(self.loss)
+        loss, s2 = self.host_read.tolist()
+        gp = self.w.gp
+        if self._seed is not None and self._seed == gp._hyper_version():
+            gp._memo["hyper"] = (self._seed, [(self.f_tc, s2, self.f_tc64)])
+        self._seed = None
+        return loss
 
     # ---------------------------------------------------------------------------------------------------------------------
     def _stage(self, sps):
@@ -119,7 +136,127 @@ class GraphedHyperStep:
         self.n_pin[0] = float(self.w.gp.num_data)
         self.n_dev.copy_(self.n_pin, non_blocking=True)
 
+    # ---------------------------------------------------------------------------------------------------------------------
+    def _fused_plan(self):
+        """(plan, kind, lr, betas, eps, dtype) when the step can be recorded without autograd (settings.fused_hyper_step), else None."""
+        from ..constraints import GreaterThan, Interval
+        from ..kernels import GridInterpolationKernel, MaternKernel, RBFKernel, ScaleKernel
+        from ..likelihoods.fnmg_likelihood import HomoskedasticNoise
+        from ..priors import named_priors
+
+        w = self.w
+        gp, opt = w.gp, w.gp_optimizer
+        if settings.fused_hyper_step.off() or settings.fused_hyper_columns.off() or gp.num_outputs != 1 or not gp.has_learnable_noise:
+            return None
+        if next(iter(named_priors(w.mll)), None) is not None:
+            return None
+        cm = gp.covar_module
+        if not isinstance(cm, GridInterpolationKernel):
+            return None
+        entries, k = [], cm.base_kernel
+        while isinstance(k, ScaleKernel):
+            entries.append((k.raw_outputscale, 1, k.raw_outputscale_constraint))
+            k = k.base_kernel
+        if type(k) is RBFKernel:
+            kind = 0
+        elif type(k) is MaternKernel:
+            kind = {0.5: 1, 1.5: 2, 2.5: 3}[k.nu]
+        else:
+            return None
+        entries.append((k.raw_lengthscale, 0, k.raw_lengthscale_constraint))
+        noise = gp.likelihood.second_noise_covar
+        if type(noise) is not HomoskedasticNoise:
+            return None
+        entries.append((noise.raw_noise, 2, GreaterThan(noise.LOWER)))
+        if len(entries) > _hip.HYPER_MAX_PARAMS or len(opt.param_groups) != 1:
+            return None
+        grp = opt.param_groups[0]
+        ps = grp["params"]
+        if len(ps) != len(entries) or {id(p) for p in ps} != {id(e[0]) for e in entries}:
+            return None                               # (a mean constant, a foreign parameter ...: the autograd recording handles those)
+        if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad") or grp.get("maximize") or grp.get("differentiable") or torch.is_tensor(grp["lr"]):
+            return None
+        dt = ps[0].dtype
+        if dt not in (torch.float32, torch.float64) or dt != gp._dtype:
+            return None
+        plan = _hip.wiski_hyper_plan()
+        plan.count = len(entries)
+        for i, (p, role, con) in enumerate(entries):
+            st = opt.state.get(p)
+            if (not p.requires_grad or not p.is_cuda or p.dtype != dt or not p.is_contiguous() or not st or "exp_avg" not in st
+                    or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32 or st["step"].numel() != 1
+                    or st["exp_avg"].dtype != dt or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous()):
+                return None
+            if role != 0 and p.numel() != 1:
+                return None
+            if role == 0 and p.numel() not in (1, gp._grid.d):
+                return None
+            if type(con) is Interval:
+                ckind, lo, hi = 1, con.lower_bound, con.upper_bound
+            elif isinstance(con, GreaterThan):
+                ckind, lo, hi = 0, con.lower_bound, 0.0
+            else:
+                return None
+            e = plan.p[i]
+            e.raw, e.exp_avg, e.exp_avg_sq, e.step = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+            e.numel, e.step_numel, e.role, e.kind, e.lower, e.upper = p.numel(), 1, role, ckind, float(lo), float(hi)
+        has_scale = any(r == 1 for _, r, _ in entries)
+        b1, b2 = grp["betas"]
+        return plan, kind, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), dt, has_scale, entries
+
+    def _capture_fused(self, sps, key, fp):
+        """The step without autograd: constraint transforms -> MLL tail -> the factor's backward launches -> columns' gradient -> chain
+        rule + Adam -> the updated hyper-parameters' columns and sigma2.  11 graph nodes."""
+        plan, kind, lr, b1, b2, eps, dt, has_scale, entries = fp
+        w = self.w
+        gp = w.gp
+        fac, st, _ = sps[0]
+        dev = st["G"].device
+        f64 = dict(dtype=torch.float64, device=dev)
+        basis = st["basis"]
+        r = basis.r
+        sizes = [r, r, r, basis.ev_tab.numel(), basis.Vtab.numel(), 1, 1]
+        buf = {"G": torch.empty((r, r), **f64), "Linv": torch.empty((r, r), **f64), "sqG": torch.empty((r, r), **f64), "packed": torch.empty(sum(sizes), **f64)}
+        v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = torch.split(buf["packed"], sizes)
+        sbasis = SpectralBasis.on_device(basis, v_V, v_ev.view(basis.ev_tab.shape), None, lam=v_lam)
+        sst = {"basis": sbasis, "G": buf["G"], "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": buf["Linv"], "sqG": buf["sqG"], "bMb": v_bMb.reshape(()),
+               "logdet": v_logdet, "kscale": None}
+        self.bufs = [buf]
+        fac._grid_dev()
+        self.n_dev = torch.zeros(1, **f64)
+        self.n_pin = torch.zeros(1, dtype=torch.float64).pin_memory()
+        grid = gp._grid
+        nell = next(p.numel() for p, role, _ in entries if role == 0)
+        mk = lambda n_: torch.empty(n_, dtype=dt, device=dev)
+        ell, s2, scale = mk(nell), mk(1), (mk(1) if has_scale else None)
+        ell2, s2n, scale2 = mk(nell), mk(1), (mk(1) if has_scale else None)
+        mid = torch.empty(9, **f64)
+        self.host_read = torch.zeros(2, **f64)
+        self.f_tc64 = torch.empty(sum(grid.g), **f64)
+        self.f_tc = torch.empty(sum(grid.g), dtype=dt, device=dev)
+        stats = gp._kernel_cache["_stats"]
+        self._stage(sps)
+        self._fused_keep = (plan, entries, ell, s2, scale, ell2, s2n, scale2, mid)      # (addresses recorded into the graph stay alive)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            grid_ops.hyper_columns(plan, grid, kind, ell, scale, s2)
+            # (the value leaves the log-determinant out, as the eager step does under skip_logdet_forward; its gradient is taken)
+            grid_ops.hyper_mid(sst["bMb"], None, s2, stats[0, 0], stats[0, 1], self.n_dev, mid, self.host_read[0:1])
+            g_tcol, g_kap = fac.mll_backward(sst, mid[5], mid[6], kap=mid[8:9])
+            g_ell, g_scale = grid_ops.stationary_columns_grad(grid, kind, ell, scale, g_tcol)
+            grid_ops.hyper_adam(plan, scale, s2, g_ell, g_scale, mid, g_kap, self.n_dev, lr, b1, b2, eps)
+            grid_ops.hyper_columns(plan, grid, kind, ell2, scale2, s2n, self.host_read[1:2], self.f_tc64, self.f_tc)
+        self.graph, self.loss, self.key = graph, self.host_read[0], key
+        self.fused = True
+        self.captures += 1
+        self.fused_captures += 1
+        self.replays_at_capture = self.replays
+
     def _capture(self, sps, key):
+        fp = self._fused_plan() if len(sps) == 1 else None
+        if fp is not None:
+            return self._capture_fused(sps, key, fp)
+        self.fused = False
         w = self.w
         gp, opt = w.gp, w.gp_optimizer
         dev = sps[0][1]["G"].device

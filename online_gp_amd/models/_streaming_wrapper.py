@@ -131,7 +131,8 @@ class StreamingSKIWrapper(torch.nn.Module):
                     self.stem(torch.cat([inputs, self._replay.sample(_REPLAY)]))
         self._ensure_eval()
         if torch.is_tensor(gp_loss):                 # the captured step's loss, read only now: the absorb above was queued behind the
-            gp_loss = float(gp_loss)                 # graph without waiting for it (one GPU idle gap less per step)
+            gs = self.__dict__.get("_graphed")       # graph without waiting for it (one GPU idle gap less per step)
+            gp_loss = gs.read_loss() if gs is not None else float(gp_loss)
         return stem_loss, gp_loss
 
     def _ensure_eval(self):

@@ -62,6 +62,9 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         inputs = self._as_rows(inputs)
         targets = targets.reshape(-1, self.target_dim)
         self._ensure_eval()
+        fast = self._evaluate_from_factor(inputs, targets)
+        if fast is not None:
+            return fast
         per_batch = []
         fused = self.target_dim == 1 and inputs.is_cuda
         # the out-of-grid check of the queries is read together with the metrics (ONE host sync at the end instead of one inside
@@ -89,6 +92,41 @@ class OnlineSKIRegression(StreamingSKIWrapper):
             return vals[0], vals[1]
         rmse, nll = torch.stack(per_batch).mean(0).tolist()
         return rmse, nll
+
+    def _evaluate_from_factor(self, inputs, targets):
+        """evaluate() of a small batch (<= 64 points, one output) straight from the spectral factor: one projection launch and ONE
+        launch for means, variances and both metrics (wiski_spectral_evaluate), one host read.  Same decisions as the posterior call
+        (batched_fixed_noise_online_gp._eval_forward): only where the factor serves the mean as well -- the PCG state is not current and
+        the factor's mean monitor is green; otherwise None and the general path runs."""
+        gp = self.gp
+        n = inputs.shape[0]
+        if not (self.target_dim == 1 and inputs.is_cuda and 0 < n <= 64 and gp.has_learnable_noise and settings.skip_posterior_variances.off()
+                and settings.fused_evaluate.on()):
+            return None
+        ms = gp._mean_state
+        if gp._memo.get("prediction_cache") is not None or (ms is not None and ms.get("ver") == gp._hyper_version()):
+            return None
+        sp = gp._spectral_state(0)
+        if sp is None:
+            return None
+        fac, st, tcol64 = sp
+        if not fac.mean_ok or "t" not in st or st["basis"].r > 512:      # (the one-launch kernel holds a query vector in 8 registers per lane)
+            return None
+        dt = gp._dtype
+        Xf = self.stem(inputs).detach().to(gp._device, dt).reshape(-1, gp._grid.d).contiguous()
+        q = fac.query(st, Xf, tcol64)
+        ws = fac.__dict__.get("_eval_ws")
+        if ws is None:
+            ws = fac._eval_ws = torch.zeros(200, dtype=torch.float64, device=gp._device)
+        s2 = gp.likelihood.second_noise.detach().reshape(-1).to(dt)
+        out = grid_ops.spectral_evaluate(q.Fs, q.prior, st["Linv"], st["t"], st["kscale"], s2, targets.reshape(-1).to(dt).contiguous(), gp._err, ws)
+        fac.mean_monitor(st, q, gp._kernel_cache["interpolation_cache"][0, :, 0], tcol64, out[3])
+        if not fac.mean_ok:                               # (a verdict read just now turned the factor's mean off)
+            return None
+        vals = out.tolist()
+        if int(vals[2]) and settings.deferred_bounds_check.off():
+            gp._raise_out_of_bounds(int(vals[2]))
+        return vals[0], vals[1]
 
     # ----- batch training
     def fit(self, inputs, targets, num_epochs, test_dataset=None):

@@ -313,6 +313,24 @@ class fused_hyper_columns(_feature_flag):
     _state = True
 
 
+class fused_hyper_step(_feature_flag):
+    """The captured Adam step (``graphed_hyper_step``) recorded WITHOUT autograd where the model has the standard parameterisation --
+    (Scale of)* RBF | Matern, homoskedastic second noise, no registered priors, plain Adam: constraint transforms, MLL tail, chain rule
+    and the Adam update are three kernels (csrc/hyper_step.hip) around the factor's backward launches, 11 graph nodes instead of 40; the
+    same graph leaves the NEXT step's Toeplitz columns and sigma2 behind, so the following refresh starts without a host read.  Off: the
+    autograd recording (what every other parameterisation takes)."""
+
+    _state = True
+
+
+class fused_evaluate(_feature_flag):
+    """``OnlineSKIRegression.evaluate`` of a batch of <= 64 points from the spectral factor as one projection launch + ONE launch for
+    means, variances and both metrics (``wiski_spectral_evaluate``) instead of the posterior object and ~18 small launches; off: the
+    general path (what larger batches and several outputs always take)."""
+
+    _state = True
+
+
 class spectral_device_refresh(_feature_flag):
     """After a hyper-parameter step, refine the spectral factor's per-dim eigenvectors on the device (subspace iteration from the
     previous ones, ``wiski_basis_eig_update``) and keep the index set, instead of a host eigh + re-selection; the refinement's

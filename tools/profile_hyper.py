@@ -12,6 +12,6 @@ def loop(a, b):
         xb, yb = Xs[i:i + 1], ys[i:i + 1]
         model.evaluate(xb, yb); model.update(xb, yb, update_gp=True)
 with settings.cg_tolerance(1e-4):
-    loop(0, 5)
-    pr = cProfile.Profile(); pr.enable(); loop(5, 25); torch.cuda.synchronize(); pr.disable()
-    pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+    loop(0, 12)
+    pr = cProfile.Profile(); pr.enable(); loop(12, 112); torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(70)
