@@ -459,6 +459,19 @@ int wiski_hyper_mid_f64(const double* d_bMb, const double* d_logdet, const doubl
  * (no weight decay, no amsgrad) of every parameter of the plan, its moments and step counters. */
 int wiski_hyper_adam_f32(const wiski_hyper_plan* plan, const float* d_scale, const float* d_s2, const float* d_gell, const float* d_gscale, const double* d_mid, const double* d_gkap, const double* d_n, double lr, double beta1, double beta2, double eps, void* stream);
 int wiski_hyper_adam_f64(const wiski_hyper_plan* plan, const double* d_scale, const double* d_s2, const double* d_gell, const double* d_gscale, const double* d_mid, const double* d_gkap, const double* d_n, double lr, double beta1, double beta2, double eps, void* stream);
+/* count <= 12 fp64 segments dst[s][0 .. n[s]) = src[s][..] and one scalar store, in ONE launch (the staging of a factor state into the static
+ * buffers of a captured hyper-parameter step: models/_graphed_step.py). */
+#define WISKI_COPY_MAX_SEGMENTS 12
+typedef struct {
+  const void* src[WISKI_COPY_MAX_SEGMENTS];
+  void* dst[WISKI_COPY_MAX_SEGMENTS];
+  int64_t n[WISKI_COPY_MAX_SEGMENTS];
+  int32_t count;
+  int32_t reserved;
+  double scalar;        /* written to scalar_dst[0] when scalar_dst != NULL */
+  void* scalar_dst;
+} wiski_copy_plan;
+int wiski_multi_copy_f64(const wiski_copy_plan* plan, void* stream);
 /* evaluate() of n <= 64 queries from the spectral factor in one launch (the reference loop scores every batch before absorbing it,
  * /root/reference/online_gp/models/online_ski_regression.py:56-78): d_F [n, r] = W B Lam^1/2 and d_prior [n] from wiski_basis_project,
  * d_Linv = chol^-1 [r, r] (ld ldl), d_t [r] = chol^-T chol^-1 Lam^1/2 h, d_s2 [1] the observation noise, d_y [n] the targets, d_err the

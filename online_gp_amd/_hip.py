@@ -51,6 +51,14 @@ class wiski_hyper_plan(ctypes.Structure):
     _fields_ = [("count", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", wiski_hyper_param * HYPER_MAX_PARAMS)]
 
 
+COPY_MAX_SEGMENTS = 12
+
+
+class wiski_copy_plan(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p * COPY_MAX_SEGMENTS), ("dst", ctypes.c_void_p * COPY_MAX_SEGMENTS), ("n", ctypes.c_int64 * COPY_MAX_SEGMENTS),
+                ("count", ctypes.c_int32), ("reserved", ctypes.c_int32), ("scalar", ctypes.c_double), ("scalar_dst", ctypes.c_void_p)]
+
+
 def sources():
     return [os.path.join(_CSRC, s) for s in _SOURCES if os.path.exists(os.path.join(_CSRC, s))]
 

@@ -234,3 +234,28 @@ int wiski_hyper_adam_f64(const wiski_hyper_plan* plan, const double* d_scale, co
   return hyper_adam_impl<double>(plan, d_scale, d_s2, d_gell, d_gscale, d_mid, d_gkap, d_n, lr, beta1, beta2, eps, stream);
 }
 }
+
+// ---------------------------------------------------------------- staging ---
+// Before a replay the factor state of this step (three r x r matrices, seven small vectors / scalars, the data count) goes into the
+// static buffers the recorded kernels read: ONE launch for all segments (it was three copies, a concatenation and a pinned upload).
+__global__ __launch_bounds__(256) void k_multi_copy(wiski_copy_plan plan) {
+  for (int s = 0; s < plan.count; ++s) {
+    const double* __restrict__ src = (const double*)plan.src[s];
+    double* __restrict__ dst = (double*)plan.dst[s];
+    const int64_t n = plan.n[s];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+  if (plan.scalar_dst && blockIdx.x == 0 && threadIdx.x == 0) ((double*)plan.scalar_dst)[0] = plan.scalar;
+}
+
+extern "C" int wiski_multi_copy_f64(const wiski_copy_plan* plan, void* stream) {
+  if (!plan || plan->count < 0 || plan->count > WISKI_COPY_MAX_SEGMENTS) return WISKI_E_BADARG;
+  int64_t most = 1;
+  for (int s = 0; s < plan->count; ++s) {
+    if (!plan->src[s] || !plan->dst[s] || plan->n[s] < 0) return WISKI_E_BADARG;
+    if (plan->n[s] > most) most = plan->n[s];
+  }
+  const unsigned blocks = (unsigned)((most + 255) / 256 < 1024 ? (most + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_multi_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *plan);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}

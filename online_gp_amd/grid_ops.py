@@ -731,6 +731,23 @@ def hyper_adam(plan, scale, s2, g_ell, g_scale, mid, g_kap, n_dev, lr, beta1, be
     _hip.check(rc, "wiski_hyper_adam")
 
 
+def multi_copy(pairs, scalar=None, scalar_dst=None):
+    """``wiski_multi_copy_f64``: dst.copy_(src) for up to 12 (dst, src) pairs of contiguous fp64 tensors (and one scalar store) in ONE launch."""
+    plan = _hip.wiski_copy_plan()
+    plan.count = len(pairs)
+    dev = None
+    for i, (dst, src) in enumerate(pairs):
+        if dst.dtype != torch.float64 or src.dtype != torch.float64 or dst.numel() != src.numel() or not dst.is_contiguous() or not src.is_contiguous():
+            raise _hip.WiskiError("multi_copy: contiguous fp64 tensors of equal size")
+        plan.src[i], plan.dst[i], plan.n[i] = src.data_ptr(), dst.data_ptr(), dst.numel()
+        dev = dst.device
+    if scalar_dst is not None:
+        plan.scalar, plan.scalar_dst = float(scalar), scalar_dst.data_ptr()
+        dev = scalar_dst.device
+    rc = _hip.lib().wiski_multi_copy_f64(ctypes.byref(plan), _hip.stream_ptr(dev))
+    _hip.check(rc, "wiski_multi_copy_f64")
+
+
 def mll_value(bMb, logdet, s2, c, ld, n):
     """``wiski_mll_value``: (val, coef [3]) fp64 device scalars of one output's Woodbury MLL tail; s2 a 1-element tensor (fp32 / fp64)."""
     val = torch.empty((), dtype=torch.float64, device=bMb.device)

@@ -120,21 +120,21 @@ class GraphedHyperStep:
         gp = self.w.gp
         if self._seed is not None and self._seed == gp._hyper_version():
             gp._memo["hyper"] = (self._seed, [(self.f_tc, s2, self.f_tc64)])
+            gp.__dict__["_s2_dev"] = (self._seed, self.f_s2)          # sigma2 on the device, for consumers that take it from there
         self._seed = None
         return loss
 
     # ---------------------------------------------------------------------------------------------------------------------
     def _stage(self, sps):
-        for (fac, st, _), buf in zip(sps, self.bufs):
+        n = float(self.w.gp.num_data)
+        for k, ((fac, st, _), buf) in enumerate(zip(sps, self.bufs)):
             basis = st["basis"]
             fac.coefficients(st)
-            buf["G"].copy_(st["G"])
-            buf["Linv"].copy_(st["Linv"])
-            buf["sqG"].copy_(st["sqG"])
-            torch.cat([st["sq"], st["zeta"], basis.lam_kuu, basis.ev_tab.reshape(-1), basis.Vtab, st["bMb"].reshape(1), st["logdet"].reshape(1)],
-                      out=buf["packed"])
-        self.n_pin[0] = float(self.w.gp.num_data)
-        self.n_dev.copy_(self.n_pin, non_blocking=True)
+            v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = buf["views"]
+            # ONE launch per output: the three r x r matrices, the seven packed pieces and (with the first output) the data count
+            grid_ops.multi_copy([(buf["G"], st["G"]), (buf["Linv"], st["Linv"]), (buf["sqG"], st["sqG"]), (v_sq, st["sq"]), (v_zeta, st["zeta"]),
+                                 (v_lam, basis.lam_kuu), (v_ev, basis.ev_tab.reshape(-1)), (v_V, basis.Vtab), (v_bMb, st["bMb"].reshape(1)),
+                                 (v_logdet, st["logdet"].reshape(1))], scalar=n if k == 0 else None, scalar_dst=self.n_dev if k == 0 else None)
 
     # ---------------------------------------------------------------------------------------------------------------------
     def _fused_plan(self):
@@ -217,14 +217,13 @@ class GraphedHyperStep:
         r = basis.r
         sizes = [r, r, r, basis.ev_tab.numel(), basis.Vtab.numel(), 1, 1]
         buf = {"G": torch.empty((r, r), **f64), "Linv": torch.empty((r, r), **f64), "sqG": torch.empty((r, r), **f64), "packed": torch.empty(sum(sizes), **f64)}
-        v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = torch.split(buf["packed"], sizes)
+        v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = buf["views"] = torch.split(buf["packed"], sizes)
         sbasis = SpectralBasis.on_device(basis, v_V, v_ev.view(basis.ev_tab.shape), None, lam=v_lam)
         sst = {"basis": sbasis, "G": buf["G"], "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": buf["Linv"], "sqG": buf["sqG"], "bMb": v_bMb.reshape(()),
                "logdet": v_logdet, "kscale": None}
         self.bufs = [buf]
         fac._grid_dev()
         self.n_dev = torch.zeros(1, **f64)
-        self.n_pin = torch.zeros(1, dtype=torch.float64).pin_memory()
         grid = gp._grid
         nell = next(p.numel() for p, role, _ in entries if role == 0)
         mk = lambda n_: torch.empty(n_, dtype=dt, device=dev)
@@ -237,6 +236,7 @@ class GraphedHyperStep:
         stats = gp._kernel_cache["_stats"]
         self._stage(sps)
         self._fused_keep = (plan, entries, ell, s2, scale, ell2, s2n, scale2, mid)      # (addresses recorded into the graph stay alive)
+        self.f_s2 = s2n
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             grid_ops.hyper_columns(plan, grid, kind, ell, scale, s2)
@@ -268,14 +268,13 @@ class GraphedHyperStep:
             sizes = [r, r, r, basis.ev_tab.numel(), basis.Vtab.numel(), 1, 1]
             buf = {"G": torch.empty((r, r), **f64), "Linv": torch.empty((r, r), **f64), "sqG": torch.empty((r, r), **f64),
                    "packed": torch.empty(sum(sizes), **f64)}
-            v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = torch.split(buf["packed"], sizes)
+            v_sq, v_zeta, v_lam, v_ev, v_V, v_bMb, v_logdet = buf["views"] = torch.split(buf["packed"], sizes)
             sbasis = SpectralBasis.on_device(basis, v_V, v_ev.view(basis.ev_tab.shape), None, lam=v_lam)
             static.append((fac, {"basis": sbasis, "G": buf["G"], "sq": v_sq, "zeta": v_zeta, "coef": v_zeta, "Linv": buf["Linv"], "sqG": buf["sqG"], "bMb": v_bMb.reshape(()),
                                  "logdet": v_logdet, "kscale": None}, None))
             self.bufs.append(buf)
             fac._grid_dev()                           # (an upload: must exist before the capture)
         self.n_dev = torch.zeros(1, **f64)
-        self.n_pin = torch.zeros(1, dtype=torch.float64).pin_memory()
         self._stage(sps)
         opt.zero_grad(set_to_none=True)               # the capture allocates the gradients in its own pool; replays rewrite them
         graph = torch.cuda.CUDAGraph()
