@@ -279,7 +279,7 @@ class SpectralWoodburyFactor:
         F = grid_ops.basis_project(self.grid, X, self.ref.Vtab, self.ref.kmax, self.ref.S, scale=sc, err=self.err)
         grid_ops.gemm(F, F, ta=True, alpha=1.0, beta=1.0, C=self.G_ref)
         t = wby.double() if wa is None else wby.double() / sc.double()       # rows of F already carry sqrt(wa)
-        self.h_ref.add_(torch.mv(F.t(), t))
+        self.h_ref.addmv_(F.t(), t)
         self.data_version += 1
         self.idle_absorbs += 1
 
@@ -321,7 +321,10 @@ class SpectralWoodburyFactor:
         # C = I + PSD: cannot fail on finite input.  With the factor its explicit inverse (r^3 / 3 flop more): every later solve
         # against it -- mean, variances, MLL terms -- is then ONE GEMM / GEMV launch instead of a blocked sweep of ~2 r / 64
         # launches.  Two launches in all for r <= 480 (dense_small.h).
-        Linv, info = grid_ops.potrf_inverse_(C)
+        info = self.__dict__.get("_info")                 # (never read back: C = I + PSD; one persistent word instead of a fill launch per refresh)
+        if info is None:
+            info = self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        Linv, info = grid_ops.potrf_inverse_(C, info=info)
         cur = {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": TS, "lam": lam, "sq": sq, "G": G,
                "chol": C, "Linv": Linv, "info": info, "tail": tail, "sqG": sqG}
         # hr = T^T h_ref, c = chol^-1 Lam^1/2 hr, b^T M b = |c|^2, t = chol^-T c, the mean coefficients and logdet (wiski_factor_tail)

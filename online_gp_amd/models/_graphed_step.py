@@ -55,7 +55,12 @@ class GraphedHyperStep:
         if max(gp._grid.g) > 64:                      # (the one-launch lag gradient; larger factors take the op-by-op form)
             return None
         gp._finish_pending()
-        gp.check_bounds()                             # the eager MLL does both first; neither may happen inside a capture
+        # the eager MLL checks the out-of-grid flag first (a host read; it may not happen inside a capture) -- unless evaluate() has
+        # just read it clean with the same statistics (models/online_ski_regression.py)
+        clean = gp.__dict__.get("_bounds_clean_at")
+        fac0 = gp.__dict__.get("_spectral", {}).get(0)
+        if gp._wsum_dirty or clean is None or fac0 is None or clean != (gp.num_data, fac0.data_version):
+            gp.check_bounds()
         sps = [gp._spectral_state(o) for o in range(gp.num_outputs)]      # one factor per output (own statistics, own hyper-parameters)
         return sps if all(sp is not None for sp in sps) else None
 
@@ -76,8 +81,9 @@ class GraphedHyperStep:
         from ..priors import REGISTRY_EPOCH
 
         def _hp(g):
-            return tuple((k_, (tuple(v) if isinstance(v, (tuple, list)) else v)) for k_, v in sorted(g.items())
-                         if k_ != "params" and isinstance(v, (int, float, bool, tuple, list, type(None))))
+            # (the entries a recorded Adam step bakes in; looked up one by one -- this runs every step)
+            return (g.get("lr") if not torch.is_tensor(g.get("lr")) else id(g.get("lr")), tuple(g.get("betas", ())), g.get("eps"), g.get("weight_decay"),
+                    g.get("amsgrad"), g.get("maximize"), g.get("capturable"), g.get("fused"), g.get("foreach"), g.get("differentiable"))
 
         key = (tuple((sp[1]["basis"].S.data_ptr(), sp[1]["basis"].r, sp[1]["basis"].kmax) for sp in sps), str(gp._dtype),
                tuple(_hp(g) for g in opt.param_groups), id(opt),

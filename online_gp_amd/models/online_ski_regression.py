@@ -125,8 +125,12 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         if not fac.mean_ok:                               # (a verdict read just now turned the factor's mean off)
             return None
         vals = out.tolist()
-        if int(vals[2]) and settings.deferred_bounds_check.off():
-            gp._raise_out_of_bounds(int(vals[2]))
+        if int(vals[2]):
+            if settings.deferred_bounds_check.off():
+                gp._raise_out_of_bounds(int(vals[2]))
+        else:
+            # the flag was clean after everything absorbed so far: the hyper step that follows need not read it again
+            gp.__dict__["_bounds_clean_at"] = (gp.num_data, fac.data_version)
         return vals[0], vals[1]
 
     # ----- batch training
