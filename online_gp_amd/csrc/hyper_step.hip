@@ -29,18 +29,28 @@ __device__ __forceinline__ double hs_profile(int kind, double r) {
   return (1.0 + s + s * s / 3.0) * exp(-s);
 }
 
-// constraint transform and its derivative w.r.t. the raw value, in the parameter dtype (as the framework evaluates them)
+// constraint transform and its backward pass, in the parameter dtype and in the framework's own operation order (softplus:
+// log1p(exp(x)) above / below the threshold of 20, backward g z / (z + 1) with z = exp(x); sigmoid: backward ((g w) (1 - y)) y) -- a
+// trajectory recorded here and one recorded through autograd then agree to the last bit of an fp32 parameter, not just to 1e-7
+__device__ __forceinline__ float hs_exp(float x) { return expf(x); }
+__device__ __forceinline__ double hs_exp(double x) { return exp(x); }
+__device__ __forceinline__ float hs_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ double hs_log1p(double x) { return log1p(x); }
 template <typename real>
-__device__ __forceinline__ real hs_transform(const wiski_hyper_param& p, real raw, real* dval) {
-  if (p.kind == 0) {                      // lower + softplus(raw)   (softplus with the framework's threshold of 20)
-    const real sp = raw > (real)20 ? raw : (real)log1p(exp((double)raw));
-    *dval = raw > (real)20 ? (real)1 : (real)(1.0 / (1.0 + exp(-(double)raw)));
-    return sp + (real)p.lower;
+__device__ __forceinline__ real hs_transform(const wiski_hyper_param& p, real raw) {
+  if (p.kind == 0) return (raw > (real)20 ? raw : hs_log1p(hs_exp(raw))) + (real)p.lower;
+  const real sg = (real)1 / ((real)1 + hs_exp(-raw));
+  return (real)p.lower + (real)(p.upper - p.lower) * sg;
+}
+template <typename real>
+__device__ __forceinline__ real hs_backward(const wiski_hyper_param& p, real raw, real g) {
+  if (p.kind == 0) {
+    if (raw > (real)20) return g;
+    const real z = hs_exp(raw);
+    return g * z / (z + (real)1);
   }
-  const real sg = (real)(1.0 / (1.0 + exp(-(double)raw)));
-  const real w = (real)(p.upper - p.lower);
-  *dval = w * sg * ((real)1 - sg);
-  return (real)p.lower + w * sg;
+  const real y = (real)1 / ((real)1 + hs_exp(-raw));
+  return ((g * (real)(p.upper - p.lower)) * ((real)1 - y)) * y;
 }
 
 template <typename real>
@@ -56,20 +66,19 @@ __global__ __launch_bounds__(256) void k_hyper_columns(wiski_hyper_plan plan, Co
     for (int i = 0; i < plan.count; ++i) {
       const wiski_hyper_param& p = plan.p[i];
       const real* raw = (const real*)p.raw;
-      real dv;
       if (p.role == 0) {
         nell = p.numel;
         for (int e = 0; e < p.numel; ++e) {
-          const real v = hs_transform<real>(p, raw[e], &dv);
+          const real v = hs_transform<real>(p, raw[e]);
           ell[e] = v;
           s_ell[e] = (double)v;
         }
       } else if (p.role == 1) {
-        const real v = hs_transform<real>(p, raw[0], &dv);
+        const real v = hs_transform<real>(p, raw[0]);
         sc = has_scale ? sc * v : v;
         has_scale = true;
       } else {
-        const real v = hs_transform<real>(p, raw[0], &dv);
+        const real v = hs_transform<real>(p, raw[0]);
         s2[0] = v;
         if (s2_f64) s2_f64[0] = (double)v;
       }
@@ -125,8 +134,7 @@ __global__ void k_hyper_adam(wiski_hyper_plan plan, const real* __restrict__ sca
   if (pi >= 0) {
     const wiski_hyper_param& p = plan.p[pi];
     real* raw = (real*)p.raw;
-    real dv;
-    const real val = hs_transform<real>(p, raw[e], &dv);
+    const real val = hs_transform<real>(p, raw[e]);
     real gv;                                                    // d loss / d (constrained value)
     if (p.role == 0) gv = g_ell[e];
     else if (p.role == 1) gv = g_scale[0] * (scale[0] / val);   // the product of the factors, divided by this one
@@ -134,19 +142,21 @@ __global__ void k_hyper_adam(wiski_hyper_plan plan, const real* __restrict__ sca
       const double s2 = (double)s2p[0], n = n_dev[0];
       gv = (real)(mid[4] * (0.5 * mid[3] / (s2 * s2) - 0.5 * n / s2) - g_kap[0] / (s2 * s2));
     }
-    const real grad = gv * dv;
+    const real grad = hs_backward<real>(p, raw[e], gv);
     // torch.optim.Adam (no weight decay, no amsgrad), arithmetic in the parameter dtype, step counter fp32
     real* m = (real*)p.exp_avg;
     real* v = (real*)p.exp_avg_sq;
     const float* stp = (const float*)p.step;
     const float step = stp[e < p.step_numel ? e : 0] + 1.f;
-    const real b1 = (real)beta1, b2 = (real)beta2;
-    const real mn = m[e] + ((real)1 - b1) * (grad - m[e]);      // lerp, as the framework's fused kernel
-    const real vn = b2 * v[e] + ((real)1 - b2) * grad * grad;
+    // (the constants as the framework's fused kernel forms them: 1 - beta and beta^step in double, then rounded to the parameter dtype --
+    //  1 - (float)0.999 is off by 1e-4 relative, which is what the second moment would then be off by)
+    const real b2 = (real)beta2, omb1 = (real)(1.0 - beta1), omb2 = (real)(1.0 - beta2);
+    const real mn = m[e] + omb1 * (grad - m[e]);                // lerp
+    const real vn = b2 * v[e] + omb2 * grad * grad;
     m[e] = mn;
     v[e] = vn;
-    const real bc1 = (real)1 - (real)pow((double)b1, (double)step);
-    const real bc2 = (real)1 - (real)pow((double)b2, (double)step);
+    const real bc1 = (real)(1.0 - pow(beta1, (double)step));
+    const real bc2 = (real)(1.0 - pow(beta2, (double)step));
     const real step_size = (real)lr / bc1;
     const real denom = (real)sqrt((double)vn) / (real)sqrt((double)bc2) + (real)eps;
     raw[e] = raw[e] - step_size * (mn / denom);

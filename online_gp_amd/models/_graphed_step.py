@@ -183,7 +183,7 @@ class GraphedHyperStep:
         if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad") or grp.get("maximize") or grp.get("differentiable") or torch.is_tensor(grp["lr"]):
             return None
         dt = ps[0].dtype
-        if dt not in (torch.float32, torch.float64) or dt != gp._dtype:
+        if dt not in (torch.float32, torch.float64):
             return None
         plan = _hip.wiski_hyper_plan()
         plan.count = len(entries)
@@ -238,7 +238,8 @@ class GraphedHyperStep:
         mid = torch.empty(9, **f64)
         self.host_read = torch.zeros(2, **f64)
         self.f_tc64 = torch.empty(sum(grid.g), **f64)
-        self.f_tc = torch.empty(sum(grid.g), dtype=dt, device=dev)
+        self.f_tc = torch.empty(sum(grid.g), dtype=gp._dtype, device=dev)
+        same = dt == gp._dtype                        # (parameters may be fp32 under an fp64 model: the columns in the model dtype by a cast node then)
         stats = gp._kernel_cache["_stats"]
         self._stage(sps)
         self._fused_keep = (plan, entries, ell, s2, scale, ell2, s2n, scale2, mid)      # (addresses recorded into the graph stay alive)
@@ -251,7 +252,9 @@ class GraphedHyperStep:
             g_tcol, g_kap = fac.mll_backward(sst, mid[5], mid[6], kap=mid[8:9])
             g_ell, g_scale = grid_ops.stationary_columns_grad(grid, kind, ell, scale, g_tcol)
             grid_ops.hyper_adam(plan, scale, s2, g_ell, g_scale, mid, g_kap, self.n_dev, lr, b1, b2, eps)
-            grid_ops.hyper_columns(plan, grid, kind, ell2, scale2, s2n, self.host_read[1:2], self.f_tc64, self.f_tc)
+            grid_ops.hyper_columns(plan, grid, kind, ell2, scale2, s2n, self.host_read[1:2], self.f_tc64, self.f_tc if same else None)
+            if not same:
+                self.f_tc.copy_(self.f_tc64)
         self.graph, self.loss, self.key = graph, self.host_read[0], key
         self.fused = True
         self.captures += 1

@@ -119,7 +119,7 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         if ws is None:
             ws = fac._eval_ws = torch.zeros(200, dtype=torch.float64, device=gp._device)
         s2c = gp.__dict__.get("_s2_dev")                  # left on the device by the captured hyper step (models/_graphed_step.py)
-        s2 = s2c[1] if s2c is not None and s2c[0] == gp._hyper_version() else gp.likelihood.second_noise.detach().reshape(-1).to(dt)
+        s2 = s2c[1] if s2c is not None and s2c[0] == gp._hyper_version() and s2c[1].dtype == dt else gp.likelihood.second_noise.detach().reshape(-1).to(dt)
         out = grid_ops.spectral_evaluate(q.Fs, q.prior, st["Linv"], st["t"], st["kscale"], s2, targets.reshape(-1).to(dt).contiguous(), gp._err, ws)
         fac.mean_monitor(st, q, gp._kernel_cache["interpolation_cache"][0, :, 0], tcol64, out[3])
         if not fac.mean_ok:                               # (a verdict read just now turned the factor's mean off)

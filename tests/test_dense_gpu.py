@@ -80,9 +80,9 @@ def test_cholesky_trsm_logdet(dtype, tol, n):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
 @pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 65, 100, 327, 449, 480, 481, 500, 512, 513, 700])
 def test_cholesky_with_explicit_inverse(dtype, tol, n):
-    """wiski_potrf_inverse: factor in place + X = L^-1.  n <= 480 is the one-workgroup path (dense_small.h: every panel
-    boundary case -- partial last block, exactly full blocks, one block); up to 512 the factor still is, with a blocked triangular solve for
-    the inverse; beyond that the blocked factorisation."""
+    """wiski_potrf_inverse: factor in place + X = L^-1.  n <= 480 is the one-launch path of cooperating workgroups (dense_coop.h: every
+    panel boundary case -- partial last block, exactly full blocks, one block, no owner tiles at all for <= 2 blocks); up to 512 the factor
+    still is, with a blocked triangular solve for the inverse; beyond that the blocked factorisation."""
     from online_gp_amd import grid_ops
 
     g = torch.Generator(device="cpu").manual_seed(1000 + n)
@@ -103,6 +103,50 @@ def test_cholesky_with_explicit_inverse(dtype, tol, n):
     assert int(grid_ops.potrf_(L2).item()) == 0
     assert torch.equal(L2, L)
     del pad
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
+def test_cooperative_cholesky_back_to_back_and_on_two_streams(dtype, tol):
+    """The cooperating-workgroups factorisation keeps its hand-over flags in a persistent block per stream that every launch leaves
+    zeroed: many launches back to back (different sizes, no synchronisation in between) and launches on a second stream give the same
+    factors and inverses as the host reference."""
+    from online_gp_amd import grid_ops
+
+    g = torch.Generator(device="cpu").manual_seed(77)
+    mats = []
+    for n in (327, 64, 480, 97, 327, 33, 449):
+        R = torch.randn(n, n, generator=g, dtype=torch.float64)
+        mats.append((R @ R.t() / n + torch.eye(n, dtype=torch.float64)).to(DEV, dtype))
+    outs = []
+    for rep in range(3):
+        for A in mats:
+            L = A.clone()
+            X, info = grid_ops.potrf_inverse_(L)
+            outs.append((A, L, X, info))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for A in mats[:3]:
+            L = A.clone()
+            X, info = grid_ops.potrf_inverse_(L)
+            outs.append((A, L, X, info))
+    torch.cuda.synchronize()
+    for A, L, X, info in outs:
+        n = A.shape[0]
+        assert int(info.item()) == 0
+        Lref = torch.linalg.cholesky(A.double())
+        assert (L.double() - Lref).abs().max().item() < tol * 10
+        assert ((X @ L).double() - torch.eye(n, dtype=torch.float64, device=DEV)).abs().max().item() < tol * 50
+
+
+def test_multi_copy_is_one_launch_for_all_segments():
+    from online_gp_amd import grid_ops
+
+    src = [torch.randn(k, device=DEV, dtype=torch.float64) for k in (1, 7, 327 * 327, 4800, 1, 33)]
+    dst = [torch.zeros_like(s_) for s_ in src]
+    n_dev = torch.zeros(1, device=DEV, dtype=torch.float64)
+    grid_ops.multi_copy(list(zip(dst, src)), scalar=12345.0, scalar_dst=n_dev)
+    assert all(torch.equal(d_, s_) for d_, s_ in zip(dst, src)) and float(n_dev) == 12345.0
 
 
 def test_small_cholesky_reports_a_non_positive_pivot():
