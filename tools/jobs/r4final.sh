@@ -21,6 +21,8 @@ rm -rf /tmp/tr; timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp
 f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
 test -n "$f" && python $R/tools/trace_timeline.py "$f" > $O/refstep_timeline.txt && head -1 $O/refstep_timeline.txt
 cd $R
+timeout 200 python tools/bench_small_potrf.py > $O/small_potrf.txt 2>&1; grep "327\|480" $O/small_potrf.txt
+timeout 200 python tools/refstep_probe.py > $O/refstep_probe.txt 2>&1; tail -2 $O/refstep_probe.txt
 python -c "
 import json; r=json.load(open('$O/bench.json')); e=r['extra']
 print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline']['net_of_empty_dispatch_frac'])
