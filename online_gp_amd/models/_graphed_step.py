@@ -40,9 +40,10 @@ class GraphedHyperStep:
         self.fused = False         # the current graph was recorded without autograd (csrc/hyper_step.hip)
         self.fused_captures = 0
         self._seed = None
+        self._prepared = self._prepared_sps = None
 
     # ---------------------------------------------------------------------------------------------------------------------
-    def _applicable(self):
+    def _applicable(self, skip_bounds=False):
         """The live factor state if this step can run as a graph, else None."""
         w = self.w
         gp, opt = w.gp, w.gp_optimizer
@@ -59,21 +60,26 @@ class GraphedHyperStep:
         # just read it clean with the same statistics (models/online_ski_regression.py)
         clean = gp.__dict__.get("_bounds_clean_at")
         fac0 = gp.__dict__.get("_spectral", {}).get(0)
-        if gp._wsum_dirty or clean is None or fac0 is None or clean != (gp.num_data, fac0.data_version):
+        if not skip_bounds and (gp._wsum_dirty or clean is None or fac0 is None or clean != (gp.num_data, fac0.data_version)):
             gp.check_bounds()
         sps = [gp._spectral_state(o) for o in range(gp.num_outputs)]      # one factor per output (own statistics, own hyper-parameters)
         return sps if all(sp is not None for sp in sps) else None
 
-    def step(self, lazy=False):
-        """One Adam step on -MLL; returns the loss, or None when the caller has to take the eager path.  lazy: return the device
-        scalar instead of reading it (the read is a synchronisation: a caller with more launches to queue -- the absorb of the
-        batch -- reads it after those; valid until the next replay)."""
-        sps = self._applicable()
+    def _token(self, sps):
+        """What a staged-but-not-yet-replayed step depends on: the factor states themselves, hyper-parameters, data count, optimiser."""
+        gp, opt = self.w.gp, self.w.gp_optimizer
+        g0 = opt.param_groups[0]
+        return (tuple(id(sp[1]) for sp in sps), tuple(sp[0].data_version for sp in sps), gp._hyper_version(), gp.num_data, id(opt), g0.get("lr") if not torch.is_tensor(g0.get("lr")) else id(g0.get("lr")),
+                tuple(g0.get("betas", ())), g0.get("eps"), g0.get("weight_decay"), g0.get("amsgrad"), g0.get("maximize"))
+
+    def _prepare(self, skip_bounds=False):
+        """Everything of a step up to the replay: applicability, warm-up count, (re-)capture, staging of the factor state.  Returns True when
+        the graph is ready to be replayed for the current state."""
+        sps = self._applicable(skip_bounds)
         if sps is None:
-            return None
+            return False
         if self.eager_calls < WARMUP_STEPS:
-            self.eager_calls += 1
-            return None
+            return None                               # (the caller counts the eager step)
         w = self.w
         gp, opt = w.gp, w.gp_optimizer
         # everything the captured graph bakes in: the index sets, the optimiser's hyper-parameters (lr, betas, eps, weight decay ...),
@@ -94,12 +100,12 @@ class GraphedHyperStep:
             # refresh, a kernel whose spectrum moves fast), stop re-capturing for a while and let the eager path run.
             if self.cooldown > 0:
                 self.cooldown -= 1
-                return None
+                return False
             if self.key is not None and self.replays - self.replays_at_capture < 4:
                 self.churn += 1
                 if self.churn >= 3:
                     self.churn, self.cooldown, self.key, self.graph = 0, 64, None, None
-                    return None
+                    return False
             else:
                 self.churn = 0
             try:
@@ -108,8 +114,44 @@ class GraphedHyperStep:
                 self.disabled = f"{type(exc).__name__}: {exc}"
                 self.graph = self.key = None
                 gp.__dict__.pop("_graph_ctx", None)
-                return None
+                return False
         self._stage(sps)
+        self._prepared = self._token(sps)
+        self._prepared_sps = sps
+        return True
+
+    def prepare(self):
+        """Called by evaluate() just before its one host read: the step that follows (update() of the same batch) finds its graph
+        checked and its factor state staged -- that work is done while the host would otherwise wait for the metrics, instead of in
+        the gap between the metrics and the replay, where the device idles."""
+        if self.graph is None or self.disabled is not None or self.eager_calls < WARMUP_STEPS or settings.graphed_hyper_step.off():
+            return
+        try:
+            if self._prepare(skip_bounds=True) is not True:       # (the flag is read by the caller, with its metrics)
+                self._prepared = None
+        except Exception:
+            self._prepared = None
+
+    def step(self, lazy=False):
+        """One Adam step on -MLL; returns the loss, or None when the caller has to take the eager path.  lazy: return the device
+        scalar instead of reading it (the read is a synchronisation: a caller with more launches to queue -- the absorb of the
+        batch -- reads it after those; valid until the next replay)."""
+        gp = self.w.gp
+        ready = False
+        if (self._prepared is not None and self.graph is not None and self.disabled is None and settings.graphed_hyper_step.on()
+                and settings.spectral_factor.on() and not gp._wsum_dirty and gp.__dict__.get("_pending_step") is None):
+            sps = self._prepared_sps
+            ready = (all(sp[0].cur is sp[1] for sp in sps) and self._token(sps) == self._prepared
+                     and gp.__dict__.get("_bounds_clean_at") == (gp.num_data, sps[0][0].data_version))
+        self._prepared = None
+        if not ready:
+            r = self._prepare()
+            self._prepared = None
+            if r is None:
+                self.eager_calls += 1
+                return None
+            if not r:
+                return None
         self.graph.replay()
         self.replays += 1
         gp.zero_grad()                                # (as the eager step: drops the gradients and moves the hyper-parameter epoch on)

@@ -124,6 +124,9 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         fac.mean_monitor(st, q, gp._kernel_cache["interpolation_cache"][0, :, 0], tcol64, out[3])
         if not fac.mean_ok:                               # (a verdict read just now turned the factor's mean off)
             return None
+        gs = self.__dict__.get("_graphed")
+        if gs is not None:
+            gs.prepare()                                  # (the hyper step of this batch: checked and staged before the host waits below)
         vals = out.tolist()
         if int(vals[2]):
             if settings.deferred_bounds_check.off():
