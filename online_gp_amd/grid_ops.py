@@ -795,16 +795,24 @@ def basis_eig_update(g_dev, tcol64, Vin, kw, kuse, ref_Vtab=None, kref=0):
     return (Vout, ev, resid) if ref_Vtab is None else (Vout, ev, resid, Tq)
 
 
-def basis_change(g_dev, Tq, kref, ref_S, kw, S, ev, tcol64, resid, work):
-    """``wiski_basis_change``: (TS [r_ref, r], lam [r], verdict [3]) for a device-refreshed basis; work: r + 1 zeroed doubles."""
+def basis_change(g_dev, Tq, kref, ref_S, kw, S, ev, tcol64, resid, work, verdict_pinned=None):
+    """``wiski_basis_change``: (TS [r_ref, r], lam [r], verdict [3]) for a device-refreshed basis; work: r + 1 zeroed doubles.
+    verdict_pinned: a pinned host tensor (fp64 [3]) the kernel writes the verdict to directly (host-mapped memory: no copy launch; read it
+    after an event recorded behind this call); the returned verdict is then that tensor."""
     d, r_ref = ref_S.shape
     r = S.shape[1]
     TS = torch.empty((r_ref, r), dtype=torch.float64, device=Tq.device)
     lam = torch.empty(r, dtype=torch.float64, device=Tq.device)
-    verdict = torch.empty(3, dtype=torch.float64, device=Tq.device)
+    if verdict_pinned is not None:
+        if not verdict_pinned.is_pinned() or verdict_pinned.dtype != torch.float64 or verdict_pinned.numel() < 3:
+            raise _hip.WiskiError("basis_change: verdict_pinned must be a pinned fp64 tensor of >= 3 elements")
+        verdict, vptr = verdict_pinned, ctypes.c_void_p(verdict_pinned.data_ptr())
+    else:
+        verdict = torch.empty(3, dtype=torch.float64, device=Tq.device)
+        vptr = _hip.dptr(verdict)
     rc = _hip.lib().wiski_basis_change(ctypes.c_int32(d), _hip.dptr(g_dev), ctypes.c_int32(kref), ctypes.c_int32(kw), ctypes.c_int32(r_ref),
                                        ctypes.c_int32(r), _hip.dptr(Tq), _hip.dptr(ref_S), _hip.dptr(S), _hip.dptr(ev),
-                                       _hip.dptr(tcol64), _hip.dptr(resid), _hip.dptr(TS), _hip.dptr(lam), _hip.dptr(work), _hip.dptr(verdict),
+                                       _hip.dptr(tcol64), _hip.dptr(resid), _hip.dptr(TS), _hip.dptr(lam), _hip.dptr(work), vptr,
                                        _hip.stream_ptr(Tq.device))
     _hip.check(rc, "wiski_basis_change")
     return TS, lam, verdict

@@ -372,13 +372,16 @@ class SpectralWoodburyFactor:
         work = self.__dict__.get("_bc_work")
         if work is None or work.shape[0] < old.r + 1:
             work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
-        TS, lam, verdict = grid_ops.basis_change(gd[0], Tq, ref.kmax, ref.S, old.kmax, old.S, ev_tab, tcol64, resid, work[:old.r + 1])
+        # (the verdict goes straight into pinned host memory from the kernel -- no copy launch; two alternating buffers: the previous
+        #  verdict may not have been read yet when the next refresh is queued)
+        hosts = self.__dict__.get("_chk_hosts")
+        if hosts is None:
+            hosts = self._chk_hosts = [torch.zeros(3, dtype=torch.float64).pin_memory(), torch.zeros(3, dtype=torch.float64).pin_memory()]
+            self._chk_events = [torch.cuda.Event(), torch.cuda.Event()]
+        slot = self._dev_refreshes_total = (self.__dict__.get("_dev_refreshes_total", 0) + 1) & 1
+        host, ev = hosts[slot], self._chk_events[slot]
+        TS, lam, _ = grid_ops.basis_change(gd[0], Tq, ref.kmax, ref.S, old.kmax, old.S, ev_tab, tcol64, resid, work[:old.r + 1], verdict_pinned=host)
         basis = SpectralBasis.on_device(old, Vtab, ev_tab, None, lam=lam)
-        host = self.__dict__.get("_chk_host")
-        if host is None:
-            host = self._chk_host = torch.empty(3, dtype=torch.float64).pin_memory()
-        host.copy_(verdict, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         # limits: the eigen-residual far below the tail; the index set may leave out up to 1.5 x the tail (or what a rank-capped
         # selection left out to begin with) before it is re-selected

@@ -18,6 +18,7 @@ import torch
 
 from .. import settings
 from ..mlls import BatchedWoodburyMarginalLogLikelihood, mll_feature_surrogate, sm_partial_mll
+from .stems import Identity
 
 _LR_FLOOR = 1e-4          # eta_min of the cosine schedules
 _REPLAY = 1024            # replay sample size of the BatchNorm refresh
@@ -165,6 +166,8 @@ class StreamingSKIWrapper(torch.nn.Module):
         return float(loss.detach())
 
     def _stem_step(self, inputs, gp_targets, noise):
+        if type(self.stem) is Identity:              # parameter-free by construction: nothing to differentiate
+            return 0
         self.stem.eval()                             # deterministic features while differentiating
         feats = self.stem(inputs)
         if not feats.requires_grad:                  # parameter-free stem
