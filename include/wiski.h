@@ -416,6 +416,9 @@ int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_
  * (parallel Jacobi), fp64, one workgroup per dim. */
 int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout, double* d_ev, double* d_resid,
                            const double* d_Vref, int32_t kref, double* d_Tq, void* stream);   /* d_Vref / d_Tq (both or neither): also T_q = Vref_q^T Vnew_q, [d][32][32] */
+/* The same refresh, adaptive: Rayleigh-Ritz in the span of the previous vectors (after niter steps of subspace iteration, normally 0 -- one Adam step
+ * leaves the new eigenvectors inside that span to ~1e-14); only if the relative residual exceeds resid_ok a second pass with two steps re-centres the span. */
+int wiski_basis_eig_update_adaptive(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout, double* d_ev, double* d_resid, const double* d_Vref, int32_t kref, double* d_Tq, int32_t niter, double resid_ok, void* stream);
 /* Companion of wiski_basis_eig_update, one launch: the Kronecker-structured change of basis d_TS [r_ref, r] from the reference basis
  * (index set d_Sref [d, r_ref]) to the refreshed one (d_S [d, r]) given d_Tq [d][32][32] = Vref_q^T Vnew_q from wiski_basis_eig_update, the eigenvalues d_lam [r]
  * of Kuu on the kept index set, and d_verdict [3] = { max eigen-residual, trace fraction the index set leaves out, eigenvalue-weighted

@@ -18,6 +18,7 @@
 //
 // Always fp64 (the factor is small; fp64 MFMA is 78 TF), x in the model's dtype.
 #include "wiski_common.h"
+#include <cstdlib>
 
 constexpr int SPB_KMAX = 32;      // eigenvectors kept per dim (table columns)
 
@@ -174,7 +175,7 @@ constexpr int EIG_G = 64, EIG_K = 32;
 __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict__ gs, const double* __restrict__ tcol, const double* __restrict__ Vin,
                                                     int kw, int kuse, double* __restrict__ Vout, double* __restrict__ ev_out,
                                                     double* __restrict__ resid_out, const double* __restrict__ Vref, int kref,
-                                                    double* __restrict__ Tq_out) {
+                                                    double* __restrict__ Tq_out, int niter, double resid_ok) {
   __shared__ double sT[EIG_G], sV[EIG_G][EIG_K + 1], sZ[EIG_G][EIG_K + 1], sH[EIG_K][EIG_K + 1], sU[EIG_K][EIG_K + 1], sCS[EIG_K / 2][2], sTh[EIG_K];
   __shared__ int sPr[EIG_K / 2][2], sRank[EIG_K];
   __shared__ double sRed[4], sRed2[4];
@@ -194,7 +195,13 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     __syncthreads();
   };
   EIG_STAMP(0);
-  for (int iter = 0; iter < 2; ++iter) {
+  // Pass 0: Rayleigh-Ritz in the span of the previous vectors (+ guard vectors), preceded by `niter` steps of subspace iteration
+  // (default 0: after one Adam step the new eigenvectors lie in that span to ~1e-14 -- measured over 60 steps at lr 1e-3 / 1e-2 --,
+  // because the guard vectors carry what rotates in).  The residual decides: above `resid_ok` (the caller passes an eighth of the limit
+  // its verdict applies) the kernel makes a second pass with two steps of subspace iteration, which re-centres the span.
+  __shared__ double sRes;
+  for (int pass = 0; pass < 2; ++pass) {
+  for (int iter = 0; iter < (pass == 0 ? niter : 2); ++iter) {
     applyK();
     // modified Gram-Schmidt on the columns of sZ (rows = lanes of a wave, g <= 64); column c is normalised by wave 0, the
     // later columns are dealt to the 4 waves
@@ -304,25 +311,9 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     sZ[i][sRank[a]] = acc;
   }
   __syncthreads();
-  for (int e = t; e < g * kw; e += 256) {
-    sV[e / kw][e % kw] = sZ[e / kw][e % kw];
-    Vout[voff + e] = sZ[e / kw][e % kw];
-  }
-  if (t < kw) ev_out[q * kw + sRank[t]] = sTh[t] > 0 ? sTh[t] : 0.0;
+  for (int e = t; e < g * kw; e += 256) sV[e / kw][e % kw] = sZ[e / kw][e % kw];
   __syncthreads();
   EIG_STAMP(4);
-  // T_q = Vref_q^T Vnew_q for the change of basis (wiski_basis_change), while the new vectors sit in LDS
-  if (Vref && Tq_out) {
-    int roff = 0;
-    for (int p = 0; p < q; ++p) roff += gs[p] * kref;
-    for (int e = t; e < kref * kw; e += 256) {
-      const int a = e / kw, b = e % kw;
-      double acc = 0;
-      for (int i = 0; i < g; ++i) acc += Vref[roff + i * kref + a] * sV[i][b];
-      Tq_out[((int64_t)q * SPB_KMAX + a) * SPB_KMAX + b] = acc;
-    }
-  }
-  EIG_STAMP(5);
   // residual of the vectors that are used (the first kuse): max_i |K v - theta v|_i / theta_max
   applyK();
   double worst = 0;
@@ -346,18 +337,49 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     for (int i = 1; i < 4; ++i) w = sRed[i] > w ? sRed[i] : w;
     double tmax = 0;
     for (int b = 0; b < kw; ++b) tmax = sTh[b] > tmax ? sTh[b] : tmax;
-    resid_out[q] = tmax > 0 ? w / tmax : 0.0;
+    sRes = tmax > 0 ? w / tmax : 0.0;
   }
+  __syncthreads();
+  if (sRes <= resid_ok) break;                        // (block-uniform)
+  }
+  // ---- outputs: the vectors (sorted), the Ritz values, T_q = Vref_q^T Vnew_q for the change of basis (while the vectors sit in LDS)
+  for (int e = t; e < g * kw; e += 256) Vout[voff + e] = sV[e / kw][e % kw];
+  if (t < kw) ev_out[q * kw + sRank[t]] = sTh[t] > 0 ? sTh[t] : 0.0;
+  if (t == 0) resid_out[q] = sRes;
+  if (Vref && Tq_out) {
+    int roff = 0;
+    for (int p = 0; p < q; ++p) roff += gs[p] * kref;
+    for (int e = t; e < kref * kw; e += 256) {
+      const int a = e / kw, b = e % kw;
+      double acc = 0;
+      for (int i = 0; i < g; ++i) acc += Vref[roff + i * kref + a] * sV[i][b];
+      Tq_out[((int64_t)q * SPB_KMAX + a) * SPB_KMAX + b] = acc;
+    }
+  }
+  EIG_STAMP(5);
 }
 
-extern "C" int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout,
-                                      double* d_ev, double* d_resid, const double* d_Vref, int32_t kref, double* d_Tq, void* stream) {
+static int eig_update_launch(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout, double* d_ev,
+                             double* d_resid, const double* d_Vref, int32_t kref, double* d_Tq, int niter, double resid_ok, void* stream) {
   if (d < 1 || d > WISKI_MAX_DIM || !d_g || !d_tcol || !d_Vin || !d_Vout || !d_ev || !d_resid || kw < 2 || kw > EIG_K || (kw & 1) || kuse < 1 || kuse > kw)
     return WISKI_E_BADARG;
   if ((d_Vref || d_Tq) && (!d_Vref || !d_Tq || kref < 1 || kref > SPB_KMAX)) return WISKI_E_BADARG;
+  if (niter < 0 || niter > 8 || !(resid_ok >= 0)) return WISKI_E_BADARG;
   hipLaunchKernelGGL(k_eig_update, dim3((unsigned)d), dim3(256), 0, (hipStream_t)stream, (int)d, d_g, d_tcol, d_Vin, (int)kw, (int)kuse, d_Vout, d_ev, d_resid,
-                     d_Vref, (int)kref, d_Tq);
+                     d_Vref, (int)kref, d_Tq, niter, resid_ok);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+// two steps of subspace iteration, then Rayleigh-Ritz (one pass, whatever the residual)
+extern "C" int wiski_basis_eig_update(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, double* d_Vout,
+                                      double* d_ev, double* d_resid, const double* d_Vref, int32_t kref, double* d_Tq, void* stream) {
+  return eig_update_launch(d, d_g, d_tcol, d_Vin, kw, kuse, d_Vout, d_ev, d_resid, d_Vref, kref, d_Tq, 2, 1e300, stream);
+}
+// Rayleigh-Ritz in the span of the previous vectors first (after `niter` steps of subspace iteration, normally 0); a second pass with two
+// steps of subspace iteration only if the relative residual of the first exceeds resid_ok
+extern "C" int wiski_basis_eig_update_adaptive(int32_t d, const int32_t* d_g, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse,
+                                               double* d_Vout, double* d_ev, double* d_resid, const double* d_Vref, int32_t kref, double* d_Tq,
+                                               int32_t niter, double resid_ok, void* stream) {
+  return eig_update_launch(d, d_g, d_tcol, d_Vin, kw, kuse, d_Vout, d_ev, d_resid, d_Vref, kref, d_Tq, niter, resid_ok, stream);
 }
 
 // ------------------------------------------------------------ change of basis ---

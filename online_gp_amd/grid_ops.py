@@ -779,18 +779,21 @@ def gaussian_metrics(mu, var, y, add_var=None):
     return out
 
 
-def basis_eig_update(g_dev, tcol64, Vin, kw, kuse, ref_Vtab=None, kref=0):
+def basis_eig_update(g_dev, tcol64, Vin, kw, kuse, ref_Vtab=None, kref=0, resid_ok=None, niter=0):
     """``wiski_basis_eig_update``: the per-dim eigenvector tables Vin ([sum g_q * kw] fp64, row-major [g_q, kw] blocks) refined for the
-    Toeplitz columns tcol64, all on the device.  Returns (Vout, ev [d, kw] descending, resid [d])."""
+    Toeplitz columns tcol64, all on the device.  Returns (Vout, ev [d, kw] descending, resid [d]).  resid_ok: the adaptive form
+    (``wiski_basis_eig_update_adaptive``): Rayleigh-Ritz in the previous span first, subspace iteration only if the residual exceeds it."""
     d = g_dev.shape[0]
     Vout = torch.empty_like(Vin)
     ev = torch.empty((d, kw), dtype=torch.float64, device=Vin.device)
     resid = torch.empty(d, dtype=torch.float64, device=Vin.device)
     Tq = None if ref_Vtab is None else torch.empty((d, 32, 32), dtype=torch.float64, device=Vin.device)
-    rc = _hip.lib().wiski_basis_eig_update(ctypes.c_int32(d), _hip.dptr(g_dev), _hip.dptr(tcol64), _hip.dptr(Vin), ctypes.c_int32(kw),
-                                           ctypes.c_int32(kuse), _hip.dptr(Vout), _hip.dptr(ev), _hip.dptr(resid),
-                                           None if ref_Vtab is None else _hip.dptr(ref_Vtab), ctypes.c_int32(kref),
-                                           None if Tq is None else _hip.dptr(Tq), _hip.stream_ptr(Vin.device))
+    args = [ctypes.c_int32(d), _hip.dptr(g_dev), _hip.dptr(tcol64), _hip.dptr(Vin), ctypes.c_int32(kw), ctypes.c_int32(kuse), _hip.dptr(Vout), _hip.dptr(ev),
+            _hip.dptr(resid), None if ref_Vtab is None else _hip.dptr(ref_Vtab), ctypes.c_int32(kref), None if Tq is None else _hip.dptr(Tq)]
+    if resid_ok is None:
+        rc = _hip.lib().wiski_basis_eig_update(*args, _hip.stream_ptr(Vin.device))
+    else:
+        rc = _hip.lib().wiski_basis_eig_update_adaptive(*args, ctypes.c_int32(int(niter)), ctypes.c_double(float(resid_ok)), _hip.stream_ptr(Vin.device))
     _hip.check(rc, "wiski_basis_eig_update")
     return (Vout, ev, resid) if ref_Vtab is None else (Vout, ev, resid, Tq)
 

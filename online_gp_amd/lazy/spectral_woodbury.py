@@ -368,7 +368,9 @@ class SpectralWoodburyFactor:
         gd = self._grid_dev()
         # three launches: the eigenvector refresh, the change of basis with its verdict, the verdict's copy to pinned memory
         ref = self.ref
-        Vtab, ev_tab, resid, Tq = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax)
+        # (adaptive: Rayleigh-Ritz in the previous span; subspace iteration only if the residual gets within a factor 8 of the verdict's limit)
+        Vtab, ev_tab, resid, Tq = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax,
+                                                            resid_ok=(tail * 1e-3 / 8.0) if settings.adaptive_eig_update.on() else None)
         work = self.__dict__.get("_bc_work")
         if work is None or work.shape[0] < old.r + 1:
             work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)

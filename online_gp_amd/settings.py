@@ -323,6 +323,15 @@ class fused_hyper_step(_feature_flag):
     _state = True
 
 
+class adaptive_eig_update(_feature_flag):
+    """Device-side eigenvector refresh after a hyper-parameter step (``spectral_device_refresh``): Rayleigh-Ritz in the span of the previous
+    eigenvectors + guard vectors first, the two steps of subspace iteration only when the residual of that gets within a factor 8 of the
+    verdict's limit (``wiski_basis_eig_update_adaptive``; one Adam step leaves the new vectors inside the old span to ~1e-14).  Off: always
+    two steps of subspace iteration, then Rayleigh-Ritz."""
+
+    _state = True
+
+
 class fused_evaluate(_feature_flag):
     """``OnlineSKIRegression.evaluate`` of a batch of <= 64 points from the spectral factor as one projection launch + ONE launch for
     means, variances and both metrics (``wiski_spectral_evaluate``) instead of the posterior object and ~18 small launches; off: the

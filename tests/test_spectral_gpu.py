@@ -374,6 +374,39 @@ def test_device_eigen_update_tracks_the_host_eigh(g, kw, kuse, drift):
         assert resid[q] < (1e-11 if g >= 30 else 1e-6)
 
 
+@pytest.mark.parametrize("drift,second_pass", [(1.002, False), (1.6, True)])
+def test_adaptive_eigen_update_takes_its_second_pass_only_when_the_residual_asks(drift, second_pass):
+    """wiski_basis_eig_update_adaptive: after a step as small as an optimiser's the Rayleigh-Ritz values in the span of the previous
+    vectors (+ guard vectors) already meet the residual bound, and the result equals the host eigh; after a large jump they do not, the
+    kernel makes its second pass (two steps of subspace iteration) by itself and the residual comes out far smaller than without it."""
+    from online_gp_amd import grid_ops
+
+    d, g, kw, kuse = 3, 50, 16, 10
+    ells = np.array([0.35, 0.5, 0.42])
+    h = 2.2 / (g - 1)
+    idx = np.abs(np.arange(g)[:, None] - np.arange(g)[None, :])
+
+    def cols(e):
+        return [np.exp(-0.5 * (np.arange(g) * h / e[q]) ** 2) for q in range(d)]
+
+    V0 = [np.linalg.eigh(c[idx])[1][:, ::-1][:, :kw] for c in cols(ells)]
+    c1 = cols(ells * np.array([drift, 1.0 / drift, drift ** 0.5]))
+    w1 = [np.linalg.eigh(c[idx])[0][::-1] for c in c1]
+    Vin = torch.as_tensor(np.concatenate([V.reshape(-1) for V in V0])).to(DEV)
+    g_dev = torch.tensor([g] * d, dtype=torch.int32, device=DEV)
+    tc = torch.as_tensor(np.concatenate(c1)).to(DEV)
+    lim = 1e-8
+    _, ev_a, res_a = grid_ops.basis_eig_update(g_dev, tc, Vin, kw, kuse, resid_ok=lim)            # adaptive
+    _, _, res_rr = grid_ops.basis_eig_update(g_dev, tc, Vin, kw, kuse, resid_ok=1e300)          # Rayleigh-Ritz only, whatever the residual
+    res_a, res_rr, ev_a = res_a.cpu().numpy(), res_rr.cpu().numpy(), ev_a.cpu().numpy()
+    if second_pass:
+        assert res_rr.max() > lim and res_a.max() < 1e-3 * res_rr.max()
+    else:
+        assert res_rr.max() <= lim and np.array_equal(res_a, res_rr)
+        for q in range(d):
+            assert np.abs(ev_a[q, :kuse] - w1[q][:kuse]).max() < 1e-11 * w1[q][0]
+
+
 def test_hyperparameter_steps_refresh_the_factor_on_the_device():
     """Small optimiser-like steps keep the index set and refine the eigenvectors on the device (no host eigh): same predictions
     as the host path, verdict within its limits; a jump that the kept index set cannot serve is caught before use."""
