@@ -4,8 +4,8 @@
 // dense_small.h's one-workgroup factorisation is bound by one CU's matrix pipes: the trailing update of n = 327 alone is ~60 us
 // of fp64 MFMA time on a single CU (64 cycles per v_mfma_f64_16x16x4), the serial chain of the 11 diagonal steps another
 // 60 us, and the explicit inverse is a second launch that cannot start before the first has ended.  Here the three kinds of
-// work run in different workgroups of one grid and hand data to each other through global memory with agent-scope
-// release / acquire flags (workgroups sit on different XCDs: different L2s):
+// work run in different workgroups of one grid and hand data to each other through global memory: write-through stores, flags,
+// loads that bypass the reader's L2 (workgroups sit on different XCDs: different L2s; see coh_store / coh_load below):
 //   workgroup 0       the serial chain: per round the diagonal step (one wave), the panel L21 = A21 L11^-T, and the update of
 //                     the NEXT block column with this panel (in place in LDS: that IS the next panel -- no global round trip);
 //                     publishes ready[k] once block column k of L (and dinv[k]) is in global memory
@@ -49,35 +49,28 @@ __global__ __launch_bounds__(SWG) void k_potrf_coop(int n, real* A, int lda, rea
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nblk = (n + SNB - 1) / SNB;
   const int l15 = lane & 15, l4 = lane >> 4;
-  auto finish = [&]() {                                    // the last workgroup out resets the flags for the next call
-    __syncthreads();
-    if (tid == 0) {
-      const int t = __hip_atomic_fetch_add(&sy->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (int)gridDim.x - 1) {
-        for (int i = 0; i < 16; ++i) {
-          __hip_atomic_store(&sy->ready[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&sy->done[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __hip_atomic_store(&sy->ticket, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  auto leave = [&]() {                                     // (one thread per workgroup) the last workgroup out resets the flags for the next call
+    const int t = __hip_atomic_fetch_add(&sy->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (int)gridDim.x - 1) {
+      for (int i = 0; i < 16; ++i) {
+        __hip_atomic_store(&sy->ready[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->done[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      __hip_atomic_store(&sy->ticket, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+  };
+  auto finish = [&]() {
+    __syncthreads();
+    if (tid == 0) leave();
   };
 
   if (blockIdx.x > (unsigned)n_owner_wg) {
     // ------------------------------------------------------------------------------------------ inverse column
-    if (w < 4) tri_inv_column4<real>(n, A, lda, dinv, X, ldx, (int)blockIdx.x - 1 - n_owner_wg, sy->ready);
-    // (waves 4..7 have nothing to do; the column's barriers count the waves still alive)
+    // (waves 4..7 have nothing to do and leave; the column's barriers count the waves still alive.  Its last flag read lies before the
+    //  barrier that ends its last block row, so thread 0 may take the ticket as soon as it is through)
     if (w >= 4) return;
-    if (tid == 0) {
-      const int t = __hip_atomic_fetch_add(&sy->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (int)gridDim.x - 1) {
-        for (int i = 0; i < 16; ++i) {
-          __hip_atomic_store(&sy->ready[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&sy->done[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __hip_atomic_store(&sy->ticket, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    tri_inv_column4<real>(n, A, lda, dinv, X, ldx, (int)blockIdx.x - 1 - n_owner_wg, sy->ready);
+    if (tid == 0) leave();
     return;
   }
 

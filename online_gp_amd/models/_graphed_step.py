@@ -10,13 +10,19 @@ framework op at a time.  Here the whole sequence (forward, backward, optimiser u
 What a replay needs is that every address the recorded kernels read is still the right one:
   * parameters, optimiser state, the model's statistics buffer: live in place, so they are;
   * the factor state (G, chol^-1, sqrt(lam), zeta, the eigenvector tables, b^T M b, logdet) is rebuilt into fresh tensors by every
-    refresh -- it is copied into static staging buffers before each replay (two r x r copies and one packed ``cat``);
-  * the data count n and 1 / sigma2 enter the recorded kernels as device scalars (n through a pinned one-element copy);
+    refresh -- it is copied into static staging buffers before each replay, by ONE launch (``wiski_multi_copy_f64``: three r x r
+    matrices, seven packed pieces and the data count, which enters the recorded kernels as a device scalar like 1 / sigma2);
   * the index set S of the basis is used in place: the graph is re-captured when the factor re-selects it (or when the learning
     rate, the optimiser, the dtype or the set of priors changes).
 The first steps run eagerly (they also serve as the warm-up the allocator wants before a capture); whenever the spectral path does
 not apply -- dense regime, rough kernel, a foreign optimiser -- the caller's eager path runs instead.  Several outputs (the Dirichlet
 classifier's two) are one graph: one factor, one set of staging buffers per output.
+
+Two refinements (round 4).  (i) For the reference's own parameterisation -- (Scale of)* RBF | Matern, homoskedastic second
+noise, plain Adam, no registered priors -- the step is recorded WITHOUT autograd (``_capture_fused``, csrc/hyper_step.hip): 11 graph
+nodes instead of 40, and the graph leaves the Toeplitz columns and sigma2 of the UPDATED hyper-parameters behind (``read_loss`` hands
+them to the model's memo together with the loss: one host read).  (ii) ``prepare()``: evaluate() of a batch checks and stages the
+step of the same batch before its own host read, so update() only has to replay.
 """
 import torch
 

@@ -15,7 +15,8 @@ torch.cuda.synchronize()
 st = (ctypes.c_longlong * (17 * 8))()
 assert _hip.lib().wiski_potrf_stamps(st) == 0
 tot = [0.0] * 4
-print("round     B  Xwait  C+st    D1   (us; wall_clock64 at 100 MHz.  X = diagonal step || previous trailing tiles + panel load)")
+print("round     B  Xwait  C+st    D1   (us; wall_clock64 at 100 MHz.  B = the diagonal step of workgroup 0 / the one workgroup, Xwait = what it then waits\n"
+      "                                  for: the other waves' tile fetches (cooperative kernel) or trailing tiles + panel load (one-workgroup kernel))")
 nr = (n + 31) // 32
 for r in range(nr):
     s = [st[r * 8 + k] for k in range(5)]
