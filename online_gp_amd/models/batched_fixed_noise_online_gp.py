@@ -569,6 +569,18 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 return None
         return fac, st, tcol64
 
+    def _measure_factor_means(self, sps):
+        """Factors whose mean monitor can no longer decide by its bound (SpectralWoodburyFactor.measure_due): measure the factor's mean
+        against the PCG mean at the current hyper-parameters on the factor's probe set (one PCG solve, rare: every few hundred steps at
+        most), which either keeps the factor serving the mean or switches it off."""
+        due = [o for o, sp in enumerate(sps) if sp[0].measure_due]
+        if not due:
+            return
+        pc = self.prediction_cache
+        for o in due:
+            fac, st, tc = sps[o]
+            fac.measure_mean(st, tc, lambda pts, o=o: grid_ops.gather(self._grid, pts, pc["pred_mean"][..., 0], self._err)[:, o])
+
     def _spectral_in_use(self):
         """Every output has a spectral factor that follows the stream and has been asked for a state recently."""
         if settings.spectral_factor.off() or self._use_dense():
@@ -796,6 +808,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use()):
             sps = [self._spectral_state(o) for o in range(out)]
             if all(sp is not None for sp in sps):
+                if not pcg_current:
+                    self._measure_factor_means(sps)
+                    pcg_current = self._memo.get("prediction_cache") is not None      # (a measurement leaves a current PCG state behind)
                 sq = [sp[0].query(sp[1], Xf, sp[2]) for sp in sps]
                 factor_mean = not pcg_current and all(sp[0].mean_ok for sp in sps)
         pc = None

@@ -110,6 +110,8 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         if sp is None:
             return None
         fac, st, tcol64 = sp
+        if fac.measure_due:                                # (the mean monitor wants a measurement: the general path takes it)
+            return None
         if not fac.mean_ok or "t" not in st or st["basis"].r > 512:      # (the one-launch kernel holds a query vector in 8 registers per lane)
             return None
         dt = gp._dtype

@@ -526,6 +526,68 @@ def test_mean_monitor_bounds_the_truncated_mean_and_falls_back_to_pcg():
         sw.MEAN_CHECK_EVERY = old_every
 
 
+def test_mean_monitor_measures_before_it_gives_the_factor_mean_up():
+    """The Cauchy-Schwarz bound of the mean monitor grows with the data and ends up orders of magnitude above the error (50 000 points
+    into a 50^3 stream: bound 1e-2, error 4e-5).  When the bound passes the tolerance the model MEASURES the factor's mean against a PCG
+    solve on a probe set: within a quarter of the tolerance the factor keeps serving the mean (and is re-measured later), beyond it the
+    mean comes from the PCG state -- in both cases the served mean meets the data-space oracle."""
+    from online_gp_amd import settings
+    from online_gp_amd.lazy import spectral_woodbury as sw
+
+    rng = np.random.default_rng(34)
+    d, g, n = 3, 14, 900
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + 0.3 * X[:, 2] + 0.05 * rng.standard_normal(n)
+    Xs = rng.uniform(-1, 1, (40, d))
+    dtype = torch.float64
+    Xst = torch.as_tensor(Xs, device=DEV, dtype=dtype)
+
+    def nudge(m, f):
+        k = m.covar_module.base_kernel
+        with torch.no_grad():
+            k.base_kernel.lengthscale = k.base_kernel.lengthscale * f
+        m._dump_caches()
+
+    def served(m):
+        mu = m(Xst).mean.cpu().numpy()
+        ell, s, s2 = _hypers(m)
+        mo, _ = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, "rbf", ell, s, s2).fit(X, y, np.ones(n)).predict(Xs)
+        return np.abs(mu - mo).max() / np.abs(mo).max()
+
+    old_every = sw.MEAN_CHECK_EVERY
+    sw.MEAN_CHECK_EVERY = 1
+    try:
+        with settings.spectral_tail(1e-5), settings.cg_tolerance(1e-10):
+            m = _model(X, y, g, dtype)
+            m.eval()
+            m(Xst).variance
+            fac = m._spectral[0]
+            with settings.spectral_mean_tolerance(1.0):           # first: learn how large bound and error are here
+                for step in range(3):
+                    nudge(m, 1.01 if step % 2 == 0 else 1 / 1.01)
+                    dev = served(m)
+            bound = fac.last_mean_bound
+            assert bound is not None and fac.mean_ok and fac.measurements == 0 and dev < bound
+            # (a) a tolerance the bound misses but the error meets four times over: one measurement, the factor keeps the mean
+            lim = max(bound / 3.0, 8.0 * dev)
+            assert lim < bound
+            with settings.spectral_mean_tolerance(lim):
+                for step in range(4):
+                    nudge(m, 1.01 if step % 2 == 0 else 1 / 1.01)
+                    dev2 = served(m)
+                    assert dev2 < lim
+                assert fac.measurements == 1 and fac.mean_ok and fac.last_measured <= 0.25 * lim
+                assert m._memo.get("prediction_cache") is None       # (the last means came from the factor again)
+            # (b) a tolerance the error itself misses: the measurement switches the factor's mean off, PCG serves (and meets the oracle)
+            fac._measured_at = -10 ** 9
+            with settings.spectral_mean_tolerance(fac.last_measured * 2.0):
+                for step in range(3):
+                    nudge(m, 1.01 if step % 2 == 0 else 1 / 1.01)
+                    dev3 = served(m)
+                assert fac.measurements == 2 and not fac.mean_ok and dev3 < 1e-6
+    finally:
+        sw.MEAN_CHECK_EVERY = old_every
+
+
 def test_reference_step_loop_at_50pow3_matches_the_cpu_port_after_hyper_drift():
     """The reference's own loop (experiments/regression.py:48-54: evaluate -> Adam step on the MLL -> condition, per batch) at the
     bench size -- 50^3, fp32, 21 743 init points, 30 steps of q = 64 at lr 1e-2 so that the hyper-parameters really move -- runs on the

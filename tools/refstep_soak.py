@@ -11,7 +11,14 @@ X0, y0 = bench.synth_stream(21743, 3, 0, dev, dt, "uniform")
 Xr, yr = bench.synth_stream(40000, 3, 31337, dev, dt, "uniform")
 with settings.cg_tolerance(1e-4), settings.variance_cg_tolerance(3e-3):
     reg = OnlineSKIRegression(Identity(3), X0, y0, 1e-3, 50, 1.0)
-    t0 = time.perf_counter()
+    t0 = tw = time.perf_counter()
+    fast = [0]
+    orig = reg._evaluate_from_factor
+    def counted(x, y):
+        r = orig(x, y)
+        fast[0] += r is not None
+        return r
+    reg._evaluate_from_factor = counted
     for i in range(4001):
         xb, yb = Xr[i * 8:(i + 1) * 8], yr[i * 8:(i + 1) * 8]
         rm, nl = reg.evaluate(xb, yb); reg.update(xb, yb)
@@ -19,6 +26,8 @@ with settings.cg_tolerance(1e-4), settings.variance_cg_tolerance(3e-3):
             torch.cuda.synchronize()
             gs, fac = reg._graphed, reg.gp._spectral[0]
             k = reg.gp.covar_module.base_kernel
-            print(i, "ms/step %.3f" % ((time.perf_counter() - t0) / max(i, 1) * 1e3), "alloc MB %.1f reserved MB %.1f" % (torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6),
+            now = time.perf_counter()
+            print(i, "ms/step %.3f (last 500: %.3f)" % ((now - t0) / max(i, 1) * 1e3, (now - tw) / 500 * 1e3), "fused evaluates", fast[0], "mean_ok", fac.mean_ok, "mean bound", fac.last_mean_bound, "measured", fac.last_measured, "x", fac.measurements, "fused graph", gs.fused, "alloc MB %.1f reserved MB %.1f" % (torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6),
                   "captures", gs.captures, "replays", gs.replays, "dev refreshes", fac.device_refreshes, "rebuilds", fac.rebuilds, "rank", fac.cur["basis"].r,
                   "rmse %.4f" % rm, "ls", [round(float(v), 4) for v in k.base_kernel.lengthscale.detach().reshape(-1)], flush=True)
+            tw = time.perf_counter()
