@@ -219,6 +219,8 @@ class SpectralWoodburyFactor:
         if lim is None:
             lim = 1e-2 if self.dtype == torch.float32 else 1e-4
         self._monitor_calls = self.__dict__.get("_monitor_calls", 0) + 1
+        if self._monitor_calls - self._measured_at >= 4 * MEAN_MEASURE_EVERY:
+            self.measure_due = True                    # (an audit whatever the bound says: one PCG solve per 2048 calls)
         if self._mean_chk is not None:
             host, ev = self._mean_chk
             ev.synchronize()
