@@ -601,8 +601,11 @@ def main():
                 fac = reg.gp.__dict__.get("_spectral", {}).get(0)
                 gs_ = reg.__dict__.get("_graphed")
                 extra["reference_step_path"] = ("spectral Woodbury factor for mean / variance / MLL (rank %d, %d reference builds, %d eigenvector refreshes on the device); "
-                                                "Adam step on the MLL as a captured HIP graph: %d captures, %d replays%s"
-                                                % (fac.cur["basis"].r, fac.rebuilds, fac.device_refreshes, 0 if gs_ is None else gs_.captures,
+                                                "Cholesky + inverse of the factor as one launch of cooperating workgroups, evaluate() of <= 64 points as one projection + one launch; "
+                                                "Adam step on the MLL as a captured HIP graph%s: %d captures, %d replays%s"
+                                                % (fac.cur["basis"].r, fac.rebuilds, fac.device_refreshes,
+                                                   " recorded without autograd (11 nodes)" if gs_ is not None and gs_.fused else "",
+                                                   0 if gs_ is None else gs_.captures,
                                                    0 if gs_ is None else gs_.replays, "" if gs_ is None or gs_.disabled is None else " (disabled: %s)" % gs_.disabled)
                                                 if fac is not None and fac.cur is not None else "wiski_pcg (mean, 64-column variance solves, Hutchinson MLL gradient)")
                 # the PCG path of the same step (what every kernel / grid falls back to): 64-column variance solves, 10 Hutchinson probes
