@@ -202,8 +202,14 @@ static int hyper_columns_impl(const wiski_hyper_plan* plan, const wiski_grid* gr
 template <typename real>
 static int hyper_adam_impl(const wiski_hyper_plan* plan, const real* d_scale, const real* d_s2, const real* d_gell, const real* d_gscale, const double* d_mid,
                            const double* d_gkap, const double* d_n, double lr, double beta1, double beta2, double eps, void* stream) {
-  if (!plan_ok(plan, WISKI_MAX_DIM) && !plan) return WISKI_E_BADARG;
-  if (!d_s2 || !d_gell || !d_mid || !d_gkap || !d_n) return WISKI_E_BADARG;
+  if (!plan || plan->count < 1 || plan->count > WISKI_HYPER_MAX_PARAMS || !d_s2 || !d_gell || !d_mid || !d_gkap || !d_n) return WISKI_E_BADARG;
+  int total = 0;
+  for (int i = 0; i < plan->count; ++i) {
+    const wiski_hyper_param& p = plan->p[i];
+    if (!p.raw || p.numel < 1 || p.role < 0 || p.role > 2 || p.kind < 0 || p.kind > 1 || (p.role != 0 && p.numel != 1)) return WISKI_E_BADARG;
+    total += p.numel;
+  }
+  if (total > 64) return WISKI_E_BADARG;                  // (one thread per element, one wave)
   for (int i = 0; i < plan->count; ++i) {
     const wiski_hyper_param& p = plan->p[i];
     if (!p.exp_avg || !p.exp_avg_sq || !p.step || (p.step_numel != 1 && p.step_numel != p.numel)) return WISKI_E_BADARG;
