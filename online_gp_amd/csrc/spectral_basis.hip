@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
   // because the guard vectors carry what rotates in).  The residual decides: above `resid_ok` (the caller passes an eighth of the limit
   // its verdict applies) the kernel makes a second pass with two steps of subspace iteration, which re-centres the span.
   __shared__ double sRes;
+  const double jac_tol = resid_ok < 1.0 ? fmax(1e-30, resid_ok * resid_ok * 1e-4) : 1e-30;
   for (int pass = 0; pass < 2; ++pass) {
   for (int iter = 0; iter < (pass == 0 ? niter : 2); ++iter) {
     applyK();
@@ -250,7 +251,10 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
       }
       off2 = wave_reduce_sum<double>(off2);
       dg2 = wave_reduce_sum<double>(dg2);
-      if (off2 <= 1e-30 * dg2) break;                 // (the start is nearly diagonal -- the previous eigenvectors: 3-4 sweeps)
+      // (the start is nearly diagonal -- the previous eigenvectors: 3-4 sweeps of ~16 us each on one wave.  The sweeps stop where the
+      //  off-diagonal mass is two orders below the residual the caller accepts: for the fp32 model's 1e-10 that is one sweep less
+      //  than the 1e-15 the fixed form iterates to)
+      if (off2 <= jac_tol * dg2) break;
       for (int step = 0; step < n - 1; ++step) {
         if (lane < np) {
           int p_, q_;

@@ -29,6 +29,27 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert built_lib.wiski_version() >= 1
 
 
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """The by-pointer structs of the C ABI (wiski_grid, wiski_hyper_plan, wiski_copy_plan) as gcc lays them out from include/wiski.h
+    against their ctypes mirrors in online_gp_amd/_hip.py: sizes and the offsets of the last members."""
+    import ctypes
+    import subprocess
+
+    from online_gp_amd import _hip
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "wiski.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(wiski_grid), sizeof(wiski_hyper_param), sizeof(wiski_hyper_plan), '
+                   'offsetof(wiski_hyper_param, upper), sizeof(wiski_copy_plan), offsetof(wiski_copy_plan, scalar), offsetof(wiski_copy_plan, scalar_dst)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(_hip.wiski_grid), ctypes.sizeof(_hip.wiski_hyper_param), ctypes.sizeof(_hip.wiski_hyper_plan), _hip.wiski_hyper_param.upper.offset,
+            ctypes.sizeof(_hip.wiski_copy_plan), _hip.wiski_copy_plan.scalar.offset, _hip.wiski_copy_plan.scalar_dst.offset]
+    assert got == want, (got, want)
+
+
 def test_workspace_query_runs_without_gpu(built_lib):
     from online_gp_amd import grid_ops
 
