@@ -482,6 +482,9 @@ int wiski_multi_copy_f64(const wiski_copy_plan* plan, void* stream);
  * means and LATENT variances in the data dtype.  d_ws: 200 doubles, zero on first use (left zero). */
 int wiski_spectral_evaluate_f32(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t, double kscale, const float* d_s2, const float* d_y, const int32_t* d_err, double* d_ws, double* d_out, float* d_mean, float* d_var, void* stream);
 int wiski_spectral_evaluate_f64(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t, double kscale, const double* d_s2, const double* d_y, const int32_t* d_err, double* d_ws, double* d_out, double* d_mean, double* d_var, void* stream);
+/* The same for a larger batch (any n; one evaluate() chunk is <= 1024): d_Y [r, n] = chol^-1 d_F^T from wiski_gemm_f64; same outputs and workspace. */
+int wiski_spectral_evaluate_y_f32(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, const double* d_t, double kscale, const float* d_s2, const float* d_y, const int32_t* d_err, double* d_ws, double* d_out, float* d_mean, float* d_var, void* stream);
+int wiski_spectral_evaluate_y_f64(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, const double* d_t, double kscale, const double* d_s2, const double* d_y, const int32_t* d_err, double* d_ws, double* d_out, double* d_mean, double* d_var, void* stream);
 /* After the factorisation, three launches: d_out (packed fp64, 6 r + 2) = hr [r] | c [r] | t [r] | coef [r] | zeta [r] | bMb | logdet | scratch [r]
  * with hr = T^T h_ref (d_TS [r_ref, r]), c = chol^-1 (sq o hr) (d_Linv = chol^-1, [r, r]), bMb = |c|^2, t = chol^-T c, coef = sq o t,
  * zeta = t / sq, logdet = 2 sum log diag d_chol. */

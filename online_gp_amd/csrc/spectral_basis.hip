@@ -868,6 +868,87 @@ __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const doubl
   }
 }
 
+// The same for larger batches (64 < n <= 1024, one evaluate() chunk): Y = chol^-1 F^T comes from the MFMA GEMM ([r, n]); a workgroup takes
+// 64 queries (lanes: coalesced across the columns of Y; the r rows dealt to its 4 waves) for |Y[:, j]|^2, |F_j|^2 and F_j . t, forms the
+// moments and its share of the two metric sums (fp64 atomics into d_ws[0..1]); the last workgroup out writes d_out and zeroes d_ws.
+template <typename real>
+__global__ __launch_bounds__(256) void k_spectral_eval_y(int n, int r, const double* __restrict__ Y, const double* __restrict__ F, const double* __restrict__ prior,
+                                                         const double* __restrict__ t, double kscale, const real* __restrict__ s2p, const real* __restrict__ y,
+                                                         const int32_t* __restrict__ err, double* ws, double* __restrict__ out, real* __restrict__ mean_out,
+                                                         real* __restrict__ var_out) {
+  __shared__ double s_d[4][64], s_c[4][64], s_m[4][64];
+  __shared__ double s_red[16];
+  __shared__ int s_last;
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  double dsum = 0, cap = 0, mu = 0;
+  if (j < n) {
+    for (int i = part; i < r; i += 4) {
+      const double yv = Y[(int64_t)i * n + j];
+      dsum += yv * yv;
+    }
+    const double* __restrict__ f = F + (int64_t)j * r;
+    for (int k = part; k < r; k += 4) {
+      const double fv = f[k];
+      cap += fv * fv;
+      mu += fv * t[k];
+    }
+  }
+  s_d[part][c] = dsum;
+  s_c[part][c] = cap;
+  s_m[part][c] = mu;
+  __syncthreads();
+  double sq = 0, nl = 0, amax = 0;
+  if (part == 0 && j < n) {
+    const double s2 = (double)s2p[0];
+    const double dg = s_d[0][c] + s_d[1][c] + s_d[2][c] + s_d[3][c];
+    const double m = s_m[0][c] + s_m[1][c] + s_m[2][c] + s_m[3][c];
+    double tl = prior[j] * kscale - (s_c[0][c] + s_c[1][c] + s_c[2][c] + s_c[3][c]);
+    tl = tl > 0 ? tl : 0.0;
+    real var = (real)((dg + tl) * s2);
+    var = var > (real)0 ? var : (real)0;
+    const real mur = (real)m;
+    if (mean_out) mean_out[j] = mur;
+    if (var_out) var_out[j] = var;
+    const real df = mur - y[j];
+    const real v = (real)((double)var + s2);
+    const real s = df * df;
+    sq = (double)s;
+    nl = (double)((real)0.5 * (s / v + (real)log((double)v) + (real)1.8378770664093453));
+    amax = fabs(m);
+  }
+  sq = block_reduce_sum(sq, s_red);
+  nl = block_reduce_sum(nl, s_red);
+  double mx = amax;                                  // (the 64 values sit in wave 0)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(mx, o);
+    mx = other > mx ? other : mx;
+  }
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(ws + 0, sq);
+    unsafeAtomicAdd(ws + 1, nl);
+    // max |mean| over the workgroups: non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(ws + 2), (unsigned long long)__double_as_longlong(mx));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int tk = __hip_atomic_fetch_add(reinterpret_cast<int*>(ws + 192), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = tk == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  const double tsq = __hip_atomic_load(ws + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double tnl = __hip_atomic_load(ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double tmx = __hip_atomic_load(ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  out[0] = sqrt(tsq / (double)n);
+  out[1] = tnl / (double)n;
+  out[2] = err ? (double)err[0] : 0.0;
+  out[3] = tmx;
+  __hip_atomic_store(ws + 0, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(ws + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(ws + 2, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<int*>(ws + 192), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename real>
 static int spectral_evaluate_impl(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t,
                                   double kscale, const real* d_s2, const real* d_y, const int32_t* d_err, double* d_ws, double* d_out, real* d_mean,
@@ -886,4 +967,24 @@ extern "C" int wiski_spectral_evaluate_f64(int32_t n, int32_t r, const double* d
                                            double kscale, const double* d_s2, const double* d_y, const int32_t* d_err, double* d_ws, double* d_out,
                                            double* d_mean, double* d_var, void* stream) {
   return spectral_evaluate_impl<double>(n, r, d_F, d_prior, d_Linv, ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var, stream);
+}
+
+template <typename real>
+static int spectral_evaluate_y_impl(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, const double* d_t, double kscale,
+                                    const real* d_s2, const real* d_y, const int32_t* d_err, double* d_ws, double* d_out, real* d_mean, real* d_var,
+                                    void* stream) {
+  if (n < 1 || r < 1 || !d_Y || !d_F || !d_prior || !d_t || !d_s2 || !d_y || !d_ws || !d_out) return WISKI_E_BADARG;
+  hipLaunchKernelGGL((k_spectral_eval_y<real>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_Y, d_F, d_prior, d_t,
+                     kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+extern "C" int wiski_spectral_evaluate_y_f32(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, const double* d_t, double kscale,
+                                             const float* d_s2, const float* d_y, const int32_t* d_err, double* d_ws, double* d_out, float* d_mean,
+                                             float* d_var, void* stream) {
+  return spectral_evaluate_y_impl<float>(n, r, d_Y, d_F, d_prior, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var, stream);
+}
+extern "C" int wiski_spectral_evaluate_y_f64(int32_t n, int32_t r, const double* d_Y, const double* d_F, const double* d_prior, const double* d_t, double kscale,
+                                             const double* d_s2, const double* d_y, const int32_t* d_err, double* d_ws, double* d_out, double* d_mean,
+                                             double* d_var, void* stream) {
+  return spectral_evaluate_y_impl<double>(n, r, d_Y, d_F, d_prior, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var, stream);
 }

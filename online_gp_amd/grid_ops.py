@@ -880,15 +880,23 @@ def spectral_var(Y, F, prior, kscale):
 
 
 def spectral_evaluate(F, prior, Linv, t, kscale, s2, y, err, ws, want_moments=False):
-    """``wiski_spectral_evaluate``: rmse / nll / out-of-grid flag / max |mean| (fp64 [4], on the device) of n <= 64 queries from the
-    spectral factor in one launch; with `want_moments` also (mean, latent variance) in y's dtype.  ws: 200 zeroed doubles, reused."""
+    """``wiski_spectral_evaluate``: rmse / nll / out-of-grid flag / max |mean| (fp64 [4], on the device) of a query batch from the spectral
+    factor: ONE launch for n <= 64 (and r <= 512), else the MFMA GEMM chol^-1 F^T + one launch (``wiski_spectral_evaluate_y``); with
+    `want_moments` also (mean, latent variance) in y's dtype.  ws: 200 zeroed doubles, reused."""
     n, r = F.shape
     out = torch.empty(4, dtype=torch.float64, device=F.device)
     mean = torch.empty(n, dtype=y.dtype, device=F.device) if want_moments else None
     var = torch.empty(n, dtype=y.dtype, device=F.device) if want_moments else None
-    rc = _hip.fn("wiski_spectral_evaluate", y.dtype)(ctypes.c_int32(n), ctypes.c_int32(r), _hip.dptr(F), _hip.dptr(prior), _hip.dptr(Linv),
-                                                     ctypes.c_int32(Linv.shape[1]), _hip.dptr(t), ctypes.c_double(float(kscale)), _hip.dptr(s2), _hip.dptr(y),
-                                                     _hip.dptr(err), _hip.dptr(ws), _hip.dptr(out), _hip.dptr(mean), _hip.dptr(var), _hip.stream_ptr(F.device))
+    if n <= 64 and r <= 512:
+        rc = _hip.fn("wiski_spectral_evaluate", y.dtype)(ctypes.c_int32(n), ctypes.c_int32(r), _hip.dptr(F), _hip.dptr(prior), _hip.dptr(Linv),
+                                                         ctypes.c_int32(Linv.shape[1]), _hip.dptr(t), ctypes.c_double(float(kscale)), _hip.dptr(s2), _hip.dptr(y),
+                                                         _hip.dptr(err), _hip.dptr(ws), _hip.dptr(out), _hip.dptr(mean), _hip.dptr(var),
+                                                         _hip.stream_ptr(F.device))
+    else:
+        Y = gemm(Linv, F, tb=True)                                                   # chol^-1 F^T  [r, n]
+        rc = _hip.fn("wiski_spectral_evaluate_y", y.dtype)(ctypes.c_int32(n), ctypes.c_int32(r), _hip.dptr(Y), _hip.dptr(F), _hip.dptr(prior), _hip.dptr(t),
+                                                           ctypes.c_double(float(kscale)), _hip.dptr(s2), _hip.dptr(y), _hip.dptr(err), _hip.dptr(ws),
+                                                           _hip.dptr(out), _hip.dptr(mean), _hip.dptr(var), _hip.stream_ptr(F.device))
     _hip.check(rc, "wiski_spectral_evaluate")
     return (out, mean, var) if want_moments else out
 

@@ -94,13 +94,14 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         return rmse, nll
 
     def _evaluate_from_factor(self, inputs, targets):
-        """evaluate() of a small batch (<= 64 points, one output) straight from the spectral factor: one projection launch and ONE
-        launch for means, variances and both metrics (wiski_spectral_evaluate), one host read.  Same decisions as the posterior call
+        """evaluate() of one chunk (<= 1024 points, one output) straight from the spectral factor: one projection launch and ONE launch
+        for means, variances and both metrics (wiski_spectral_evaluate; beyond 64 points or rank 512 the MFMA GEMM chol^-1 F^T + one
+        launch), one host read.  Same decisions as the posterior call
         (batched_fixed_noise_online_gp._eval_forward): only where the factor serves the mean as well -- the PCG state is not current and
         the factor's mean monitor is green; otherwise None and the general path runs."""
         gp = self.gp
         n = inputs.shape[0]
-        if not (self.target_dim == 1 and inputs.is_cuda and 0 < n <= 64 and gp.has_learnable_noise and settings.skip_posterior_variances.off()
+        if not (self.target_dim == 1 and inputs.is_cuda and 0 < n <= EVAL_CHUNK and gp.has_learnable_noise and settings.skip_posterior_variances.off()
                 and settings.fused_evaluate.on()):
             return None
         ms = gp._mean_state
@@ -112,7 +113,7 @@ class OnlineSKIRegression(StreamingSKIWrapper):
         fac, st, tcol64 = sp
         if fac.measure_due:                                # (the mean monitor wants a measurement: the general path takes it)
             return None
-        if not fac.mean_ok or "t" not in st or st["basis"].r > 512:      # (the one-launch kernel holds a query vector in 8 registers per lane)
+        if not fac.mean_ok or "t" not in st:
             return None
         dt = gp._dtype
         Xf = self.stem(inputs).detach().to(gp._device, dt).reshape(-1, gp._grid.d).contiguous()
