@@ -172,6 +172,17 @@ constexpr int EIG_G = 64, EIG_K = 32;
     __builtin_amdgcn_wave_barrier();                  \
   } while (0)
 
+__device__ __forceinline__ double eig_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  return y * (2.0 - x * y);
+}
+__device__ __forceinline__ double eig_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+
 __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict__ gs, const double* __restrict__ tcol, const double* __restrict__ Vin,
                                                     int kw, int kuse, double* __restrict__ Vout, double* __restrict__ ev_out,
                                                     double* __restrict__ resid_out, const double* __restrict__ Vref, int kref,
@@ -239,63 +250,94 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
   }
   __syncthreads();
   EIG_STAMP(2);
-  // Rayleigh-Ritz by parallel cyclic Jacobi on ONE wave: the ~100 dependent phases of a few sweeps then cost their instructions, not
-  // a workgroup barrier each (which was most of this kernel's time)
-  const int n = (kw + 1) & ~1, np = n / 2;
+  // Rayleigh-Ritz by parallel cyclic Jacobi on ONE wave (the ~100 dependent phases of a few sweeps then cost their instructions, not a
+  // workgroup barrier each).  A step rotates kw / 2 disjoint pairs at once; disjoint rotations commute, so the whole step is ONE pass
+  // over the matrix:  H' = J^T H J  element by element from the old H (four reads), U' = U J (two reads), written to a second buffer
+  // (rows 0 .. and 32 .. of sZ, free here) -- two wave-level synchronisations per step instead of three dependent read-modify-write
+  // phases.  Index a is rotated with partner(a) (round robin: (2 step - a) mod (n - 1), the last index against `step`):
+  //     x'_a = alpha_a x_a + beta_a x_partner(a),   alpha = c,  beta = -s for the smaller index of the pair, +s for the larger.
+  const int n = kw;                                   // (even: checked by the host entry)
   if (wv == 0) {
+    double(*Hc)[EIG_K + 1] = sH;
+    double(*Uc)[EIG_K + 1] = sU;
+    double(*Hn)[EIG_K + 1] = sZ;
+    double(*Un)[EIG_K + 1] = sZ + EIG_K;
+    double* sAl = &sCS[0][0];                         // alpha[a], a < n <= 32  (sCS holds 32 doubles)
+    double* sBe = sTh;                                // beta[a]                (sTh is filled after the sweeps)
+    int* sPa = &sPr[0][0];                            // partner[a]
+    int ea[EIG_K * EIG_K / 64];                       // this lane's elements (a << 8 | b); slots past n^2 point at (0, 0) and are not stored
+#pragma unroll
+    for (int i = 0; i < EIG_K * EIG_K / 64; ++i) {
+      const int e = lane + 64 * i;
+      ea[i] = e < n * n ? ((e / n) << 8) | (e % n) : 0;
+    }
     for (int sweep = 0; sweep < 12; ++sweep) {
       double off2 = 0, dg2 = 0;
       for (int e = lane; e < kw * kw; e += 64) {
-        const double v = sH[e / kw][e % kw];
+        const double v = Hc[e / kw][e % kw];
         if (e / kw == e % kw) dg2 += v * v; else off2 += v * v;
       }
       off2 = wave_reduce_sum<double>(off2);
       dg2 = wave_reduce_sum<double>(dg2);
-      // (the start is nearly diagonal -- the previous eigenvectors: 3-4 sweeps of ~16 us each on one wave.  The sweeps stop where the
-      //  off-diagonal mass is two orders below the residual the caller accepts: for the fp32 model's 1e-10 that is one sweep less
-      //  than the 1e-15 the fixed form iterates to)
+      // (the start is nearly diagonal -- the previous eigenvectors: 3-6 sweeps.  The sweeps stop where the off-diagonal mass is two orders
+      //  below the residual the caller accepts: for the fp32 model's 1e-10 that is a sweep less than the 1e-15 the fixed form iterates to)
+#ifdef WISKI_EIG_TIMING
+      if (blockIdx.x == 0 && lane == 0) { resid_out[16 + pass] = (double)sweep; resid_out[18 + pass] = off2 / dg2; }
+#endif
       if (off2 <= jac_tol * dg2) break;
       for (int step = 0; step < n - 1; ++step) {
-        if (lane < np) {
-          int p_, q_;
-          if (lane == 0) { p_ = n - 1; q_ = step; }
-          else { p_ = (step + lane) % (n - 1); q_ = (step - lane + (n - 1)) % (n - 1); }
-          if (p_ > q_) { const int x = p_; p_ = q_; q_ = x; }
-          sPr[lane][0] = p_; sPr[lane][1] = q_;
+        if (lane < n) {
+          const int a = lane;
+          const int pa = a == n - 1 ? step : (a == step ? n - 1 : (2 * step - a + 2 * (n - 1)) % (n - 1));
+          const int p_ = a < pa ? a : pa, q_ = a < pa ? pa : a;
           double c = 1.0, sn = 0.0;
-          if (q_ < kw) {
-            const double apq = sH[p_][q_];
-            if (apq != 0.0) {
-              const double theta = (sH[q_][q_] - sH[p_][p_]) / (2.0 * apq);
-              const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-              c = 1.0 / sqrt(tt * tt + 1.0);
-              sn = tt * c;
+          const double apq = Hc[p_][q_];
+          if (fabs(apq) > 1e-290) {
+            // (reciprocal / reciprocal square root + two Newton steps each instead of IEEE division and square root -- ~50 instead of ~150
+            //  dependent fp64 instructions on the step's serial path; c^2 + s^2 = 1 holds to rounding either way)
+            const double theta = (Hc[q_][q_] - Hc[p_][p_]) * eig_rcp(2.0 * apq);
+            const double at = fabs(theta);
+            double tt;
+            if (at > 1e100) tt = 0.5 * eig_rcp(theta);
+            else {
+              const double w2 = at * at + 1.0;
+              tt = eig_rcp(at + w2 * eig_rsq(w2));
+              tt = theta >= 0 ? tt : -tt;
             }
+            c = eig_rsq(tt * tt + 1.0);
+            sn = tt * c;
           }
-          sCS[lane][0] = c; sCS[lane][1] = sn;
+          sAl[a] = c;
+          sBe[a] = a == p_ ? -sn : sn;
+          sPa[a] = pa;
         }
         WAVE_SYNC();
-        for (int e = lane; e < np * kw; e += 64) {
-          const int pi = e / kw, k = e % kw;
-          const int p_ = sPr[pi][0], q_ = sPr[pi][1];
-          if (q_ >= kw) continue;
-          const double c = sCS[pi][0], sn = sCS[pi][1];
-          const double akp = sH[k][p_], akq = sH[k][q_];
-          sH[k][p_] = c * akp - sn * akq; sH[k][q_] = sn * akp + c * akq;
-          const double ukp = sU[k][p_], ukq = sU[k][q_];
-          sU[k][p_] = c * ukp - sn * ukq; sU[k][q_] = sn * ukp + c * ukq;
+        // (the element list of a lane is the same in every step: indices precomputed, the loop unrolled so that the LDS reads of all its
+        //  elements are in flight together -- a rolled loop with its two divisions per element cost ~3000 cycles per step)
+#pragma unroll
+        for (int i = 0; i < EIG_K * EIG_K / 64; ++i) {
+          if (64 * i >= n * n) break;                 // (wave-uniform: kw = 22 needs 8 of the 16 slots)
+          const int a = ea[i] >> 8, b2 = ea[i] & 255;
+          const int pa = sPa[a], pb = sPa[b2];
+          const double ala = sAl[a], bea = sBe[a], alb = sAl[b2], beb = sBe[b2];
+          const double h = ala * (alb * Hc[a][b2] + beb * Hc[a][pb]) + bea * (alb * Hc[pa][b2] + beb * Hc[pa][pb]);
+          const double u = alb * Uc[a][b2] + beb * Uc[a][pb];
+          if (lane + 64 * i < n * n) {
+            Hn[a][b2] = h;
+            Un[a][b2] = u;
+          }
         }
         WAVE_SYNC();
-        for (int e = lane; e < np * kw; e += 64) {
-          const int pi = e / kw, k = e % kw;
-          const int p_ = sPr[pi][0], q_ = sPr[pi][1];
-          if (q_ >= kw) continue;
-          const double c = sCS[pi][0], sn = sCS[pi][1];
-          const double apk = sH[p_][k], aqk = sH[q_][k];
-          sH[p_][k] = c * apk - sn * aqk; sH[q_][k] = sn * apk + c * aqk;
-        }
-        WAVE_SYNC();
+        { double(*tH)[EIG_K + 1] = Hc; Hc = Hn; Hn = tH; }
+        { double(*tU)[EIG_K + 1] = Uc; Uc = Un; Un = tU; }
       }
+    }
+    if (Hc != sH) {                                   // (wave-uniform) an odd number of steps: the result sits in the second buffer
+      for (int e = lane; e < n * n; e += 64) {
+        sH[e / n][e % n] = Hc[e / n][e % n];
+        sU[e / n][e % n] = Uc[e / n][e % n];
+      }
+      WAVE_SYNC();
     }
   }
   __syncthreads();

@@ -28,4 +28,4 @@ for name, args in (("two iterations", None), ("adaptive (resid_ok 1.25e-10)", (0
     torch.cuda.synchronize()
     s = resid.cpu().numpy()
     st = s[8:15]
-    print(name, "resid", s[:3], "us from start:", [round((v - st[0]) / 100.0, 1) for v in st])
+    print(name, "resid", s[:3], "us from start:", [round(float(v - st[0]) / 100.0, 1) for v in st], "Jacobi sweeps (pass 0, 1):", s[16:18], "off2/dg2 at the last check:", s[18:20])
