@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
   // phases.  Index a is rotated with partner(a) (round robin: (2 step - a) mod (n - 1), the last index against `step`):
   //     x'_a = alpha_a x_a + beta_a x_partner(a),   alpha = c,  beta = -s for the smaller index of the pair, +s for the larger.
   const int n = kw;                                   // (even: checked by the host entry)
-  if (wv == 0) {
+  {
+    // One wave issues a VALU / LDS instruction every ~6 cycles (tools/ubench/clock_ubench.hip), and a step on ONE wave was ~650 of them
+    // (4000 cycles, 35 us per sweep): the element pass is dealt to all four waves (<= 4 elements per thread) between two workgroup
+    // barriers; the rotation parameters stay on wave 0.
     double(*Hc)[EIG_K + 1] = sH;
     double(*Uc)[EIG_K + 1] = sU;
     double(*Hn)[EIG_K + 1] = sZ;
@@ -265,29 +268,34 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
     double* sAl = &sCS[0][0];                         // alpha[a], a < n <= 32  (sCS holds 32 doubles)
     double* sBe = sTh;                                // beta[a]                (sTh is filled after the sweeps)
     int* sPa = &sPr[0][0];                            // partner[a]
-    int ea[EIG_K * EIG_K / 64];                       // this lane's elements (a << 8 | b); slots past n^2 point at (0, 0) and are not stored
+    __shared__ int sStop;
+    int ea[EIG_K * EIG_K / 256];                      // this thread's elements (a << 8 | b); slots past n^2 are not stored
 #pragma unroll
-    for (int i = 0; i < EIG_K * EIG_K / 64; ++i) {
-      const int e = lane + 64 * i;
+    for (int i = 0; i < EIG_K * EIG_K / 256; ++i) {
+      const int e = t + 256 * i;
       ea[i] = e < n * n ? ((e / n) << 8) | (e % n) : 0;
     }
     for (int sweep = 0; sweep < 12; ++sweep) {
-      double off2 = 0, dg2 = 0;
-      for (int e = lane; e < kw * kw; e += 64) {
-        const double v = Hc[e / kw][e % kw];
-        if (e / kw == e % kw) dg2 += v * v; else off2 += v * v;
-      }
-      off2 = wave_reduce_sum<double>(off2);
-      dg2 = wave_reduce_sum<double>(dg2);
-      // (the start is nearly diagonal -- the previous eigenvectors: 3-6 sweeps.  The sweeps stop where the off-diagonal mass is two orders
-      //  below the residual the caller accepts: for the fp32 model's 1e-10 that is a sweep less than the 1e-15 the fixed form iterates to)
+      if (wv == 0) {
+        double off2 = 0, dg2 = 0;
+        for (int e = lane; e < kw * kw; e += 64) {
+          const double v = Hc[e / kw][e % kw];
+          if (e / kw == e % kw) dg2 += v * v; else off2 += v * v;
+        }
+        off2 = wave_reduce_sum<double>(off2);
+        dg2 = wave_reduce_sum<double>(dg2);
 #ifdef WISKI_EIG_TIMING
-      if (blockIdx.x == 0 && lane == 0) { resid_out[16 + pass] = (double)sweep; resid_out[18 + pass] = off2 / dg2; }
+        if (blockIdx.x == 0 && lane == 0) { resid_out[16 + pass] = (double)sweep; resid_out[18 + pass] = off2 / dg2; }
 #endif
-      if (off2 <= jac_tol * dg2) break;
+        // (the start is nearly diagonal -- the previous eigenvectors: 1-3 sweeps.  The sweeps stop where the off-diagonal mass is two orders
+        //  below the residual the caller accepts: for the fp32 model's 1e-10 that is a sweep less than the 1e-15 the fixed form iterates to)
+        if (lane == 0) sStop = off2 <= jac_tol * dg2;
+      }
+      __syncthreads();
+      if (sStop) break;                               // (block-uniform)
       for (int step = 0; step < n - 1; ++step) {
-        if (lane < n) {
-          const int a = lane;
+        if (t < n) {
+          const int a = t;
           const int pa = a == n - 1 ? step : (a == step ? n - 1 : (2 * step - a + 2 * (n - 1)) % (n - 1));
           const int p_ = a < pa ? a : pa, q_ = a < pa ? pa : a;
           double c = 1.0, sn = 0.0;
@@ -311,33 +319,29 @@ __global__ __launch_bounds__(256) void k_eig_update(int d, const int* __restrict
           sBe[a] = a == p_ ? -sn : sn;
           sPa[a] = pa;
         }
-        WAVE_SYNC();
-        // (the element list of a lane is the same in every step: indices precomputed, the loop unrolled so that the LDS reads of all its
-        //  elements are in flight together -- a rolled loop with its two divisions per element cost ~3000 cycles per step)
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < EIG_K * EIG_K / 64; ++i) {
-          if (64 * i >= n * n) break;                 // (wave-uniform: kw = 22 needs 8 of the 16 slots)
+        for (int i = 0; i < EIG_K * EIG_K / 256; ++i) {
           const int a = ea[i] >> 8, b2 = ea[i] & 255;
           const int pa = sPa[a], pb = sPa[b2];
           const double ala = sAl[a], bea = sBe[a], alb = sAl[b2], beb = sBe[b2];
           const double h = ala * (alb * Hc[a][b2] + beb * Hc[a][pb]) + bea * (alb * Hc[pa][b2] + beb * Hc[pa][pb]);
           const double u = alb * Uc[a][b2] + beb * Uc[a][pb];
-          if (lane + 64 * i < n * n) {
+          if (t + 256 * i < n * n) {
             Hn[a][b2] = h;
             Un[a][b2] = u;
           }
         }
-        WAVE_SYNC();
+        __syncthreads();
         { double(*tH)[EIG_K + 1] = Hc; Hc = Hn; Hn = tH; }
         { double(*tU)[EIG_K + 1] = Uc; Uc = Un; Un = tU; }
       }
     }
-    if (Hc != sH) {                                   // (wave-uniform) an odd number of steps: the result sits in the second buffer
-      for (int e = lane; e < n * n; e += 64) {
+    if (Hc != sH) {                                   // (block-uniform) an odd number of steps: the result sits in the second buffer
+      for (int e = t; e < n * n; e += 256) {
         sH[e / n][e % n] = Hc[e / n][e % n];
         sU[e / n][e % n] = Uc[e / n][e % n];
       }
-      WAVE_SYNC();
     }
   }
   __syncthreads();
