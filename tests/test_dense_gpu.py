@@ -1,6 +1,8 @@
 """GPU: dense MFMA building blocks against plain PyTorch references of the same ops
 (asymmetric operands so a transposed C-write cannot pass)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -137,6 +139,33 @@ def test_cooperative_cholesky_back_to_back_and_on_two_streams(dtype, tol):
         Lref = torch.linalg.cholesky(A.double())
         assert (L.double() - Lref).abs().max().item() < tol * 10
         assert ((X @ L).double() - torch.eye(n, dtype=torch.float64, device=DEV)).abs().max().item() < tol * 50
+
+
+def test_one_workgroup_cholesky_path_still_factorises():
+    """The one-workgroup factorisation + separate inverse (dense_small.h) is what a stream under graph capture takes, and what
+    WISKI_POTRF_COOP=0 selects: run it in a child process (the switch is read once per process) against the host reference."""
+    import subprocess
+    import sys
+
+    code = (
+        "import torch\n"
+        "from online_gp_amd import grid_ops\n"
+        "for dt, tol in ((torch.float64, 1e-9), (torch.float32, 5e-3)):\n"
+        "    for n in (31, 64, 200, 327, 480, 512):\n"
+        "        g = torch.Generator(device='cpu').manual_seed(n)\n"
+        "        R = torch.randn(n, n, generator=g, dtype=torch.float64)\n"
+        "        A = (R @ R.t() / n + torch.eye(n, dtype=torch.float64)).to('cuda', dt)\n"
+        "        L = A.clone(); X, info = grid_ops.potrf_inverse_(L)\n"
+        "        assert int(info.item()) == 0\n"
+        "        Lref = torch.linalg.cholesky(A.double())\n"
+        "        assert (L.double() - Lref).abs().max().item() < tol, (dt, n)\n"
+        "        assert ((X @ L).double() - torch.eye(n, dtype=torch.float64, device='cuda')).abs().max().item() < 10 * tol, (dt, n)\n"
+        "print('one-workgroup path ok')\n"
+    )
+    env = dict(os.environ, WISKI_POTRF_COOP="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "one-workgroup path ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_multi_copy_is_one_launch_for_all_segments():
