@@ -168,6 +168,29 @@ def test_one_workgroup_cholesky_path_still_factorises():
     assert out.returncode == 0 and "one-workgroup path ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_cholesky_with_inverse_inside_a_captured_graph():
+    """A stream under graph capture takes the two-launch path (the cooperative kernel's flag block is allocated on first use, which a
+    capture forbids): the recorded factorisation replays correctly."""
+    from online_gp_amd import grid_ops
+
+    n = 200
+    g = torch.Generator(device="cpu").manual_seed(1)
+    R = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = (R @ R.t() / n + torch.eye(n, dtype=torch.float64)).to(DEV)
+    info = torch.zeros(1, dtype=torch.int32, device=DEV)
+    grid_ops.potrf_inverse_(A.clone(), info=info)                  # (warm-up outside the capture)
+    torch.cuda.synchronize()
+    graph, work = torch.cuda.CUDAGraph(), A.clone()
+    with torch.cuda.graph(graph):
+        work.copy_(A)
+        X, _ = grid_ops.potrf_inverse_(work, info=info)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    assert ((X @ work) - torch.eye(n, dtype=torch.float64, device=DEV)).abs().max().item() < 1e-12
+
+
 def test_multi_copy_is_one_launch_for_all_segments():
     from online_gp_amd import grid_ops
 
