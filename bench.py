@@ -502,7 +502,7 @@ def main():
                     del Vm
                 spmm_bytes = lambda kc: ((grid.R + 1) // 2 * grid.m + 2 * kc * grid.m) * es
                 roofline_secondary = [
-                    {"kernel": "k_spmm_sym_cols (+ k_transpose_cm_rm): half-stencil A_h . V for 64 right-hand sides (PCG variance / probe solves)",
+                    {"kernel": "k_spmm_sym_bcast (+ k_transpose_cm_rm, k_spmv_reduce): half-stencil A_h . V for 64 right-hand sides (PCG variance / probe solves; coefficients by vector loads + DPP row broadcast, csrc/spmm_sym_bcast.h)",
                      "bound": "hbm", "achieved": spmm_bytes(64) / (spmm[64] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": spmm_bytes(64) / (spmm[64] * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": spmm[64], "algorithmic_bytes_per_launch": spmm_bytes(64),
                      "flop_per_launch": 2 * grid.R * grid.m * 64, "vector_fma_frac_of_157_TFLOPs": 2 * grid.R * grid.m * 64 / (spmm[64] * 1e-6) / 157e12,

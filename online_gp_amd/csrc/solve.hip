@@ -831,6 +831,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 #include "spmv_sym_dma.h"
 #include "spmv_sym_dma_mc.h"
 #include "spmm_sym_cols.h"
+#include "spmm_sym_bcast.h"
 
 // Which wide half-stencil kernel serves (G, k): the LDS-DMA pipelined one (d = 3, fp32, one right-hand side; 4 chunks)
 // or the LDS-window one (anything else with m % 4 == 0; up to 7 chunks).  WISKI_SYM_DMA=0 forces the latter,
@@ -864,6 +865,15 @@ static inline bool sym_use_cols(int k) {
     g_spmm_cols = e ? atoi(e) : 1;
   }
   return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 240 us at k = 64 (670)
+}
+// fp32, 64 columns: the DPP-broadcast form (spmm_sym_bcast.h).  WISKI_SPMM_BCAST=0 keeps the scalar-path kernel.
+static int g_spmm_bcast = -1;
+static inline bool sym_use_bcast() {
+  if (g_spmm_bcast < 0) {
+    const char* e = getenv("WISKI_SPMM_BCAST");
+    g_spmm_bcast = e ? atoi(e) : 1;
+  }
+  return g_spmm_bcast != 0;
 }
 static inline int spmmc_kp(int k) { return (k + 15) / 16 * 16; }
 // A few right-hand sides (2 <= k < 32; d = 3, fp32): the multi-column LDS-DMA kernel (spmv_sym_dma_mc.h), 4 (2) columns per pass
@@ -951,6 +961,24 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     const int ntile = (m + SPMMC_RT - 1) / SPMMC_RT, nblk = (ntile + 3) / 4;    // 4 tiles (waves) per block
     dim3 grd((unsigned)((nblk + 7) / 8 * 8), (unsigned)((kp + 63) / 64));
     const int ng = sym_groups(G.d);
+    if constexpr (sizeof(real) == 4) {
+      if (kp == 64 && sym_use_bcast()) {   // coefficients on the vector path, DPP row broadcast (spmm_sym_bcast.h)
+        const int64_t a_len = (int64_t)(7 * ng - 3) * m;
+#define SPMMB_LAUNCH(VAR)                                                                                                          \
+  do {                                                                                                                             \
+    if (dots) launch_timed(k_spmm_sym_bcast<true, VAR>, grd, dim3(256), 0, s, G, A_h, a_len, (const real*)Vt, k, ng, Ot, dots);      \
+    else launch_timed(k_spmm_sym_bcast<false, VAR>, grd, dim3(256), 0, s, G, A_h, a_len, (const real*)Vt, k, ng, Ot, dots);         \
+  } while (0)
+#ifdef WISKI_SPMMB_ABLATE
+        if (g_spmm_bcast == 3) SPMMB_LAUNCH(3);
+        else if (g_spmm_bcast == 4) SPMMB_LAUNCH(4);
+        else
+#endif
+          SPMMB_LAUNCH(1);
+#undef SPMMB_LAUNCH
+        return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+      }
+    }
     if (kp == 64) {
       if (dots) launch_timed(k_spmm_sym_cols<real, true, 64>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
       else launch_timed(k_spmm_sym_cols<real, false, 64>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
