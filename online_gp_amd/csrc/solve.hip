@@ -858,15 +858,25 @@ static inline bool sym_use_dma(const GridDev<real>& G, int k) {
 }
 // Many right-hand sides (k >= 32): the lanes-are-columns SpMM (spmm_sym_cols.h) reads A_h once per 64 columns and leaves
 // ONE finished vector per column in part[0] (no atomically accumulated partial).  WISKI_SPMM_COLS=0 disables it.
-static int g_spmm_cols = -1;
-static inline bool sym_use_cols(int k) {
+static int g_spmm_cols = -1, g_spmm_cols_min = -1;
+static inline bool sym_use_bcast();
+static inline bool sym_use_cols(int k, size_t es) {
   if (g_spmm_cols < 0) {
     const char* e = getenv("WISKI_SPMM_COLS");
     g_spmm_cols = e ? atoi(e) : 1;
+    const char* mn = getenv("WISKI_SPMM_COLS_MIN");
+    g_spmm_cols_min = mn ? atoi(mn) : 0;
+    // the row-major images (64 columns per slice) must fit behind part[0]: 64 m <= 7 k m
+    if (g_spmm_cols_min && g_spmm_cols_min < 16) g_spmm_cols_min = 16;
   }
-  return g_spmm_cols != 0 && k >= 32;     // measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 240 us at k = 64 (670)
+  if (g_spmm_cols == 0) return false;
+  if (g_spmm_cols_min) return k >= g_spmm_cols_min;
+  // Scalar-path kernel, measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 240 us at k = 64 (670) -> from 32 columns.
+  // The broadcast kernel costs the same for any k <= 64 (fp32 131..140 us, fp64 322..369 us) against 158 us (fp32, 4-column LDS-DMA
+  // kernel) / 290 us (fp64, LDS-window kernel) at k = 16 and 229 / 429 us at k = 24: from 16 (fp32) / 24 (fp64) columns.
+  return k >= (sym_use_bcast() ? (es == 4 ? 16 : 24) : 32);
 }
-// fp32, 64 columns: the DPP-broadcast form (spmm_sym_bcast.h).  WISKI_SPMM_BCAST=0 keeps the scalar-path kernel.
+// The DPP-broadcast form of the many-column product (spmm_sym_bcast.h), both precisions, any d.  WISKI_SPMM_BCAST=0 keeps the scalar-path kernel.
 static int g_spmm_bcast = -1;
 static inline bool sym_use_bcast() {
   if (g_spmm_bcast < 0) {
@@ -886,7 +896,7 @@ static inline bool sym_use_dma_mc(const GridDev<real>& G, int k) {
     const char* e = getenv("WISKI_SYM_DMA_MC");
     g_sym_dma_mc = e ? atoi(e) : 1;
   }
-  return g_sym_dma_mc != 0 && G.d == 3 && k >= 2 && !sym_use_cols(k) && (G.m % 4) == 0 && G.g[2] >= 4 &&
+  return g_sym_dma_mc != 0 && G.d == 3 && k >= 2 && !sym_use_cols(k, sizeof(real)) && (G.m % 4) == 0 && G.g[2] >= 4 &&
          symdma_mc_lds_bytes(G.g[2], k >= 4 ? 4 : 2) <= 64 * 1024;
 }
 // number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
@@ -899,7 +909,7 @@ static inline int sym_nch(const GridDev<real>& G, int k) {
 // atomically accumulated one (to be re-zeroed once consumed)
 template <typename real>
 static inline int sym_partials(const GridDev<real>& G, int k, int* zl) {
-  if (sym_use_cols(k)) { *zl = 0; return 1; }
+  if (sym_use_cols(k, sizeof(real))) { *zl = 0; return 1; }
   *zl = 1;
   return sym_nch<real>(G, k) + 1;
 }
@@ -947,12 +957,37 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
   if (shard_tab && !(sizeof(real) == 4 && sym_use_dma<real>(G, k))) return WISKI_E_BADARG;
   const bool ranged = g_hi >= 0;
   if (ranged && (shard_tab || k != 1 || g_lo < 0 || g_hi < g_lo || g_hi > sym_groups(G.d))) return WISKI_E_BADARG;
-  if (sym_use_cols(k) && !ranged) {
+  if (sym_use_cols(k, sizeof(real)) && !ranged) {
     // part[0] <- A V (column-major, written by the product itself); the row-major copy of V lives behind it
     const int m = G.m, kp = spmmc_kp(k);
     const int64_t km = (int64_t)k * m;
     real* Vt = part + km;
     real* Ot = part;
+    if (sym_use_bcast()) {   // coefficients on the vector path, DPP row broadcast (spmm_sym_bcast.h); operands in 64-column slices
+      const int ns = (k + 63) / 64;
+      dim3 tg((unsigned)((m + 63) / 64), (unsigned)ns);
+      if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true, true>), tg, dim3(256), 0, s, m, k, 64 * ns, V, Vt, add, beta, dots);
+      else hipLaunchKernelGGL((k_transpose_cm_rm<real, false, true>), tg, dim3(256), 0, s, m, k, 64 * ns, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
+      const int ng = sym_groups(G.d);
+      const int64_t a_len = (int64_t)(7 * ng - 3) * m;
+      constexpr int RT = 16;   // rows per wave tile (measured at 50^3, fp32 / fp64: RT = 8 155 / 452 us, 16 137 / 372, 24 150 / 379, 32 149 / 411)
+      const int ntb = (m + RT - 1) / RT, nbb = (ntb + 3) / 4;                  // 4 tiles (waves) per block
+      // grid.x is padded to a multiple of 8: workgroup b runs on XCD b % 8 and takes tile (b % 8) * (grid.x / 8) + b / 8 (see below)
+      dim3 gb((unsigned)((nbb + 7) / 8 * 8), (unsigned)ns);
+#define SPMMB_LAUNCH(VAR)                                                                                                                  \
+  do {                                                                                                                                     \
+    if (dots) launch_timed(k_spmm_sym_bcast<real, true, RT, VAR>, gb, dim3(256), 0, s, G, A_h, a_len, (const real*)Vt, k, ng, Ot, dots);     \
+    else launch_timed(k_spmm_sym_bcast<real, false, RT, VAR>, gb, dim3(256), 0, s, G, A_h, a_len, (const real*)Vt, k, ng, Ot, dots);        \
+  } while (0)
+#ifdef WISKI_SPMMB_ABLATE
+      if (g_spmm_bcast == 3) SPMMB_LAUNCH(3);
+      else if (g_spmm_bcast == 4) SPMMB_LAUNCH(4);
+      else
+#endif
+        SPMMB_LAUNCH(1);
+#undef SPMMB_LAUNCH
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
     dim3 tg((unsigned)((m + 63) / 64), (unsigned)((kp + 63) / 64));
     if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true>), tg, dim3(256), 0, s, m, k, kp, V, Vt, add, beta, dots);
     else hipLaunchKernelGGL((k_transpose_cm_rm<real, false>), tg, dim3(256), 0, s, m, k, kp, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
@@ -961,24 +996,6 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     const int ntile = (m + SPMMC_RT - 1) / SPMMC_RT, nblk = (ntile + 3) / 4;    // 4 tiles (waves) per block
     dim3 grd((unsigned)((nblk + 7) / 8 * 8), (unsigned)((kp + 63) / 64));
     const int ng = sym_groups(G.d);
-    if constexpr (sizeof(real) == 4) {
-      if (kp == 64 && sym_use_bcast()) {   // coefficients on the vector path, DPP row broadcast (spmm_sym_bcast.h)
-        const int64_t a_len = (int64_t)(7 * ng - 3) * m;
-#define SPMMB_LAUNCH(VAR)                                                                                                          \
-  do {                                                                                                                             \
-    if (dots) launch_timed(k_spmm_sym_bcast<true, VAR>, grd, dim3(256), 0, s, G, A_h, a_len, (const real*)Vt, k, ng, Ot, dots);      \
-    else launch_timed(k_spmm_sym_bcast<false, VAR>, grd, dim3(256), 0, s, G, A_h, a_len, (const real*)Vt, k, ng, Ot, dots);         \
-  } while (0)
-#ifdef WISKI_SPMMB_ABLATE
-        if (g_spmm_bcast == 3) SPMMB_LAUNCH(3);
-        else if (g_spmm_bcast == 4) SPMMB_LAUNCH(4);
-        else
-#endif
-          SPMMB_LAUNCH(1);
-#undef SPMMB_LAUNCH
-        return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
-      }
-    }
     if (kp == 64) {
       if (dots) launch_timed(k_spmm_sym_cols<real, true, 64>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);
       else launch_timed(k_spmm_sym_cols<real, false, 64>, grd, dim3(256), 0, s, G, A_h, (const real*)Vt, k, kp, ng, Ot, dots);

@@ -1,4 +1,4 @@
-// Symmetric half-stencil SpMM for 64 right-hand sides, fp32: the coefficients travel on the VECTOR path and are broadcast by DPP.
+// Symmetric half-stencil SpMM for 64 right-hand sides: the coefficients travel on the VECTOR path and are broadcast by DPP.
 // Included by solve.hip after spmm_sym_cols.h (same tiling, same operands, same results up to the order of the fp additions).
 //
 // k_spmm_sym_cols keeps a lane = a column and feeds every wave-uniform stencil coefficient through the scalar unit (s_load ->
@@ -19,9 +19,13 @@
 // belong to rows outside the grid.
 #pragma once
 
-constexpr int SPMMB_RT = 16;
+// fp64 (v_fmac_f64_dpp: the 64-bit DPP forms of gfx90a+ allow exactly this control, row_newbcast): a 16-byte load brings 2 coefficients per
+// lane, 32 per instruction; a row of V is 512 B.
 
-typedef float spmmb_f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a dword-aligned address
+// 16 bytes of coefficients from an address that is only aligned to the element size
+template <typename real> struct spmmb_vec;
+template <> struct spmmb_vec<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct spmmb_vec<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
 
 template <typename F, int... I>
 __device__ __forceinline__ void spmmb_for_impl(F&& fn, std::integer_sequence<int, I...>) {
@@ -32,47 +36,63 @@ __device__ __forceinline__ void spmmb_for(F&& fn) {
   spmmb_for_impl(fn, std::make_integer_sequence<int, N>{});
 }
 
+// A VALU write of a VGPR needs two wait states before a DPP read of it, and the compiler's hazard recogniser does not look into
+// inline asm.  The coefficient registers are written by loads, but the clamped / unclamped load branches merge in front of the
+// FMAs and a merge may be a v_mov: every FMA block opens with the two wait states.  (Tile heights whose registers spill -- fp64
+// at RT = 32 -- got copies in between the FMAs and wrong digits: RT stays where nothing spills, 94 / 173 VGPRs at RT = 16.)
+__device__ __forceinline__ void spmmb_dpp_guard() { asm volatile("s_nop 1"); }
+
 // acc += coef[lane BC of this lane's 16-lane row] * w
 template <int BC>
 __device__ __forceinline__ void spmmb_fma(float& acc, float coef, float w) {
   asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(coef), "v"(w), "n"(BC));
 }
+template <int BC>
+__device__ __forceinline__ void spmmb_fma(double& acc, double coef, double w) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(coef), "v"(w), "n"(BC));
+}
 
-// One wave = RT rows x 64 columns, four waves per block.  Vt row-major [m][64], Ot column-major [k][m].
+// One wave = RT rows x 64 columns, four waves per block; blockIdx.y = the 64-column slice.  Vt: one row-major [m][64] image per
+// slice (k_transpose_cm_rm<.., SLICED>), Ot column-major [k][m].
 // DOT: dots[c] += sum_j Vt[j][c] * Ot[c][j].  a_len = number of reals in A_h.
 // VAR = 1: the product.  Timing ablations (wrong results; WISKI_SPMM_BCAST=3 / 4 in a -DWISKI_SPMMB_ABLATE build): 3 without the
 // FMAs (loads only: 117 us at 50^3), 4 without the window loads (FMAs + coefficient loads: 97 us); the product takes 138 us.
 // Requesting the operands of both terms before the first FMA (one memory latency per group) beats term-by-term order by 5 us.
-template <bool DOT, int VAR>
-__global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const float* __restrict__ A_h, int64_t a_len, const float* __restrict__ Vt,
-                                                        int k, int ng, float* __restrict__ Ot, double* __restrict__ dots) {
-  constexpr int RT = SPMMB_RT, WN = RT + 6, KP = 64;
+template <typename real, bool DOT, int RT, int VAR>
+__global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<real> G, const real* __restrict__ A_h, int64_t a_len, const real* __restrict__ Vt,
+                                                        int k, int ng, real* __restrict__ Ot, double* __restrict__ dots) {
+  static_assert(RT % 4 == 0, "column-major stores are 16-byte groups of rows");
+  typedef typename spmmb_vec<real>::type cvec;
+  constexpr int WN = RT + 6, KP = 64;
+  constexpr int CPL = 16 / (int)sizeof(real);     // coefficients per lane and load
+  constexpr int CL = 16 * CPL;                    // coefficients per load instruction (the 16 lanes of a row)
   const int m = G.m, d = G.d;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = 4 * ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) + wv;   // XCD-contiguous row ranges (see the launch)
   const bool active = tile * RT < m;               // padding waves recompute tile 0 and discard it (they must reach the barrier)
   const int j0 = active ? tile * RT : 0;
-  const float* __restrict__ vcol = Vt + lane;      // this lane's column (Vt is padded to 64 columns)
-  const int l4 = 4 * (lane & 15);
-  float acc[RT];
+  const int c = blockIdx.y * 64 + lane;            // this lane's column (the last slice is padded to 64 columns with zeros)
+  const real* __restrict__ vcol = Vt + (int64_t)blockIdx.y * m * KP + lane;
+  const int l4 = CPL * (lane & 15);
+  real acc[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+  for (int r = 0; r < RT; ++r) acc[r] = (real)0;
   const int cP = ng - 1;                           // prefix code of the centre: (7^(d-1) - 1) / 2
 
   // NL 16-byte loads of the coefficient span that starts at real `base` of A_h; lanes that would leave A_h are clamped into it
-  auto load_span = [&](auto nl_tag, int64_t base, spmmb_f4u* cf) {
+  auto load_span = [&](auto nl_tag, int64_t base, cvec* cf) {
     constexpr int NL = decltype(nl_tag)::value;
-    if (base >= 0 && base + 64 * NL <= a_len) {    // wave-uniform: always, except at the two ends of A_h
-      const float* __restrict__ p = A_h + base + l4;
+    if (base >= 0 && base + CL * NL <= a_len) {    // wave-uniform: always, except at the two ends of A_h
+      const real* __restrict__ p = A_h + base + l4;
 #pragma unroll
-      for (int n = 0; n < NL; ++n) cf[n] = *reinterpret_cast<const spmmb_f4u*>(p + 64 * n);
+      for (int n = 0; n < NL; ++n) cf[n] = *reinterpret_cast<const cvec*>(p + CL * n);
     } else {
 #pragma unroll
       for (int n = 0; n < NL; ++n) {
-        int64_t i = base + 64 * n + l4;
-        i = i < 0 ? 0 : (i > a_len - 4 ? a_len - 4 : i);
-        cf[n] = *reinterpret_cast<const spmmb_f4u*>(A_h + i);
+        int64_t i = base + CL * n + l4;
+        i = i < 0 ? 0 : (i > a_len - CPL ? a_len - CPL : i);
+        cf[n] = *reinterpret_cast<const cvec*>(A_h + i);
       }
     }
   };
@@ -82,17 +102,17 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
     constexpr int RS = CENTRE ? 4 : 7;               // reals per row
     constexpr int S0 = CENTRE ? 3 : 0;               // first stored digit
     constexpr int T0 = CENTRE ? 4 : 0;               // first digit of the transposed term (digit 3 of the centre group is the diagonal)
-    constexpr int ND = (RT * RS + 63) / 64, NT = (WN * RS + 63) / 64;
-    float win[WN], src[WN];
-    spmmb_f4u cd[ND], ct[NT];
+    constexpr int ND = (RT * RS + CL - 1) / CL, NT = (WN * RS + CL - 1) / CL;
+    real win[WN], src[WN];
+    cvec cd[ND], ct[NT];
     const int wb = j0 + f - 3, ib = j0 - f - 3;
     auto load_direct = [&]() {
       load_span(std::integral_constant<int, ND>{}, gbase + (int64_t)RS * j0, cd);
       if constexpr (VAR == 4) {
 #pragma unroll
-        for (int e = 0; e < WN; ++e) win[e] = 1.f + e;
+        for (int e = 0; e < WN; ++e) win[e] = (real)(1 + e);
       } else if (wb >= 0 && wb + WN <= m) {
-        const float* __restrict__ wp = vcol + (int64_t)wb * KP;
+        const real* __restrict__ wp = vcol + (int64_t)wb * KP;
 #pragma unroll
         for (int e = 0; e < WN; ++e) win[e] = wp[e * KP];
       } else {
@@ -108,16 +128,16 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
       load_span(std::integral_constant<int, NT>{}, gbase + (int64_t)RS * ib, ct);
       if constexpr (VAR == 4) {
 #pragma unroll
-        for (int e = 0; e < WN; ++e) src[e] = 2.f + e;
+        for (int e = 0; e < WN; ++e) src[e] = (real)(2 + e);
       } else if (ib >= 0 && ib + WN <= m) {
-        const float* __restrict__ sp = vcol + (int64_t)ib * KP;
+        const real* __restrict__ sp = vcol + (int64_t)ib * KP;
 #pragma unroll
         for (int e = 0; e < WN; ++e) src[e] = sp[e * KP];
       } else {
 #pragma unroll
         for (int e = 0; e < WN; ++e) {
           const int i = ib + e;
-          src[e] = (i >= 0 && i < m) ? vcol[(int64_t)i * KP] : 0.f;     // wave-uniform condition
+          src[e] = (i >= 0 && i < m) ? vcol[(int64_t)i * KP] : (real)0;     // wave-uniform condition
         }
       }
     };
@@ -129,9 +149,10 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
 #pragma unroll
         for (int n = 0; n < ND; ++n) asm volatile("" ::"v"(cd[n]));
       } else {
+        spmmb_dpp_guard();
         spmmb_for<RT * RS>([&](auto it) {
           constexpr int idx = decltype(it)::value, r = idx / RS, s = S0 + idx % RS;
-          spmmb_fma<(idx % 64) / 4>(acc[r], cd[idx / 64][idx % 4], win[r + s]);
+          spmmb_fma<(idx % CL) / CPL>(acc[r], cd[idx / CL][idx % CPL], win[r + s]);
         });
       }
     };
@@ -143,9 +164,10 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
 #pragma unroll
         for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(ct[n]));
       } else {
+        spmmb_dpp_guard();
         spmmb_for<WN * RS>([&](auto it) {
           constexpr int idx = decltype(it)::value, e = idx / RS, s = S0 + idx % RS, r = e + s - 6;
-          if constexpr (s >= T0 && r >= 0 && r < RT) spmmb_fma<(idx % 64) / 4>(acc[r], ct[idx / 64][idx % 4], src[e]);
+          if constexpr (s >= T0 && r >= 0 && r < RT) spmmb_fma<(idx % CL) / CPL>(acc[r], ct[idx / CL][idx % CPL], src[e]);
         });
       }
     };
@@ -166,14 +188,14 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
   }
 
   double dot = 0;
-  const bool cw = lane < k && active;               // this lane writes (padding columns and padding waves do not)
+  const bool cw = c < k && active;               // this lane writes (padding columns and padding waves do not)
   if (j0 + RT <= m) {
-    float* __restrict__ op = Ot + (int64_t)(lane < k ? lane : 0) * m + j0;      // j0 and m are multiples of 4: 16-byte aligned
+    real* __restrict__ op = Ot + (int64_t)(c < k ? c : 0) * m + j0;      // j0 and m are multiples of 4: 16-byte aligned
 #pragma unroll
     for (int r = 0; r < RT; r += 4)
-      if (cw) store4<float>(op + r, acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+      if (cw) store4<real>(op + r, acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
     if (DOT) {
-      const float* __restrict__ vp = vcol + (int64_t)j0 * KP;
+      const real* __restrict__ vp = vcol + (int64_t)j0 * KP;
 #pragma unroll
       for (int r = 0; r < RT; ++r) dot += (double)vp[r * KP] * (double)acc[r];
     }
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       const int j = j0 + r;
-      if (j < m && cw) Ot[(int64_t)lane * m + j] = acc[r];
+      if (j < m && cw) Ot[(int64_t)c * m + j] = acc[r];
       if (DOT && j < m && active) dot += (double)vcol[(int64_t)j * KP] * (double)acc[r];
     }
   }
@@ -189,6 +211,6 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<float> G, const 
     __shared__ double s_dot[4][64];
     s_dot[wv][lane] = active ? dot : 0.0;
     __syncthreads();
-    if (wv == 0 && lane < k) pcg_dot_add(dots, lane, s_dot[0][lane] + s_dot[1][lane] + s_dot[2][lane] + s_dot[3][lane]);
+    if (wv == 0 && c < k) pcg_dot_add(dots, c, s_dot[0][lane] + s_dot[1][lane] + s_dot[2][lane] + s_dot[3][lane]);
   }
 }

@@ -86,7 +86,8 @@ __device__ __forceinline__ void spmmc_span(const real* __restrict__ p, F&& fn) {
 
 // column-major [k][m] -> row-major [m][kp] (kp = k rounded up to 64; padding columns are written as zeros).
 // DOT: dots[c] += beta * sum_i V[c][i] * add[c][i]  (slotted, see PcgScal).
-template <typename real, bool DOT>
+// SLICED: one [m][64] image per 64 columns (blockIdx.y), the operand layout of k_spmm_sym_bcast; kp is a multiple of 64 then.
+template <typename real, bool DOT, bool SLICED = false>
 __global__ __launch_bounds__(256) void k_transpose_cm_rm(int m, int k, int kp, const real* __restrict__ V, real* __restrict__ Vt,
                                                          const real* __restrict__ add, real beta, double* __restrict__ dots) {
   __shared__ real tile[64][65];
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(256) void k_transpose_cm_rm(int m, int k, int kp, c
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int i = i0 + ty + 4 * u, c = c0 + tx;
-    if (i < m && c < kp) Vt[(int64_t)i * kp + c] = tile[tx][ty + 4 * u];
+    if (SLICED) {
+      if (i < m) Vt[((int64_t)blockIdx.y * m + i) * 64 + tx] = tile[tx][ty + 4 * u];
+    } else if (i < m && c < kp) Vt[(int64_t)i * kp + c] = tile[tx][ty + 4 * u];
   }
   if (DOT) {
 #pragma unroll

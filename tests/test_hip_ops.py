@@ -302,7 +302,7 @@ def test_spmv_and_kron(d, g, tdt, ndt, tol, half):
     A = _t(B2.A, tdt)
     if half:
         A = grid_ops.half_stencil_from_offset_major(grid, A[(grid.R - 1) // 2:].contiguous())
-    for k in (1, 2, 3, 5, 9, 17, 33, 50, 64):       # 49..64 columns, fp32, half: the DPP-broadcast SpMM (csrc/spmm_sym_bcast.h)
+    for k in (1, 2, 3, 5, 9, 17, 33, 50, 64):       # >= 16 columns, half: the DPP-broadcast SpMM (csrc/spmm_sym_bcast.h)
         V = rng.standard_normal((k, grid.m)).astype(ndt)
         add = rng.standard_normal((k, grid.m)).astype(ndt)
         out = grid_ops.stencil_spmv(grid, A, _t(V, tdt), _t(add, tdt), 0.7)
@@ -430,7 +430,7 @@ def test_fused_spectral_pcg_on_anisotropic_grids(gs, tdt, ndt, tol):
 
 
 @pytest.mark.parametrize("gs,k", [(gs, k) for k in (3, 7, 12) for gs in [(9, 8, 12), (20, 17, 12), (12, 50, 6), (8, 8, 53), (50, 20, 20)]] +
-                         [((9, 8, 12), 56), ((12, 50, 6), 64)])     # 49..64 columns: the broadcast SpMM with the p . Ap epilogue
+                         [((9, 8, 12), 56), ((12, 50, 6), 64), ((8, 8, 53), 20)])     # >= 16 columns: the broadcast SpMM with the p . Ap epilogue
 def test_fused_spectral_pcg_many_columns(gs, k):
     """fp32 solves with >= 3 right-hand sides take the multi-column slab kernel of the preconditioner (k_spec_slab_mfma_mc: a
     block owns a slab for a strided set of columns, both output halves from one forward transform): columns per block 1 and > 1
@@ -483,13 +483,14 @@ def test_half_stencil_spmv_dma_kernel_on_3d_grids(gs):
         assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("k", [49, 64, 100])
+@pytest.mark.parametrize("tdt,tol", [(torch.float32, 2e-5), (torch.float64, 1e-13)])
+@pytest.mark.parametrize("k", [16, 49, 64, 100])
 @pytest.mark.parametrize("gs", [(6, 10, 14), (8, 5, 9), (4, 4, 4), (20, 24, 50), (5, 7, 64), (4, 5, 7), (30, 10)])
-def test_half_stencil_spmm_broadcast_kernel(gs, k):
-    """fp32 products with 49..64 right-hand sides take k_spmm_sym_bcast (csrc/spmm_sym_bcast.h: coefficients by vector loads +
-    DPP row broadcast; k = 100 is padded to 112 columns and stays on the scalar-path kernel k_spmm_sym_cols): ragged last tile
-    (m % 16 != 0), grids smaller than a window (every window clamped / zeroed, coefficient spans clamped at both ends of A_h),
-    d = 2 and 3; against the C oracle's full-stencil product."""
+def test_half_stencil_spmm_broadcast_kernel(gs, k, tdt, tol):
+    """Products with >= 16 right-hand sides take k_spmm_sym_bcast (csrc/spmm_sym_bcast.h: coefficients by vector loads +
+    DPP row broadcast, v_fmac_f32_dpp / v_fmac_f64_dpp; operands in 64-column slices, k = 100: a full slice and one padded
+    from 36 columns): ragged last tile (m % 16 != 0), grids smaller than a window (every window clamped / zeroed, coefficient
+    spans clamped at both ends of A_h), d = 2 and 3, both precisions; against the C oracle's full-stencil product."""
     from online_gp_amd import grid_ops
 
     rng = np.random.default_rng(5)
@@ -502,12 +503,12 @@ def test_half_stencil_spmm_broadcast_kernel(gs, k):
     noise = rng.uniform(0.5, 2.0, n)
     B2 = cport.MatrixFreeWISKI(gb, list(gs), sigma2=0.5, dtype=np.float64)
     B2.absorb(X, y, noise, init=True)
-    A = grid_ops.half_stencil_from_offset_major(grid, _t(B2.A, torch.float32)[(grid.R - 1) // 2:].contiguous())
+    A = grid_ops.half_stencil_from_offset_major(grid, _t(B2.A, tdt)[(grid.R - 1) // 2:].contiguous())
     V = rng.standard_normal((k, grid.m))
     add = rng.standard_normal((k, grid.m))
-    out = grid_ops.stencil_spmv(grid, A, _t(V, torch.float32), _t(add, torch.float32), 0.4)
+    out = grid_ops.stencil_spmv(grid, A, _t(V, tdt), _t(add, tdt), 0.4)
     ref = B2.stencil_mv(V) + 0.4 * add
-    assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    assert np.abs(out.double().cpu().numpy() - ref).max() < tol * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 1e-11)])

@@ -222,3 +222,19 @@ def test_stencil_shard_group_arithmetic_is_a_partition():
             covered = sorted(sl for lo, hi in ranges for sl in grid_ops.half_stencil_group_slices(grid, lo, hi))
             assert covered[0][0] == 0 and covered[-1][1] == (grid.R + 1) // 2 * grid.m
             assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+
+
+def test_dpp_broadcast_spmm_has_no_valu_to_dpp_hazard():
+    """The 64-column half-stencil product issues its FMAs as inline-asm v_fmac_f32_dpp / v_fmac_f64_dpp (csrc/spmm_sym_bcast.h), which
+    hipcc's hazard recogniser does not see: the gfx950 ISA of every instantiation must not read a coefficient register through DPP
+    within two wait states of a VALU write to it, and must not spill (tools/check_dpp_hazards.py)."""
+    import shutil
+    import subprocess
+    import sys
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_dpp_hazards.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 hazards") == 4, r.stdout          # fp32 / fp64, with and without the p . Ap epilogue
