@@ -499,6 +499,14 @@ def main():
                     Ah = model._kernel_cache["WtW"].stencil
                     grid_ops.stencil_spmv(grid, Ah, Vm)
                     spmm[kc] = event_us(lambda i: grid_ops.stencil_spmv(grid, Ah, Vm), 4)
+                    if kc == 64:      # the product kernel alone, by its own dispatch timestamps (the call above adds the input transpose,
+                        torch.cuda.synchronize(dev)     # the final beta * add reduction and a stream-ordered 256 MB scratch allocation)
+                        lib.wiski_prof_start(ctypes.c_int32(64))
+                        for _ in range(8):
+                            grid_ops.stencil_spmv(grid, Ah, Vm)
+                        torch.cuda.synchronize(dev)
+                        tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+                        spmm_kernel_us = tms.value * 1e3 / nl.value if lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl)) == 0 and nl.value else None
                     del Vm
                 spmm_bytes = lambda kc: ((grid.R + 1) // 2 * grid.m + 2 * kc * grid.m) * es
                 roofline_secondary = [
@@ -506,8 +514,14 @@ def main():
                      "bound": "hbm", "achieved": spmm_bytes(64) / (spmm[64] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": spmm_bytes(64) / (spmm[64] * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": spmm[64], "algorithmic_bytes_per_launch": spmm_bytes(64),
                      "flop_per_launch": 2 * grid.R * grid.m * 64, "vector_fma_frac_of_157_TFLOPs": 2 * grid.R * grid.m * 64 / (spmm[64] * 1e-6) / 157e12,
-                     "k16_us_4_columns_per_pass_kernel": spmm[16], "k16_frac": spmm_bytes(16) / (spmm[16] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "timing": "median of 5 torch.cuda.Event brackets of 4 products (wiski_stencil_spmv_sym, back to back)"},
+                     "k16_us": spmm[16], "k16_frac": spmm_bytes(16) / (spmm[16] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "kernel_only_us": spmm_kernel_us,
+                     "kernel_only_frac_of_hbm": None if not spmm_kernel_us else spmm_bytes(64) / (spmm_kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "kernel_only_frac_of_unpacked_vector_fma_78.6_TFLOPs": None if not spmm_kernel_us else 2 * grid.R * grid.m * 64 / (spmm_kernel_us * 1e-6) / 78.6e12,
+                     "bound_note": "2.74 G lane-FMAs through v_fmac_f32_dpp (no packed DPP form: 70 us at the unpacked issue rate) and 2.2 GB of V-window rows "
+                                   "L2 -> L1; the 150 MB of HBM traffic (19 us) are not what bounds it (DESIGN 3.4)",
+                     "timing": "median of 5 torch.cuda.Event brackets of 4 products (wiski_stencil_spmv_sym, back to back: transpose + product + reduction); "
+                               "kernel_only_us: start/stop events on the product kernel's own dispatch, 8 launches"},
                     {"kernel": "k_scatter_stats_sym (statistics scatter of q points; memory-side atomics)", "bound": "hbm",
                      "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_us": sc_us, "algorithmic_bytes_per_point": sc_bytes, "points_per_s": q / (sc_us * 1e-6),
