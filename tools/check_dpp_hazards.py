@@ -1,6 +1,6 @@
 """Static check of the gfx950 ISA of csrc/solve.hip: no `v_fmac_f32_dpp` / `v_fmac_f64_dpp` of k_spmm_sym_bcast reads (as its DPP
-operand, src0) a VGPR that a VALU instruction wrote fewer than two wait states earlier, and the kernels neither spill nor use
-AGPR copies.  The FMAs are inline asm (csrc/spmm_sym_bcast.h), which hipcc's hazard recogniser does not look into.
+operand, src0) a VGPR that a VALU instruction wrote fewer than two wait states earlier, none follows a write of EXEC (v_cmpx, or any
+instruction whose destination is exec) by fewer than five, and the kernels neither spill nor use AGPR copies.  The FMAs are inline asm (csrc/spmm_sym_bcast.h), which hipcc's hazard recogniser does not look into.
 Usage: python tools/check_dpp_hazards.py [path/to/solve.s]   (without an argument: compiles solve.hip to ISA first, ~25 s)"""
 import os
 import re
@@ -25,7 +25,7 @@ def scan(txt):
     for name in re.findall(r"^(_Z\d+k_spmm_sym_bcast\w+):", txt, re.M):
         body = txt[txt.index(name + ":"):]
         body = body[:body.index("s_endpgm")]
-        hist, bad, n, spills = [], 0, 0, 0
+        hist, bad, n, spills, exec_age = [], 0, 0, 0, 99
         for line in body.split("\n"):
             s = line.strip()
             if not s or s[0] in ";." or s.endswith(":"):
@@ -38,8 +38,12 @@ def scan(txt):
                 n += 1
                 src0 = _regs(args[1].split()[0])
                 bad += sum(1 for ws, w in hist if ws < 2 and (w & src0))
+                bad += exec_age < 5
             adv = int(args[0]) + 1 if op == "s_nop" else 1
             hist = [(ws + adv, w) for ws, w in hist if ws + adv < 3]
+            exec_age += adv
+            if op.startswith("v_cmpx") or (args and args[0].split() and args[0].split()[0].startswith("exec")):
+                exec_age = 0
             if op.startswith("v_") and not op.startswith("v_cmp"):
                 hist.append((0, _regs(args[0].split()[0])))
         res[name] = (n, bad, spills)

@@ -23,6 +23,18 @@ test -n "$f" && python $R/tools/trace_timeline.py "$f" > $O/refstep_timeline.txt
 cd $R
 timeout 200 python tools/bench_small_potrf.py > $O/small_potrf.txt 2>&1; grep "327\|480" $O/small_potrf.txt
 timeout 200 python tools/refstep_probe.py > $O/refstep_probe.txt 2>&1; tail -2 $O/refstep_probe.txt
+# the many-column half-stencil product: scalar-path kernel (WISKI_SPMM_BCAST=0) against the DPP-broadcast one, both precisions
+rm -f $O/spmm_bcast_probe.txt
+for dt in f32 f64; do for b in 0 1; do for k in 16 24 32 64 100; do
+  echo "== $dt k=$k WISKI_SPMM_BCAST=$b" >> $O/spmm_bcast_probe.txt
+  WISKI_SPMM_BCAST=$b timeout 300 python tools/spmv_probe.py --k $k --reps 20 --dtype $dt 2>&1 | grep "half\|diff" >> $O/spmm_bcast_probe.txt
+done; done; done
+grep -A1 "k=64" $O/spmm_bcast_probe.txt | grep -v "^--"
+# kernel mix of 64 predictive variances on the PCG path
+cd /tmp
+rm -rf /tmp/pv; WISKI_NO_SPECTRAL=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv -o v -- python $R/tools/var_probe.py 64 > $O/var_pcg.log 2>&1
+cp /tmp/pv/v_kernel_stats.csv $O/variance_pcg_kernel_stats.csv; grep "variance of" $O/var_pcg.log | tail -1
+cd $R
 python -c "
 import json; r=json.load(open('$O/bench.json')); e=r['extra']
 print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline']['net_of_empty_dispatch_frac'])
