@@ -581,6 +581,16 @@ static inline int sym_groups(int d) {
   for (int q = 0; q < d - 1; ++q) np *= 7;
   return (np + 1) / 2;
 }
+// XCD-contiguous row ranges for the half-stencil SpMV kernels (spmv_sym_dma.h; WISKI_SYM_XCD=0: plain blockIdx.x = row block).
+// 50^3 fp32 (LDS-DMA kernel): 18.1 -> 17.7 us back to back, 21.3 -> 20.5 us per dispatch inside bench.py.
+static int g_sym_xcd = -1;
+static inline bool sym_xcd_map() {
+  if (g_sym_xcd < 0) {
+    const char* e = getenv("WISKI_SYM_XCD");
+    g_sym_xcd = e ? atoi(e) : 1;
+  }
+  return g_sym_xcd != 0;
+}
 static int g_sym_nch = 0;   // tuning override (WISKI_SYM_NCH)
 static int g_sym_bs = 0;    // tuning override (WISKI_SYM_BLOCK): threads per block of the wide symmetric SpMV
 static inline int sym_block() {
@@ -618,11 +628,16 @@ extern "C" int wiski_sym_dbg(long long* out) { return hipMemcpyFromSymbol(out, H
 template <typename real, int KC, bool DOT>
 __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, const real* __restrict__ A_h, const real* __restrict__ V, int k,
                                                            int ng, int nch, int span, int W4, real* __restrict__ part,
-                                                           const real* __restrict__ add, real beta, double* __restrict__ dots, int g_lo, int g_hi) {
+                                                           const real* __restrict__ add, real beta, double* __restrict__ dots, int g_lo, int g_hi,
+                                                           int xcd_rb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_off[176];
   __shared__ double s_red[16];
   const int m = G.m, d = G.d;
+  // xcd_rb != 0: XCD-contiguous row blocks (see spmv_sym_dma.h): grid.x = 8 * xcd_rb, workgroup b (on XCD b % 8) takes row block
+  // (b % 8) * xcd_rb + b / 8, so the v windows an XCD's L2 has to hold are those of ONE contiguous range of rows
+  const int rbx = xcd_rb ? (int)(blockIdx.x & 7) * xcd_rb + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (xcd_rb && (int64_t)rbx * (blockDim.x >> 6) * 256 >= m) return;      // block-uniform, before the first barrier
   const int ch = blockIdx.y;
   const int c0 = blockIdx.z * KC;
   // the groups of this launch, [g_lo, g_hi) -- all ng of them, or the share of a stencil-sharded replica (wiski_shard) --
@@ -645,7 +660,7 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
   for (int e = lane; e < KC * 4 * W4; e += 64) tw[e] = (real)0;
   __syncthreads();
   SYM_STAMP(1);
-  const int iw0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 256;   // first row of this wave
+  const int iw0 = (rbx * (blockDim.x >> 6) + wave) * 256;   // first row of this wave
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;
   const int64_t km = (int64_t)k * m;
@@ -1015,7 +1030,9 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       // (the zero regions of wiski_pcg_zero_regions must not depend on the sharding)
       const int np = tab.n ? tab.n : g_sym_dma_parts;
       if (np > g_sym_dma_parts) return WISKI_E_BADARG;
-      dim3 grd((unsigned)((G.m + 255) / 256), (unsigned)np);
+      const int nrb = (G.m + 255) / 256;
+      const int xcd_rb = sym_xcd_map() ? (nrb + 7) / 8 : 0;
+      dim3 grd((unsigned)(xcd_rb ? 8 * xcd_rb : nrb), (unsigned)np);
       // the light chunk joins when the heavy ones are ~3 / 7 through their stream: proportional to the stream's length
       const int delay = (int)((int64_t)g_sym_dma_delay * G.m / 125000);
 #define SYMDMA(NST, DOT)                                                                                                          \
@@ -1026,7 +1043,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         return WISKI_E_LAUNCH;                                                                                                    \
       lds_set = sh;                                                                                                               \
     }                                                                                                                             \
-    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab); \
+    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab, xcd_rb); \
   } while (0)
       if (g_sym_dma_nst == 3) {
         if (dots) SYMDMA(3, true); else SYMDMA(3, false);
@@ -1042,7 +1059,9 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       const int kc = k >= 4 ? 4 : 2;
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
       const size_t sh = symdma_mc_lds_bytes(G.g[2], kc);
-      dim3 grd((unsigned)((G.m + 255) / 256), 4u, (unsigned)((k + kc - 1) / kc));
+      const int nrb = (G.m + 255) / 256;
+      const int xcd_rb = sym_xcd_map() ? (nrb + 7) / 8 : 0;
+      dim3 grd((unsigned)(xcd_rb ? 8 * xcd_rb : nrb), 4u, (unsigned)((k + kc - 1) / kc));
 #define SYMDMAMC(KC, DOT)                                                                                                          \
   do {                                                                                                                             \
     static size_t lds_set = 0;                                                                                                     \
@@ -1051,7 +1070,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         return WISKI_E_LAUNCH;                                                                                                     \
       lds_set = sh;                                                                                                                \
     }                                                                                                                              \
-    launch_timed(k_spmv_sym_dma_mc<KC, DOT>, grd, dim3(64), sh, s, G, A_h, V, k, W4, WP, part, add, beta, dots);                   \
+    launch_timed(k_spmv_sym_dma_mc<KC, DOT>, grd, dim3(64), sh, s, G, A_h, V, k, W4, WP, part, add, beta, dots, xcd_rb);           \
   } while (0)
       if (kc == 4) { if (dots) SYMDMAMC(4, true); else SYMDMAMC(4, false); }
       else { if (dots) SYMDMAMC(2, true); else SYMDMAMC(2, false); }
@@ -1072,7 +1091,9 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
   if (span > cap) span = cap > 0 ? cap : 0;
   const int W4 = ((256 + span + 10 + 3) / 4) | 1;
   const size_t sh = (size_t)nw * (7 * 256 + kc * 4 * W4) * sizeof(real);
-  dim3 grd((unsigned)((G.m + 4 * bs - 1) / (4 * bs)), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
+  const int nrb = (G.m + 4 * bs - 1) / (4 * bs);
+  const int xcd_rb = sym_xcd_map() ? (nrb + 7) / 8 : 0;
+  dim3 grd((unsigned)(xcd_rb ? 8 * xcd_rb : nrb), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
 #define SPMV4S(KC)                                                                                                                              \
   do {                                                                                                                                          \
     static size_t lds_set[2] = {0, 0};   /* > 48 KB of dynamic LDS needs an opt-in per kernel */                                                \
@@ -1083,9 +1104,9 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       lds_set[di] = sh;                                                                                                                         \
     }                                                                                                                                           \
     if (dots) launch_timed(k_stencil_spmv4_sym<real, KC, true>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots,   \
-                           ranged ? g_lo : 0, ranged ? g_hi : ng);                                                                              \
+                           ranged ? g_lo : 0, ranged ? g_hi : ng, xcd_rb);                                                                      \
     else launch_timed(k_stencil_spmv4_sym<real, KC, false>, grd, dim3(bs), sh, s, G, A_h, V, k, ng, nch, span, W4, part, add, beta, dots,       \
-                      ranged ? g_lo : 0, ranged ? g_hi : ng);                                                                                   \
+                      ranged ? g_lo : 0, ranged ? g_hi : ng, xcd_rb);                                                                           \
   } while (0)
   if (kc == 4) SPMV4S(4);
   else if (kc == 2) SPMV4S(2);

@@ -42,6 +42,13 @@
 // instruction per tile in the loop, 17 instead of 36 granules left for the epilogue) shortens the epilogue (0.92 -> 0.58 us per
 // wave) but the atomics in the loop slow the stream (1 300 -> 1 050..1 170 tiles/us): 19.15 us against 18.45 us back to back.
 //
+// Round 4: XCD-contiguous row blocks.  Workgroups are dealt to the 8 XCDs round-robin by linear id; with blockIdx.x = row block every XCD
+// streamed every 8th row block and pulled ALL of v through its own L2 (8 x 0.5 MB per launch).  The grid is now padded to 8 * ceil(nrb / 8)
+// and workgroup b takes row block (b % 8) * ceil(nrb / 8) + b / 8: an XCD owns one contiguous eighth of the rows for all parts, fetches only
+// that eighth of v (+ the 3-plane halo of the windows) and its neighbouring row blocks share window lines in ITS L2: 18.1 -> 17.7 us back
+// to back (tools/spmv_probe.py, 200 launches), 21.3 -> 20.5 us per dispatch by bench.py's events; the delay / parts / ring-depth optima do
+// not move (delay 0..18: 17.7..18.1; 5 / 6 parts 19.1 / 19.9; ring depth 3: 26.5).  WISKI_SYM_XCD=0 restores the plain mapping (also for the LDS-window kernel k_stencil_spmv4_sym).
+//
 // Requires d == 3, m % 4 == 0.  part holds (nparts + 1) * m reals: part[y] = direct term of part y (plain stores),
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
 #pragma once
@@ -120,7 +127,7 @@ struct SymDmaParts {
 template <int NST, bool DOT>
 __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const float* __restrict__ A_h, const float* __restrict__ V, int W4, int WP,
                                                      int nparts, float* __restrict__ part, const float* __restrict__ add, float beta,
-                                                     double* __restrict__ dots, int delay, SymDmaParts tab) {
+                                                     double* __restrict__ dots, int delay, SymDmaParts tab, int xcd_rb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int m = G.m, S0 = G.stride[0], S1 = G.stride[1];
@@ -156,7 +163,11 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   // are about three tiles in (50^3: delay = 12, 18.5 -> 18.1 us back to back; 6..8 and 14..20 are no better than 0, 24+ worse).
   if (!tab.n && nparts == 4 && blockIdx.y == 3)
     for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(16);
-  const int iw0 = blockIdx.x * 256;
+  // xcd_rb != 0: grid.x is padded to 8 * xcd_rb and workgroup b (on XCD b % 8) takes row block (b % 8) * xcd_rb + b / 8, so every
+  // XCD sweeps ONE contiguous eighth of the rows (for all parts) and fetches only that eighth of v (+ the 3-plane halo) into its L2
+  const int rb = xcd_rb ? (int)(blockIdx.x & 7) * xcd_rb + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (xcd_rb && rb * 256 >= G.m) return;
+  const int iw0 = rb * 256;
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;
   const int nrows = m - iw0 < 256 ? m - iw0 : 256;

@@ -19,7 +19,7 @@
 template <int KC, bool DOT>
 __global__ __launch_bounds__(64) void k_spmv_sym_dma_mc(GridDev<float> G, const float* __restrict__ A_h, const float* __restrict__ V, int k, int W4,
                                                         int WP, float* __restrict__ part, const float* __restrict__ add, float beta,
-                                                        double* __restrict__ dots) {
+                                                        double* __restrict__ dots, int xcd_rb) {
   constexpr int NST = 2, NPARTS = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -27,7 +27,10 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma_mc(GridDev<float> G, const 
   const int c0 = blockIdx.z * KC;                  // first column of this pass
   const int y = blockIdx.y;
   const int d0 = (y + 1) & 3, p1lo = d0 == 0 ? 3 : 0, ntile = d0 == 0 ? 4 : 7;
-  const int iw0 = blockIdx.x * 256;
+  // xcd_rb != 0: XCD-contiguous row blocks (spmv_sym_dma.h)
+  const int rb = xcd_rb ? (int)(blockIdx.x & 7) * xcd_rb + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (xcd_rb && rb * 256 >= G.m) return;
+  const int iw0 = rb * 256;
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;
   const int nrows = m - iw0 < 256 ? m - iw0 : 256;
