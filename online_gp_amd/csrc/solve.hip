@@ -581,15 +581,19 @@ static inline int sym_groups(int d) {
   for (int q = 0; q < d - 1; ++q) np *= 7;
   return (np + 1) / 2;
 }
-// XCD-contiguous row ranges for the half-stencil SpMV kernels (spmv_sym_dma.h; WISKI_SYM_XCD=0: plain blockIdx.x = row block).
-// 50^3 fp32 (LDS-DMA kernel): 18.1 -> 17.7 us back to back, 21.3 -> 20.5 us per dispatch inside bench.py.
-static int g_sym_xcd = -1;
-static inline bool sym_xcd_map() {
-  if (g_sym_xcd < 0) {
+// XCD-contiguous row ranges for the half-stencil SpMV kernels (spmv_sym_dma.h).  Taken where A_h is served by the 256 MB Infinity
+// Cache: 50^3 fp32 (LDS-DMA kernel, 86 MB) 18.1 -> 17.7 us back to back, 21.3 -> 20.5 us per dispatch inside bench.py; 50^3 fp64
+// (LDS-window kernel, 172 MB) 36.8 -> 36.2 us.  NOT where A_h streams from HBM: at 30^4 (7.8 GB fp64 / 3.9 GB fp32) eight separate
+// address streams are slower than one interleaved stream (1342 -> 1409 us, 738 -> 754 us: DRAM page locality), so the plain
+// blockIdx.x = row block mapping stays there.  WISKI_SYM_XCD=0 / 1 forces it off / on.
+static int g_sym_xcd = -2;
+static inline bool sym_xcd_map(int64_t a_bytes) {
+  if (g_sym_xcd == -2) {
     const char* e = getenv("WISKI_SYM_XCD");
-    g_sym_xcd = e ? atoi(e) : 1;
+    g_sym_xcd = e ? atoi(e) : -1;
   }
-  return g_sym_xcd != 0;
+  if (g_sym_xcd >= 0) return g_sym_xcd != 0;
+  return a_bytes <= (int64_t)192 << 20;
 }
 static int g_sym_nch = 0;   // tuning override (WISKI_SYM_NCH)
 static int g_sym_bs = 0;    // tuning override (WISKI_SYM_BLOCK): threads per block of the wide symmetric SpMV
@@ -1031,7 +1035,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       const int np = tab.n ? tab.n : g_sym_dma_parts;
       if (np > g_sym_dma_parts) return WISKI_E_BADARG;
       const int nrb = (G.m + 255) / 256;
-      const int xcd_rb = sym_xcd_map() ? (nrb + 7) / 8 : 0;
+      const int xcd_rb = sym_xcd_map((int64_t)(7 * sym_groups(G.d) - 3) * G.m * (int64_t)sizeof(real)) ? (nrb + 7) / 8 : 0;
       dim3 grd((unsigned)(xcd_rb ? 8 * xcd_rb : nrb), (unsigned)np);
       // the light chunk joins when the heavy ones are ~3 / 7 through their stream: proportional to the stream's length
       const int delay = (int)((int64_t)g_sym_dma_delay * G.m / 125000);
@@ -1060,7 +1064,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
       const int W4 = symdma_w4(G.g[2]), WP = symdma_wp(G.g[2]);
       const size_t sh = symdma_mc_lds_bytes(G.g[2], kc);
       const int nrb = (G.m + 255) / 256;
-      const int xcd_rb = sym_xcd_map() ? (nrb + 7) / 8 : 0;
+      const int xcd_rb = sym_xcd_map((int64_t)(7 * sym_groups(G.d) - 3) * G.m * (int64_t)sizeof(real)) ? (nrb + 7) / 8 : 0;
       dim3 grd((unsigned)(xcd_rb ? 8 * xcd_rb : nrb), 4u, (unsigned)((k + kc - 1) / kc));
 #define SYMDMAMC(KC, DOT)                                                                                                          \
   do {                                                                                                                             \
@@ -1092,7 +1096,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
   const int W4 = ((256 + span + 10 + 3) / 4) | 1;
   const size_t sh = (size_t)nw * (7 * 256 + kc * 4 * W4) * sizeof(real);
   const int nrb = (G.m + 4 * bs - 1) / (4 * bs);
-  const int xcd_rb = sym_xcd_map() ? (nrb + 7) / 8 : 0;
+  const int xcd_rb = sym_xcd_map((int64_t)(7 * ng - 3) * G.m * (int64_t)sizeof(real)) ? (nrb + 7) / 8 : 0;
   dim3 grd((unsigned)(xcd_rb ? 8 * xcd_rb : nrb), (unsigned)nch, (unsigned)((k + kc - 1) / kc));
 #define SPMV4S(KC)                                                                                                                              \
   do {                                                                                                                                          \
