@@ -27,20 +27,8 @@ import torch
 
 from .. import _hip, grid_ops, settings
 
-_SIDE = {}
-
-
-def _side_stream(device):
-    """The refresh stream.  WISKI_TL_SIDE_PRIORITY=low asks for the lowest stream priority the device offers, so that the refresh
-    kernels yield to the solver's (experiment hook: tools/jobs/r4prio.sh)."""
-    import os
-    if os.environ.get("WISKI_TL_SIDE_PRIORITY", "") == "low":
-        try:
-            pr = torch.cuda.Stream.priority_range()
-            return torch.cuda.Stream(device=device, priority=max(pr))
-        except Exception:  # noqa: BLE001
-            pass
-    return torch.cuda.Stream(device=device)         # device -> side stream of the refreshes (streams are never destroyed by torch: one per device, not one per model)
+_SIDE = {}         # device -> side stream of the refreshes (streams are never destroyed by torch: one per device, not one per model;
+                   # HIP offers no priority below the default -- priority_range() = (0, -1) -- so the refresh cannot be made to yield)
 _WORK = {}         # (device, r) -> refresh workspace, shared by the blocks of successive models (refreshes of one device serialise on _SIDE)
 KMAX = 32          # per-dim eigenvectors the projection kernel can take (wiski_basis_project)
 MAXR = 480         # one-workgroup Cholesky + inverse (wiski_potrf_inverse) and the slab kernel's LDS staging (512)
@@ -110,7 +98,7 @@ class TwoLevelBlock:
             _WORK[wkey] = torch.empty(nb, dtype=torch.uint8, device=device)
         self.work = _WORK[wkey]
         if str(device) not in _SIDE:
-            _SIDE[str(device)] = _side_stream(device)
+            _SIDE[str(device)] = torch.cuda.Stream(device=device)
         self.side = _SIDE[str(device)]
         self.in_flight = None                  # (event, step it was launched at, buffer index)
         self.failed = False
