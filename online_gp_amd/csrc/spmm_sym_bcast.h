@@ -58,7 +58,8 @@ __device__ __forceinline__ void spmmb_fma(double& acc, double coef, double w) {
 // VAR = 1: the product.  Timing ablations (wrong results; WISKI_SPMM_BCAST=3 / 4 in a -DWISKI_SPMMB_ABLATE build): 3 without the
 // FMAs (loads only: 117 us at 50^3), 4 without the window loads (FMAs + coefficient loads: 97 us); the product takes 138 us.
 // Requesting the operands of both terms before the first FMA (one memory latency per group) beats term-by-term order by 5 us;
-// a barrier per group (to keep the block's four waves, whose windows overlap by 6 rows, in step for L1 hits) costs 2..5 us.
+// a barrier per group (to keep the block's four waves, whose windows overlap by 6 rows, in step for L1 hits) costs 2..5 us; term-by-term
+// order ENFORCED with scheduling barriers (79 instead of 94 VGPRs, fp64 124 instead of 173) is 6 us slower in fp32 and no faster in fp64.
 template <typename real, bool DOT, int RT, int VAR>
 __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<real> G, const real* __restrict__ A_h, int64_t a_len, const real* __restrict__ Vt,
                                                         int k, int ng, real* __restrict__ Ot, double* __restrict__ dots) {
