@@ -644,6 +644,52 @@ __global__ __launch_bounds__(256) void k_set_identity(int n, real* __restrict__ 
   X[(int64_t)i * ldx + j] = i == j ? (real)1 : (real)0;
 }
 
+// Two-level blocked Cholesky for the dense regime beyond the one-launch kernels (480 < n; the model reaches n <= 2048): big blocks of
+// BB <= 448 rows.  A diagonal block is factorised AND inverted by ONE launch of the cooperating-workgroups kernel (dense_small.h /
+// dense_coop.h: ~150 us at 256, ~190 us at 327), the panel below it is one MFMA GEMM with that inverse (L21 = A21 L11^-T, into
+// scratch), the trailing update a second one (A22 -= L21 L21^T) and the panel is copied back: 3 launches + 1 copy per big block
+// instead of the 64-wide right-looking loop's 16 x (one-wave diagonal kernel 59 us + apply-inverse 13 us + GEMM 40 us) at n = 1000
+// (BASELINE config 4, the BayesOpt loop on a 10^3 grid: 5 factorisations per step were 60 % of its GPU time).
+// Returns WISKI_SMALL_UNAVAILABLE before touching A when the device refuses the small kernels' LDS.
+static bool two_level_potrf_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("WISKI_POTRF_TWO_LEVEL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+template <typename real>
+static int potrf_two_level(int n, real* d_A, int lda, int32_t* d_info, hipStream_t s) {
+  if (n < 1 || !d_A || !d_info || lda < n) return WISKI_E_BADARG;
+  constexpr int BBMAX = 448;
+  const int nbig = (n + BBMAX - 1) / BBMAX;
+  const int BB = ((n + nbig - 1) / nbig + SNB - 1) / SNB * SNB;          // equal blocks, multiple of the small kernels' 32
+  const int nblk = (BB + SNB - 1) / SNB;
+  const size_t nX = (size_t)BB * BB, nP = (size_t)(n > BB ? n - BB : 1) * BB, nD = (size_t)nblk * SNB * SNB;
+  real* scr = nullptr;
+  if (hipMallocAsync((void**)&scr, (nX + nP + nD) * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+  real *X = scr, *P = scr + nX, *dinv = P + nP;
+  int rc = WISKI_OK;
+  for (int j = 0; j < n && rc == WISKI_OK; j += BB) {
+    const int bb = n - j < BB ? n - j : BB;
+    real* Ajj = d_A + (int64_t)j * lda + j;
+    rc = potrf_small<real>(bb, Ajj, lda, dinv, X, BB, d_info, s);         // L_jj in place, X = L_jj^-1 (dense, zeros above the diagonal)
+    if (rc) break;                                                       // (WISKI_SMALL_UNAVAILABLE can only come from the first block)
+    const int rows = n - j - bb;
+    if (rows > 0) {
+      real* A21 = d_A + (int64_t)(j + bb) * lda + j;
+      real* A22 = d_A + (int64_t)(j + bb) * lda + (j + bb);
+      rc = launch_gemm<real>(0, 1, rows, bb, bb, (real)1, A21, lda, X, BB, (real)0, P, BB, s);                    // L21 = A21 L_jj^-T
+      if (rc == WISKI_OK) rc = launch_gemm<real>(0, 1, rows, rows, bb, (real)-1, P, BB, P, BB, (real)1, A22, lda, s);   // A22 -= L21 L21^T
+      if (rc == WISKI_OK && hipMemcpy2DAsync(A21, (size_t)lda * sizeof(real), P, (size_t)BB * sizeof(real), (size_t)bb * sizeof(real), (size_t)rows,
+                                             hipMemcpyDeviceToDevice, s) != hipSuccess)
+        rc = WISKI_E_LAUNCH;
+    }
+  }
+  (void)hipFreeAsync(scr, s);
+  return rc;
+}
+
 template <typename real>
 static int potrf_full(int n, real* d_A, int lda, int32_t* d_info, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -651,7 +697,12 @@ static int potrf_full(int n, real* d_A, int lda, int32_t* d_info, void* stream) 
     const int rs = potrf_small_entry<real>(n, d_A, lda, (real*)nullptr, 0, d_info, s);
     if (rs != WISKI_SMALL_UNAVAILABLE) return rs;
   }
-  int rc = potrf_impl<real>(n, d_A, lda, d_info, s);
+  int rc = WISKI_SMALL_UNAVAILABLE;
+  if (n > SMALL_N_MAX_POTRF && small_path_enabled() && two_level_potrf_enabled()) {
+    rc = potrf_two_level<real>(n, d_A, lda, d_info, s);
+    if (rc != WISKI_OK && rc != WISKI_SMALL_UNAVAILABLE) return rc;
+  }
+  if (rc == WISKI_SMALL_UNAVAILABLE) rc = potrf_impl<real>(n, d_A, lda, d_info, s);
   if (rc) return rc;
   const int64_t tot = (int64_t)n * n;
   hipLaunchKernelGGL((k_zero_upper<real>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, d_A, lda);

@@ -57,8 +57,11 @@ def test_gemm_large_tile_kernel(dtype, tol, ta, tb, M, N, K, pad):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
-@pytest.mark.parametrize("n", [17, 64, 200, 1000])
+@pytest.mark.parametrize("n", [17, 64, 200, 513, 897, 1000, 1345, 2048])
 def test_cholesky_trsm_logdet(dtype, tol, n):
+    """n > 512: the two-level blocked factorisation (dense.hip: potrf_two_level -- big diagonal blocks through the one-launch Cholesky +
+    inverse, panel and trailing update as two GEMMs): 2 blocks with a short second one (513), 3 / 4 equal blocks, 5 blocks at the model's
+    largest size."""
     from online_gp_amd import grid_ops
 
     g = torch.Generator(device="cpu").manual_seed(n)
@@ -212,6 +215,9 @@ def test_small_cholesky_reports_a_non_positive_pivot():
 
 def test_not_pd_sets_info_and_psd_safe_adds_jitter():
     from online_gp_amd import grid_ops
+
+    w = torch.randn(900, 700, device=DEV, dtype=torch.float64)          # two-level path: rank 700 < 900, the failure is in the SECOND big block
+    assert int(grid_ops.potrf_((w @ w.t()).clone()).item()) != 0
 
     v = torch.randn(50, 3, device=DEV, dtype=torch.float64)
     A = v @ v.t()                                   # rank 3: not PD
