@@ -658,34 +658,56 @@ static bool two_level_potrf_enabled() {
   }();
   return on;
 }
+// d_X != nullptr: also the explicit inverse X = L^-1 (n x n, ldx).  The diagonal blocks' inverses are written straight into X by the
+// factorisation; block row I of the rest follows from the rows above it with two GEMMs, X[I, 0:i0] = -X_II (L[I, 0:i0] X[0:i0, 0:i0]).
 template <typename real>
-static int potrf_two_level(int n, real* d_A, int lda, int32_t* d_info, hipStream_t s) {
-  if (n < 1 || !d_A || !d_info || lda < n) return WISKI_E_BADARG;
+static int potrf_two_level(int n, real* d_A, int lda, int32_t* d_info, hipStream_t s, real* d_X = nullptr, int ldx = 0) {
+  if (n < 1 || !d_A || !d_info || lda < n || (d_X && ldx < n)) return WISKI_E_BADARG;
   constexpr int BBMAX = 448;
   const int nbig = (n + BBMAX - 1) / BBMAX;
   const int BB = ((n + nbig - 1) / nbig + SNB - 1) / SNB * SNB;          // equal blocks, multiple of the small kernels' 32
   const int nblk = (BB + SNB - 1) / SNB;
-  const size_t nX = (size_t)BB * BB, nP = (size_t)(n > BB ? n - BB : 1) * BB, nD = (size_t)nblk * SNB * SNB;
+  const size_t nX = d_X ? 0 : (size_t)BB * BB, nP = (size_t)(n > BB ? n - BB : 1) * BB, nD = (size_t)nblk * SNB * SNB, nS = d_X ? (size_t)BB * n : 0;
   real* scr = nullptr;
-  if (hipMallocAsync((void**)&scr, (nX + nP + nD) * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
-  real *X = scr, *P = scr + nX, *dinv = P + nP;
+  if (hipMallocAsync((void**)&scr, (nX + nP + nD + nS) * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
+  real *Xs = scr, *P = scr + nX, *dinv = P + nP, *S = dinv + nD;
   int rc = WISKI_OK;
+  bool zeroed = false;
   for (int j = 0; j < n && rc == WISKI_OK; j += BB) {
     const int bb = n - j < BB ? n - j : BB;
     real* Ajj = d_A + (int64_t)j * lda + j;
-    rc = potrf_small<real>(bb, Ajj, lda, dinv, X, BB, d_info, s);         // L_jj in place, X = L_jj^-1 (dense, zeros above the diagonal)
+    real* X = d_X ? d_X + (int64_t)j * ldx + j : Xs;
+    const int ldxx = d_X ? ldx : BB;
+    rc = potrf_small<real>(bb, Ajj, lda, dinv, X, ldxx, d_info, s);       // L_jj in place, X = L_jj^-1 (dense, zeros above the diagonal)
     if (rc) break;                                                       // (WISKI_SMALL_UNAVAILABLE can only come from the first block)
+    if (d_X && !zeroed) {                                                // everything of X outside the diagonal blocks (block 0 is already written)
+      for (int I = 0; I < n && rc == WISKI_OK; I += BB) {
+        const int bi = n - I < BB ? n - I : BB;
+        if (I > 0 && hipMemset2DAsync(d_X + (int64_t)I * ldx, (size_t)ldx * sizeof(real), 0, (size_t)I * sizeof(real), (size_t)bi, s) != hipSuccess) rc = WISKI_E_LAUNCH;
+        if (I + bi < n && hipMemset2DAsync(d_X + (int64_t)I * ldx + I + bi, (size_t)ldx * sizeof(real), 0, (size_t)(n - I - bi) * sizeof(real), (size_t)bi, s) != hipSuccess)
+          rc = WISKI_E_LAUNCH;
+      }
+      zeroed = true;
+      if (rc) break;
+    }
     const int rows = n - j - bb;
     if (rows > 0) {
       real* A21 = d_A + (int64_t)(j + bb) * lda + j;
       real* A22 = d_A + (int64_t)(j + bb) * lda + (j + bb);
-      rc = launch_gemm<real>(0, 1, rows, bb, bb, (real)1, A21, lda, X, BB, (real)0, P, BB, s);                    // L21 = A21 L_jj^-T
+      rc = launch_gemm<real>(0, 1, rows, bb, bb, (real)1, A21, lda, X, ldxx, (real)0, P, BB, s);                  // L21 = A21 L_jj^-T
       if (rc == WISKI_OK) rc = launch_gemm<real>(0, 1, rows, rows, bb, (real)-1, P, BB, P, BB, (real)1, A22, lda, s);   // A22 -= L21 L21^T
       if (rc == WISKI_OK && hipMemcpy2DAsync(A21, (size_t)lda * sizeof(real), P, (size_t)BB * sizeof(real), (size_t)bb * sizeof(real), (size_t)rows,
                                              hipMemcpyDeviceToDevice, s) != hipSuccess)
         rc = WISKI_E_LAUNCH;
     }
   }
+  if (d_X && rc == WISKI_OK)
+    for (int i0 = BB; i0 < n && rc == WISKI_OK; i0 += BB) {
+      const int bb = n - i0 < BB ? n - i0 : BB;
+      rc = launch_gemm<real>(0, 0, bb, i0, i0, (real)1, d_A + (int64_t)i0 * lda, lda, d_X, ldx, (real)0, S, n, s);                 // S = L[I, 0:i0] X[0:i0, 0:i0]
+      if (rc == WISKI_OK)
+        rc = launch_gemm<real>(0, 0, bb, i0, bb, (real)-1, d_X + (int64_t)i0 * ldx + i0, ldx, S, n, (real)0, d_X + (int64_t)i0 * ldx, ldx, s);   // X[I, 0:i0] = -X_II S
+    }
   (void)hipFreeAsync(scr, s);
   return rc;
 }
@@ -717,6 +739,15 @@ static int potrf_inverse(int n, real* d_A, int lda, real* d_X, int ldx, int32_t*
   if (n <= SMALL_N_MAX && small_path_enabled()) {
     const int rs = potrf_small_entry<real>(n, d_A, lda, d_X, ldx, d_info, s);
     if (rs != WISKI_SMALL_UNAVAILABLE) return rs;
+  }
+  if (n > SMALL_N_MAX_POTRF && small_path_enabled() && two_level_potrf_enabled()) {     // (n = 481..512: the one-launch factor + a blocked solve, below)
+    int rt = potrf_two_level<real>(n, d_A, lda, d_info, s, d_X, ldx);
+    if (rt == WISKI_OK) {
+      const int64_t tot2 = (int64_t)n * n;
+      hipLaunchKernelGGL((k_zero_upper<real>), dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s, n, d_A, lda);
+      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+    }
+    if (rt != WISKI_SMALL_UNAVAILABLE) return rt;
   }
   int rc = potrf_full<real>(n, d_A, lda, d_info, stream);
   if (rc) return rc;

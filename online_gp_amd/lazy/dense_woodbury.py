@@ -5,7 +5,7 @@ Instead of a root of A = W^T D^-1 W (rank deficient until n >= m, hence the
 reference's Cholesky jitter) the symmetric root of Kt is used, which is exact
 and jitter-free:  with G = Kt^(1/2) (Kronecker eigenbasis),
     B = I + G A G  (SPD, eigenvalues >= 1),   B = C C^T   (wiski_potrf)
-    M = (Kt^-1 + A)^-1 = G B^-1 G = T^T T,  T = C^-1 G     (wiski_trsm + MFMA wiski_gemm)
+    M = (Kt^-1 + A)^-1 = G B^-1 G = T^T T,  T = C^-1 G     (explicit C^-1 from wiski_potrf_inverse + MFMA wiski_gemm)
     logdet(I + L^T Kt L) = logdet(B) = 2 sum log diag C     (Sylvester; BWM:27)
 M (m x m, a few MB) is then cached: every later posterior call is two gathers.
 """
@@ -27,8 +27,18 @@ class DenseInducingPosterior(_Operator):
         B = grid_ops.kron_spectral_mm(grid, eigen, AG, kscale=self.kscale, power=0.5)            # G A G
         B = 0.5 * (B + B.t())
         B.diagonal().add_(1.0)
-        self.chol = grid_ops.psd_safe_cholesky(B.contiguous())                                   # C
-        T = grid_ops.trsm_(self.chol, G.clone(), trans=False)                                    # C^-1 G
+        # C and C^-1 from one call (wiski_potrf_inverse: one launch for m <= 480, the two-level blocked form beyond), T = C^-1 G as ONE
+        # GEMM instead of a blocked triangular solve with m right-hand sides; a non-positive pivot takes the jitter escalation
+        Bc = B.contiguous()
+        C0 = Bc.clone()
+        Cinv, info = grid_ops.potrf_inverse_(C0)
+        if int(info.item()) == 0 and bool(torch.isfinite(C0.diagonal()).all()):
+            self.chol = C0                                                                       # C
+            T = grid_ops.gemm(Cinv, G)                                                           # C^-1 G
+        else:
+            self.chol = grid_ops.psd_safe_cholesky(Bc)
+            T = grid_ops.trsm_(self.chol, G.clone(), trans=False)
+        del Cinv
         self.dense = grid_ops.gemm(T, T, ta=True)                                                # M = T^T T
         self.logdet = grid_ops.chol_logdet(self.chol)
         self.last_iters, self.last_relres = 0, []

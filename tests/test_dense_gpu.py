@@ -83,11 +83,12 @@ def test_cholesky_trsm_logdet(dtype, tol, n):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-10)])
-@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 65, 100, 327, 449, 480, 481, 500, 512, 513, 700])
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 65, 100, 327, 449, 480, 481, 500, 512, 513, 700, 897, 1000, 1345, 2048])
 def test_cholesky_with_explicit_inverse(dtype, tol, n):
     """wiski_potrf_inverse: factor in place + X = L^-1.  n <= 480 is the one-launch path of cooperating workgroups (dense_coop.h: every
     panel boundary case -- partial last block, exactly full blocks, one block, no owner tiles at all for <= 2 blocks); up to 512 the factor
-    still is, with a blocked triangular solve for the inverse; beyond that the blocked factorisation."""
+    still is, with a blocked triangular solve for the inverse; beyond that the two-level blocked factorisation, whose diagonal-block inverses
+    are assembled into X by two GEMMs per block row (dense.hip: potrf_two_level)."""
     from online_gp_amd import grid_ops
 
     g = torch.Generator(device="cpu").manual_seed(1000 + n)

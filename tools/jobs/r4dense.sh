@@ -1,9 +1,9 @@
 #!/bin/bash
-# two-level blocked Cholesky (480 < n <= 2048): tests, timing against the 64-wide loop, BASELINE config 4 loop
+# two-level blocked Cholesky (+ explicit inverse) for 512 < n <= 2048: tests, timing against the 64-wide loop, BASELINE config 4 loop
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4dense; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_dense_gpu.py -x -q -m gpu 2>&1 | tail -3 | tee $O/tests.txt
+timeout 1200 python -m pytest tests/test_dense_gpu.py tests/test_harness_gpu.py tests/test_mll_gpu.py -x -q -m gpu 2>&1 | tail -3 | tee $O/tests.txt
 rm -f $O/potrf.txt
 for t in 0 1; do
   echo "== WISKI_POTRF_TWO_LEVEL=$t" >> $O/potrf.txt
