@@ -318,10 +318,16 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
                        int ldc, hipStream_t s) {
   if (M <= 0 || N <= 0) return WISKI_OK;
   {
-    // small tiles while the 64 x 64 grid would leave more than half of the 256 CUs without a tile (and there is enough K to matter)
+    // Small tiles while the 64 x 64 grid is about one tile per CU or less (and there is enough K to matter).  Round 4 (tools/gemm_mid_probe.py,
+    // profiles/r04_gemm_mid.txt): a 64 x 64 tile is ONE 4-wave workgroup, so up to ~256 tiles a CU holds one wave per SIMD and nothing hides
+    // the LDS / global latency of its K loop; the 32 x 32 kernel puts 4 workgroups on a CU for the same output.  fp64 n = 800 / 1000 / 1200 /
+    // 1400: 92 / 116 / 157 / 198 us -> 38 / 62 / 105 / 178 us (27..33 TF instead of 11..28); fp32: 65 / 84 / 101 / 117 -> 34 / 50 / 103 / 131 us.
+    // Hence below 500 (fp64) / 300 (fp32) tiles of 64 x 64; it was 128 for both.  WISKI_GEMM32_MAX_TILES overrides.
     const int64_t nb64 = (int64_t)((N + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
     static const bool small_on = [] { const char* e = getenv("WISKI_GEMM32"); return !(e && e[0] == '0'); }();
-    if (small_on && nb64 < 128 && K >= 64 && (int64_t)M * N >= 32 * 32 * 8) {
+    static const int small_max_env = [] { const char* e = getenv("WISKI_GEMM32_MAX_TILES"); return e ? atoi(e) : 0; }();
+    const int small_max = small_max_env > 0 ? small_max_env : (sizeof(real) == 8 ? 500 : 300);
+    if (small_on && nb64 < small_max && K >= 64 && (int64_t)M * N >= 32 * 32 * 8) {
       dim3 g3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
       if (!ta && !tb) hipLaunchKernelGGL((k_gemm32<real, false, false>), g3, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
       else if (ta && !tb) hipLaunchKernelGGL((k_gemm32<real, true, false>), g3, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
