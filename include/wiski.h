@@ -363,10 +363,13 @@ int wiski_precond_apply_f32(const wiski_grid* grid, const float* d_evec, const f
  *   wiski_gemm   C[M,N] = alpha op(A) op(B) + beta C   (ta/tb != 0: transposed operand), MFMA
  *   wiski_potrf  in-place lower Cholesky (upper triangle zeroed); *d_info |= 1 on a
  *                non-positive pivot (caller adds jitter and retries, like psd_safe_cholesky)
- *                n <= 480: ONE launch (one workgroup, 32-wide panels in LDS, MFMA trailing updates)
- *   wiski_potrf_inverse  the same factorisation plus the explicit inverse X = L^-1 (n x n, ldx; n <= 480: one more launch, one
- *                workgroup per 32-column block) -- what a consumer wants that solves against the factor many times (the
- *                spectral Woodbury factor: mean, variances, MLL terms are then single GEMM / GEMV launches)
+ *                n <= 512: ONE launch (cooperating workgroups: serial chain on one, one owner wave per trailing tile; 32-wide
+ *                panels in LDS, MFMA trailing updates); 512 < n: two-level blocked -- diagonal blocks of 256..448 rows through that
+ *                launch (which also inverts them), panel and trailing update as two MFMA GEMMs per block
+ *   wiski_potrf_inverse  the same factorisation plus the explicit inverse X = L^-1 (n x n, ldx; n <= 480: the same launch, one
+ *                workgroup per 32-column block trailing the factor; beyond: the diagonal blocks' inverses + two GEMMs per block
+ *                row) -- what a consumer wants that solves against the factor many times (the spectral and the dense Woodbury
+ *                factor: mean, variances, MLL terms are then single GEMM / GEMV launches)
  *   wiski_trsm   in-place solve  L X = B (trans = 0)  or  L^T X = B (trans = 1), B is n x nrhs
  *   wiski_logdiag  *d_out += sum_i log A[i,i]   (double) */
 int wiski_gemm_f32(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, float alpha, const float* d_A, int32_t lda, const float* d_B, int32_t ldb, float beta, float* d_C, int32_t ldc, void* stream);
