@@ -30,6 +30,10 @@ for dt in f32 f64; do for b in 0 1; do for k in 16 24 32 64 100; do
   WISKI_SPMM_BCAST=$b timeout 300 python tools/spmv_probe.py --k $k --reps 20 --dtype $dt 2>&1 | grep "half\|diff" >> $O/spmm_bcast_probe.txt
 done; done; done
 grep -A1 "k=64" $O/spmm_bcast_probe.txt | grep -v "^--"
+# dense regime: GEMM / Cholesky / TRSM at n = 1024 .. 4096, the two-level factorisation at the model's sizes, BASELINE config 4 loop
+timeout 300 python tools/bench_dense.py 2>&1 | grep -v amdgpu > $O/dense.txt; grep '"n": 1024' $O/dense.txt
+timeout 300 python tools/bench_small_potrf.py 600 900 1000 1500 2048 2>&1 | grep -v amdgpu >> $O/dense.txt
+timeout 600 python tools/c4_probe.py 200 2>&1 | tail -1 >> $O/dense.txt; tail -1 $O/dense.txt
 # kernel mix of 64 predictive variances on the PCG path
 cd /tmp
 rm -rf /tmp/pv; WISKI_NO_SPECTRAL=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv -o v -- python $R/tools/var_probe.py 64 > $O/var_pcg.log 2>&1
