@@ -12,8 +12,10 @@ DEV = "cuda"
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 45), (257, 301, 129), (1000, 96, 1000)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 45), (257, 301, 129), (1000, 96, 1000), (1000, 1000, 1000), (1111, 900, 257), (1500, 1500, 100)])
 def test_gemm_all_transposes(dtype, tol, ta, tb, M, N, K):
+    """Small outputs and the dense regime's mid sizes (up to 500 / 300 tiles of 64 x 64 in fp64 / fp32) run on the 32 x 32-tile kernel,
+    (1500, 1500, 100) on the 64 x 64-tile one (too many tiles for the small kernel, too little K for the 128 x 128 one)."""
     from online_gp_amd import grid_ops
 
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
