@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<real> G, const r
   const bool active = tile * RT < m;               // padding waves recompute tile 0 and discard it (they must reach the barrier)
   const int j0 = active ? tile * RT : 0;
   const int c = blockIdx.y * 64 + lane;            // this lane's column (the last slice is padded to 64 columns with zeros)
-  const real* __restrict__ vcol = Vt + (int64_t)blockIdx.y * m * KP + lane;
+  const real* __restrict__ vslice = Vt + (int64_t)blockIdx.y * m * KP;     // wave-uniform: the window loads below are SGPR base + lane + immediate
+  const real* __restrict__ vcol = vslice + lane;
   const int l4 = CPL * (lane & 15);
   real acc[RT];
 #pragma unroll
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<real> G, const r
 #pragma unroll
         for (int e = 0; e < WN; ++e) win[e] = (real)(1 + e);
       } else if (wb >= 0 && wb + WN <= m) {
-        const real* __restrict__ wp = vcol + (int64_t)wb * KP;
+        const real* __restrict__ wp = vslice + (int64_t)(wb + WN / 2) * KP;       // uniform base at the middle row: every row within the signed 13-bit immediate
 #pragma unroll
-        for (int e = 0; e < WN; ++e) win[e] = wp[e * KP];
+        for (int e = 0; e < WN; ++e) win[e] = wp[(e - WN / 2) * KP + lane];
       } else {
 #pragma unroll
         for (int e = 0; e < WN; ++e) {
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<real> G, const r
 #pragma unroll
         for (int e = 0; e < WN; ++e) src[e] = (real)(2 + e);
       } else if (ib >= 0 && ib + WN <= m) {
-        const real* __restrict__ sp = vcol + (int64_t)ib * KP;
+        const real* __restrict__ sp = vslice + (int64_t)(ib + WN / 2) * KP;
 #pragma unroll
-        for (int e = 0; e < WN; ++e) src[e] = sp[e * KP];
+        for (int e = 0; e < WN; ++e) src[e] = sp[(e - WN / 2) * KP + lane];
       } else {
 #pragma unroll
         for (int e = 0; e < WN; ++e) {
