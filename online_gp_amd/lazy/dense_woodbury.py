@@ -32,7 +32,7 @@ class DenseInducingPosterior(_Operator):
         Bc = B.contiguous()
         C0 = Bc.clone()
         Cinv, info = grid_ops.potrf_inverse_(C0)
-        if int(info.item()) == 0 and bool(torch.isfinite(C0.diagonal()).all()):
+        if bool(((info[0] == 0) & torch.isfinite(C0.diagonal()).all()).item()):                 # one host read
             self.chol = C0                                                                       # C
             T = grid_ops.gemm(Cinv, G)                                                           # C^-1 G
         else:
