@@ -1,0 +1,13 @@
+#!/bin/bash
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4denseref; mkdir -p $O; cd $R
+timeout 600 python tools/dense_refstep_probe.py 2>&1 | grep -v amdgpu | tee $O/out.txt
+cd /tmp; rm -rf /tmp/dr; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dr -o d -- python $R/tools/dense_refstep_probe.py 1 > /dev/null 2>&1
+python - <<'PY' | tee -a $O/out.txt
+import csv
+rows=list(csv.DictReader(open('/tmp/dr/d_kernel_stats.csv')))
+tot=sum(float(r['TotalDurationNs']) for r in rows); n=sum(int(r['Calls']) for r in rows)
+print('d = 1 only (100 steps): GPU kernel time total ms', tot/1e6, 'launches', n, 'per step', n/100)
+for r in sorted(rows, key=lambda r: -int(r['Calls']))[:40]:
+    print(r['Name'][:110].ljust(110), r['Calls'].rjust(6), f"{float(r['AverageNs'])/1e3:7.1f} us")
+PY
