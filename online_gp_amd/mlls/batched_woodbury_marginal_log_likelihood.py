@@ -44,6 +44,25 @@ class trace_probe_refresh_every(settings._value_context):
     _global_value = 16
 
 
+def _current_dense_posterior(model, o, A):
+    """The model's cached dense posterior factor of output o if it belongs to the CURRENT hyper-parameters and statistics, else None.
+    The model drops its prediction cache whenever data are absorbed or zero_grad() / hyperparameters_changed() is called, and stamps
+    it with the parameters' version counters (models/batched_fixed_noise_online_gp.py: prediction_cache, _hyper_version)."""
+    from ..lazy.dense_woodbury import DenseInducingPosterior
+
+    memo = getattr(model, "_memo", None)
+    if not memo or "pending_rank_update" in memo:
+        return None
+    pc = memo.get("prediction_cache")
+    if pc is None or pc.get("ver") != model._hyper_version():
+        return None
+    cov = pc.get("pred_cov")
+    cand = cov.ops[o] if hasattr(cov, "ops") else (cov if o == 0 else None)
+    if isinstance(cand, DenseInducingPosterior) and cand.wtw is A and cand.dense is not None:
+        return cand
+    return None
+
+
 class _WoodburyTerms(torch.autograd.Function):
     """(b^T M b, logdet(I + Kt A)) as a differentiable function of (tcol, kappa = 1/sigma2)."""
 
@@ -66,15 +85,19 @@ class _WoodburyTerms(torch.autograd.Function):
             logdet = st["logdet"].clone() if want_logdet else torch.zeros((), dtype=torch.float64, device=dev)
             return st["bMb"].clone(), logdet
         tcol = tcol64.detach().to(dt).contiguous()
-        kap = float(kappa.detach())
+        post = _current_dense_posterior(model, o, A) if dense else None
+        # (the reference's loop evaluates a batch and then takes its MLL step at the same hyper-parameters and data: the posterior
+        # factor evaluate() has just built -- Kronecker eigenbasis on the host, Cholesky + inverse, two m x m GEMMs -- IS this step's)
+        kap = post.kscale if post is not None else float(kappa.detach())
         # plain eigenbasis of Kt: the dense factor and the SLQ logdet need it; the streaming hyper step
         # (skip_logdet_forward, large grid) does not -- 3 host eigh + an upload saved per step
-        eig = grid_ops.kron_eigen(grid, tcol) if (dense or want_logdet) else None
+        eig = grid_ops.kron_eigen(grid, tcol) if ((dense and post is None) or (want_logdet and not dense)) else None
         if dense:
             # small grid: everything from the dense factor, exact trace (S = A - A M A by Woodbury)
             from ..lazy.dense_woodbury import DenseInducingPosterior
 
-            post = DenseInducingPosterior(grid, A, tcol, kap, eig)
+            if post is None:
+                post = DenseInducingPosterior(grid, A, tcol, kap, eig)
             U, _ = post.solve_columns(b[None])
             Z = b[None] - grid_ops.stencil_spmv(grid, A.stencil, U)              # z = Kt^-1 mu = b - A mu
             Ad = A.evaluate().contiguous()

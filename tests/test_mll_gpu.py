@@ -356,3 +356,62 @@ def test_mll_adds_registered_priors_before_dividing_by_n():
     s = float(osc); dsdraw = (s - 1e-4) * (12.0 - s) / (12.0 - 1e-4)
     want = ((2.0 - 1.0) / s - 0.15) * dsdraw / 30
     assert abs(float(g1 - g0) - want) < 1e-6
+
+
+@pytest.mark.parametrize("nout", [1, 2])
+def test_dense_mll_reuses_the_posterior_factor_evaluate_has_just_built(nout):
+    """Dense regime, the reference's step order (evaluate -> MLL step at the same hyper-parameters and data): the MLL's forward takes the
+    model's current posterior factor instead of building its own (mlls/...: _current_dense_posterior).  Value and gradients equal
+    those of a model that has no prediction cache; after zero_grad() (the reference's signal that the hyper-parameters moved), after
+    new data and after a parameter write the cached factor is NOT taken."""
+    from online_gp_amd.lazy import dense_woodbury
+    from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(4)
+    n = 60
+    X = rng.uniform(-1, 1, (n, 2)); Y = np.stack([np.sin(2 * X[:, 0]) + X[:, 1], np.cos(X[:, 0] * X[:, 1])], 1)[:, :nout] + 0.1 * rng.standard_normal((n, nout))
+    Xt, Yt = torch.as_tensor(X, device=DEV), torch.as_tensor(Y, device=DEV)
+    gb = torch.tensor([[-1.1, 1.1]] * 2, dtype=torch.float64)
+
+    def build():
+        return FixedNoiseOnlineSKIGP(Xt[:40], Yt[:40], None, grid_bounds=gb, grid_size=8, learn_additional_noise=True)
+
+    def value_and_grads(model):
+        mll = BatchedWoodburyMarginalLogLikelihood(model.likelihood, model)
+        for p in model.parameters():
+            p.grad = None
+        v = mll(None, None).sum()
+        v.backward()
+        return float(v.detach()), [p.grad.detach().clone() for p in model.parameters() if p.requires_grad and p.grad is not None]
+
+    built = []
+    orig = dense_woodbury.DenseInducingPosterior.__init__
+
+    def counting(self, *a, **k):
+        built.append(1)
+        return orig(self, *a, **k)
+
+    dense_woodbury.DenseInducingPosterior.__init__ = counting
+    try:
+        ref = build(); ref.train()
+        v0, g0 = value_and_grads(ref)                                  # no cache: builds its own factor(s)
+        assert len(built) == nout
+        m = build(); m.eval()
+        m(Xt[40:44]).variance                                          # evaluate(): the model builds and caches its factor(s)
+        nb = len(built)
+        v1, g1 = value_and_grads(m)                                    # the MLL step takes them
+        assert len(built) == nb
+        assert abs(v1 - v0) <= 1e-12 * abs(v0) and len(g0) == len(g1)
+        for a, b in zip(g0, g1):
+            assert (a - b).abs().max().item() <= 1e-10 * max(a.abs().max().item(), 1e-3)
+        m.zero_grad()                                                  # "the hyper-parameters may have moved": cache gone
+        nb = len(built); value_and_grads(m); assert len(built) == nb + nout
+        m.eval(); m(Xt[40:44]).variance
+        m.condition_on_observations(Xt[40:48], Yt[40:48], inplace=True)  # new data: the cached factor is stale (or a pending rank update)
+        nb = len(built); v2, _ = value_and_grads(m)
+        r2 = FixedNoiseOnlineSKIGP(Xt[:48], Yt[:48], None, grid_bounds=gb, grid_size=8, learn_additional_noise=True); r2.train()
+        v3, _ = value_and_grads(r2)
+        assert abs(v2 - v3) <= 1e-9 * abs(v3)
+    finally:
+        dense_woodbury.DenseInducingPosterior.__init__ = orig
