@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libwiski_hip.so")
 _SOURCES = ["interp_gather.hip", "scatter_stats.hip", "solve.hip", "spectral.hip", "dense.hip", "collective.hip", "stream_step.hip", "spectral_basis.hip", "hyper_columns.hip", "two_level.hip", "hyper_step.hip"]
-_HEADERS = ["wiski_common.h", "spmv_sym_dma.h", "spmv_sym_dma_mc.h", "spmm_sym_cols.h", "scatter_owner.h", os.path.join("..", "..", "include", "wiski.h")]
+_HEADERS = ["wiski_common.h", "spmv_sym_dma.h", "spmv_sym_dma_mc.h", "spmm_sym_cols.h", "spmm_sym_bcast.h", "scatter_owner.h", "dense_small.h", "dense_coop.h",
+            os.path.join("..", "..", "include", "wiski.h")]
 MAX_DIM = 4
 
 _lib = None
