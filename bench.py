@@ -782,7 +782,7 @@ def main():
                          "infinity_cache_resident": bool(spmv_bytes < 200e6),
                          "empty_dispatch_us": empty_us.value,
                          "net_of_empty_dispatch_frac": (spmv_bytes / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if net_us > 0 else None,
-                         "timing": "start/stop HIP events attached to each SpMV dispatch (hipExtLaunchKernel) on its launch stream, every 4th timed step; read once per block after it has drained",
+                         "timing": "start/stop HIP events attached to each SpMV dispatch (hipExtLaunchKernel) on its launch stream, every 4th timed step; read once per block after it has drained.  The event pair brackets [predecessor complete -> this kernel complete], i.e. it contains the dispatch latency in front of the first wave (an empty kernel reads 4 us by it; under rocprofv3 the same dispatches read 24.2 us by events and 18.4 us by the trace's begin / end timestamps), which is why rocprofv3_avg_launch_us is lower",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
                          "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es},
