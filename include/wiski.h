@@ -383,6 +383,14 @@ int wiski_trsm_f64(int32_t trans, int32_t n, int32_t nrhs, const double* d_L, in
 int wiski_logdiag_f32(int32_t n, const float* d_A, int32_t lda, double* d_out, void* stream);
 int wiski_logdiag_f64(int32_t n, const double* d_A, int32_t lda, double* d_out, void* stream);
 
+/* The dense regime's posterior factor in ONE call (lazy/dense_woodbury.py; BFN:343-404 with Kt^(1/2) as the root, BWM:27 for the logdet):
+ *   G = Kt^(1/2) (the Kronecker eigenbasis d_evec / d_eval of wiski_kron_spectral_mm applied to the identity),  B = I + sym(G A G),
+ *   B = C C^T with X = C^-1 (wiski_potrf_inverse),  T = X G,  M = T^T T = (Kt^-1 + A)^-1,  *d_logdiag += sum_i log C[i,i].
+ * d_A_half: the native half stencil; d_work: 4 m^2 reals; d_chol, d_M: [m, m] row-major outputs; *d_info |= 1 on a non-positive pivot (the
+ * caller escalates jitter as psd_safe_cholesky does).  m <= 4096.  All launches are queued on `stream`; nothing is read back. */
+int wiski_dense_factor_f32(const wiski_grid* grid, const float* d_A_half, const float* d_evec, const float* d_eval, float kscale, float* d_work, int64_t work_elems, float* d_chol, float* d_M, double* d_logdiag, int32_t* d_info, void* stream);
+int wiski_dense_factor_f64(const wiski_grid* grid, const double* d_A_half, const double* d_evec, const double* d_eval, double kscale, double* d_work, int64_t work_elems, double* d_chol, double* d_M, double* d_logdiag, int32_t* d_info, void* stream);
+
 /* a6 -- replaces UpdatedRootLazyTensor.collect_vector (URLT:69-119): in-place rank-q update of a root /
  * inverse-root pair.  On entry L L^T = A and R^T L = I (R = L^-T), both [m][r] row-major with leading
  * dimensions ldl / ldr; V [m][q] (ldv) holds the new columns (W^T scaled by 1/sqrt(noise), BFN:163-168).  On

@@ -977,6 +977,53 @@ static int root_update_impl(int m, int r, int q, real* d_L, int ldl, real* d_R, 
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
+// ------------------------------------------------------ dense Woodbury factor, one call ---
+// The whole build of lazy/dense_woodbury.py (the dense regime's posterior factor, BFN:343-404 with Kt^(1/2) as the root) queued from C:
+//   G = Kt^(1/2) (Kronecker eigenbasis applied to the identity),  B = I + sym(G A G),  B = C C^T and X = C^-1 (wiski_potrf_inverse),
+//   T = X G,  M = T^T T = (Kt^-1 + A)^-1,  *d_logdiag += sum log diag C.
+// Fifteen-odd launches issued back to back instead of one framework op at a time (the dense reference step is host-bound: DESIGN 7).
+// work: 4 m^2 reals (G, AG / T, B scratch, X).  d_chol [m, m] receives C, d_M [m, m] receives M.  *d_info |= 1 on a non-positive pivot
+// (the caller then takes the jitter escalation, like psd_safe_cholesky).
+template <typename real>
+__global__ __launch_bounds__(256) void k_sym_plus_identity(int n, const real* __restrict__ B, real* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  const int i = (int)(e / n), j = (int)(e % n);
+  out[e] = (real)0.5 * (B[e] + B[(int64_t)j * n + i]) + (i == j ? (real)1 : (real)0);
+}
+static inline int spectral_mm_any(const wiski_grid* g, const float* ev, const float* el, float ks, const float* V, int k, float* tmp, float* out, void* s) {
+  return wiski_kron_spectral_mm_f32(g, ev, el, ks, 0.f, 0.5f, 0.f, V, k, tmp, out, s);
+}
+static inline int spectral_mm_any(const wiski_grid* g, const double* ev, const double* el, double ks, const double* V, int k, double* tmp, double* out, void* s) {
+  return wiski_kron_spectral_mm_f64(g, ev, el, ks, 0.0, 0.5, 0.0, V, k, tmp, out, s);
+}
+static inline int spmv_sym_any(const wiski_grid* g, const float* A, const float* V, int k, float* out, void* s) { return wiski_stencil_spmv_sym_f32(g, A, V, k, nullptr, 0.f, out, s); }
+static inline int spmv_sym_any(const wiski_grid* g, const double* A, const double* V, int k, double* out, void* s) { return wiski_stencil_spmv_sym_f64(g, A, V, k, nullptr, 0.0, out, s); }
+
+template <typename real>
+static int dense_factor_impl(const wiski_grid* grid, const real* d_A_half, const real* d_evec, const real* d_eval, real kscale, real* d_work, int64_t work_elems,
+                             real* d_chol, real* d_M, double* d_logdiag, int32_t* d_info, void* stream) {
+  if (!grid || !d_A_half || !d_evec || !d_eval || !d_work || !d_chol || !d_M || !d_logdiag || !d_info) return WISKI_E_BADARG;
+  int64_t m64 = 1;
+  for (int q = 0; q < grid->d; ++q) m64 *= grid->g[q];
+  if (m64 < 1 || m64 > 4096 || work_elems < 4 * m64 * m64) return WISKI_E_BADARG;
+  const int m = (int)m64;
+  hipStream_t s = (hipStream_t)stream;
+  real *G = d_work, *T = G + m64 * m64, *Bs = T + m64 * m64, *X = Bs + m64 * m64;
+  const unsigned nb = (unsigned)((m64 * m64 + 255) / 256);
+  hipLaunchKernelGGL((k_set_identity<real>), dim3(nb), dim3(256), 0, s, m, X, m);                  // X as the identity, for now
+  int rc = spectral_mm_any(grid, d_evec, d_eval, kscale, X, m, T, G, stream);                       // G = Kt^(1/2)      (symmetric)
+  if (rc == WISKI_OK) rc = spmv_sym_any(grid, d_A_half, G, m, T, stream);                           // rows of T = columns of A G
+  if (rc == WISKI_OK) rc = spectral_mm_any(grid, d_evec, d_eval, kscale, T, m, X, Bs, stream);       // G A G
+  if (rc != WISKI_OK) return rc;
+  hipLaunchKernelGGL((k_sym_plus_identity<real>), dim3(nb), dim3(256), 0, s, m, (const real*)Bs, d_chol);
+  rc = potrf_inverse<real>(m, d_chol, m, X, m, d_info, stream);                                     // C in place, X = C^-1
+  if (rc == WISKI_OK) rc = launch_gemm<real>(0, 0, m, m, m, (real)1, X, m, G, m, (real)0, T, m, s);   // T = C^-1 G
+  if (rc == WISKI_OK) rc = launch_gemm<real>(1, 0, m, m, m, (real)1, T, m, T, m, (real)0, d_M, m, s); // M = T^T T
+  if (rc == WISKI_OK) rc = logdiag_impl<real>(m, d_chol, m, d_logdiag, stream);
+  return rc;
+}
+
 extern "C" {
 int wiski_gemm_f32(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, float alpha, const float* A, int32_t lda, const float* B, int32_t ldb, float beta, float* C, int32_t ldc, void* s) {
   if (!A || !B || !C || K < 0) return WISKI_E_BADARG;
@@ -986,6 +1033,8 @@ int wiski_gemm_f64(int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K, doub
   if (!A || !B || !C || K < 0) return WISKI_E_BADARG;
   return launch_gemm<double>(ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, (hipStream_t)s);
 }
+int wiski_dense_factor_f32(const wiski_grid* g, const float* A_half, const float* evec, const float* eval, float kscale, float* work, int64_t work_elems, float* chol, float* M, double* logdiag, int32_t* info, void* s) { return dense_factor_impl<float>(g, A_half, evec, eval, kscale, work, work_elems, chol, M, logdiag, info, s); }
+int wiski_dense_factor_f64(const wiski_grid* g, const double* A_half, const double* evec, const double* eval, double kscale, double* work, int64_t work_elems, double* chol, double* M, double* logdiag, int32_t* info, void* s) { return dense_factor_impl<double>(g, A_half, evec, eval, kscale, work, work_elems, chol, M, logdiag, info, s); }
 int wiski_potrf_f32(int32_t n, float* A, int32_t lda, int32_t* info, void* s) { return potrf_full<float>(n, A, lda, info, s); }
 int wiski_potrf_f64(int32_t n, double* A, int32_t lda, int32_t* info, void* s) { return potrf_full<double>(n, A, lda, info, s); }
 int wiski_potrf_inverse_f32(int32_t n, float* A, int32_t lda, float* X, int32_t ldx, int32_t* info, void* s) { return potrf_inverse<float>(n, A, lda, X, ldx, info, s); }

@@ -663,6 +663,24 @@ def root_update_(L, R, V):
     return L, R
 
 
+def dense_factor(grid, A_half, eigen, kscale):
+    """The dense regime's posterior factor in one C call (``wiski_dense_factor``): returns (M = (Kt^-1 + A)^-1 [m, m], C with
+    I + sym(G A G) = C C^T, logdet(I + Kt A) as a 0-dim fp64 tensor, info int32[1] -- non-zero on a non-positive pivot)."""
+    evec, evals = eigen[0], eigen[1]
+    assert len(eigen) == 2 and is_half_stencil(grid, A_half)
+    m, dt, dev = grid.m, A_half.dtype, A_half.device
+    work = torch.empty(4 * m * m, dtype=dt, device=dev)
+    chol = torch.empty((m, m), dtype=dt, device=dev)
+    M = torch.empty((m, m), dtype=dt, device=dev)
+    ld = torch.zeros(1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _hip.fn("wiski_dense_factor", dt)(grid.ref, _hip.dptr(A_half), _hip.dptr(evec.contiguous()), _hip.dptr(evals.contiguous()), _hip.creal(dt)(kscale),
+                                           _hip.dptr(work), ctypes.c_int64(work.numel()), _hip.dptr(chol), _hip.dptr(M), _hip.dptr(ld), _hip.dptr(info),
+                                           _hip.stream_ptr(dev))
+    _hip.check(rc, "wiski_dense_factor")
+    return M, chol, 2.0 * ld[0], info
+
+
 def chol_logdet(L):
     out = torch.zeros(1, dtype=torch.float64, device=L.device)
     rc = _hip.fn("wiski_logdiag", L.dtype)(ctypes.c_int32(L.shape[0]), _hip.dptr(L), ctypes.c_int32(L.shape[1]), _hip.dptr(out),

@@ -21,6 +21,20 @@ class DenseInducingPosterior(_Operator):
         m = grid.m
         self.shape = torch.Size([m, m])
         self.dtype, self.device = tcol.dtype, tcol.device
+        if wtw.stencil.is_contiguous() and grid_ops.is_half_stencil(grid, wtw.stencil) and len(eigen) == 2:
+            # the whole build queued by ONE C call (wiski_dense_factor: G = Kt^(1/2), B = I + sym(G A G), C and C^-1, T = C^-1 G, M = T^T T, logdet)
+            M, C0, logdet, info = grid_ops.dense_factor(grid, wtw.stencil, eigen, self.kscale)
+            if bool(((info[0] == 0) & torch.isfinite(C0.diagonal()).all()).item()):             # one host read
+                self.chol, self.dense, self.logdet = C0, M, logdet
+                self.last_iters, self.last_relres = 0, []
+                self.updates = 0
+                return
+        self._build_stepwise(grid, wtw, eigen, m)
+        self.last_iters, self.last_relres = 0, []
+        self.updates = 0          # rank-q updates applied since the last fresh factorisation
+
+    def _build_stepwise(self, grid, wtw, eigen, m):
+        """The same factor one library call at a time: full-stencil layouts, and the jitter escalation after a non-positive pivot."""
         eye = torch.eye(m, dtype=self.dtype, device=self.device)
         G = grid_ops.kron_spectral_mm(grid, eigen, eye, kscale=self.kscale, power=0.5)          # Kt^(1/2), symmetric [m, m]
         AG = grid_ops.stencil_spmv(grid, wtw.stencil, G)                                         # rows = columns of A G (A, G symmetric)
@@ -41,8 +55,6 @@ class DenseInducingPosterior(_Operator):
         del Cinv
         self.dense = grid_ops.gemm(T, T, ta=True)                                                # M = T^T T
         self.logdet = grid_ops.chol_logdet(self.chol)
-        self.last_iters, self.last_relres = 0, []
-        self.updates = 0          # rank-q updates applied since the last fresh factorisation
 
     def rank_update(self, wtw_new, x, wa, err):
         """Posterior for the statistics A + W(x)^T diag(wa) W(x), from this one, in O(m^2 q):
