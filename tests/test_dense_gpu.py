@@ -466,3 +466,31 @@ def test_root_update_device_and_host_eigensolve(dtype, tol, q):
     want = A + V @ V.t()
     assert ((L @ L.t()).double().cpu() - want).abs().max() < tol * want.abs().max()
     assert ((R.t() @ L).double().cpu() - torch.eye(m, dtype=torch.float64)).abs().max() < 50 * tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("d,g", [(1, 64), (2, 30), (3, 10), (2, 7)])
+def test_dense_factor_one_call_equals_the_stepwise_build(dtype, tol, d, g):
+    """wiski_dense_factor (the dense regime's posterior factor as one C-ABI call: G = Kt^(1/2), B = I + sym(G A G), C, C^-1, T = C^-1 G,
+    M = T^T T, logdet) against the same build one library call at a time (lazy/dense_woodbury.py: _build_stepwise)."""
+    from online_gp_amd.lazy.dense_woodbury import DenseInducingPosterior
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(d * 100 + g)
+    n = 150
+    X = torch.as_tensor(rng.uniform(-1, 1, (n, d)), device=DEV, dtype=dtype)
+    y = torch.as_tensor(np.sin(2 * rng.uniform(-1, 1, n)), device=DEV, dtype=dtype)[:, None]
+    gb = torch.tensor([[-1.1, 1.1]] * d, dtype=torch.float64)
+    model = FixedNoiseOnlineSKIGP(X, y, None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+    assert model._use_dense()
+    post = model._posterior_op(0)
+    assert isinstance(post, DenseInducingPosterior) and post.chol is not None
+    alt = object.__new__(DenseInducingPosterior)
+    for k in ("grid", "wtw", "tcol", "kscale", "eigen", "shape", "dtype", "device"):
+        setattr(alt, k, getattr(post, k))
+    alt._build_stepwise(post.grid, post.wtw, post.eigen, post.grid.m)
+    sc = alt.dense.abs().max().item()
+    assert (post.dense - alt.dense).abs().max().item() <= tol * sc
+    assert (post.chol - alt.chol).abs().max().item() <= tol * alt.chol.abs().max().item()
+    assert abs(float(post.logdet) - float(alt.logdet)) <= tol * max(abs(float(alt.logdet)), 1.0)
+    assert torch.equal(post.chol, torch.tril(post.chol))
