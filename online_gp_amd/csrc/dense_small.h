@@ -555,12 +555,17 @@ static CoopSync* coop_sync_for(int dev, hipStream_t s) {
   return p;
 }
 
+// A caller off the critical path (the two-level block's refresh on its side stream) asks for the ONE-workgroup factorisation: the cooperating
+// form spreads ~18 workgroups with the panel's LDS over as many CUs for ~100 us, and a kernel of the main stream that needs every wave slot
+// at once (the LDS-DMA SpMV: 248 of an XCD's 256) then pays a second dispatch round.  Set / cleared around the call by wiski_potrf_quiet().
+static int g_potrf_quiet = 0;
+extern "C" void wiski_potrf_quiet(int on) { g_potrf_quiet = on; }
 static bool coop_path_enabled() {
   static const bool on = [] {
     const char* e = getenv("WISKI_POTRF_COOP");
     return !(e && e[0] == '0');
   }();
-  return on;
+  return on && !g_potrf_quiet;
 }
 
 // Factor (and optionally invert: d_X != nullptr) a small matrix.  d_dinv: scratch [nblk][32][32].

@@ -8,6 +8,8 @@
 // Everything is queued on the caller's stream (the package uses a side stream: a stale block costs CG iterations, never accuracy).
 #include "wiski_common.h"
 
+extern "C" void wiski_potrf_quiet(int on);   // dense_small.h (dense.hip): the next factorisations take the one-workgroup path
+
 using tl_f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // G[i][j] += sum_{p in chunk} F[p][i] F[p][j] for one 32 x 32 tile (ti >= tj) and one chunk of rows (blockIdx.y).
@@ -117,7 +119,15 @@ int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t
   // N = (D^-1 + gscale G)^-1 with D = kscale lam:  C = I + (gscale D)^1/2 G (gscale D)^1/2,  N = (gscale D)^1/2 C^-1 (gscale D)^1/2 / gscale
   if (int rc = wiski_woodbury_c(r, d_G, d_lam_unit, kscale * gscale, C, lam, sq, nullptr, stream)) return rc;
   if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) return WISKI_E_LAUNCH;
-  if (int rc = wiski_potrf_inverse_f64(r, C, r, Li, r, info, stream)) return rc;
+  {
+    // the refresh has two streaming steps of slack and runs beside the solver: the one-workgroup factorisation (one CU) instead of the
+    // cooperating one (WISKI_TL_QUIET_POTRF=0: the latter)
+    static const bool quiet = [] { const char* e = getenv("WISKI_TL_QUIET_POTRF"); return !(e && e[0] == '0'); }();
+    if (quiet) wiski_potrf_quiet(1);
+    const int rcp = wiski_potrf_inverse_f64(r, C, r, Li, r, info, stream);
+    if (quiet) wiski_potrf_quiet(0);
+    if (rcp) return rcp;
+  }
   if (int rc = wiski_gemm_f64(1, 0, r, r, r, 1.0, Li, r, Li, r, 0.0, T, r, stream)) return rc;
   hipLaunchKernelGGL(k_tl_scale_cast, dim3((unsigned)((r * r + 255) / 256)), dim3(256), 0, s, (int)r, (const double*)T, (const double*)sq, 1.0 / gscale,
                      (const int32_t*)info, d_N);
