@@ -5,6 +5,25 @@
 // The reference densifies W^T (m x q) and adds a dense m x m outer product per
 // update; here each streamed point touches exactly its 4^d x 4^d stencil block.
 #include "wiski_common.h"
+
+// The half-stencil atomics of k_scatter_stats_sym.  WISKI_SCATTER_ATOMIC_MOD (timing builds, tools/jobs/r4scatmod.sh): cache-policy bits on the
+// atomic -- does any of them leave A_h better placed for the SpMV that follows?  0 = the default (what ships).  Measured (bench traces, SpMV
+// dispatches right after the absorb / absorb kernel): default 18.0-18.2 us / 66.6-67.4 us, sc1 18.1-18.4 / 67.7, nt 18.3-18.4 / 69.3, sc1 nt 18.2-18.3 / 68.7 -- no.
+#ifndef WISKI_SCATTER_ATOMIC_MOD
+#define WISKI_SCATTER_ATOMIC_MOD 0
+#endif
+__device__ __forceinline__ void stencil_atomic(float* p, float v) {
+#if WISKI_SCATTER_ATOMIC_MOD == 1
+  asm volatile("global_atomic_add_f32 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif WISKI_SCATTER_ATOMIC_MOD == 2
+  asm volatile("global_atomic_add_f32 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif WISKI_SCATTER_ATOMIC_MOD == 3
+  asm volatile("global_atomic_add_f32 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#else
+  unsafeAtomicAdd(p, v);
+#endif
+}
+__device__ __forceinline__ void stencil_atomic(double* p, double v) { unsafeAtomicAdd(p, v); }
 #include <atomic>
 #include <cstdlib>
 
@@ -312,9 +331,9 @@ __global__ __launch_bounds__(256) void k_scatter_stats_sym(GridDev<real> G, cons
           const real v = wap * s_val[loc][a] * s_val[loc][((pk >> 8) & 0xff) * 4 + b2];
           const int64_t row = s_idx[loc][a];
           if (g == 0) {
-            if (b2 >= a2 && v != (real)0) atomic_add_real(A + row * 4 + (b2 - a2), v);
+            if (b2 >= a2 && v != (real)0) stencil_atomic(A + row * 4 + (b2 - a2), v);
           } else if (v != (real)0) {
-            atomic_add_real(A + (int64_t)(7 * g - 3) * m + row * 7 + (b2 - a2 + 3), v);
+            stencil_atomic(A + (int64_t)(7 * g - 3) * m + row * 7 + (b2 - a2 + 3), v);
           }
         }
       }

@@ -1,0 +1,16 @@
+#!/bin/bash
+# cache-policy bits on the absorb's half-stencil atomics (timing builds build/libwiski_scatmodN.so: 1 sc1, 2 nt, 3 sc1 nt): does any of them leave
+# A_h better placed for the SpMVs that follow?  bench trace: SpMV by position in the solve, the absorb kernel, updates/s
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4scatmod; mkdir -p $O; rm -f $O/out.txt
+cd /tmp
+for m in 0 1 2 3 0; do
+  rm -rf /tmp/prof_b
+  if [ $m = 0 ]; then unset WISKI_HIP_SO; else export WISKI_HIP_SO=$R/build/libwiski_scatmod$m.so; fi
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python $R/bench.py --no-cpu-baseline --no-extras --blocks 8 > $O/prof.log 2>&1
+  echo "== atomic mod $m" >> $O/out.txt
+  python $R/tools/spmv_trace_split.py /tmp/prof_b/bench_kernel_trace.csv | grep "^   [012] \|^all" >> $O/out.txt
+  grep "k_scatter_stats_sym" /tmp/prof_b/bench_kernel_stats.csv | awk -F'","|",|,' '{print "scatter avg ns", $(NF-4)}' >> $O/out.txt
+  grep -o '"value": [0-9.]*' $O/prof.log | head -1 >> $O/out.txt
+done
+cat $O/out.txt
