@@ -1,6 +1,8 @@
 #!/bin/bash
 # cache-policy bits on the absorb's half-stencil atomics (timing builds build/libwiski_scatmodN.so: 1 sc1, 2 nt, 3 sc1 nt): does any of them leave
 # A_h better placed for the SpMVs that follow?  bench trace: SpMV by position in the solve, the absorb kernel, updates/s
+# build the variants first (on the build host):  for m in 1 2 3; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWISKI_SCATTER_ATOMIC_MOD=$m -c online_gp_amd/csrc/scatter_stats.hip -o build/scat_mod$m.o &&
+#   hipcc --offload-arch=gfx950 -fPIC -shared -o build/libwiski_scatmod$m.so build/scat_mod$m.o $(ls build/obj/*.o | grep -v scatter_stats) -ldl; done
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4scatmod; mkdir -p $O; rm -f $O/out.txt
 cd /tmp
