@@ -47,7 +47,8 @@
 // and workgroup b takes row block (b % 8) * ceil(nrb / 8) + b / 8: an XCD owns one contiguous eighth of the rows for all parts, fetches only
 // that eighth of v (+ the 3-plane halo of the windows) and its neighbouring row blocks share window lines in ITS L2: 18.1 -> 17.7 us back
 // to back (tools/spmv_probe.py, 200 launches), 21.3 -> 20.5 us per dispatch by bench.py's events; the delay / parts / ring-depth optima do
-// not move (delay 0..18: 17.7..18.1; 5 / 6 parts 19.1 / 19.9; ring depth 3: 26.5).  Taken while A_h is Infinity-Cache resident (<= 192 MB; solve.hip: sym_xcd_map -- a stencil that streams from HBM prefers ONE interleaved address stream); WISKI_SYM_XCD=0 / 1 forces the plain / contiguous mapping, also for the LDS-window kernel k_stencil_spmv4_sym.
+// not move (delay 0..18: 17.7..18.1; 5 / 6 parts 19.1 / 19.9; ring depth 3: 26.5); issuing the v windows before the first A_h tile instead of after
+// it changes nothing, back to back or inside the solver (17.5..17.9 either way on one box, trace means 17.9..18.25).  Taken while A_h is Infinity-Cache resident (<= 192 MB; solve.hip: sym_xcd_map -- a stencil that streams from HBM prefers ONE interleaved address stream); WISKI_SYM_XCD=0 / 1 forces the plain / contiguous mapping, also for the LDS-window kernel k_stencil_spmv4_sym.
 //
 // Requires d == 3, m % 4 == 0.  part holds (nparts + 1) * m reals: part[y] = direct term of part y (plain stores),
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
