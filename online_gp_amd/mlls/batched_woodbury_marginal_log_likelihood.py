@@ -76,7 +76,7 @@ class _WoodburyTerms(torch.autograd.Function):
         m = grid.m
         dense = model._use_dense()
         ctx.spectral = None
-        sp = None if dense else model._spectral_state(o)
+        sp = model._spectral_state(o) if model._spectral_allowed() else None
         if sp is not None:
             # smooth kernel on a large grid: both terms, exactly differentiable, from the dense factor in the dominant
             # Kronecker eigenspace (lazy/spectral_woodbury.py) -- no probe vectors, no solves
@@ -284,7 +284,7 @@ class BatchedWoodburyMarginalLogLikelihood(torch.nn.Module):
                 s2 = s2[o] if s2.numel() > 1 else s2[0]
             else:
                 s2 = torch.ones((), dtype=torch.float64, device=model._device)
-            sp = gctx["sp"][o] if gctx is not None else (None if model._use_dense() else model._spectral_state(o))
+            sp = gctx["sp"][o] if gctx is not None else (model._spectral_state(o) if model._spectral_allowed() else None)
             if sp is not None:
                 out.append(_SpectralMll.apply(tcol, s2, model, o, want_logdet, sp, n))
                 continue

@@ -55,7 +55,7 @@ class GraphedHyperStep:
         gp, opt = w.gp, w.gp_optimizer
         if self.disabled is not None or settings.graphed_hyper_step.off() or settings.spectral_factor.off():
             return None
-        if torch.device(gp._device).type != "cuda" or gp._use_dense() or w.mll.clear_caches_every_iteration:
+        if torch.device(gp._device).type != "cuda" or not gp._spectral_allowed() or w.mll.clear_caches_every_iteration:
             return None
         if not isinstance(opt, torch.optim.Adam) or not all(g.get("capturable") and g.get("fused") for g in opt.param_groups):
             return None

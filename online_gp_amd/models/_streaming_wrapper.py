@@ -58,6 +58,7 @@ class StreamingSKIWrapper(torch.nn.Module):
     def _setup(self, stem, gp, lr, init_x):
         self.stem = stem.to(init_x.device)
         self.gp = gp
+        gp.__dict__["_stream_owner"] = True          # the per-batch loop may take the spectral pipeline on small grids too (settings.spectral_dense_regime)
         self.mll = BatchedWoodburyMarginalLogLikelihood(gp.likelihood, gp)
         self._make_optimizers(lr, lr)
         self._replay = _ReplayBuffer(init_x)

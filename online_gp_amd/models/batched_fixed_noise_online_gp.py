@@ -415,6 +415,16 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
     def _use_dense(self):
         return settings.dense_small_grids.on() and self._grid.m <= settings.max_cholesky_size.value()
 
+    def _spectral_allowed(self):
+        """May a request go to the spectral factor (lazy/spectral_woodbury.py)?  Beyond the dense regime always; inside it only for
+        the reference's per-batch loop, whose owner (a streaming wrapper) has said so -- direct users of the model, BO posteriors
+        and fantasies keep the nodal dense factor with its cached M and rank-q updates."""
+        if settings.spectral_factor.off():
+            return False
+        if not self._use_dense():
+            return True
+        return settings.spectral_dense_regime.on() and bool(self.__dict__.get("_stream_owner"))
+
     def _precond(self, o, tcol):
         """(eigen tuple, shift) of wiski_pcg's preconditioner (Kt^-1 + a kron_q diag(t_q))^-1.
         t_q = per-dim marginal of the row sums of W^T D^-1 W (the data-density profile: the
@@ -522,7 +532,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         """(factor, state, fp64 Toeplitz columns on the device) of the reduced-eigenbasis Woodbury factor
         (lazy/spectral_woodbury.py) for the current hyper-parameters and statistics, or None where it does not apply:
         dense regime, switched off, or a prior whose numerical rank exceeds settings.spectral_max_rank."""
-        if settings.spectral_factor.off() or self._use_dense():
+        if not self._spectral_allowed():
             return None
         from ..lazy import spectral_woodbury as sw
 
@@ -583,7 +593,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
 
     def _spectral_in_use(self):
         """Every output has a spectral factor that follows the stream and has been asked for a state recently."""
-        if settings.spectral_factor.off() or self._use_dense():
+        if not self._spectral_allowed():
             return False
         facs = self.__dict__.get("_spectral", {})
         dirty = self.__dict__.get("_spectral_dirty", {})

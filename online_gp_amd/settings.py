@@ -282,6 +282,16 @@ class spectral_factor(_feature_flag):
     _state = True
 
 
+class spectral_dense_regime(_feature_flag):
+    """Small inducing grids (m <= max_cholesky_size: the reference's own configurations) take the reference's per-batch loop
+    -- evaluate -> Adam step on the MLL -> condition (experiments/regression.py:48-54) -- through the spectral factor's device
+    pipeline as well (at FULL rank for rough kernels: no truncation at all), where the owner of the model asks for it
+    (the streaming wrappers do: ``model._stream_owner``).  Off: every dense-regime request builds the nodal dense factor
+    (lazy/dense_woodbury.py), one framework op at a time."""
+
+    _state = True
+
+
 class spectral_tail(_value_context):
     """Fraction of trace(Kuu) the reduced eigenbasis may leave out (None: 1e-6 in fp32 -- 4e-4 of a variance at 50^3, against the fp32 parity bar of 1e-2 -- and 1e-9 in fp64).  The left-out
     prior variance of each query is added back to its predictive variance and bounds the remaining error."""

@@ -23,4 +23,8 @@ for d, g in cases:
             reg.evaluate(xb, yb)
             reg.update(xb, yb)
             torch.cuda.synchronize(); tot.append(time.perf_counter() - t0)
-        print("d = %d, grid %d^%d (m = %d), q = %d: %.3f ms per step" % (d, g, d, g ** d, qs, float(np.median(tot[8:])) * 1e3), flush=True)
+        fac = reg.gp.__dict__.get("_spectral", {}).get(0)
+        gs = reg.__dict__.get("_graphed")
+        info = "" if fac is None or fac.cur is None else " | spectral rank %d (ref %d), device refreshes %d, rebuilds %d, graph replays %s fused %s disabled %s" % (
+            fac.cur["basis"].r, fac.ref.r, fac.device_refreshes, fac.rebuilds, getattr(gs, "replays", None), getattr(gs, "fused", None), getattr(gs, "disabled", None))
+        print("d = %d, grid %d^%d (m = %d), q = %d: %.3f ms per step%s" % (d, g, d, g ** d, qs, float(np.median(tot[8:])) * 1e3, info), flush=True)
