@@ -486,7 +486,7 @@ typedef struct {
   void* scalar_dst;
 } wiski_copy_plan;
 int wiski_multi_copy_f64(const wiski_copy_plan* plan, void* stream);
-/* evaluate() of n <= 64 queries from the spectral factor in one launch (the reference loop scores every batch before absorbing it,
+/* evaluate() of n <= 64 queries from the spectral factor (r <= 1024) in one launch (the reference loop scores every batch before absorbing it,
  * /root/reference/online_gp/models/online_ski_regression.py:56-78): d_F [n, r] = W B Lam^1/2 and d_prior [n] from wiski_basis_project,
  * d_Linv = chol^-1 [r, r] (ld ldl), d_t [r] = chol^-T chol^-1 Lam^1/2 h, d_s2 [1] the observation noise, d_y [n] the targets, d_err the
  * out-of-grid flag (may be NULL).  d_out (fp64 [4]) = { rmse, mean Gaussian nll, flag, max |mean| }; d_mean / d_var (may be NULL): the

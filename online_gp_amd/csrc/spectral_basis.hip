@@ -791,7 +791,8 @@ extern "C" int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, c
 // ticket) turns the accumulators into variances and the batch metrics, writes
 //     d_out = { rmse, mean nll, out-of-grid flag (d_err), max_j |mean_j| }           (fp64: one host read)
 // (and, if asked, the means / latent variances in the data dtype), and zeroes d_ws again.  d_ws: 200 doubles, ZERO on first use.
-template <typename real>
+// (M: 64-wide chunks of a row of chol^-1 a lane holds -- 8 for r <= 512, 16 for r <= 1024: the full-rank factors of the small grids)
+template <typename real, int M>
 __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const double* __restrict__ F, const double* __restrict__ prior, const double* __restrict__ Linv,
                                                        int ldl, const double* __restrict__ t, double kscale, const real* __restrict__ s2p,
                                                        const real* __restrict__ y, const int32_t* __restrict__ err, double* ws, double* __restrict__ out,
@@ -801,11 +802,11 @@ __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const doubl
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int q0 = blockIdx.y * 8, nq = n - q0 < 8 ? n - q0 : 8;
-  double f[8][8];
+  double f[8][M];
 #pragma unroll
   for (int qq = 0; qq < 8; ++qq)
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
       f[qq][m] = (qq < nq && k < r) ? F[(int64_t)(q0 + qq) * r + k] : 0.0;
     }
@@ -815,9 +816,9 @@ __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const doubl
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const int i = blockIdx.x * 8 + w * 2 + rr;
-    double li[8];
+    double li[M];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
       li[m] = (i < r && k <= i) ? Linv[(int64_t)i * ldl + k] : 0.0;      // (chol^-1 is lower triangular)
     }
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const doubl
     for (int qq = 0; qq < 8; ++qq) {
       double d = 0.0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) d += li[m] * f[qq][m];
+      for (int m = 0; m < M; ++m) d += li[m] * f[qq][m];
       d = wave_reduce_sum<double>(d);
       acc[qq] += d * d;
     }
@@ -837,9 +838,9 @@ __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const doubl
   if (threadIdx.x < nq) unsafeAtomicAdd(ws + q0 + threadIdx.x, s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
   if (blockIdx.x == 0) {
     // means and |F_j|^2 of this workgroup's queries: wave w takes queries w and w + 4
-    double tv[8];
+    double tv[M];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
       tv[m] = k < r ? t[k] : 0.0;
     }
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(256) void k_spectral_eval(int n, int r, const doubl
       const int qq = w + 4 * u;
       double mu = 0.0, cap = 0.0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
+      for (int m = 0; m < M; ++m) {
         // (f is indexed by the compile-time unrolled u, w is wave-uniform: select instead of a dynamic register index)
         const double fv = w == 0 ? f[4 * u][m] : w == 1 ? f[4 * u + 1][m] : w == 2 ? f[4 * u + 2][m] : f[4 * u + 3][m];
         mu += fv * tv[m];
@@ -999,9 +1000,13 @@ template <typename real>
 static int spectral_evaluate_impl(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t,
                                   double kscale, const real* d_s2, const real* d_y, const int32_t* d_err, double* d_ws, double* d_out, real* d_mean,
                                   real* d_var, void* stream) {
-  if (n < 1 || n > 64 || r < 1 || r > 512 || ldl < r || !d_F || !d_prior || !d_Linv || !d_t || !d_s2 || !d_y || !d_ws || !d_out) return WISKI_E_BADARG;
-  hipLaunchKernelGGL((k_spectral_eval<real>), dim3((unsigned)((r + 7) / 8), (unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_F,
-                     d_prior, d_Linv, (int)ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var);
+  if (n < 1 || n > 64 || r < 1 || r > 1024 || ldl < r || !d_F || !d_prior || !d_Linv || !d_t || !d_s2 || !d_y || !d_ws || !d_out) return WISKI_E_BADARG;
+  if (r <= 512)
+    hipLaunchKernelGGL((k_spectral_eval<real, 8>), dim3((unsigned)((r + 7) / 8), (unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_F,
+                       d_prior, d_Linv, (int)ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var);
+  else
+    hipLaunchKernelGGL((k_spectral_eval<real, 16>), dim3((unsigned)((r + 7) / 8), (unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_F,
+                       d_prior, d_Linv, (int)ldl, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 extern "C" int wiski_spectral_evaluate_f32(int32_t n, int32_t r, const double* d_F, const double* d_prior, const double* d_Linv, int32_t ldl, const double* d_t,

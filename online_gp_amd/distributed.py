@@ -361,5 +361,5 @@ class ShardedStatsUpdater:
             m._wsum_host[o] += tot[1 + o]
         m.num_data = m.num_data + int(tot[0])
         m._dump_caches()
-        for o in list(m.__dict__.get("_spectral", {})):
-            m.__dict__.setdefault("_spectral_dirty", {})[o] = True       # the all-reduced increment bypassed the factor
+        for fac in m.__dict__.get("_spectral", {}).values():
+            fac.stale = True                                             # the all-reduced increment bypassed the factor

@@ -899,13 +899,13 @@ def spectral_var(Y, F, prior, kscale):
 
 def spectral_evaluate(F, prior, Linv, t, kscale, s2, y, err, ws, want_moments=False):
     """``wiski_spectral_evaluate``: rmse / nll / out-of-grid flag / max |mean| (fp64 [4], on the device) of a query batch from the spectral
-    factor: ONE launch for n <= 64 (and r <= 512), else the MFMA GEMM chol^-1 F^T + one launch (``wiski_spectral_evaluate_y``); with
+    factor: ONE launch for n <= 64 (and r <= 1024), else the MFMA GEMM chol^-1 F^T + one launch (``wiski_spectral_evaluate_y``); with
     `want_moments` also (mean, latent variance) in y's dtype.  ws: 200 zeroed doubles, reused."""
     n, r = F.shape
     out = torch.empty(4, dtype=torch.float64, device=F.device)
     mean = torch.empty(n, dtype=y.dtype, device=F.device) if want_moments else None
     var = torch.empty(n, dtype=y.dtype, device=F.device) if want_moments else None
-    if n <= 64 and r <= 512:
+    if n <= 64 and r <= 1024:
         rc = _hip.fn("wiski_spectral_evaluate", y.dtype)(ctypes.c_int32(n), ctypes.c_int32(r), _hip.dptr(F), _hip.dptr(prior), _hip.dptr(Linv),
                                                          ctypes.c_int32(Linv.shape[1]), _hip.dptr(t), ctypes.c_double(float(kscale)), _hip.dptr(s2), _hip.dptr(y),
                                                          _hip.dptr(err), _hip.dptr(ws), _hip.dptr(out), _hip.dptr(mean), _hip.dptr(var),

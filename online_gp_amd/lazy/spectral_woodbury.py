@@ -186,6 +186,7 @@ class SpectralWoodburyFactor:
         self.G_ref = self.h_ref = None
         self.data_version = 0
         self.cur = None
+        self.stale = False         # the statistics changed behind the factor's back (large batch, all-reduce, idle): rebuild from the stencil when next asked
         self.rebuilds = 0          # reference builds from the stencil (diagnostics / tests)
         self.idle_absorbs = 0      # batches followed since anybody last asked for a state (see the model's _spectral_absorb)
         self.last_rel_bound = 0.0
@@ -202,6 +203,18 @@ class SpectralWoodburyFactor:
         self.last_measured = None  # max |mean_factor - mean_pcg| / max |mean_pcg| on the probe set, when last measured
         self._measured_at = 0
         self.measurements = 0
+
+    def clone(self):
+        """A factor for a COPY of the statistics (functional conditioning clones the caches, BFN:276-285): own G_ref / h_ref, the
+        bases and the current state shared (they are never written in place), nothing in flight carried over."""
+        new = object.__new__(type(self))
+        new.__dict__.update(self.__dict__)
+        new.G_ref = None if self.G_ref is None else self.G_ref.clone()
+        new.h_ref = None if self.h_ref is None else self.h_ref.clone()
+        new._chk = new._mean_chk = None
+        for k in ("_bc_work", "_chk_hosts", "_chk_events", "_mean_host", "_eval_ws", "_info", "_last"):
+            new.__dict__.pop(k, None)               # (buffers kernels of the original may still be writing)
+        return new
 
     # ---------------------------------------------------------------------- mean-truncation monitor --
     def mean_monitor(self, st, query, b, tcol_dev, scale):

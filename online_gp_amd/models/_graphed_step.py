@@ -24,12 +24,29 @@ nodes instead of 40, and the graph leaves the Toeplitz columns and sigma2 of the
 them to the model's memo together with the loss: one host read).  (ii) ``prepare()``: evaluate() of a batch checks and stages the
 step of the same batch before its own host read, so update() only has to replay.
 """
+import contextlib
+import gc
+
 import torch
 
 from .. import _hip, grid_ops, settings
 from ..lazy.spectral_woodbury import SpectralBasis
 
 WARMUP_STEPS = 3
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is being captured: a collection that happens to free another model's CUDAGraph (or
+    anything else whose destructor calls into the runtime) in the middle of a capture aborts the process.  torch.cuda.graph() collects
+    once on entry; this keeps the allocation-triggered collections out until the capture has ended."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GraphedHyperStep:
@@ -291,9 +308,11 @@ class GraphedHyperStep:
         stats = gp._kernel_cache["_stats"]
         self._stage(sps)
         self._fused_keep = (plan, entries, ell, s2, scale, ell2, s2n, scale2, mid)      # (addresses recorded into the graph stay alive)
-        self.f_s2 = s2n
+        # sigma2 of the updated hyper-parameters, left on the device in the MODEL's dtype for evaluate() (fp32 parameters under an fp64
+        # model -- the default kernel under fp64 data -- : the fp64 copy the graph writes next to the loss)
+        self.f_s2 = s2n if same else (self.host_read[1:2] if gp._dtype == torch.float64 else s2n)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph), torch.no_grad():
+        with _no_gc(), torch.cuda.graph(graph), torch.no_grad():
             grid_ops.hyper_columns(plan, grid, kind, ell, scale, s2)
             # (the value leaves the log-determinant out, as the eager step does under skip_logdet_forward; its gradient is taken)
             grid_ops.hyper_mid(sst["bMb"], None, s2, stats[0, 0], stats[0, 1], self.n_dev, mid, self.host_read[0:1])
@@ -337,7 +356,9 @@ class GraphedHyperStep:
         graph = torch.cuda.CUDAGraph()
         gp._graph_ctx = {"sp": static, "n": self.n_dev}
         try:
-            with torch.cuda.graph(graph):
+            # (enable_grad: evaluate() may have been called under torch.no_grad() -- the reference driver does -- and prepare() re-captures
+            #  from there; a recording without autograd would fail and disable the graphed step for good)
+            with _no_gc(), torch.enable_grad(), torch.cuda.graph(graph):
                 with settings.skip_logdet_forward(True):
                     loss = -w.mll(None, None).sum()
                 loss.backward()

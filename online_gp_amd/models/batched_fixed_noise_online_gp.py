@@ -151,6 +151,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             self._absorb(self._kernel_cache, train_inputs, train_targets, train_noise_term, init=True)
         else:
             self._kernel_cache = kernel_cache
+            facs = kernel_cache.get("_spectral")
+            if facs:
+                # the spectral factor(s) follow the statistics they describe (bayesopt.py:86-96 re-initialises the model from the
+                # previous model's cache at every step: a factor kept on the model object would be rebuilt from the stencil each time)
+                for fac in facs.values():
+                    fac.err = self._err
+                self.__dict__["_spectral"] = facs
             if "_cnt" in kernel_cache:
                 # hand-over path (bayesopt.py:86-96): recover sum_p 1/noise_p from the row sums (rows of W sum to one)
                 self._wsum_dev = kernel_cache["_cnt"].sum(dim=1, dtype=torch.float64)
@@ -201,7 +208,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             new_ops = [StencilWtW(self._grid, cp[o], cl(op.root), cl(op.inv_root)) for o, op in enumerate(ops)]
         else:
             new_ops = [op.clone() for op in ops]
-        return self._pack_cache(cache["interpolation_cache"].clone(), stats, new_ops, cnt)
+        new = self._pack_cache(cache["interpolation_cache"].clone(), stats, new_ops, cnt)
+        facs = cache.get("_spectral")
+        if facs:
+            new["_spectral"] = {o: fac.clone() for o, fac in facs.items() if fac.ref is not None and not fac.stale}
+        return new
 
     def _stencil_pack(self, ops):
         """The [out, H, m] tensor the outputs' half stencils are views of, if they (still) are: consecutive, same shape."""
@@ -551,11 +562,13 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             return None                                  # not applicable at these hyper-parameters (remembered)
         _, tcol64 = ent
         facs = self.__dict__.setdefault("_spectral", {})
+        self._kernel_cache["_spectral"] = facs           # (travels with the statistics: kernel_cache hand-over, functional conditioning)
         fac = facs.get(o)
         if fac is None:
             fac = facs[o] = sw.SpectralWoodburyFactor(self._grid, self._dtype, self._device, self._err)
         kscale = 1.0 / self._hyper()[o][1]
-        if self.__dict__.get("_spectral_dirty", {}).pop(o, False):
+        if fac.stale:
+            fac.stale = False
             # statistics changed behind the factor's back: rebuild from the stencil (and forget the state derived from the old ones)
             fac.ref = fac.cur = None
             fac.data_version += 1
@@ -596,8 +609,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if not self._spectral_allowed():
             return False
         facs = self.__dict__.get("_spectral", {})
-        dirty = self.__dict__.get("_spectral_dirty", {})
-        return all((f := facs.get(o)) is not None and f.ref is not None and f.cur is not None and not dirty.get(o, False) and f.idle_absorbs < 8
+        return all((f := facs.get(o)) is not None and f.ref is not None and f.cur is not None and not f.stale and f.idle_absorbs < 8
                    for o in range(self.num_outputs))
 
     def _spectral_absorb(self, o, X, wa, wby, init=False, bypass=False):
@@ -609,13 +621,14 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             # rebuilt from scratch / changed by an all-reduce / a batch large enough that re-projecting the stencil on
             # demand (r SpMV columns) is cheaper than following it / nobody has asked the factor anything for 8 batches (a
             # streaming loop that only wants means must not pay a projection + GEMM per step): mark, rebuild when next asked
-            self.__dict__.setdefault("_spectral_dirty", {})[o] = True
+            fac.stale = True                             # (on the factor, not the model: it travels with the kernel cache)
             return
         fac.absorb(X, wa, wby)
 
     def _drop_spectral(self):
         self.__dict__.pop("_spectral", None)
-        self.__dict__.pop("_spectral_dirty", None)
+        if self._kernel_cache is not None:
+            self._kernel_cache.pop("_spectral", None)
         self._memo.pop("spectral", None)
 
     # --------------------------------------------------------------- caches --

@@ -44,6 +44,9 @@ class OnlineSKIBotorchModel(FixedNoiseOnlineSKIGP):
                          covar_module=covar_module, kernel_cache=kernel_cache, grid_bounds=grid_bounds, grid_size=grid_size,
                          learn_additional_noise=learn_additional_noise, **kwargs)
         self._is_custom_likelihood = True
+        # a BO loop refits the hyper-parameters at every step (bayesopt.py:187): its MLL steps take the device pipeline of the spectral
+        # factor on small grids as well (settings.spectral_dense_regime)
+        self.__dict__["_stream_owner"] = True
 
     def forward(self, X):
         if X is not None and X.dim() > 2 and X.shape[0] == 1:   # :37-42

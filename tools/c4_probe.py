@@ -38,8 +38,12 @@ def make_model(train_x, train_y, old):
 
 
 t0 = time.perf_counter()
-rows, *_ = harness.bayesopt(ackley, bounds, make_model, init_x, init_y, steps, batch_size=q, fit_iters=4, num_candidates=128)
+rows, _, _, last = harness.bayesopt(ackley, bounds, make_model, init_x, init_y, steps, batch_size=q, fit_iters=4, num_candidates=128)
 tot = time.perf_counter() - t0
 r = rows[20:]
 print(f"{steps} steps in {tot:.2f} s; per step after warm-up: fit {1e3 * np.mean([x['fit_time'] for x in r]):.2f} ms (4 Adam steps on the MLL), "
-      f"acqf {1e3 * np.mean([x['acqf_time'] for x in r]):.2f} ms (128 candidate sets of q = 3), condition {1e3 * np.mean([x['condition_time'] for x in r]):.2f} ms")
+      f"acqf {1e3 * np.mean([x['acqf_time'] for x in r]):.2f} ms (128 candidate sets of q = 3), condition {1e3 * np.mean([x['condition_time'] for x in r]):.2f} ms, "
+      f"total {1e3 * np.mean([x['total'] for x in r]):.2f} ms")
+fac = last.__dict__.get("_spectral", {}).get(0)
+if fac is not None and fac.cur is not None:
+    print(f"spectral factor: rank {fac.cur['basis'].r} (reference {fac.ref.r}), device refreshes {fac.device_refreshes}, rebuilds from the stencil {fac.rebuilds}")
