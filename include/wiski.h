@@ -236,7 +236,9 @@ typedef struct wiski_twolevel {
   const int32_t* d_off;      /* [g0 + 1]: the selected modes of slab i0 are d_off[i0] .. d_off[i0 + 1] - 1 in block order */
   const uint16_t* d_pos;     /* [r]: x << 8 | y of every selected mode, block order (sorted by i0) */
   const float* d_N;          /* [r][r] row-major, symmetric positive definite, block order */
-  uint64_t* d_cs;            /* [r] exchange words {application number << 32 | fp32 bits}, zeroed ONCE by the caller */
+  uint64_t* d_cs;            /* [r + 1]: r exchange words {application number << 32 | fp32 bits} + one sticky count of exchange words that
+                              * never arrived (their writer block was not co-resident: the application then used a stale coefficient --
+                              * drop the block); zeroed ONCE by the caller.  Refused (WISKI_E_BADARG) where 2 g0 exceeds the CU count */
 } wiski_twolevel;
 
 /* Deferred convergence poll.  wiski_pcg_async_* = wiski_pcg_* plus a host-side handle (zero-initialised by the caller,

@@ -601,6 +601,10 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
           __builtin_amdgcn_s_sleep(1);
           wv = __hip_atomic_load(tl.cs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // (a word that never arrived -- its writer block was not resident: a partitioned device, CUs held by other work -- leaves a
+        //  stale coefficient in this application: counted in the sticky word behind the exchange words; the owner of the block reads
+        //  it with the next refresh's verdict and drops the block)
+        if ((unsigned)(wv >> 32) != tl.epoch) atomicAdd(tl.cs + tl.r, 1ull);
         sC[e] = __uint_as_float((unsigned)wv);
       }
       __syncthreads();
@@ -1059,6 +1063,8 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
   if (two_level && (sizeof(real) != 4 || k != 1 || two_level->r < 1 || two_level->r > SPEC_TL_MAXR || two_level->nslab < 1 || two_level->nslab > g0 ||
                     !two_level->d_mask || !two_level->d_off || !two_level->d_pos || !two_level->d_N || !two_level->d_cs))
     return WISKI_E_BADARG;
+  // the exchange spins on words other blocks of the SAME launch write: all 2 g0 blocks (one per CU, ~100 KB of LDS each) must be resident
+  if (two_level && 2 * g0 > spec_cu_count()) return WISKI_E_BADARG;
   if constexpr (sizeof(real) == 4) {
     const int gm = g1 > g2 ? g1 : g2;
     const bool even = g1 % 2 == 0 && g2 % 2 == 0;      // 8-byte loads need 8-byte aligned rows

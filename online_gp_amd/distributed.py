@@ -256,18 +256,34 @@ class ShardedStatsUpdater:
             if dots is not None:
                 dist.all_reduce(dots, op=dist.ReduceOp.SUM, group=group)
 
-        # Transport of the per-product all-reduce.  On the nccl (= RCCL) backend the default is the C route: wiski_allreduce_stats
-        # on an ncclComm_t of our own -- vector + p.Ap slots in ONE grouped launch on the solve's stream, no re-entry into Python
-        # per CG iteration.  WISKI_SHARD_TRANSPORT=torch forces the callback above through torch.distributed's communicator
-        # (the only route on gloo: the path the two-rank single-GPU test exercises); =rccl forces the C route.
+        # Transport of the per-product all-reduce.  Default: the callback above, through torch.distributed's communicator -- the route
+        # every multi-process test exercises.  WISKI_SHARD_TRANSPORT=rccl takes the C route instead: wiski_allreduce_stats on an
+        # ncclComm_t of our own -- vector + p.Ap slots in ONE grouped launch on the solve's stream, no re-entry into Python per CG
+        # iteration.  It is opt-in until a run on >= 2 GPUs has passed the sharded tests on it (no such node was available in rounds
+        # 4-5: only its 1-rank form has run on hardware), and it checks itself once against torch's all-reduce before it is used.
         comm = None
         import os
 
-        want = os.environ.get("WISKI_SHARD_TRANSPORT", "rccl" if dist.get_backend(group) == "nccl" else "torch")
-        if want == "rccl" and not gloo_cuda and m._dtype == torch.float32:      # (the C route sums fp32 vectors)
+        want = os.environ.get("WISKI_SHARD_TRANSPORT", "torch")
+        if want == "rccl" and dist.get_backend(group) == "nccl" and not gloo_cuda and m._dtype == torch.float32:      # (the C route sums fp32 vectors)
             if getattr(self, "_shard_comm", None) is None:
-                self._shard_comm = RcclCommunicator(group)
-            comm = self._shard_comm.handle
+                sc = RcclCommunicator(group)
+                # (sums of small integers: exact in fp32 / fp64 whatever the reduction order)
+                probe = torch.arange(1, 1025, dtype=torch.float32, device=m._device) * (1 + dist.get_rank(group))
+                pb, ps = probe[:16].clone(), probe[:4].double()
+                refs = [t.clone() for t in (probe, pb, ps)]
+                for t in refs:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                try:
+                    sc.allreduce_stats_([probe], pb, None, ps)
+                    ok = all(bool(torch.equal(a, b)) for a, b in zip((probe, pb, ps), refs))
+                except Exception:
+                    ok = False
+                flag = torch.tensor([0 if ok else 1], device=m._device)
+                dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+                self._shard_comm = sc if int(flag.item()) == 0 else False
+            if self._shard_comm:
+                comm = self._shard_comm.handle
         self.shard_transport = "rccl" if comm is not None else "torch"
         return m.enter_stencil_shard(dist.get_rank(group), world, allreduce, comm=comm)
 

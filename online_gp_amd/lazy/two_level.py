@@ -77,7 +77,7 @@ class TwoLevelBlock:
         self.d_off = torch.as_tensor(off).to(device)
         self.d_mask = torch.as_tensor(mask.view(np.int64).reshape(-1)).to(device)
         self.d_pos = torch.as_tensor(pos.view(np.int16)).to(device)
-        self.d_cs = torch.zeros(max(r, 4), dtype=torch.int64, device=device)          # exchange words, zeroed once (epoch 0 is never used)
+        self.d_cs = torch.zeros(max(r, 4) + 1, dtype=torch.int64, device=device)      # exchange words, zeroed once (epoch 0 is never used); [r]: sticky time-out count
         self.N = [torch.zeros((r, r), dtype=torch.float32, device=device) for _ in range(2)]
         self.active = -1                       # index of the N buffer the solver reads, -1: none yet
         self.struct = grid_ops.TwoLevelStruct(r, self.nslab, self.d_mask.data_ptr(), self.d_off.data_ptr(), self.d_pos.data_ptr(),
@@ -109,26 +109,32 @@ class TwoLevelBlock:
     def launch_refresh(self, points, step, weight, gscale=1.0, subsample=None):
         """Queue, on the side stream: G += sum F^T diag(wa) F over `points` [(X, wa or None), ...], then N -> the spare buffer."""
         tgt = 1 - self.active if self.active >= 0 else 0
+        # (the concatenation / weights / sub-sampling run on the MAIN stream, where their sources were produced and will be recycled: a
+        #  side-stream read of a caller's temporary could see it overwritten by the main stream's allocator)
+        if len(points) == 1:
+            X, wa = points[0]
+        else:
+            X = torch.cat([p_[0] for p_ in points], dim=0)
+            wa = None if all(p_[1] is None for p_ in points) else torch.cat(
+                [p_[1] if p_[1] is not None else torch.ones(p_[0].shape[0], dtype=p_[0].dtype, device=self.device) for p_ in points])
+        sc = None if wa is None else wa.to(X.dtype).sqrt().contiguous()
+        sub = subsample if subsample else settings.two_level_subsample.value()
+        if sub > 1 and X.shape[0] >= 64 * sub:
+            # G is a sum of one rank-one term per point: every sub-th point with weight `sub` estimates it without bias, and a
+            # preconditioner needs no more (the projection + Gram product are the refresh's only O(points) work)
+            X = X[::sub]
+            sc = (sc[::sub] * (sub ** 0.5)).contiguous() if sc is not None else torch.full((X.shape[0],), float(sub) ** 0.5, dtype=X.dtype, device=self.device)
+        X = X.contiguous()
         main = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
-        ready.record(main)                       # the batches were produced on (or before) the main stream's current position
+        ready.record(main)                       # the batch and everything derived from it above
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
-            # one batch: as it is; several: one concatenation, then ONE C call queues projection + Gram product per 16384 points,
-            # wiski_woodbury_c, the one-workgroup Cholesky + inverse, N = Lam^1/2 C^-1 Lam^1/2 in fp32 (wiski_twolevel_refresh)
-            if len(points) == 1:
-                X, wa = points[0]
-            else:
-                X = torch.cat([p_[0] for p_ in points], dim=0)
-                wa = None if all(p_[1] is None for p_ in points) else torch.cat(
-                    [p_[1] if p_[1] is not None else torch.ones(p_[0].shape[0], dtype=p_[0].dtype, device=self.device) for p_ in points])
-            sc = None if wa is None else wa.to(X.dtype).sqrt().contiguous()
-            sub = subsample if subsample else settings.two_level_subsample.value()
-            if sub > 1 and X.shape[0] >= 64 * sub:
-                # G is a sum of one rank-one term per point: every sub-th point with weight `sub` estimates it without bias, and a
-                # preconditioner needs no more (the projection + Gram product are the refresh's only O(points) work)
-                X = X[::sub]
-                sc = (sc[::sub] * (sub ** 0.5)).contiguous() if sc is not None else torch.full((X.shape[0],), float(sub) ** 0.5, dtype=X.dtype, device=self.device)
+            # ONE C call queues projection + Gram product per 16384 points, wiski_woodbury_c, the one-workgroup Cholesky + inverse,
+            # N = Lam^1/2 C^-1 Lam^1/2 in fp32 (wiski_twolevel_refresh)
+            X.record_stream(self.side)
+            if sc is not None:
+                sc.record_stream(self.side)
             X = X.contiguous()
             rc = _hip.lib().wiski_twolevel_refresh_f32(self.grid.ref, _hip.dptr(X), ctypes.c_int64(X.shape[0]), _hip.dptr(sc), _hip.dptr(self.Vtab),
                                                         ctypes.c_int32(self.kw), _hip.dptr(self.S), ctypes.c_int32(self.r), _hip.dptr(self.lam_unit),
@@ -139,7 +145,8 @@ class TwoLevelBlock:
             # verdict of the refresh (a failed factorisation poisons N): lands in pinned memory before `done`, read without a sync
             if getattr(self, "_ok_host", None) is None:
                 self._ok_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._ok_host.copy_(torch.isfinite(self.N[tgt]).all().to(torch.int32).reshape(1), non_blocking=True)
+            # (... and so does an exchange word that timed out in the slab kernel since the last verdict: d_cs[r], sticky)
+            self._ok_host.copy_((torch.isfinite(self.N[tgt]).all() & (self.d_cs[self.r] == 0)).to(torch.int32).reshape(1), non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.side)
         self.in_flight = (done, step, tgt)

@@ -977,8 +977,15 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
 
     # ------------------------------------------------- two-level preconditioner --
     def _two_level_applies(self):
-        return (settings.two_level_preconditioner.on() and self.num_outputs == 1 and self._grid.d == 3 and self._dtype == torch.float32
-                and max(self._grid.g) <= 64 and not self._use_dense())
+        if not (settings.two_level_preconditioner.on() and self.num_outputs == 1 and self._grid.d == 3 and self._dtype == torch.float32
+                and max(self._grid.g) <= 64 and not self._use_dense()):
+            return False
+        # the slab kernel's coefficient exchange spins on words written by other blocks of the same launch: all 2 g0 blocks must be
+        # co-resident (one per CU) -- not on a partitioned device or a part with fewer CUs (the C side refuses as well)
+        cus = self.__dict__.get("_cu_count")
+        if cus is None:
+            cus = self.__dict__["_cu_count"] = torch.cuda.get_device_properties(self._device).multi_processor_count if self._device.type == "cuda" else 0
+        return 2 * self._grid.g[0] <= cus
 
     def _two_level_note(self, X, wa, init=False):
         """Every point the statistics absorb is either pending for, or part of, the exact block of the two-level preconditioner
