@@ -177,6 +177,48 @@ def dense_reference_timings(dev):
     return out
 
 
+def dense_regime_reference_steps(dev):
+    """The reference's per-batch loop (evaluate -> Adam step on the MLL -> condition; experiments/regression.py:48-54, OSR:113-146) on the
+    SMALL inducing grids every shipped reference configuration uses (BASELINE configs 1 / 4 / 5: 64 nodes, 10^3 Matern-5/2, 30^2 Matern-1/2),
+    fp64, q = 1 and 8: ms per step through the device pipeline (settings.spectral_dense_regime), and the same loop with the
+    pipeline off (the nodal dense factor, one framework op at a time: round 4's path) for the 64-node case."""
+    from online_gp_amd import settings
+    from online_gp_amd.kernels import MaternKernel, ScaleKernel
+    from online_gp_amd.models import Identity, OnlineSKIRegression
+
+    dt = torch.float64
+    out = {}
+
+    def leg(d, g, kind, nsteps=(40, 30)):
+        cov = None if kind == "rbf" else ScaleKernel(MaternKernel(nu={"matern12": 0.5, "matern52": 2.5}[kind], ard_num_dims=d)).to(dev)
+        X0, y0 = synth_stream(200, d, 0, dev, dt, "uniform")
+        Xr, yr = synth_stream(1024, d, 31337, dev, dt, "uniform")
+        reg = OnlineSKIRegression(Identity(d), X0, y0, 1e-3, g, 1.0, covar_module=cov)
+        res, lo = {}, 0
+        for qs, nst in zip((1, 8), nsteps):
+            ts = []
+            for _ in range(nst):
+                xb, yb = Xr[lo:lo + qs], yr[lo:lo + qs]; lo += qs
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                reg.evaluate(xb, yb)
+                reg.update(xb, yb)
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            res[f"ms_per_step_q{qs}"] = float(np.median(ts[8:])) * 1e3
+        fac = reg.gp.__dict__.get("_spectral", {}).get(0)
+        gs = reg.__dict__.get("_graphed")
+        res["path"] = ("device pipeline: spectral factor of rank %d of m = %d, %d eigenvector refreshes on the device, hyper step replayed %d times as a captured graph%s"
+                       % (fac.cur["basis"].r, g ** d, fac.device_refreshes, 0 if gs is None else gs.replays, " (recorded without autograd)" if gs is not None and gs.fused else "")
+                       if fac is not None and fac.cur is not None else "nodal dense factor, op by op")
+        return res
+
+    for d, g, kind in ((1, 64, "rbf"), (2, 30, "rbf"), (3, 10, "rbf"), (2, 30, "matern12"), (3, 10, "matern52")):
+        out[f"{g}^{d}_{kind}"] = leg(d, g, kind)
+    with settings.spectral_dense_regime(False):
+        out["64^1_rbf_pipeline_off"] = leg(1, 64, "rbf", nsteps=(20, 16))
+    out["note"] = "fp64 data, default (fp32) hyper-parameters, lr 1e-3; median over the steady steps; matern12 / matern52 have no spectral gap: full rank"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,9 +392,14 @@ def main():
             model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=False)
         R = len(block_s)
         med = float(np.median(block_s))
-        sec, dropped = block_seconds(block_s)
-        extra = {"blocks": R, "blocks_dropped": dropped, "block_ms_first_median_last_min": [block_s[0] * 1e3, med * 1e3, block_s[-1] * 1e3, min(block_s) * 1e3],
+        # the headline counts EVERY timed block (round 5; rounds 1-4 left blocks > 1.5x the median out as host hiccups and said so): what a
+        # hiccup-free mean would read is in extra, with the blocks it would have left out
+        sec = float(np.sum(block_s)) / R
+        sec_kept, dropped = block_seconds(block_s)
+        extra = {"blocks": R, "blocks_dropped": 0, "block_ms_first_median_last_min": [block_s[0] * 1e3, med * 1e3, block_s[-1] * 1e3, min(block_s) * 1e3],
                  "updates_per_s_median_block": world * K * q / med, "updates_per_s_all_blocks": world * K * q * R / float(np.sum(block_s)),
+                 "updates_per_s_without_blocks_over_1.5x_median": world * K * q / sec_kept,
+                 "blocks_over_1.5x_median_ms": [b * 1e3 for b in block_s if b > 1.5 * med],
                  "timed_region_s": float(np.sum(block_s)), "cg_iters_per_step_mean": float(np.mean(iters)),
                  "stream_points_per_pass": int(model.num_data), "note": "each pass re-starts from the init data and streams at most a 3droad-sized "
                  "stream (434 874 points) of fresh synthetic points"}
@@ -370,7 +417,7 @@ def main():
                 # all N q points and solves), the statistics all-reduce is the north-star form
                 for ex in ("stencil", "points", "stats"):
                     _, _, bs, its, _, _ = run_stream(args.stream, ex, max(3, R // 4), 0, profile=False)
-                    extra[f"updates_per_s_exchange_{ex}"] = world * K * q / block_seconds(bs)[0]
+                    extra[f"updates_per_s_exchange_{ex}"] = world * K * q / (float(np.sum(bs)) / len(bs))
                     extra[f"cg_iters_exchange_{ex}"] = float(np.mean(its))
                 # the part of the path that divides work across ranks: predictive variances shard over the query points
                 from online_gp_amd.distributed import sharded_posterior_moments
@@ -396,14 +443,14 @@ def main():
                 # second value: the road-like clustered stream of SURVEY 8d (3droad IS road-like)
                 other = "clustered" if args.stream == "uniform" else "uniform"
                 _, _, bs, its, _, _ = run_stream(other, "auto", R, 0, profile=False)          # as many blocks as the headline, same seeds
-                extra[f"{other}_stream_updates_per_s"] = K * q / block_seconds(bs)[0]
+                extra[f"{other}_stream_updates_per_s"] = K * q / (float(np.sum(bs)) / len(bs))
                 extra[f"{other}_stream_cg_iters_per_step_mean"] = float(np.mean(its))
 
                 # the reference's own CG tolerance (config/regression.yaml:24-27: cg_tolerance 1e-2; the headline uses 1e-4), and what
                 # each tolerance costs in accuracy: predictive mean after the same 24 streamed steps against a 1e-7 solve
                 with settings.cg_tolerance(1e-2):
                     _, _, bs, its, _, _ = run_stream(args.stream, "auto", max(3, R // 3), 0, profile=False)
-                extra["updates_per_s_at_reference_cg_tolerance_1e-2"] = K * q / block_seconds(bs)[0]
+                extra["updates_per_s_at_reference_cg_tolerance_1e-2"] = K * q / (float(np.sum(bs)) / len(bs))
                 extra["cg_iters_per_step_mean_at_1e-2"] = float(np.mean(its))
                 Xa, ya = synth_stream(args.n_init, d, 0, dev, dtype, args.stream)
                 Xb, yb = synth_stream(24 * q, d, 555, dev, dtype, args.stream)
@@ -693,6 +740,8 @@ def main():
                 del reg, gp
                 torch.cuda.empty_cache()
             extra["dense_regime"] = dense_reference_timings(dev)
+            gc_settle()
+            extra["dense_regime"]["reference_step"] = dense_regime_reference_steps(dev)
         except Exception as exc:  # noqa: BLE001
             extra.setdefault("errors", []).append(("extras (variance / reference step / dense legs): " + repr(exc))[:400])
 
@@ -717,11 +766,11 @@ def main():
         # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (tools/pmc_traffic.py),
         # NOT in this run -- read back from the committed profile and labelled with its source
         traffic, traffic_source = None, None
-        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if args.grid == 50 and d == 3 and kname in pmc["kernels"]:
-                    traffic, traffic_source = pmc["kernels"][kname]["hbm_bytes_per_launch"], "profiles/" + fn + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    traffic, traffic_source = pmc["kernels"][kname]["hbm_bytes_per_launch"], "profiles/" + fn + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed with the round: NOT measured in this run)"
                     break
             except Exception:  # noqa: BLE001
                 pass
@@ -731,13 +780,13 @@ def main():
         try:
             import csv
 
-            for fn in ("r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
+            for fn in ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
                 if not os.path.exists(os.path.join(ROOT, "profiles", fn)):
                     continue
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:
                     for row in csv.DictReader(fh):
                         if args.grid == 50 and d == 3 and args.dtype == "f32" and row["Name"].replace("void ", "").startswith(kname):
-                            rp_us, rp_src = float(row["AverageNs"]) / 1e3, f"profiles/{fn} (rocprofv3 --kernel-trace --stats of this command, an earlier take)"
+                            rp_us, rp_src = float(row["AverageNs"]) / 1e3, f"profiles/{fn} (rocprofv3 --kernel-trace --stats of this command, the take committed with the round: NOT measured in this run)"
                             break
                 break
         except Exception:  # noqa: BLE001
@@ -774,8 +823,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches": spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
-                         "rocprofv3_avg_launch_us": rp_us, "rocprofv3_frac": (spmv_bytes / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
-                         "rocprofv3_source": rp_src,
+                         # everything in `committed_take` (and `traffic` above) was read back from files under profiles/: a separate run of
+                         # this command under rocprofv3, committed with the round -- evidence beside this run's own events, not part of them
+                         "committed_take": {"rocprofv3_avg_launch_us": rp_us, "rocprofv3_frac": (spmv_bytes / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
+                                            "source": rp_src},
                          # how to read `frac`: the 86 MB operand is re-read every launch and is served by the 256 MB Infinity
                          # Cache, not by HBM (a bare LDS-DMA read of it runs at 7.2-8 TB/s, profiles/r02_stream_ubench.txt);
                          # and every per-dispatch time contains what an empty dispatch costs by the same clock
@@ -800,6 +851,10 @@ def main():
                                            "share_of_step": sc["avg_launch_us"] / step_us,
                                            "roofline_kernel_us_per_step": it_mean * avg_ms * 1e3, "roofline_kernel_share_of_step": it_mean * avg_ms * 1e3 / step_us,
                                            "note": "kernel-only times of this run (event brackets / per-dispatch events) over the measured ms_per_step"}
+        # SURVEY 8(d)'s batch sizes for the plain step (evaluate mean -> absorb -> refresh, fixed hyper-parameters), beside the headline's q
+        if all(k_ in extra for k_ in ("step_ms_q1", "step_ms_q64", "step_ms_q1024", "updates_per_s_q16384")):
+            extra["plain_step_updates_per_s_by_q"] = {"1": 1e3 / extra["step_ms_q1"], "64": 64e3 / extra["step_ms_q64"], "1024": 1024e3 / extra["step_ms_q1024"],
+                                                      str(q): world * K * q / sec, "16384": extra["updates_per_s_q16384"]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, tol)
