@@ -419,6 +419,7 @@ def main():
                     _, _, bs, its, _, _ = run_stream(args.stream, ex, max(3, R // 4), 0, profile=False)
                     extra[f"updates_per_s_exchange_{ex}"] = world * K * q / (float(np.sum(bs)) / len(bs))
                     extra[f"cg_iters_exchange_{ex}"] = float(np.mean(its))
+                    extra[f"cg_iters_exchange_{ex}_last_block"] = float(np.mean(its[-K:]))
                 # the part of the path that divides work across ranks: predictive variances shard over the query points
                 from online_gp_amd.distributed import sharded_posterior_moments
 

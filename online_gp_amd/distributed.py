@@ -326,6 +326,18 @@ class ShardedStatsUpdater:
             self._update_points(X, Y, noise, world)
             return
         self.last_exchange = "stats"
+        # the two-level preconditioner's block follows the stream point by point (lazy/two_level.py); an all-reduced increment carries no
+        # points, so the shards' coordinates (+ weights) are all-gathered beside it -- q (d + 1) reals per rank, against the 86 MB of the
+        # statistics -- and noted by the tracker in _absorb.  Without a process group able to gather (comm-only callers): this rank's
+        # shard weighted by the number of ranks, an unbiased estimate of the same sum.
+        m.__dict__["_stats_world"] = world
+        m.__dict__.pop("_stats_points", None)
+        applies = getattr(m, "_two_level_applies", None)
+        if self.comm is None and m.num_outputs == 1 and applies is not None and applies() and m.__dict__.get("_two_level") is not None:
+            X2 = X.reshape(-1, m._grid.d).to(m._device, m._dtype)
+            wa_loc = torch.ones((X2.shape[0], 1), dtype=m._dtype, device=m._device) if noise is None else 1.0 / noise[:, :1].to(m._device, m._dtype).clamp_min(1e-7)
+            allp, _ = self._gather_rows(torch.cat([X2, wa_loc], dim=1).contiguous(), world)
+            m.__dict__["_stats_points"] = (allp[:, :m._grid.d].contiguous(), None if noise is None else allp[:, m._grid.d].contiguous())
         delta = self._delta_cache()
         halves = m._half_buffers()
         # the carried residual R = b - Z - A U stays valid across the exchange: every rank adds its shard's innovation

@@ -509,8 +509,10 @@ def kron_eigen(grid, tcol, profiles=None, host_out=None):
 
 
 def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max_iter=1000, check_every=10, workspace=None,
-        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None, inplace=False, R=None):
+        raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None, inplace=False, R=None, two_level=None):
     """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres).
+    two_level: a TwoLevelStruct (include/wiski.h: wiski_twolevel) -- the exact block on the dominant modes inside the fused
+    preconditioner (``wiski_pcg_twolevel_f32``: one column, fp32, d = 3, eigen tables given).
     eigen = (evec, evals) from :func:`kron_eigen` selects the spectral
     preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions.
     R [k, m] (optional, contiguous): caller-owned residual buffer, left holding RHS - Z - A U;
@@ -530,12 +532,15 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
     relres = (ctypes.c_double * k)()
     cr = _hip.creal(RHS2.dtype)
     evec, evals, evec2 = (tuple(eigen) + (None,))[:3] if eigen is not None else (None, None, None)
-    rc = _hip.fn("wiski_pcg", RHS2.dtype)(grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(evec), _hip.dptr(evec2),
-                                          _hip.dptr(evals),
-                                          cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
-                                          _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
-                                          ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
-                                          ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.dptr(R), _hip.stream_ptr(RHS2.device))
+    common = (grid.ref, _hip.dptr(A_st), _hip.dptr(tcol.contiguous()), cr(kscale), _hip.dptr(evec), _hip.dptr(evec2), _hip.dptr(evals),
+              cr(shift), _hip.dptr(RHS2), ctypes.c_int32(k),
+              _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
+              ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
+              ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.dptr(R), _hip.stream_ptr(RHS2.device))
+    if two_level is not None and k == 1 and RHS2.dtype == torch.float32 and evec is not None:
+        rc = _hip.lib().wiski_pcg_twolevel_f32(*common, None, ctypes.c_int32(0), None, ctypes.byref(two_level))
+    else:
+        rc = _hip.fn("wiski_pcg", RHS2.dtype)(*common)
     if rc == -4 and not raise_on_fail:
         # gpytorch emits a NumericalWarning when CG stops at max_cg_iterations; callers also see it in `relres`
         warnings.warn(f"wiski_pcg stopped at max_iter={max_iter} with relative residual {max(relres):.3e} (tolerance {tol:.1e})",

@@ -188,12 +188,13 @@ class InducingPosterior(_Operator):
         self.last_iters = 0
         self.last_relres = []
 
-    def solve_columns(self, RHS, U=None, Z=None, warm=False, first_check=0, inplace=False, R=None):
+    def solve_columns(self, RHS, U=None, Z=None, warm=False, first_check=0, inplace=False, R=None, two_level=None):
         """RHS [k, m] -> (U, Z) with U = M RHS.  inplace: write into the given U, Z even on a cold start.
-        R [k, m] (optional): caller-owned residual buffer, left holding RHS - Z - A U; warm=2 starts from it."""
+        R [k, m] (optional): caller-owned residual buffer, left holding RHS - Z - A U; warm=2 starts from it.
+        two_level: the exact block of the two-level preconditioner for this solve (one column; lazy/two_level.py)."""
         U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, inplace=inplace, tol=self.tol,
                                      max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace, eigen=self.eigen,
-                                     shift=self.shift, first_check=first_check, err=self.err, R=R)
+                                     shift=self.shift, first_check=first_check, err=self.err, R=R, two_level=two_level)
         self.last_iters, self.last_relres, self.last_err = it, res, grid_ops.pcg.last_err
         self.last_converged = grid_ops.pcg.last_converged
         return U, Z

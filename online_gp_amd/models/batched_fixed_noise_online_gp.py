@@ -270,9 +270,20 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         # keeps R exact under the increment, and the next refresh starts without an A U product
         ms = self._mean_state
         mine = cache is self._kernel_cache
-        if mine and self.num_outputs == 1:
+        if (mine or half_delta is not None) and self.num_outputs == 1:
             if half_delta is not None:
-                self._two_level_lose()               # the increment arrives by all-reduce: other ranks' points never pass here
+                # the increment arrives by all-reduce: other ranks' points never pass here.  The updater hands the gathered coordinates over
+                # (_stats_points); failing that the block -- a PRECONDITIONER whose G is a sum of one rank-one term per point -- takes this
+                # rank's shard weighted by the number of ranks, an unbiased estimate of the whole increment
+                sw = self.__dict__.get("_stats_world")
+                pts = self.__dict__.pop("_stats_points", None)
+                if pts is not None and not init:
+                    self._two_level_note(pts[0], pts[1])            # every rank's points, gathered beside the all-reduce (distributed.py)
+                elif sw and not init:
+                    w1 = torch.full((X.shape[0],), float(sw), dtype=self._dtype, device=self._device) if unit else float(sw) / noise[:, 0].clamp_min(1e-7)
+                    self._two_level_note(X, w1)
+                else:
+                    self._two_level_lose()
             else:
                 self._two_level_note(X, None if unit else (1.0 / noise[:, 0] if init else 1.0 / noise[:, 0].clamp_min(1e-7)), init=init)
         carry = (mine and half_delta is None and not init and ms is not None and ms.get("R_ok", False)
@@ -689,6 +700,16 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
                 tcol, s2, _ = hyper[o]
                 Uo.copy_(grid_ops.kron_toeplitz_mm(self._grid, tcol, Zo, 1.0 / s2))   # keep U = Kt Z under the new hypers
                 carried = False
+            # the exact block of the two-level preconditioner, where one is being tracked (the streaming fast path takes it through
+            # wiski_stream_step; this is the generic refresh -- e.g. after a statistics all-reduce, the north-star exchange)
+            tl = None
+            tr = self.__dict__.get("_two_level") if (out == 1 and warm and self._two_level_applies()) else None
+            pst = self._memo.get("precond", {}).get(o) if tr is not None else None
+            if pst is not None and "eig_host" in pst and pst.get("eig") is post.eigen:
+                tl = tr.for_step(self._grid, self._device, pst, post.kscale, float(self._wsum[0]), self._err,
+                                 lockstep=settings.two_level_lockstep.on(), last_iters=(getattr(self, "_last_iters", None) or [0])[0])
+                if tr.switched:
+                    self._poll_hint_sticky = 2               # a new block: poll after 2 iterations, then after every one (as _two_level_step)
             # warm refreshes poll convergence first where the previous one converged (streaming steps are
             # alike), every 8th one an iteration earlier, and then after every iteration
             fc, probe = 0, False
@@ -700,7 +721,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             # from scratch every 16th refresh so that fp rounding of the recursion cannot accumulate)
             if carried and getattr(self, "_refresh_count", 0) % 16 == 0:
                 carried = False
-            post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=2 if carried else warm, first_check=fc, inplace=True, R=Ro)
+            post.solve_columns(b[o, :, 0][None], U=Uo, Z=Zo, warm=2 if carried else warm, first_check=fc, inplace=True, R=Ro, two_level=tl)
             if fc:
                 self._note_poll(post.last_iters, fc, probe)
             self._last_rel = None                    # this path does not keep the converged residual: timer-paced probes only

@@ -129,6 +129,43 @@ def test_block_follows_the_stream_and_cuts_the_iterations():
         assert np.abs(Gdev[j] - Gcol[k_]).max() < 2e-4 * np.abs(Gdev).max(), j
 
 
+def test_generic_refresh_takes_the_block_too():
+    """The three generic calls (mean -> condition_on_observations -> prediction_cache: what a statistics all-reduce leaves the
+    data-parallel step with, distributed.py) solve with the two-level block as the one-call step does: same iteration level (it was
+    6-7 against 2-3 before round 5: the generic refresh ran on the separable preconditioner alone), same posterior mean."""
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    g, q, steps = 24, 452, 40
+    n0 = 2400
+    X, y = _clustered(n0 + steps * q, 0)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    res = {}
+    for mode in ("fast", "generic", "generic_off"):
+        with settings.two_level_preconditioner(mode != "generic_off"), settings.two_level_rank(128), settings.skip_posterior_variances(True), \
+                settings.cg_tolerance(1e-4), settings.deferred_bounds_check(True), torch.no_grad():
+            m = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+            m.prediction_cache
+            its = []
+            for s in range(steps):
+                sl = slice(n0 + s * q, n0 + (s + 1) * q)
+                if mode == "fast":
+                    m.stream_step(X[sl], y[sl])
+                    m._finish_pending()
+                else:
+                    m(X[sl]).mean
+                    m.condition_on_observations(X[sl], y[sl], inplace=True)
+                    m.prediction_cache
+                its.append(m._last_iters[0])
+            mean = grid_ops.gather(m._grid, X[:256], m._mean_state["U"], m._err)[:, 0].clone()
+            res[mode] = (float(np.mean(its[8:])), mean)
+    assert res["generic"][0] <= res["fast"][0] + 0.5, res
+    assert res["generic"][0] <= res["generic_off"][0] - 0.8, res
+    sc = res["generic_off"][1].abs().max().item()
+    assert (res["generic"][1] - res["generic_off"][1]).abs().max().item() < 2e-3 * sc
+    assert (res["generic"][1] - res["fast"][1]).abs().max().item() < 2e-3 * sc
+
+
 def test_tracker_gives_up_when_points_bypass_it_and_after_a_hyper_step():
     from online_gp_amd import settings
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
