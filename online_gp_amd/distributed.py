@@ -333,11 +333,20 @@ class ShardedStatsUpdater:
         m.__dict__["_stats_world"] = world
         m.__dict__.pop("_stats_points", None)
         applies = getattr(m, "_two_level_applies", None)
-        if self.comm is None and m.num_outputs == 1 and applies is not None and applies() and m.__dict__.get("_two_level") is not None:
+        want_tl = applies is not None and applies() and m.__dict__.get("_two_level") is not None
+        in_use = getattr(m, "_spectral_in_use", None)
+        want_fac = in_use is not None and in_use() and X.reshape(-1, m._grid.d).shape[0] <= 2048
+        gathered_pts = None
+        if self.comm is None and m.num_outputs == 1 and (want_tl or want_fac):
             X2 = X.reshape(-1, m._grid.d).to(m._device, m._dtype)
-            wa_loc = torch.ones((X2.shape[0], 1), dtype=m._dtype, device=m._device) if noise is None else 1.0 / noise[:, :1].to(m._device, m._dtype).clamp_min(1e-7)
-            allp, _ = self._gather_rows(torch.cat([X2, wa_loc], dim=1).contiguous(), world)
-            m.__dict__["_stats_points"] = (allp[:, :m._grid.d].contiguous(), None if noise is None else allp[:, m._grid.d].contiguous())
+            n2 = None if noise is None else noise[:, :1].to(m._device, m._dtype)
+            wa_loc = torch.ones((X2.shape[0], 1), dtype=m._dtype, device=m._device) if n2 is None else 1.0 / n2.clamp_min(1e-7)
+            wby_loc = Y[:, :1].to(m._device, m._dtype) if n2 is None else Y[:, :1].to(m._device, m._dtype) / n2
+            allp, _ = self._gather_rows(torch.cat([X2, wa_loc, wby_loc], dim=1).contiguous(), world)
+            dd = m._grid.d
+            gathered_pts = (allp[:, :dd].contiguous(), None if noise is None else allp[:, dd].contiguous(), allp[:, dd + 1].contiguous())
+            if want_tl:
+                m.__dict__["_stats_points"] = gathered_pts[:2]
         delta = self._delta_cache()
         halves = m._half_buffers()
         # the carried residual R = b - Z - A U stays valid across the exchange: every rank adds its shard's innovation
@@ -390,4 +399,7 @@ class ShardedStatsUpdater:
         m.num_data = m.num_data + int(tot[0])
         m._dump_caches()
         for fac in m.__dict__.get("_spectral", {}).values():
-            fac.stale = True                                             # the all-reduced increment bypassed the factor
+            if gathered_pts is not None and want_fac and fac.ref is not None and not fac.stale:
+                fac.absorb(*gathered_pts)                                    # the same points, gathered beside the all-reduce: the factor stays exact
+            else:
+                fac.stale = True                                             # the all-reduced increment bypassed the factor

@@ -399,6 +399,10 @@ def _worker_c5(rank, world, port, tmpdir):
         if s % 5 == 4:
             model.posterior(Xt[:4]).mean                            # posterior requests between synchronisation points
     ok = upd.last_exchange == "stats" and model.num_data == n0 + q * steps
+    # (round 5) the spectral factor that serves the posterior requests follows the all-reduced increments through the gathered points:
+    # built from the stencil ONCE, not once per synchronisation point
+    fac = model.__dict__.get("_spectral", {}).get(0)
+    ok = ok and fac is not None and fac.rebuilds == 1
     s2 = float(model._sigma2(0))
     ell = model.covar_module.base_kernel.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1)
     osc = float(model.covar_module.base_kernel.outputscale.detach().double())
