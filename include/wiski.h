@@ -350,9 +350,11 @@ int wiski_pcg_twolevel_f32(const wiski_grid* grid, const float* d_A_st, const fl
  * and inverse of C = I + (gscale D_S)^1/2 G (gscale D_S)^1/2.  gscale = 1: the block for the statistics as they are; > 1: for a
  * stream expected to have grown by that factor while the block is in use (the block is applied some steps after it was computed
  * and until the next one arrives; for a stationary stream G grows in proportion to the absorbed weight).  n = 0 just re-derives
- * N from G.  d_work: scratch of wiski_twolevel_refresh_workspace_bytes(r) bytes. */
+ * N from G.  d_work: scratch of wiski_twolevel_refresh_workspace_bytes(r) bytes.  The verdict travels without a launch of the caller's:
+ * *d_bad (device or pinned host int32, zeroed by the caller; may be NULL) |= 1 if the factorisation failed or N has a non-finite entry
+ * (N is then poisoned with NaNs), |= 2 if *d_sticky != 0 (d_sticky: the time-out word wiski_twolevel.d_cs + r of the block, or NULL). */
 int64_t wiski_twolevel_refresh_workspace_bytes(int32_t r);
-int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_scale, const double* d_V, int32_t kw, const int32_t* d_S, int32_t r, const double* d_lam_unit, double kscale, double gscale, double* d_G, void* d_work, int64_t work_bytes, float* d_N, void* stream);
+int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_scale, const double* d_V, int32_t kw, const int32_t* d_S, int32_t r, const double* d_lam_unit, double kscale, double gscale, double* d_G, void* d_work, int64_t work_bytes, float* d_N, const uint64_t* d_sticky, int32_t* d_bad, void* stream);
 /* One application of the fused preconditioner on its own (what a CG iteration does to its residual; test and tooling entry):
  * d_y = P r, d_t = Kt^-1 P r, *d_rho (device double) += r . P r, for one m-vector d_r; d_w0 (m reals) and d_w1 (2 m reals)
  * are scratch.  two_level as above or NULL.  d = 3, every g_q <= 64, g_1 g_2 % 4 == 0. */

@@ -6,7 +6,7 @@
 // update; here each streamed point touches exactly its 4^d x 4^d stencil block.
 #include "wiski_common.h"
 
-// The half-stencil atomics of k_scatter_stats_sym.  WISKI_SCATTER_ATOMIC_MOD (timing builds, tools/jobs/r4scatmod.sh): cache-policy bits on the
+// The half-stencil atomics of k_scatter_stats_sym.  WISKI_SCATTER_ATOMIC_MOD (timing builds; the round-4 job script is in the git history): cache-policy bits on the
 // atomic -- does any of them leave A_h better placed for the SpMV that follows?  0 = the default (what ships).  Measured (bench traces, SpMV
 // dispatches right after the absorb / absorb kernel): default 18.0-18.2 us / 66.6-67.4 us, sc1 18.1-18.4 / 67.7, nt 18.3-18.4 / 69.3, sc1 nt 18.2-18.3 / 68.7 -- no.
 #ifndef WISKI_SCATTER_ATOMIC_MOD

@@ -66,14 +66,22 @@ __global__ __launch_bounds__(256) void k_gram_acc(int n, int r, int chunk, const
   }
 }
 
-// N32[i][j] = sq[i] sq[j] T[i][j] / gscale; a failed factorisation (*info != 0: G was corrupted) poisons N with NaNs so that the
-// caller's finiteness check keeps the block from ever being switched in
+// N32[i][j] = sq[i] sq[j] T[i][j] / gscale; a failed factorisation (*info != 0: G was corrupted) poisons N with NaNs so that the block can
+// never be used by accident, and the refresh's verdict goes where the caller reads it without a launch of its own: `bad` (device or pinned
+// host memory, zeroed by the caller, may be NULL) |= 1 for a failed factorisation or a non-finite entry of N, |= 2 when the slab kernel's
+// exchange has counted a word that never arrived since the block was built (*sticky != 0; wiski_twolevel.d_cs[r]).
 __global__ void k_tl_scale_cast(int r, const double* __restrict__ T, const double* __restrict__ sq, double inv_gscale, const int32_t* __restrict__ info,
-                                float* __restrict__ N) {
+                                float* __restrict__ N, const unsigned long long* __restrict__ sticky, int32_t* bad) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < r * r) {
     const int i = e / r, j = e - i * r;
-    N[e] = *info ? __builtin_nanf("") : (float)(sq[i] * sq[j] * T[e] * inv_gscale);
+    const float v = *info ? __builtin_nanf("") : (float)(sq[i] * sq[j] * T[e] * inv_gscale);
+    N[e] = v;
+    if (bad) {
+      int b = (e == 0 && *info) || !(fabsf(v) <= 3.4028234e38f) ? 1 : 0;
+      if (e == 0 && sticky && *sticky != 0ull) b |= 2;
+      if (b) __hip_atomic_fetch_or(bad, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -89,6 +97,7 @@ int64_t wiski_twolevel_refresh_workspace_bytes(int32_t r) {
 
 int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t n, const float* d_scale, const double* d_V, int32_t kw, const int32_t* d_S,
                                int32_t r, const double* d_lam_unit, double kscale, double gscale, double* d_G, void* d_work, int64_t work_bytes, float* d_N,
+                               const uint64_t* d_sticky, int32_t* d_bad,
                                void* stream) {
   if (!(gscale > 0)) return WISKI_E_BADARG;
   if (!grid || n < 0 || (n > 0 && !d_x) || !d_V || !d_S || r < 1 || r > 512 || !d_lam_unit || !d_G || !d_work || !d_N) return WISKI_E_BADARG;
@@ -130,7 +139,7 @@ int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t
   }
   if (int rc = wiski_gemm_f64(1, 0, r, r, r, 1.0, Li, r, Li, r, 0.0, T, r, stream)) return rc;
   hipLaunchKernelGGL(k_tl_scale_cast, dim3((unsigned)((r * r + 255) / 256)), dim3(256), 0, s, (int)r, (const double*)T, (const double*)sq, 1.0 / gscale,
-                     (const int32_t*)info, d_N);
+                     (const int32_t*)info, d_N, (const unsigned long long*)d_sticky, d_bad);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 }

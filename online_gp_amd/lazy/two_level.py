@@ -136,17 +136,19 @@ class TwoLevelBlock:
             if sc is not None:
                 sc.record_stream(self.side)
             X = X.contiguous()
+            # verdict of the refresh (a failed factorisation poisons N; an exchange word that timed out in the slab kernel since the block was
+            # built: d_cs[r], sticky): written by the refresh's last kernel straight into pinned memory, read at tick() without a sync
+            if getattr(self, "_bad_host", None) is None:
+                self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._bad_host[0] = 0                    # (the previous verdict was consumed when its refresh was switched in: nothing is in flight)
             rc = _hip.lib().wiski_twolevel_refresh_f32(self.grid.ref, _hip.dptr(X), ctypes.c_int64(X.shape[0]), _hip.dptr(sc), _hip.dptr(self.Vtab),
                                                         ctypes.c_int32(self.kw), _hip.dptr(self.S), ctypes.c_int32(self.r), _hip.dptr(self.lam_unit),
                                                         ctypes.c_double(self.kscale), ctypes.c_double(gscale), _hip.dptr(self.G), _hip.dptr(self.work),
-                                                        ctypes.c_int64(self.work.numel()), _hip.dptr(self.N[tgt]), _hip.stream_ptr(self.device))
+                                                        ctypes.c_int64(self.work.numel()), _hip.dptr(self.N[tgt]),
+                                                        ctypes.c_void_p(self.d_cs.data_ptr() + 8 * self.r), ctypes.c_void_p(self._bad_host.data_ptr()),
+                                                        _hip.stream_ptr(self.device))
             _hip.check(rc, "wiski_twolevel_refresh")
             self._keep = (X, sc)                     # alive until the side stream has read them (replaced by the next refresh)
-            # verdict of the refresh (a failed factorisation poisons N): lands in pinned memory before `done`, read without a sync
-            if getattr(self, "_ok_host", None) is None:
-                self._ok_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            # (... and so does an exchange word that timed out in the slab kernel since the last verdict: d_cs[r], sticky)
-            self._ok_host.copy_((torch.isfinite(self.N[tgt]).all() & (self.d_cs[self.r] == 0)).to(torch.int32).reshape(1), non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.side)
         self.in_flight = (done, step, tgt)
@@ -170,7 +172,7 @@ class TwoLevelBlock:
                 return False
             done.synchronize()
         self.in_flight = None
-        if not int(self._ok_host[0]):
+        if int(self._bad_host[0]):
             self.failed = True                  # G is corrupt (non-finite points reached it): the tracker drops the block
             return False
         self.active = tgt

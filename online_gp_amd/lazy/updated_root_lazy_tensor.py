@@ -51,12 +51,20 @@ class UpdatedRootLazyTensor(_Operator):
 
     # -- roots: Cholesky branch of gpytorch's root_decomposition (m <= max_cholesky_size), URLT:121-133
     def _ensure_roots(self):
+        triangular = False
         if self.root is None:
             L = grid_ops.psd_safe_cholesky(self.tensor, jitter=settings.cholesky_jitter.value())
             self.root = L
+            triangular = True
         if self.inv_root is None:
-            eye = torch.eye(self.shape[-1], dtype=self.dtype, device=self.device)
-            Linv = grid_ops.trsm_(self.root, eye, trans=False) if bool((self.root == torch.tril(self.root)).all()) else torch.linalg.inv(self.root)
+            # (a root this object has just factorised is triangular: one blocked substitution; a root handed in by the caller -- any square
+            #  root, e.g. one carried through rank-q updates -- takes the general inverse.  No look at the entries: the comparison
+            #  `root == tril(root)` this replaced was a host synchronisation per call)
+            if triangular:
+                eye = torch.eye(self.shape[-1], dtype=self.dtype, device=self.device)
+                Linv = grid_ops.trsm_(self.root, eye, trans=False)
+            else:
+                Linv = torch.linalg.inv_ex(self.root).inverse
             self.inv_root = Linv.t().contiguous()                                        # R = L^-T
 
     def root_decomposition(self, **kwargs):
