@@ -53,6 +53,9 @@ typedef struct wiski_grid {
 } wiski_grid;
 
 int wiski_version(void);
+/* A hipStream_t for work off the critical path (lazy/two_level.py: the refresh of the two-level block), at the device's lowest priority
+ * when asked: beside a kernel of the caller's stream that fills every wave slot the dispatcher then serves the caller first. */
+int wiski_side_stream_create(int32_t lowest_priority, void** out);
 
 /* a1 -- replaces covar_module(X).evaluate_kernel() (BFN:143,205,261,421):
  * cubic (Keys a=-0.5) interpolation indices/values, T=4^d taps per point,

@@ -425,6 +425,18 @@ static int wt_columns_impl(const wiski_grid* grid, const real* d_x, int64_t n, r
 
 extern "C" {
 int wiski_version(void) { return WISKI_VERSION; }
+// A stream for work off the critical path (the refresh of the two-level block): created at the device's LOWEST priority, so that where it
+// shares the device with a kernel of the caller's stream that wants every wave slot at once (the LDS-DMA SpMV) the dispatcher serves the
+// caller's queue first.  *out: a hipStream_t the caller owns (never destroyed by the library).
+int wiski_side_stream_create(int32_t lowest_priority, void** out) {
+  if (!out) return WISKI_E_BADARG;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lowest_priority ? least : 0) != hipSuccess) { (void)hipGetLastError(); return WISKI_E_LAUNCH; }
+  *out = (void*)s;
+  return WISKI_OK;
+}
 int wiski_interp_f32(const wiski_grid* g, const float* x, int64_t n, int32_t* idx, float* val, int32_t* err, void* s) { return interp_impl<float>(g, x, n, idx, val, err, s); }
 int wiski_interp_f64(const wiski_grid* g, const double* x, int64_t n, int32_t* idx, double* val, int32_t* err, void* s) { return interp_impl<double>(g, x, n, idx, val, err, s); }
 int wiski_gather_zero_f32(const wiski_grid* g, const float* x, int64_t n, const float* V, int32_t k, float* out, int32_t* err, void* z1, int64_t n1, void* z2, int64_t n2, int32_t* zeroed, void* s) { return gather_zero_impl<float>(g, x, n, V, k, out, err, z1, n1, z2, n2, zeroed, s); }

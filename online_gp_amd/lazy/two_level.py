@@ -98,7 +98,17 @@ class TwoLevelBlock:
             _WORK[wkey] = torch.empty(nb, dtype=torch.uint8, device=device)
         self.work = _WORK[wkey]
         if str(device) not in _SIDE:
-            _SIDE[str(device)] = torch.cuda.Stream(device=device)
+            # lowest device priority (torch's own range stops at "normal"): the refresh kernels then yield wave slots to the SpMV of the
+            # main stream where they meet (WISKI_TL_SIDE_PRIORITY=normal: a plain torch stream, as before round 5)
+            import os
+
+            side = None
+            if os.environ.get("WISKI_TL_SIDE_PRIORITY", "low") == "low":
+                h = ctypes.c_void_p()
+                with torch.cuda.device(device):
+                    if _hip.lib().wiski_side_stream_create(ctypes.c_int32(1), ctypes.byref(h)) == 0 and h.value:
+                        side = torch.cuda.ExternalStream(h.value, device=device)
+            _SIDE[str(device)] = side if side is not None else torch.cuda.Stream(device=device)
         self.side = _SIDE[str(device)]
         self.in_flight = None                  # (event, step it was launched at, buffer index)
         self.failed = False
