@@ -401,8 +401,8 @@ class SpectralWoodburyFactor:
         basis = cur["basis"]
         if key[1:] != cur["key"][1:] or not basis.device_refreshable() or not settings.spectral_device_refresh.on():
             return False
-        if self._dev_refreshes >= RESELECT_EVERY:      # re-select the index set now and then (it only ever grows stale)
-            return False
+        if self._dev_refreshes >= RESELECT_EVERY and basis.r < self.grid.m:      # re-select the index set now and then (it only ever grows stale;
+            return False                                                         #  a FULL basis -- small grids, no spectral gap -- has nothing to select)
         return True
 
     def _verdict(self):
