@@ -678,7 +678,6 @@ static int potrf_two_level(int n, real* d_A, int lda, int32_t* d_info, hipStream
   if (hipMallocAsync((void**)&scr, (nX + nP + nD + nS) * sizeof(real), s) != hipSuccess) return WISKI_E_LAUNCH;
   real *Xs = scr, *P = scr + nX, *dinv = P + nP, *S = dinv + nD;
   int rc = WISKI_OK;
-  bool zeroed = false;
   for (int j = 0; j < n && rc == WISKI_OK; j += BB) {
     const int bb = n - j < BB ? n - j : BB;
     real* Ajj = d_A + (int64_t)j * lda + j;
@@ -686,16 +685,6 @@ static int potrf_two_level(int n, real* d_A, int lda, int32_t* d_info, hipStream
     const int ldxx = d_X ? ldx : BB;
     rc = potrf_small<real>(bb, Ajj, lda, dinv, X, ldxx, d_info, s);       // L_jj in place, X = L_jj^-1 (dense, zeros above the diagonal)
     if (rc) break;                                                       // (WISKI_SMALL_UNAVAILABLE can only come from the first block)
-    if (d_X && !zeroed) {                                                // everything of X outside the diagonal blocks (block 0 is already written)
-      for (int I = 0; I < n && rc == WISKI_OK; I += BB) {
-        const int bi = n - I < BB ? n - I : BB;
-        if (I > 0 && hipMemset2DAsync(d_X + (int64_t)I * ldx, (size_t)ldx * sizeof(real), 0, (size_t)I * sizeof(real), (size_t)bi, s) != hipSuccess) rc = WISKI_E_LAUNCH;
-        if (I + bi < n && hipMemset2DAsync(d_X + (int64_t)I * ldx + I + bi, (size_t)ldx * sizeof(real), 0, (size_t)(n - I - bi) * sizeof(real), (size_t)bi, s) != hipSuccess)
-          rc = WISKI_E_LAUNCH;
-      }
-      zeroed = true;
-      if (rc) break;
-    }
     const int rows = n - j - bb;
     if (rows > 0) {
       real* A21 = d_A + (int64_t)(j + bb) * lda + j;
@@ -706,6 +695,13 @@ static int potrf_two_level(int n, real* d_A, int lda, int32_t* d_info, hipStream
                                              hipMemcpyDeviceToDevice, s) != hipSuccess)
         rc = WISKI_E_LAUNCH;
     }
+  }
+  if (d_X && rc == WISKI_OK) {
+    // X above the diagonal blocks: zero, in ONE launch (the products below read X[0:i0, 0:i0] as a full matrix; the blocks below the
+    // diagonal are written by them; four 2-D fills per call before round 5)
+    const int64_t tot = (int64_t)n * n;
+    hipLaunchKernelGGL((k_zero_upper<real>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, d_X, ldx);
+    if (hipGetLastError() != hipSuccess) rc = WISKI_E_LAUNCH;
   }
   if (d_X && rc == WISKI_OK)
     for (int i0 = BB; i0 < n && rc == WISKI_OK; i0 += BB) {
