@@ -315,6 +315,20 @@ class SpectralWoodburyFactor:
     def build_reference(self, basis, stencil, b):
         """G_ref = B^T A B, h_ref = B^T b from the model's statistics (r SpMV columns in chunks of 64)."""
         r = basis.r
+        if self.grid.m <= settings.max_cholesky_size.value():
+            # small grid (the dense regime, where this build recurs: fit() rebuilds the statistics every epoch): all r basis functions as
+            # ONE many-column stencil product and one MFMA GEMM instead of r / 64 chunks of product + d mode products + gather each
+            Bc = self._basis_columns(basis, 0, r)                                  # [r, m], model dtype
+            AB = grid_ops.stencil_spmv(self.grid, stencil, Bc)                     # rows = A b_j
+            Bd = Bc.double().contiguous()
+            G = grid_ops.gemm(AB.double().contiguous(), Bd, tb=True)               # (A B)^T B
+            self.G_ref = (0.5 * (G + G.t())).contiguous()
+            self.h_ref = torch.mv(Bd, b.reshape(-1).double()).contiguous()
+            self.ref = basis
+            self.cur = None
+            self.data_version += 1
+            self.rebuilds += 1
+            return
         G = torch.empty((r, r), dtype=torch.float64, device=self.device)
         for lo in range(0, r, 64):
             hi = min(lo + 64, r)
