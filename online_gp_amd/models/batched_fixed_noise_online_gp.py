@@ -849,7 +849,18 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         pcg_current = self._memo.get("prediction_cache") is not None or (ms is not None and ms.get("ver") == self._hyper_version())
         hypers_moved = not pcg_current and ms is not None          # (means only, no PCG state at all: a cold solve, then warm ones)
         factor_mean = False
-        if settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use()):
+        try_spectral = settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use())
+        if try_spectral and self._use_dense():
+            # small grid: the cached nodal factor (M: two gathers per request, rank-q updates after conditioning at fixed hyper-parameters --
+            # acquisition loops, fantasies) answers whenever it is current or one rank-q update away; the spectral factor serves the requests
+            # that follow a hyper-parameter step (its refresh stays on the device), and only where somebody -- an MLL step, evaluate() --
+            # has already built it
+            pend = self._memo.get("pending_rank_update")
+            dense_current = self._memo.get("prediction_cache") is not None or (pend is not None and pend[3] == self._hyper_version())
+            facs = self.__dict__.get("_spectral", {})
+            have_factor = all((f := facs.get(o)) is not None and f.ref is not None and not f.stale for o in range(out))
+            try_spectral = have_factor and not dense_current
+        if try_spectral:
             sps = [self._spectral_state(o) for o in range(out)]
             if all(sp is not None for sp in sps):
                 if not pcg_current:

@@ -391,22 +391,32 @@ def _worker_c5(rank, world, port, tmpdir):
     cov = GridInterpolationKernel(ScaleKernel(MaternKernel(nu=0.5, ard_num_dims=2)), grid_size=30, num_dims=2, grid_bounds=gb)
     model = OnlineSKIBotorchModel(Xt[:n0], yt[:n0], nt[:n0], covar_module=cov, learn_additional_noise=True)
     model.eval()
+    from online_gp_amd.mlls import BatchedWoodburyMarginalLogLikelihood
+
+    mll = BatchedWoodburyMarginalLogLikelihood(model.likelihood, model)
+    with torch.no_grad():
+        mll(None, None)                                             # (a BO / AL loop scores the MLL: this builds the spectral factor)
     upd = ShardedStatsUpdater(model, exchange="stats")
     for s in range(steps):
         lo = n0 + s * q
         mine = slice(lo + rank, lo + q, world)                      # round-robin shard of the batch (3 points per rank)
         upd.update(Xt[mine], yt[mine], nt[mine])
         if s % 5 == 4:
-            model.posterior(Xt[:4]).mean                            # posterior requests between synchronisation points
+            model.posterior(Xt[:4]).mean                            # posterior and MLL requests between synchronisation points
+            with torch.no_grad():
+                mll(None, None)
     ok = upd.last_exchange == "stats" and model.num_data == n0 + q * steps
-    # (round 5) the spectral factor that serves the posterior requests follows the all-reduced increments through the gathered points:
-    # built from the stencil ONCE, not once per synchronisation point
+    # (round 5) the spectral factor follows the all-reduced increments through the points gathered beside the all-reduce: built from the
+    # stencil ONCE, not once per synchronisation point -- and stays exact (MLL against the data-space oracle below)
     fac = model.__dict__.get("_spectral", {}).get(0)
     ok = ok and fac is not None and fac.rebuilds == 1
+    with torch.no_grad():
+        mll_val = float(mll(None, None))
     s2 = float(model._sigma2(0))
     ell = model.covar_module.base_kernel.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1)
     osc = float(model.covar_module.base_kernel.outputscale.detach().double())
     O = dataspace.DataSpaceGP(gb.numpy(), 30, "matern12", ell, osc, s2).fit(X, y, nz)
+    ok = ok and abs(mll_val - O.mll()) < 1e-6 * abs(O.mll())
     Xq = rng.uniform(0, 1, (12, 2))                                  # same draw on both ranks
     mo, vo = O.predict(Xq)
     post = model.posterior(torch.as_tensor(Xq, device=dev))
