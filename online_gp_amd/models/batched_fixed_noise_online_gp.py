@@ -850,6 +850,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         hypers_moved = not pcg_current and ms is not None          # (means only, no PCG state at all: a cold solve, then warm ones)
         factor_mean = False
         try_spectral = settings.skip_posterior_variances.off() or (hypers_moved and self._spectral_in_use())
+        if not try_spectral and self._use_dense() and self._spectral_in_use():
+            try_spectral = True                      # small grid, means only (the classifier's predict): a factor in use serves them too
         if try_spectral and self._use_dense():
             # small grid: the cached nodal factor (M: two gathers per request, rank-q updates after conditioning at fixed hyper-parameters --
             # acquisition loops, fantasies) answers whenever it is current or one rank-q update away; the spectral factor serves the requests

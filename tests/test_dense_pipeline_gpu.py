@@ -110,3 +110,38 @@ def test_small_grid_loop_losses_and_hyper_parameters_equal_the_nodal_dense_path(
     assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
     assert np.abs(ha[0] - hb[0]).max() <= 1e-7 and abs(ha[1] - hb[1]) <= 1e-7 and abs(ha[2] - hb[2]) <= 1e-7
     assert np.abs(ma - mb).max() <= 1e-6 * np.abs(mb).max() and np.abs(va / vb - 1).max() <= 1e-6
+
+
+def test_two_output_classifier_loop_on_a_small_grid_matches_the_oracle_per_output():
+    """The Dirichlet classifier's predict -> update loop (online_ski_classifier.py:71-88; two outputs, per-point fixed noise, hyper-parameter
+    step per batch) on a 16^2 grid in fp64: after 25 batches the two regression outputs behind the arg-max equal the data-space oracle on
+    the Dirichlet-transformed problem at each output's own drifted hyper-parameters, and the means-only predict() was answered by the
+    spectral factors (no nodal factor rebuilt per call)."""
+    from oracle import dataspace
+    from online_gp_amd.models import Identity, OnlineSKIClassifier
+    from online_gp_amd.models.online_ski_classifier import dirichlet_transform
+
+    rng = np.random.default_rng(2)
+    n0, q, steps = 120, 8, 25
+    X = rng.uniform(-0.9, 0.9, (n0 + q * steps + 32, 2))
+    lab = (np.sin(3 * X[:, 0]) + X[:, 1] > 0).astype(np.int64)
+    Xt, lt = torch.as_tensor(X, device=DEV, dtype=torch.float64), torch.as_tensor(lab, device=DEV)
+    clf = OnlineSKIClassifier(Identity(2), Xt[:n0], lt[:n0], 0.01, 1e-2, 16, 1.0)
+    for i in range(steps):
+        sl = slice(n0 + i * q, n0 + (i + 1) * q)
+        clf.predict(Xt[sl])
+        clf.update(Xt[sl], lt[sl])
+    n = n0 + q * steps
+    facs = clf.gp.__dict__.get("_spectral", {})
+    assert len(facs) == 2 and all(f.cur is not None and f.device_refreshes >= steps - 6 for f in facs.values())
+    assert clf.gp._memo.get("prediction_cache") is None          # predict() did not fall back to the nodal factor
+    ty, _, s2i = dirichlet_transform(lt[:n], 0.01)
+    k = clf.gp.covar_module.base_kernel
+    means = clf.gp(Xt[n:n + 32]).mean.double().cpu().numpy()      # [2, 32]
+    ls = k.base_kernel.lengthscale.detach().double()
+    for o in range(2):
+        ell = (ls[o] if ls.dim() > 2 else ls).cpu().numpy().reshape(-1)
+        osc = float(k.outputscale.detach().double().reshape(-1)[o if k.outputscale.numel() > 1 else 0])
+        O = dataspace.DataSpaceGP([[-1.0, 1.0]] * 2, 16, "rbf", ell, osc, 1.0).fit(X[:n], ty[:, o].double().cpu().numpy(), s2i[:, o].double().cpu().numpy())
+        mo, _ = O.predict(X[n:n + 32])
+        assert np.abs(means[o] - mo).max() <= 1e-4 * np.abs(mo).max(), (o, np.abs(means[o] - mo).max() / np.abs(mo).max())
