@@ -126,26 +126,31 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, real alpha, c
 // a stride of 144 reals (= 16 mod 32 banks): the 16-lane groups of an operand read fall on disjoint banks.
 // Global loads are 16-byte vectors where a tile is interior and the leading dimension allows it, scalar and predicated at the
 // edges.  Used from 128 x 128 outputs with >= 2 * (number of CUs) ... see launch_gemm.
-constexpr int G2M = 128, G2N = 128, G2LD = 144;
+constexpr int G2M = 128, G2N = 128;
+// (round 5) the same kernel on a 64 x 64 tile (TM = 64, 8 waves of 32 x 16): for outputs of ~150..500 such tiles -- the r x r products of the
+// spectral factor at rank 700..1000, the trailing updates of the two-level Cholesky -- where the 128-tile grid leaves most CUs idle and the
+// un-pipelined 64 x 64 / 32 x 32 kernels wait for every K tile; LDS row stride TM + 16 (= 16 mod 32 banks for both tile sizes)
 template <typename real> struct G2K { static constexpr int value = sizeof(real) == 4 ? 32 : 16; };
 
-template <typename real, bool TA, bool TB, int NW>
+template <typename real, bool TA, bool TB, int NW, int TM = 128>
 __global__ __launch_bounds__(64 * NW) void k_gemm128(int M, int N, int K, real alpha, const real* __restrict__ A, int lda, const real* __restrict__ B,
                                                  int ldb, real beta, real* __restrict__ C, int ldc) {
   constexpr int NT = 64 * NW;                             // 4 waves (64 x 64 each) or 8 waves (64 x 32 each: twice the waves per CU when the grid is one block per CU)
-  constexpr int BK = G2K<real>::value, EPT = BK * 128 / NT;   // elements per thread and operand tile
-  constexpr int TPL = NT / 128;                           // threads per row of an operand tile stored along k
-  constexpr int BT = 8 / NW * 2;                          // 16-column MFMA tiles per wave along N (4 | 2)
+  constexpr int BK = G2K<real>::value, EPT = BK * TM / NT;   // elements per thread and operand tile
+  constexpr int TPL = NT / TM;                            // threads per row of an operand tile stored along k
+  constexpr int G2LD = TM + 16;
+  constexpr int AT = TM / 2 / 16;                         // 16-row MFMA tiles per wave along M (2 wave rows)
+  constexpr int BT = TM / (NW / 2) / 16;                  // 16-column MFMA tiles per wave along N (NW / 2 wave columns)
   constexpr int VW = 16 / (int)sizeof(real);              // reals per 16-byte vector
   __shared__ real sA2[2][BK][G2LD];                       // two stages: the next tile is written while this one is read (one barrier per K tile)
   __shared__ real sB2[2][BK][G2LD];
   using acc_t = typename Acc4<real>::type;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = NW == 4 ? w >> 1 : w >> 2, wc = NW == 4 ? w & 1 : w & 3;
-  const int m0 = blockIdx.y * G2M, n0 = blockIdx.x * G2N;
-  acc_t acc[4][BT];
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
+  acc_t acc[AT][BT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < AT; ++a)
 #pragma unroll
     for (int b = 0; b < BT; ++b)
 #pragma unroll
@@ -219,13 +224,13 @@ __global__ __launch_bounds__(64 * NW) void k_gemm128(int M, int N, int K, real a
     real(*sB)[G2LD] = sB2[cur];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      real af[4], bf[BT];
+      real af[AT], bf[BT];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = sA[ks + (lane >> 4)][wr * 64 + a * 16 + (lane & 15)];
+      for (int a = 0; a < AT; ++a) af[a] = sA[ks + (lane >> 4)][wr * (TM / 2) + a * 16 + (lane & 15)];
 #pragma unroll
       for (int b = 0; b < BT; ++b) bf[b] = sB[ks + (lane >> 4)][wc * (16 * BT) + b * 16 + (lane & 15)];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < AT; ++a)
 #pragma unroll
         for (int b = 0; b < BT; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
     }
@@ -237,12 +242,12 @@ __global__ __launch_bounds__(64 * NW) void k_gemm128(int M, int N, int K, real a
     cur ^= 1;
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < AT; ++a)
 #pragma unroll
     for (int b = 0; b < BT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = m0 + wr * 64 + a * 16 + frag_row<real>(lane, r);
+        const int gi = m0 + wr * (TM / 2) + a * 16 + frag_row<real>(lane, r);
         const int gj = n0 + wc * (16 * BT) + b * 16 + (lane & 15);
         if (gi < M && gj < N) {
           const int64_t e = (int64_t)gi * ldc + gj;
@@ -324,6 +329,31 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
     // 1400: 92 / 116 / 157 / 198 us -> 38 / 62 / 105 / 178 us (27..33 TF instead of 11..28); fp32: 65 / 84 / 101 / 117 -> 34 / 50 / 103 / 131 us.
     // Hence below 500 (fp64) / 300 (fp32) tiles of 64 x 64; it was 128 for both.  WISKI_GEMM32_MAX_TILES overrides.
     const int64_t nb64 = (int64_t)((N + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
+    {
+      // (round 5) the pipelined kernel on a 64 x 64 tile with 8 waves, between WISKI_GEMM64P_MIN and _MAX output tiles
+      // where it wins (tools/gemm_mid_probe.py, profiles/r05_gemm_mid.txt; n = side of a square product):
+      //   fp32  n = 800 .. 1600: 35 / 50 / 98 / 116 / 132 us -> 29 / 37 / 65 / 75 / 109 us (n = 1000: 40 -> 54 TF, TN 62 TF)   => 110 .. 800 tiles
+      //   fp64  n = 1400 / 1600: 178 / 249 us -> 135 / 205 us (TN 116 / 175); at n = 1000 only A^T B gains (58.5 -> 53 us)   => 440 .. 900 tiles, A^T B from 240
+      static const int p_min_env = [] { const char* e = getenv("WISKI_GEMM64P_MIN"); return e ? atoi(e) : -1; }();
+      static const int p_max_env = [] { const char* e = getenv("WISKI_GEMM64P_MAX"); return e ? atoi(e) : -1; }();
+      static const int p_nw = [] { const char* e = getenv("WISKI_GEMM64P_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
+      const int p_min = p_min_env >= 0 ? p_min_env : (sizeof(real) == 4 ? 110 : (ta && !tb ? 240 : 440));
+      const int p_max = p_max_env >= 0 ? p_max_env : (sizeof(real) == 4 ? 800 : 900);
+      if (nb64 >= p_min && nb64 <= p_max && K >= 128) {
+        dim3 g6((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+#define G64P(NWV)                                                                                                                                      \
+  do {                                                                                                                                                 \
+    if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false, NWV, 64>), g6, dim3(64 * NWV), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);      \
+    else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false, NWV, 64>), g6, dim3(64 * NWV), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);   \
+    else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true, NWV, 64>), g6, dim3(64 * NWV), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);   \
+    else hipLaunchKernelGGL((k_gemm128<real, true, true, NWV, 64>), g6, dim3(64 * NWV), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);                   \
+  } while (0)
+        if (p_nw == 4) G64P(4);
+        else G64P(8);
+#undef G64P
+        return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+      }
+    }
     static const bool small_on = [] { const char* e = getenv("WISKI_GEMM32"); return !(e && e[0] == '0'); }();
     static const int small_max_env = [] { const char* e = getenv("WISKI_GEMM32_MAX_TILES"); return e ? atoi(e) : 0; }();
     const int small_max = small_max_env > 0 ? small_max_env : (sizeof(real) == 8 ? 500 : 300);

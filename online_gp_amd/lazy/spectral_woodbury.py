@@ -386,7 +386,7 @@ class SpectralWoodburyFactor:
             defect_ok = wdef <= tail
             if not defect_ok:
                 return {"need_reference": True, "basis": basis, "tail": tail}
-        GT = grid_ops.gemm(self.G_ref, TS)                                    # [r_ref, r]
+        GT = grid_ops.gemm(self.G_ref, TS, ta=True)                           # G_ref TS [r_ref, r]: G_ref is symmetric, and A^T B is the faster form of the fp64 tile kernels
         G = grid_ops.gemm(TS, GT, ta=True)                                    # T^T G_ref T
         C, lam, sq, sqG = grid_ops.woodbury_c(G, basis.lam_kuu, kscale)       # I + Lam^1/2 G Lam^1/2 (and Lam^1/2 G for the MLL backward)
         # C = I + PSD: cannot fail on finite input.  With the factor its explicit inverse (r^3 / 3 flop more): every later solve

@@ -11,7 +11,7 @@ def bench(fn, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 for dt in (torch.float64, torch.float32):
-    for n in (600, 800, 1000, 1200, 1400):
+    for n in (400, 600, 800, 1000, 1200, 1400, 1600, 2048):
         A = torch.randn(n, n, device="cuda", dtype=dt); B = torch.randn(n, n, device="cuda", dtype=dt); C = torch.empty_like(A)
         out = []
         for ta, tb in ((False, False), (True, False), (False, True)):
