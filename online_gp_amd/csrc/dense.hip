@@ -138,7 +138,11 @@ __global__ __launch_bounds__(64 * NW) void k_gemm128(int M, int N, int K, real a
   constexpr int NT = 64 * NW;                             // 4 waves (64 x 64 each) or 8 waves (64 x 32 each: twice the waves per CU when the grid is one block per CU)
   constexpr int BK = G2K<real>::value, EPT = BK * TM / NT;   // elements per thread and operand tile
   constexpr int TPL = NT / TM;                            // threads per row of an operand tile stored along k
-  constexpr int G2LD = TM + 16;
+  // LDS row stride.  fp32: TM + 16 (= 16 mod 32 banks: the two 16-lane rows of an operand read fall on disjoint banks).  fp64: a read phase is ONE
+  // row of 16 doubles (all 32 banks, any stride); what the stride decides there is the k-major re-tiling of an operand that is contiguous along k
+  // (A in A B, B in A B^T): 8 lanes write the same column of rows kb, kb + 2, ...: TM + 16 doubles = 0 mod 32 banks put all of them on one bank
+  // pair (8-way conflict), TM + 2 spreads them over all (round 5: A B at n = 1000 62 -> see profiles/r05_gemm_mid.txt)
+  constexpr int G2LD = sizeof(real) == 8 ? TM + 2 : TM + 16;
   constexpr int AT = TM / 2 / 16;                         // 16-row MFMA tiles per wave along M (2 wave rows)
   constexpr int BT = TM / (NW / 2) / 16;                  // 16-column MFMA tiles per wave along N (NW / 2 wave columns)
   constexpr int VW = 16 / (int)sizeof(real);              // reals per 16-byte vector
@@ -333,11 +337,11 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
       // (round 5) the pipelined kernel on a 64 x 64 tile with 8 waves, between WISKI_GEMM64P_MIN and _MAX output tiles
       // where it wins (tools/gemm_mid_probe.py, profiles/r05_gemm_mid.txt; n = side of a square product):
       //   fp32  n = 800 .. 1600: 35 / 50 / 98 / 116 / 132 us -> 29 / 37 / 65 / 75 / 109 us (n = 1000: 40 -> 54 TF, TN 62 TF)   => 110 .. 800 tiles
-      //   fp64  n = 1400 / 1600: 178 / 249 us -> 135 / 205 us (TN 116 / 175); at n = 1000 only A^T B gains (58.5 -> 53 us)   => 440 .. 900 tiles, A^T B from 240
+      //   fp64  n = 1000 / 1400 / 1600: 61 / 178 / 249 us -> 57 / 124 / 189 us (A^T B 53 / 116 / 175, A B^T 71 -> 60 at 1000)   => 240 .. 900 tiles
       static const int p_min_env = [] { const char* e = getenv("WISKI_GEMM64P_MIN"); return e ? atoi(e) : -1; }();
       static const int p_max_env = [] { const char* e = getenv("WISKI_GEMM64P_MAX"); return e ? atoi(e) : -1; }();
       static const int p_nw = [] { const char* e = getenv("WISKI_GEMM64P_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
-      const int p_min = p_min_env >= 0 ? p_min_env : (sizeof(real) == 4 ? 110 : (ta && !tb ? 240 : 440));
+      const int p_min = p_min_env >= 0 ? p_min_env : (sizeof(real) == 4 ? 110 : 240);
       const int p_max = p_max_env >= 0 ? p_max_env : (sizeof(real) == 4 ? 800 : 900);
       if (nb64 >= p_min && nb64 <= p_max && K >= 128) {
         dim3 g6((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
