@@ -700,20 +700,22 @@ extern "C" int wiski_spectral_var(int32_t n, int32_t r, const double* d_Y, const
 // out (packed, fp64): hr [r] | c [r] | t [r] | coef [r] | zeta [r] | bMb | logdet | v [r] (scratch).
 __global__ __launch_bounds__(1024) void k_tail_a(int r_ref, int r, const double* __restrict__ TS, const double* __restrict__ h_ref, const double* __restrict__ sq,
                                                  double* __restrict__ out) {
-  __shared__ double s_p[16][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + lane;
+  // 16 columns per workgroup (r / 16 workgroups: 63 at r = 1000 -- it was r / 64 = 16, i.e. 16 CUs for an 8 MB matrix-vector product),
+  // the rows dealt to 64 groups of 16 lanes (a row segment of 16 doubles = one 128-byte line)
+  __shared__ double s_p[64][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
   double acc = 0;
   if (j < r) {
-#pragma unroll 8
-    for (int i = wv; i < r_ref; i += 16) acc += TS[(int64_t)i * r + j] * h_ref[i];
+#pragma unroll 4
+    for (int i = rg; i < r_ref; i += 64) acc += TS[(int64_t)i * r + j] * h_ref[i];
   }
-  s_p[wv][lane] = acc;
+  s_p[rg][c] = acc;
   __syncthreads();
-  if (wv == 0 && j < r) {
+  if (rg == 0 && j < r) {
     double hr = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) hr += s_p[w][lane];
+    for (int w = 0; w < 64; ++w) hr += s_p[w][c];
     out[j] = hr;
     out[5 * r + 2 + j] = sq[j] * hr;
   }
@@ -733,22 +735,22 @@ __global__ __launch_bounds__(1024) void k_tail_b(int r, const double* __restrict
 
 __global__ __launch_bounds__(1024) void k_tail_c(int r, const double* __restrict__ Linv, const double* __restrict__ chol, const double* __restrict__ sq,
                                                  double* __restrict__ out) {
-  __shared__ double s_p[16][64], s_red[16];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + lane;
+  __shared__ double s_p[64][17], s_red[16];
+  const int cc = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + cc;                    // (16 columns per workgroup, as k_tail_a)
   const double* __restrict__ c = out + r;
   double acc = 0;
   if (j < r) {
-    const int i0 = blockIdx.x * 64;                      // rows below the block's first column (the strict upper part is zero)
-#pragma unroll 8
-    for (int i = i0 + wv; i < r; i += 16) acc += Linv[(int64_t)i * r + j] * c[i];
+    const int i0 = blockIdx.x * 16;                      // rows below the block's first column (the strict upper part is zero)
+#pragma unroll 4
+    for (int i = i0 + rg; i < r; i += 64) acc += Linv[(int64_t)i * r + j] * c[i];
   }
-  s_p[wv][lane] = acc;
+  s_p[rg][cc] = acc;
   __syncthreads();
-  if (wv == 0 && j < r) {
+  if (rg == 0 && j < r) {
     double tv = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) tv += s_p[w][lane];
+    for (int w = 0; w < 64; ++w) tv += s_p[w][cc];
     const double s = sq[j];
     out[2 * r + j] = tv;
     out[3 * r + j] = s * tv;
@@ -775,9 +777,9 @@ extern "C" int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, c
                                  const double* d_chol, double* d_out, void* stream) {
   if (r_ref < 1 || r < 1 || !d_TS || !d_href || !d_sq || !d_Linv || !d_chol || !d_out) return WISKI_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tail_a, dim3((unsigned)((r + 63) / 64)), dim3(1024), 0, s, (int)r_ref, (int)r, d_TS, d_href, d_sq, d_out);
+  hipLaunchKernelGGL(k_tail_a, dim3((unsigned)((r + 15) / 16)), dim3(1024), 0, s, (int)r_ref, (int)r, d_TS, d_href, d_sq, d_out);
   hipLaunchKernelGGL(k_tail_b, dim3((unsigned)((r + 15) / 16)), dim3(1024), 0, s, (int)r, d_Linv, d_out);
-  hipLaunchKernelGGL(k_tail_c, dim3((unsigned)((r + 63) / 64)), dim3(1024), 0, s, (int)r, d_Linv, d_chol, d_sq, d_out);
+  hipLaunchKernelGGL(k_tail_c, dim3((unsigned)((r + 15) / 16)), dim3(1024), 0, s, (int)r, d_Linv, d_chol, d_sq, d_out);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
 
