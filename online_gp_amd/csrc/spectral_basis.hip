@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_basis_project(GridDev<double> G, const 
       }
       voff += G.g[q] * kmax;
     }
-    if (prior && lane == 0) {
+    if (prior && lane == 0 && blockIdx.y == 0) {
       double pr = ok ? 1.0 : 0.0;
       int toff = 0;
       for (int q = 0; q < d; ++q) {
@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void k_basis_project(GridDev<double> G, const 
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const double sc = scale ? (double)scale[p] : 1.0;
-    for (int j = lane; j < r; j += 64) {
+    // (gridDim.y > 1: few points -- evaluate() of a batch of 1..16, the absorb of the same batch -- with the r columns dealt to
+    //  gridDim.y workgroups instead of one wave walking all of them: r = 1000, one point: 20 -> 5 us)
+    const int jper = ((r + (int)gridDim.y - 1) / (int)gridDim.y + 63) & ~63;
+    const int jlo = (int)blockIdx.y * jper, jhi = jlo + jper < r ? jlo + jper : r;
+    for (int j = jlo + lane; j < jhi; j += 64) {
       double v = sc;
       for (int q = 0; q < d; ++q) v *= s_P[wave][q][S[(int64_t)q * r + j]];
       if (colscale) v *= colscale[j];
@@ -123,7 +127,9 @@ static int basis_project_impl(const wiski_grid* grid, const real* d_x, int64_t n
   if (n == 0) return WISKI_OK;
   int64_t nb = (n + 3) / 4;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL((k_basis_project<real>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, (int)kmax, d_S, (int)r, d_scale,
+  unsigned ny = 1;                                   // few points, many columns: split the columns over workgroups
+  if (n <= 64 && r > 128) ny = (unsigned)((r + 127) / 128 < 16 ? (r + 127) / 128 : 16);
+  hipLaunchKernelGGL((k_basis_project<real>), dim3((unsigned)nb, ny), dim3(256), 0, (hipStream_t)stream, G, d_x, n, d_V, (int)kmax, d_S, (int)r, d_scale,
                      d_colscale, d_tcol, d_F, ldf, d_prior, d_err);
   return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
 }
