@@ -220,7 +220,7 @@ typedef struct wiski_shard {
 } wiski_shard;
 int wiski_shard_groups(int32_t d, int32_t rank, int32_t nranks, int32_t* g_lo, int32_t* g_hi);
 
-/* Two-level preconditioner of the fused fp32 solve (d = 3, one right-hand side).  The separable model
+/* Two-level preconditioner of the fused fp32 solve (d = 3).  The separable model
  * P = (Kt^-1 + a kron_q diag(t_q))^-1 is exact only for a separable data density; on road-like (line-clustered) streams
  * W^T D^-1 W is far from that and a warm CG step needs 6 iterations instead of 2.5.  In the generalized eigenbasis X of the
  * separable model (the tables wiski_pcg already transforms with: X^T (kron diag t) X = I, Kt = X^-T D X^-1) the system
@@ -242,6 +242,10 @@ typedef struct wiski_twolevel {
   uint64_t* d_cs;            /* [r + 1]: r exchange words {application number << 32 | fp32 bits} + one sticky count of exchange words that
                               * never arrived (their writer block was not co-resident: the application then used a stale coefficient --
                               * drop the block); zeroed ONCE by the caller.  Refused (WISKI_E_BADARG) where 2 g0 exceeds the CU count */
+  float* d_mc;               /* [2][mc_cols][r] scratch of the multi-column form, or NULL: solves with k > 1 columns apply the block around the
+                              * slab launch (two small launches per application: c_S = X_S^T r per column from the mode-0 image, d = N c_S;
+                              * the slab kernel then substitutes d for the selected entries) -- no exchange words, no co-residency needed */
+  int32_t mc_cols;           /* columns d_mc has room for; k > mc_cols (or d_mc == NULL with k > 1): WISKI_E_BADARG */
 } wiski_twolevel;
 
 /* Deferred convergence poll.  wiski_pcg_async_* = wiski_pcg_* plus a host-side handle (zero-initialised by the caller,
@@ -344,7 +348,8 @@ int wiski_scatter_stats_step_sharded_f64(const wiski_grid* grid, const double* d
 int wiski_pcg_sharded_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard);
 int wiski_pcg_sharded_f64(const wiski_grid* grid, const double* d_A_st, const double* d_tcol, double kscale, const double* d_evec, const double* d_evec2, const double* d_eval, double shift, const double* d_RHS, int32_t k, double* d_U, double* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard);
 /* wiski_pcg_async / wiski_pcg_sharded with the two-level block (two_level may be NULL: then exactly wiski_pcg_sharded).
- * two_level != NULL needs the fused path: d = 3, every g_q <= 64, k = 1, eigen tables given; f64: WISKI_E_BADARG. */
+ * two_level != NULL needs the fused path: d = 3, every g_q <= 64, eigen tables given, k = 1 or 2 <= k <= two_level->mc_cols;
+ * f64: WISKI_E_BADARG. */
 int wiski_pcg_twolevel_f32(const wiski_grid* grid, const float* d_A_st, const float* d_tcol, float kscale, const float* d_evec, const float* d_evec2, const float* d_eval, float shift, const float* d_RHS, int32_t k, float* d_U, float* d_Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* d_work, int64_t work_bytes, int32_t* h_iters, double* h_relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, float* d_R, void* stream, wiski_pcg_async* handle, int32_t mode, const wiski_shard* shard, const wiski_twolevel* two_level);
 /* Refresh of the block in ONE call, everything queued on `stream`: G (r x r fp64, caller-owned, running sum) += F^T F with
  * F = diag(d_scale) W(d_x) X_S for the n points absorbed since the last refresh (d_scale [n] = sqrt of the per-point weights, or
@@ -362,6 +367,9 @@ int wiski_twolevel_refresh_f32(const wiski_grid* grid, const float* d_x, int64_t
  * d_y = P r, d_t = Kt^-1 P r, *d_rho (device double) += r . P r, for one m-vector d_r; d_w0 (m reals) and d_w1 (2 m reals)
  * are scratch.  two_level as above or NULL.  d = 3, every g_q <= 64, g_1 g_2 % 4 == 0. */
 int wiski_precond_apply_f32(const wiski_grid* grid, const float* d_evec, const float* d_evec2, const float* d_eval, float kscale, float shift, const float* d_r, float* d_w0, float* d_w1, float* d_y, float* d_t, double* d_rho, const wiski_twolevel* two_level, void* stream);
+/* The same for k grid vectors at once (the multi-column kernels of the 64-column variance / probe solves): d_r, d_y, d_t [k][m],
+ * d_w0 k m reals, d_w1 2 k m reals, d_rho [k] doubles (+=).  two_level with k > 1 needs its d_mc scratch (k <= mc_cols). */
+int wiski_precond_apply_cols_f32(const wiski_grid* grid, const float* d_evec, const float* d_evec2, const float* d_eval, float kscale, float shift, const float* d_r, int32_t k, float* d_w0, float* d_w1, float* d_y, float* d_t, double* d_rho, const wiski_twolevel* two_level, void* stream);
 
 /* Dense Woodbury-factor path for small grids (the reference's own regime, m <=
  * max_cholesky_size): a10 `Q = I + L^T Kuu L` GEMM (BFN:350-355), a12 Cholesky

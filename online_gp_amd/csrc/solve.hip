@@ -2112,7 +2112,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   // host convergence polls: after `first_check` iterations, then every `check_every`
   auto due = [&](int i) { return i == max_iter || i == first_check || (i > first_check && (i - first_check) % check_every == 0); };
   const bool fused_cg = spectral && wide && spectral_fused_ok<real>(G);
-  if (two_level && !(fused_cg && sizeof(real) == 4 && k == 1)) return WISKI_E_BADARG;   // the exact block lives in the fused fp32 slab kernel
+  if (two_level && !(fused_cg && sizeof(real) == 4)) return WISKI_E_BADARG;   // the exact block lives in the fused fp32 slab kernels (k > 1: launch_slab checks the scratch)
   bool pending = false;   // fused path: update_x of iteration it-1 not applied yet
   // publish: fold the convergence poll of iteration `it` into this update; returns its sequence number (0: nothing launched)
   auto flush_update = [&](bool publish = false) -> long long {
@@ -2326,6 +2326,15 @@ int wiski_precond_apply_f32(const wiski_grid* grid, const float* evec, const flo
   if (!evec || !eval || !d_r || !w0 || !w1 || !d_y || !d_t || !d_rho || !spectral_fused_ok<float>(G) || G.m % 4) return WISKI_E_BADARG;
   PcgScal S{d_rho - 1, 1, nullptr};          // rho(0) = base + k (1 + 2 * 0) = d_rho; nothing else of S is touched at it = 0, apply = 0
   return launch_spectral_fused_cg<float>(G, evec, evec2, eval, kscale, shift, const_cast<float*>(d_r), 1, w0, w1, 0, 0, 0.0, d_y, d_t, (float*)nullptr, 0, 0,
+                                         (float*)nullptr, (float*)nullptr, S, (hipStream_t)stream, (const float*)nullptr, two_level);
+}
+// ... of k grid vectors at once (the multi-column kernels): d_r, d_y, d_t [k][m], w0 k m reals, w1 2 k m reals, d_rho [k] doubles (+=).
+int wiski_precond_apply_cols_f32(const wiski_grid* grid, const float* evec, const float* evec2, const float* eval, float kscale, float shift, const float* d_r, int32_t k, float* w0, float* w1, float* d_y, float* d_t, double* d_rho, const wiski_twolevel* two_level, void* stream) {
+  GridDev<float> G;
+  if (int rc = make_grid_dev<float>(grid, &G)) return rc;
+  if (!evec || !eval || !d_r || !w0 || !w1 || !d_y || !d_t || !d_rho || k < 1 || !spectral_fused_ok<float>(G) || G.m % 4) return WISKI_E_BADARG;
+  PcgScal S{d_rho - k, k, nullptr};          // rho(0) = base + k
+  return launch_spectral_fused_cg<float>(G, evec, evec2, eval, kscale, shift, const_cast<float*>(d_r), k, w0, w1, 0, 0, 0.0, d_y, d_t, (float*)nullptr, 0, 0,
                                          (float*)nullptr, (float*)nullptr, S, (hipStream_t)stream, (const float*)nullptr, two_level);
 }
 int wiski_pcg_sharded_f64(const wiski_grid* g, const double* A, const double* tcol, double kscale, const double* evec, const double* evec2, const double* eval, double shift, const double* RHS, int32_t k, double* U, double* Z, int32_t warm, double tol, int32_t max_iter, int32_t check_every, int32_t first_check, void* work, int64_t wb, int32_t* iters, double* relres, const int32_t* d_err, int32_t* h_err, int32_t a_sym, double* R, void* s, wiski_pcg_async* as, int32_t amode, const wiski_shard* shard) {

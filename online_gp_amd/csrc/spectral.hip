@@ -657,6 +657,152 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
   SPEC_STAMP(5);
 }
 
+// ----------------------------------------------- two-level block, many columns ---
+// The exact block for a multi-column solve.  The k = 1 slab kernel exchanges its r selected coefficients between the blocks of ONE
+// launch (stamped words, a spin per application); with k columns that is k r words per application and a wait per column in every
+// participating block.  Here the block is applied around the slab launch instead -- nothing spins, nothing needs co-residency:
+//   k_tl_coef_mc   (one workgroup per selected slab and column, in front of the slab launch): the selected coefficients
+//                  c_S = X_S^T r straight from the mode-0 image, in two stages (the distinct x of the slab's modes first)
+//   k_tl_apply_mc  (one workgroup per 32 rows of N and column): d = N c_S, rho[c] += c_S . d
+//   k_spec_slab_mfma_mc<..., TL = true>: the lanes that hold a selected entry of C3 replace it by d (y-half) / d / lambda (t-half)
+//   and leave it out of their rho term.
+// (First form: ONE kernel, a workgroup per column walking the selected slabs with a wave per mode -- 64 CUs busy, every mode a
+//  latency-bound chain of g2 LDS round trips: 106 us per application at 50^3, r = 192, 64 columns.)
+constexpr int TLC_NT = 256;
+static inline size_t tl_coef_mc_lds(int g1, int g2) { return (size_t)(g1 * (g2 | 1) + g1 * g1 + g2 * g2 + 64 * g2) * sizeof(float); }
+
+__global__ __launch_bounds__(TLC_NT) void k_tl_coef_mc(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
+                                                       const float* __restrict__ src, TwoLevelDev tl, float* __restrict__ cS) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float sC[SPEC_TL_MAXR];
+  __shared__ int sSlab;
+  const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2], m = G.m;
+  const int ldy = g2 | 1;                          // odd row stride: consecutive threads walk a column of Y conflict-free
+  float* sY = reinterpret_cast<float*>(smem);      // [g1][ldy]   mode-0 image of this slab
+  float* sV1 = sY + g1 * ldy;                      // [b][x]
+  float* sV2 = sV1 + g1 * g1;                      // [b][y]
+  const int c = blockIdx.y, t = threadIdx.x;
+  if (t < 64) {                                    // the blockIdx.x-th slab that holds selected modes (g0 <= 64: one ballot)
+    const bool has = t < g0 && tl.off[t + 1] > tl.off[t];
+    const unsigned long long bal = __ballot(has);
+    if (has && __popcll(bal & ((1ull << t) - 1ull)) == (int)blockIdx.x) sSlab = t;
+    if (t == 0 && __popcll(bal) <= (int)blockIdx.x) sSlab = g0;
+  }
+  const int ne = g1 * g2;
+  // all three images in one round of independent loads (g <= 64: at most 16 elements per thread and image)
+  constexpr int NB = 64 * 64 / TLC_NT;
+  float v1[NB], v2[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = t + TLC_NT * j;
+    v1[j] = e < g1 * g1 ? V1[e] : 0.f;
+    v2[j] = e < g2 * g2 ? V2[e] : 0.f;
+  }
+  for (int e = t; e < SPEC_TL_MAXR; e += TLC_NT) sC[e] = 0.f;
+  __syncthreads();                                 // sSlab
+  const int i0 = sSlab;
+  if (i0 >= g0) return;                            // block-uniform (nslab overstated: nothing to do)
+  const float* __restrict__ col = src + (int64_t)c * m + (int64_t)i0 * ne;
+  const int o0 = tl.off[i0], ns = tl.off[i0 + 1] - o0;
+  float vy[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = t + TLC_NT * j;
+    vy[j] = e < ne ? col[e] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = t + TLC_NT * j;
+    if (e < g1 * g1) sV1[e] = v1[j];
+    if (e < g2 * g2) sV2[e] = v2[j];
+    if (e < ne) sY[(e / g2) * ldy + (e % g2)] = vy[j];
+  }
+  __syncthreads();
+  // stage 1: T[xi][b2] = sum_b1 V1[b1][x_xi] Y[b1][b2] for the nx distinct x of this slab's modes (rows of the mask that are not
+  // empty), a thread per (xi, b2) and four xi per pass; stage 2: c_e = sum_b2 T[xi(e)][b2] V2[b2][y_e], a thread per mode.
+  // (nx g1 g2 + ns g2 multiply-adds instead of ns g1 g2: the modes of a slab share few x.)
+  __shared__ unsigned char sXi[64];                // x -> index among the distinct ones
+  __shared__ unsigned char sXl[64];                // index -> x
+  __shared__ int sNx;
+  if (t < 64) {
+    const bool has = tl.mask[i0 * 64 + t] != 0ull;
+    const unsigned long long bal = __ballot(has);
+    const int xi = __popcll(bal & ((1ull << t) - 1ull));
+    sXi[t] = (unsigned char)xi;
+    if (has) sXl[xi] = (unsigned char)t;
+    if (t == 0) sNx = __popcll(bal);
+  }
+  __syncthreads();
+  const int nx = sNx;
+  float* sTT = sV2 + g2 * g2;                      // [nx][g2], behind the three images
+  for (int o = t; o < ((nx + 3) / 4) * g2; o += TLC_NT) {
+    const int xq = o / g2, b2 = o - xq * g2;
+    int xs[4];
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xs[j] = sXl[4 * xq + j < nx ? 4 * xq + j : 0];
+    for (int b = 0; b < g1; ++b) {
+      const float yv = sY[b * ldy + b2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc4[j] += sV1[b * g1 + xs[j]] * yv;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * xq + j < nx) sTT[(4 * xq + j) * g2 + b2] = acc4[j];
+  }
+  __syncthreads();
+  for (int e = t; e < ns; e += TLC_NT) {
+    const unsigned pp = tl.pos[o0 + e];
+    const int x = pp >> 8, y = pp & 255u;
+    const float* __restrict__ tr = sTT + (int)sXi[x] * g2;
+    float a0 = 0.f, a1 = 0.f;
+    int b = 0;
+    for (; b + 1 < g2; b += 2) {
+      a0 += tr[b] * sV2[b * g2 + y];
+      a1 += tr[b + 1] * sV2[(b + 1) * g2 + y];
+    }
+    if (b < g2) a0 += tr[b] * sV2[b * g2 + y];
+    sC[e] = a0 + a1;
+  }
+  __syncthreads();
+  for (int e = t; e < ns; e += TLC_NT) cS[(int64_t)c * tl.r + o0 + e] = sC[e];
+}
+
+constexpr int TLA_ROWS = 32;
+__global__ __launch_bounds__(256) void k_tl_apply_mc(TwoLevelDev tl, const float* __restrict__ cS, float* __restrict__ dS, double* __restrict__ rho) {
+  const int c = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int r = tl.r;
+  const float* __restrict__ cc = cS + (int64_t)c * r;
+  const int e0 = blockIdx.x * TLA_ROWS + w * (TLA_ROWS / 4);
+  float d[TLA_ROWS / 4];
+#pragma unroll
+  for (int i = 0; i < TLA_ROWS / 4; ++i) d[i] = 0.f;
+  for (int q0 = 0; q0 < r; q0 += 64) {             // per 64 columns: the wave's 8 rows of N + c_S as 9 independent loads
+    const int q = q0 + lane;
+    const bool ok = q < r;
+    const float cq = ok ? cc[q] : 0.f;
+    float nv[TLA_ROWS / 4];
+#pragma unroll
+    for (int i = 0; i < TLA_ROWS / 4; ++i) {
+      const int e = e0 + i;
+      nv[i] = (ok && e < r) ? tl.N[(int64_t)e * r + q] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TLA_ROWS / 4; ++i) d[i] += nv[i] * cq;
+  }
+  float rs = 0.f;
+#pragma unroll
+  for (int i = 0; i < TLA_ROWS / 4; ++i) {
+    const float v = wave_reduce_sum<float>(d[i]);
+    const int e = e0 + i;
+    if (lane == 0 && e < r) {
+      dS[(int64_t)c * r + e] = v;
+      rs += cc[e] * v;
+    }
+  }
+  if (rho != nullptr && lane == 0 && rs != 0.f) unsafeAtomicAdd(rho + c, (double)rs);
+}
+
 // ------------------------------------- slab, fp32 on the matrix cores, many columns ---
 // k_spec_slab_mfma for multi-column solves (predictive variances, probe solves).  There a block per (slab, half, column)
 // is 2 g0 k blocks of 115 KB LDS -- one per CU at a time, each a serial chain of [5 matrix loads, 4 products, 4 barriers]
@@ -665,11 +811,13 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
 // are formed from the C3 fragment kept in registers (6 products per column instead of 8), and the next column's slab is
 // fetched into registers while the current one is in the matrix cores.
 //   LDS: bufA, bufB, sV1, sV2 (stride LDT), sB1, sB2 per half (stride LDN): 115 KB, 150 KB with a generalized eigenbasis.
-template <int KS, int VW, int NW>
+// TL: the two-level block (see k_tl_coef_mc / k_tl_apply_mc, which have run on `src` and left d = N c_S in dS [k][r]).
+template <int KS, int VW, int NW, bool TL>
 __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G, const float* __restrict__ V1, const float* __restrict__ V2,
                                                            const float* __restrict__ Z1, const float* __restrict__ Z2,
                                                            const float* __restrict__ evals, float kscale, float shift,
-                                                           const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho) {
+                                                           const float* __restrict__ src, float* __restrict__ dst, int k, double* __restrict__ rho,
+                                                           TwoLevelDev tl, const float* __restrict__ dS) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_red[16];
   __shared__ float sE[128];                       // eigenvalues of dims 1 | 2, zero padded to 64 each
@@ -716,6 +864,24 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G,
     }
   }
   const float l0 = kscale * evals[i0];
+  // (TL) selection masks of this slab's rows and, per row, the block index of its first selected mode (block order = raster order)
+  __shared__ unsigned long long sMask[TL ? 64 : 1];
+  __shared__ int sPre[TL ? 64 : 1];
+  if constexpr (TL) {
+    if (t < 64) {
+      const int o0 = tl.off[i0];
+      const unsigned long long mx = tl.off[i0 + 1] > o0 ? tl.mask[i0 * 64 + t] : 0ull;
+      int v = __popcll(mx);
+      const int own = v;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int up = __shfl_up(v, dlt);
+        if (t >= dlt) v += up;
+      }
+      sMask[t] = mx;
+      sPre[t] = o0 + v - own;
+    }
+  }
   __syncthreads();
   spec_f32x4 acc[2][2];
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -728,7 +894,10 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G,
         for (int r = 0; r < 4; ++r) out[(wr * 16 * RT + a * 16 + l4 * 4 + r) * ld + wc * 32 + cc * 16 + l15] = acc[a][cc][r];
   };
   // spectral factors of this thread's 16 C3 entries: the same for every column
+  // (TL) eidx >= 0: this entry is selected mode eidx of the block -- its factors become 1 / lambda (t-half) and 1 (y-half) of d
   float f1v[2][2][4], f2v[2][2][4];
+  int eidx[2][2][4];
+  bool any_sel = false;
 #pragma unroll
   for (int a = 0; a < RT; ++a)
 #pragma unroll
@@ -740,12 +909,34 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G,
         const float f1 = __frcp_rn(1.f + shift * lam);
         f1v[a][cc][r] = f1;
         f2v[a][cc][r] = lam * f1;
+        eidx[a][cc][r] = -1;
+        if constexpr (TL) {
+          const int x = wr * 16 * RT + a * 16 + l4 * 4 + r, y = wc * 32 + cc * 16 + l15;
+          const unsigned long long mx = sMask[x];
+          if ((mx >> y) & 1ull) {
+            eidx[a][cc][r] = sPre[x] + __popcll(mx & ((1ull << y) - 1ull));
+            f1v[a][cc][r] = 1.f / lam;
+            f2v[a][cc][r] = 1.f;
+            any_sel = true;
+          }
+        }
       }
     }
   for (; c < k; c += gridDim.y) {
     const int cn = c + gridDim.y;
     const bool more = cn < k;                     // block-uniform
     if (more) tX.issue(src + (int64_t)cn * m + (int64_t)i0 * g1 * g2, g1, g2);
+    float dv[2][2][4];
+    if constexpr (TL) {
+      if (any_sel) {
+#pragma unroll
+        for (int a = 0; a < RT; ++a)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[a][cc][r] = eidx[a][cc][r] >= 0 ? dS[(int64_t)c * tl.r + eidx[a][cc][r]] : 0.f;
+      }
+    }
     // P2: A = V1^T (sV1 [b][x]), B = X (bufA [b][y])  -> C2 natural (bufB, stride LDN)
     spec_mfma_product<false, false, KS, RT>(sV1, bufA, wr, wc, lane, acc);
     store_tiles(bufB, SPEC_LDN);
@@ -760,9 +951,12 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma_mc(GridDev<float> G,
       for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[a][cc][r];
+          float v = acc[a][cc][r];
+          bool sel = false;
+          if constexpr (TL) sel = any_sel && eidx[a][cc][r] >= 0;
+          if (sel) v = dv[a][cc][r];              // (its rho term c_S . N c_S was added by k_tl_apply_mc)
+          else rho_lane += f2v[a][cc][r] * v * v; // r^T P r in the eigenbasis (padding: lam = 0)
           c3[a][cc][r] = v;
-          rho_lane += f2v[a][cc][r] * v * v;      // r^T P r in the eigenbasis (padding: lam = 0)
           acc[a][cc][r] = v * f1v[a][cc][r];
         }
     store_tiles(bufA, SPEC_LDN);                  // bufA (X) was last read by P2, a barrier ago
@@ -1060,11 +1254,13 @@ template <typename real>
 static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, const real* Z1, const real* Z2, const real* evals, real kscale,
                        real shift, const real* src, real* dst, int k, double* rho, hipStream_t s, const wiski_twolevel* two_level = nullptr) {
   const int g0 = G.g[0], g1 = G.g[1], g2 = G.g[2];
-  if (two_level && (sizeof(real) != 4 || k != 1 || two_level->r < 1 || two_level->r > SPEC_TL_MAXR || two_level->nslab < 1 || two_level->nslab > g0 ||
+  if (two_level && (sizeof(real) != 4 || k < 1 || two_level->r < 1 || two_level->r > SPEC_TL_MAXR || two_level->nslab < 1 || two_level->nslab > g0 ||
                     !two_level->d_mask || !two_level->d_off || !two_level->d_pos || !two_level->d_N || !two_level->d_cs))
     return WISKI_E_BADARG;
-  // the exchange spins on words other blocks of the SAME launch write: all 2 g0 blocks (one per CU, ~100 KB of LDS each) must be resident
-  if (two_level && 2 * g0 > spec_cu_count()) return WISKI_E_BADARG;
+  // one column: the exchange spins on words other blocks of the SAME launch write: all 2 g0 blocks (one per CU, ~100 KB of LDS each) must
+  // be resident.  Several columns: the block is applied around the slab launch (k_tl_coef_mc, k_tl_apply_mc) and needs its 2 k r scratch instead
+  if (two_level && k == 1 && 2 * g0 > spec_cu_count()) return WISKI_E_BADARG;
+  if (two_level && k > 1 && (!two_level->d_mc || two_level->mc_cols < k)) return WISKI_E_BADARG;
   if constexpr (sizeof(real) == 4) {
     const int gm = g1 > g2 ? g1 : g2;
     const bool even = g1 % 2 == 0 && g2 % 2 == 0;      // 8-byte loads need 8-byte aligned rows
@@ -1110,8 +1306,21 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
       slab_waves = (e && atoi(e) == 4) ? 4 : 8;
     }
     // three or more columns: blocks that own a slab for a strided set of columns (about one block per CU)
-    if (k >= 3 && getenv("WISKI_SLAB_MC_OFF") == nullptr) {
+    if (two_level ? k >= 2 : (k >= 3 && getenv("WISKI_SLAB_MC_OFF") == nullptr)) {
       const bool alt = Z1 != V1 || Z2 != V2;
+      float* tl_c = two_level ? two_level->d_mc : nullptr;                                       // c_S [k][r]
+      const float* tl_d = two_level ? two_level->d_mc + (int64_t)two_level->mc_cols * two_level->r : nullptr;   // N c_S [k][r]
+      if (two_level) {
+        const size_t lb = tl_coef_mc_lds(g1, g2);
+        static size_t lb_set = 0;
+        if (lb > lb_set) {
+          if (hipFuncSetAttribute((const void*)k_tl_coef_mc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb) != hipSuccess) return WISKI_E_LAUNCH;
+          lb_set = lb;
+        }
+        hipLaunchKernelGGL(k_tl_coef_mc, dim3((unsigned)two_level->nslab, (unsigned)k), dim3(TLC_NT), lb, s, G, V1, V2, src, tl, tl_c);
+        hipLaunchKernelGGL(k_tl_apply_mc, dim3((unsigned)((two_level->r + TLA_ROWS - 1) / TLA_ROWS), (unsigned)k), dim3(256), 0, s, tl,
+                           (const float*)tl_c, const_cast<float*>(tl_d), rho);
+      }
       const size_t lds = SPEC_SLAB_MFMA_LDS + (alt ? (size_t)2 * 64 * SPEC_LDN * sizeof(float) : 0);
       int nb = spec_cu_count() / g0;
       nb = nb < 1 ? 1 : (nb > k ? k : nb);
@@ -1122,17 +1331,23 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
   do {                                                                                                                                            \
     static size_t lds_set = 0;                                                                                                                    \
     if (lds > lds_set) {                                                                                                                          \
-      if (hipFuncSetAttribute((const void*)k_spec_slab_mfma_mc<KS, VW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
-          hipFuncSetAttribute((const void*)k_spec_slab_mfma_mc<KS, VW, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)   \
-        return WISKI_E_LAUNCH;                                                                                                                    \
+      for (const void* fp : {(const void*)k_spec_slab_mfma_mc<KS, VW, 4, false>, (const void*)k_spec_slab_mfma_mc<KS, VW, 8, false>,             \
+                             (const void*)k_spec_slab_mfma_mc<KS, VW, 4, true>, (const void*)k_spec_slab_mfma_mc<KS, VW, 8, true>})               \
+        if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WISKI_E_LAUNCH;                   \
       lds_set = lds;                                                                                                                              \
     }                                                                                                                                             \
-    if (slab_waves == 8)                                                                                                                          \
-      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 8>), dim3((unsigned)g0, (unsigned)nb), dim3(512), lds, s, G, V1, V2, Z1, Z2, evals, kscale, \
-                         shift, src, dst, k, rho);                                                                                                \
+    if (two_level && slab_waves == 8)                                                                                                             \
+      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 8, true>), dim3((unsigned)g0, (unsigned)nb), dim3(512), lds, s, G, V1, V2, Z1, Z2, evals,   \
+                         kscale, shift, src, dst, k, rho, tl, tl_d);                                                     \
+    else if (two_level)                                                                                                                           \
+      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 4, true>), dim3((unsigned)g0, (unsigned)nb), dim3(256), lds, s, G, V1, V2, Z1, Z2, evals,   \
+                         kscale, shift, src, dst, k, rho, tl, tl_d);                                                     \
+    else if (slab_waves == 8)                                                                                                                     \
+      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 8, false>), dim3((unsigned)g0, (unsigned)nb), dim3(512), lds, s, G, V1, V2, Z1, Z2, evals,  \
+                         kscale, shift, src, dst, k, rho, tl, (const float*)nullptr);                                                             \
     else                                                                                                                                          \
-      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 4>), dim3((unsigned)g0, (unsigned)nb), dim3(256), lds, s, G, V1, V2, Z1, Z2, evals, kscale, \
-                         shift, src, dst, k, rho);                                                                                                \
+      hipLaunchKernelGGL((k_spec_slab_mfma_mc<KS, VW, 4, false>), dim3((unsigned)g0, (unsigned)nb), dim3(256), lds, s, G, V1, V2, Z1, Z2, evals,  \
+                         kscale, shift, src, dst, k, rho, tl, (const float*)nullptr);                                                             \
   } while (0)
 #define SLAB_MC(KS)              \
   do {                           \

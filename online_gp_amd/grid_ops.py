@@ -323,7 +323,7 @@ class _Shard(ctypes.Structure):
 class TwoLevelStruct(ctypes.Structure):
     """include/wiski.h: wiski_twolevel"""
     _fields_ = [("r", ctypes.c_int32), ("nslab", ctypes.c_int32), ("d_mask", ctypes.c_void_p), ("d_off", ctypes.c_void_p), ("d_pos", ctypes.c_void_p),
-                ("d_N", ctypes.c_void_p), ("d_cs", ctypes.c_void_p)]
+                ("d_N", ctypes.c_void_p), ("d_cs", ctypes.c_void_p), ("d_mc", ctypes.c_void_p), ("mc_cols", ctypes.c_int32)]
 
 
 def shard_groups(d, rank, nranks):
@@ -472,6 +472,22 @@ def precond_apply(grid, eig, kscale, shift, r, two_level=None):
     return y, t, rho[1]
 
 
+def precond_apply_cols(grid, eig, kscale, shift, R, two_level=None):
+    """`precond_apply` for the k rows of R [k, m] through the multi-column kernels (``wiski_precond_apply_cols``): (Y, T, rho [k])."""
+    evec, evals, evec2 = (tuple(eig) + (None,))[:3]
+    R = R.contiguous()
+    k, m = R.shape
+    w0 = torch.empty(k * m, dtype=R.dtype, device=R.device)
+    w1 = torch.empty(2 * k * m, dtype=R.dtype, device=R.device)
+    Y, T = torch.empty_like(R), torch.empty_like(R)
+    rho = torch.zeros(k, dtype=torch.float64, device=R.device)
+    rc = _hip.lib().wiski_precond_apply_cols_f32(grid.ref, _hip.dptr(evec), _hip.dptr(evec2), _hip.dptr(evals), ctypes.c_float(kscale), ctypes.c_float(shift),
+                                                 _hip.dptr(R), ctypes.c_int32(k), _hip.dptr(w0), _hip.dptr(w1), _hip.dptr(Y), _hip.dptr(T), _hip.dptr(rho),
+                                                 ctypes.byref(two_level) if two_level is not None else None, _hip.stream_ptr(R.device))
+    _hip.check(rc, "wiski_precond_apply_cols")
+    return Y, T, rho
+
+
 def kron_eigen(grid, tcol, profiles=None, host_out=None):
     """Per-dim (generalized) eigen-decomposition of the d small symmetric-Toeplitz Kronecker
     factors (host side, fp64, O(d g^3) -- done when the hyper-parameters or the data-density
@@ -512,7 +528,8 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
         raise_on_fail=False, eigen=None, shift=0.0, first_check=0, err=None, inplace=False, R=None, two_level=None):
     """Solve (Kt^-1 + A) U = RHS, Kt = kscale*Kuu.  Returns (U, Z, iters, relres).
     two_level: a TwoLevelStruct (include/wiski.h: wiski_twolevel) -- the exact block on the dominant modes inside the fused
-    preconditioner (``wiski_pcg_twolevel_f32``: one column, fp32, d = 3, eigen tables given).
+    preconditioner (``wiski_pcg_twolevel_f32``: fp32, d = 3, eigen tables given; one column, or up to ``two_level.mc_cols``
+    columns when the block carries the multi-column scratch ``d_mc``; otherwise the argument is ignored).
     eigen = (evec, evals) from :func:`kron_eigen` selects the spectral
     preconditioner (Kt^-1 + shift I)^-1; otherwise Kt itself preconditions.
     R [k, m] (optional, contiguous): caller-owned residual buffer, left holding RHS - Z - A U;
@@ -537,7 +554,7 @@ def pcg(grid, A_st, tcol, kscale, RHS, U=None, Z=None, warm=False, tol=1e-6, max
               _hip.dptr(U), _hip.dptr(Z), ctypes.c_int32(int(warm)), ctypes.c_double(tol), ctypes.c_int32(max_iter),
               ctypes.c_int32(check_every), ctypes.c_int32(first_check), _hip.dptr(buf), ctypes.c_int64(need), ctypes.byref(iters), relres, _hip.dptr(err), ctypes.byref(h_err),
               ctypes.c_int32(1 if is_half_stencil(grid, A_st) else 0), _hip.dptr(R), _hip.stream_ptr(RHS2.device))
-    if two_level is not None and k == 1 and RHS2.dtype == torch.float32 and evec is not None:
+    if two_level is not None and (k == 1 or (two_level.d_mc and k <= two_level.mc_cols)) and RHS2.dtype == torch.float32 and evec is not None:
         rc = _hip.lib().wiski_pcg_twolevel_f32(*common, None, ctypes.c_int32(0), None, ctypes.byref(two_level))
     else:
         rc = _hip.fn("wiski_pcg", RHS2.dtype)(*common)

@@ -187,13 +187,25 @@ class InducingPosterior(_Operator):
         self.device = tcol.device
         self.last_iters = 0
         self.last_relres = []
+        self.two_level_provider = None   # callable (operator, columns) -> TwoLevelStruct or None for solves that name no block (set by the model)
+        self.last_two_level = None       # what the last solve used
 
     def solve_columns(self, RHS, U=None, Z=None, warm=False, first_check=0, inplace=False, R=None, two_level=None):
         """RHS [k, m] -> (U, Z) with U = M RHS.  inplace: write into the given U, Z even on a cold start.
         R [k, m] (optional): caller-owned residual buffer, left holding RHS - Z - A U; warm=2 starts from it.
-        two_level: the exact block of the two-level preconditioner for this solve (one column; lazy/two_level.py)."""
+        two_level: the exact block of the two-level preconditioner for this solve (lazy/two_level.py; default: the operator's own)."""
+        k = RHS.shape[0] if RHS.dim() > 1 else 1
+        if two_level is None and self.two_level_provider is not None:
+            two_level = self.two_level_provider(self, k)          # the stream's block for THIS eigenbasis as it stands now, or None
+        self.last_two_level = two_level
+        ce = self.check_every
+        if k >= 16 and k * self.grid.m >= (1 << 21):
+            # a wide solve: one iteration is hundreds of microseconds of kernels, a convergence poll a few -- look after every
+            # iteration from the first one that can have converged (stopping up to check_every - 1 iterations earlier)
+            ce = 1
+            first_check = first_check or (2 if two_level is not None else 3)
         U, Z, it, res = grid_ops.pcg(self.grid, self.wtw.stencil, self.tcol, self.kscale, RHS, U=U, Z=Z, warm=warm, inplace=inplace, tol=self.tol,
-                                     max_iter=self.max_iter, check_every=self.check_every, workspace=self.workspace, eigen=self.eigen,
+                                     max_iter=self.max_iter, check_every=ce, workspace=self.workspace, eigen=self.eigen,
                                      shift=self.shift, first_check=first_check, err=self.err, R=R, two_level=two_level)
         self.last_iters, self.last_relres, self.last_err = it, res, grid_ops.pcg.last_err
         self.last_converged = grid_ops.pcg.last_converged

@@ -31,6 +31,7 @@ _SIDE = {}         # device -> side stream of the refreshes (streams are never d
                    # HIP offers no priority below the default -- priority_range() = (0, -1) -- so the refresh cannot be made to yield)
 _WORK = {}         # (device, r) -> refresh workspace, shared by the blocks of successive models (refreshes of one device serialise on _SIDE)
 KMAX = 32          # per-dim eigenvectors the projection kernel can take (wiski_basis_project)
+MC_COLS = 64       # columns of a multi-column solve the block can serve (the variance / probe chunks of the model)
 MAXR = 480         # one-workgroup Cholesky + inverse (wiski_potrf_inverse) and the slab kernel's LDS staging (512)
 
 
@@ -80,8 +81,9 @@ class TwoLevelBlock:
         self.d_cs = torch.zeros(max(r, 4) + 1, dtype=torch.int64, device=device)      # exchange words, zeroed once (epoch 0 is never used); [r]: sticky time-out count
         self.N = [torch.zeros((r, r), dtype=torch.float32, device=device) for _ in range(2)]
         self.active = -1                       # index of the N buffer the solver reads, -1: none yet
+        self.mc = torch.empty((2, MC_COLS, r), dtype=torch.float32, device=device)   # c_S and d = N c_S per column of a multi-column solve
         self.struct = grid_ops.TwoLevelStruct(r, self.nslab, self.d_mask.data_ptr(), self.d_off.data_ptr(), self.d_pos.data_ptr(),
-                                              self.N[0].data_ptr(), self.d_cs.data_ptr())
+                                              self.N[0].data_ptr(), self.d_cs.data_ptr(), self.mc.data_ptr(), MC_COLS)
         # --- what the refresh reads: per-dim tables [g_q, kw] of the eigenvectors the selection uses (descending), fp64
         kw = int(max((len(D[q]) - 1 - idx[q]).max() for q in range(3))) + 1
         self.kw = kw
@@ -165,6 +167,45 @@ class TwoLevelBlock:
         self.weight_at_launch = weight
         self.refreshes += 1
 
+    def rebuild_from_stencil(self, stencil, weight):
+        """G = X_S^T A X_S from the statistics themselves (r stencil-product columns in chunks of 64 + d mode products each), N from it,
+        on the CURRENT stream, switched in at once: what a block costs where no history of points in this eigenbasis exists -- after a
+        hyper-parameter step, a handed-over kernel cache, an all-reduced statistics delta (~1.5 ms at 50^3, r = 192; the streaming
+        refresh pipeline then continues from it)."""
+        g, dev, r = self.grid.g, self.device, self.r
+        Vq, o = [], 0
+        for q in range(3):
+            Vq.append(self.Vtab[o:o + g[q] * self.kw].reshape(g[q], self.kw))
+            o += g[q] * self.kw
+        S = self.S.long()
+        G = torch.empty((r, r), dtype=torch.float64, device=dev)
+        for lo in range(0, r, 64):
+            hi = min(lo + 64, r)
+            c = hi - lo
+            Bc = Vq[0][:, S[0, lo:hi]].t()
+            for q in (1, 2):
+                Bc = Bc.reshape(c, -1, 1) * Vq[q][:, S[q, lo:hi]].t().reshape(c, 1, -1)
+            AB = grid_ops.stencil_spmv(self.grid, stencil, Bc.reshape(c, self.grid.m).to(torch.float32).contiguous())
+            P = AB.double().reshape((c,) + tuple(g))
+            for q in range(3):
+                P = torch.tensordot(P, Vq[q], dims=([1], [0]))
+            G[lo:hi] = P[(slice(None), S[0], S[1], S[2])]
+        self.G = (0.5 * (G + G.t())).contiguous()
+        if getattr(self, "_bad_host", None) is None:
+            self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._bad_host[0] = 0
+        rc = _hip.lib().wiski_twolevel_refresh_f32(self.grid.ref, None, ctypes.c_int64(0), None, _hip.dptr(self.Vtab), ctypes.c_int32(self.kw),
+                                                    _hip.dptr(self.S), ctypes.c_int32(r), _hip.dptr(self.lam_unit), ctypes.c_double(self.kscale),
+                                                    ctypes.c_double(1.0), _hip.dptr(self.G), _hip.dptr(self.work), ctypes.c_int64(self.work.numel()),
+                                                    _hip.dptr(self.N[0]), None, None, _hip.stream_ptr(dev))
+        _hip.check(rc, "wiski_twolevel_refresh")
+        self.active = 0
+        self.struct.d_N = self.N[0].data_ptr()
+        self.in_flight = None
+        self.weight_at_launch = weight
+        self.refreshes += 1
+        self.rebuilt = True
+
     def tick(self, step, lag, lockstep=False):
         """Switch a finished refresh in.  lockstep (replicas that must take identical iterations): exactly `lag` steps after it was
         launched, waiting for it if need be.  Otherwise: as soon as it is found complete (no wait), at the latest 4 `lag` steps on.
@@ -208,6 +249,8 @@ class TwoLevelTracker:
         self.switched = False      # the last for_step() switched a new block in
         self.seen_iters = []       # CG iterations of the first warm steps under the separable model alone (the gate below)
         self.last_q = 0
+        self.wanted = False        # the gate has opened once for this stream (survives lose(): see rebuild())
+        self.rebuilds = 0
 
     def reset(self):
         self.__init__()
@@ -222,6 +265,29 @@ class TwoLevelTracker:
 
     def lose(self):
         self.pending, self.pending_n, self.covered, self.block, self.block_key = [], 0, False, None, None
+
+    def rebuild(self, grid, device, pst, kscale, stencil, weight, err):
+        """A block for the eigenbasis of `pst` straight from the statistics (TwoLevelBlock.rebuild_from_stencil): for streams the gate
+        has opened for, when the block was lost to a hyper-parameter step / a density-profile re-solve / points that bypassed the
+        tracker.  Every absorbed point is in the stencil, so the tracker is whole again afterwards.  Returns the struct, or None."""
+        if not self.wanted or pst is None or "eig_host" not in pst or settings.two_level_rebuild.off():
+            return None
+        blk = TwoLevelBlock(grid, device, pst["eig_host"], kscale, settings.two_level_rank.value(), err)
+        blk.rebuild_from_stencil(stencil, weight)
+        self.block, self.block_key, self._eig_ref = blk, (id(pst["eig"][0]), float(kscale), settings.two_level_rank.value()), pst["eig"]
+        self.pending, self.pending_n, self.covered = [], 0, True
+        self.rebuilds += 1
+        return blk.struct
+
+    def current(self, pst, kscale):
+        """The block as it stands, for a solve that is not a streaming step (variance / probe / fantasy columns; any number of
+        columns up to the block's scratch): its struct if one is active for exactly this eigenbasis, else None.  No side effects --
+        the refresh pipeline moves with for_step() only; points still pending cost such a solve iterations, nothing else."""
+        blk = self.block
+        if (blk is None or not self.covered or blk.failed or blk.active < 0 or pst is None or "eig" not in pst or
+                self.block_key != (id(pst["eig"][0]), float(kscale), settings.two_level_rank.value())):
+            return None
+        return blk.struct
 
     def for_step(self, grid, device, pst, kscale, weight, err, lockstep=False, last_iters=0, subsample=None):
         """Called once per fast streaming step, after its batch was noted: returns the TwoLevelStruct to solve with (or None)
@@ -247,6 +313,7 @@ class TwoLevelTracker:
                     self.lose()                         # decided: not needed for this stream (stops the hoarding of points)
                 return None
             self.block = TwoLevelBlock(grid, device, pst["eig_host"], kscale, settings.two_level_rank.value(), err)
+            self.wanted = True
             self.block_key = key
             self._eig_ref = pst["eig"]          # keeps the id in the key from being recycled
         blk = self.block

@@ -503,9 +503,35 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if self._use_dense():
             return DenseInducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, grid_ops.kron_eigen(self._grid, tcol))
         eig, shift = self._precond(o, tcol)
-        return InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
+        post = InducingPosterior(self._grid, _wtw_ops(self._kernel_cache["WtW"])[o], tcol, 1.0 / s2, _default_tol(self._dtype),
                                  settings.max_cg_iterations.value(), workspace=self._pcg_ws, check_every=settings.cg_check_every.value(),
                                  eigen=eig, shift=shift, err=self._err)
+        # the exact block of the two-level preconditioner, where the stream keeps one for this eigenbasis: every solve through this
+        # operator that names no block of its own asks for it when it runs (the operator outlives many streaming steps)
+        if o == 0:
+            import weakref
+
+            ref = weakref.ref(self)
+            post.two_level_provider = lambda op, k: (ref()._two_level_for_solve(op, k) if ref() is not None else None)
+        return post
+
+    def _two_level_for_solve(self, post, k):
+        """The stream's two-level block for a solve of k columns through `post` (variances, probes, fantasies: 15 -> 4-5 iterations
+        per 64-column solve on the road-like stream): the tracker's block if it belongs to the operator's
+        eigenbasis; where it was lost (hyper-parameter step, profile re-solve, points behind the tracker's back) and the solve is
+        wide, a block rebuilt from the statistics (settings.two_level_rebuild)."""
+        tr = self.__dict__.get("_two_level") if self._two_level_applies() else None
+        if tr is None:
+            return None
+        pst = self._memo.get("precond", {}).get(0)
+        if pst is None or pst.get("eig") is not post.eigen:
+            return None
+        tl = tr.current(pst, post.kscale)
+        if tl is None and k >= 16 and tr.wanted:
+            tl = tr.rebuild(self._grid, self._device, pst, post.kscale, post.wtw.stencil, float(self._wsum[0]), self._err)
+            if tl is not None:
+                self._poll_hint_sticky = 2                   # a new block: the next warm steps poll after 2 iterations (as _two_level_step)
+        return tl
 
     # ------------------------------------------------------- stencil shard --
     def enter_stencil_shard(self, rank, world, allreduce, allreduce_full=None, comm=None):

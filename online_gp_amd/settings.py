@@ -229,6 +229,16 @@ class two_level_rank(_value_context):
     _global_value = 192
 
 
+class two_level_rebuild(_feature_flag):
+    """Where the stream's two-level block was lost -- a hyper-parameter step or a density-profile re-solve moved the eigenbasis, points
+    reached the statistics behind the tracker's back -- rebuild it from the statistics themselves (X_S^T A X_S: r stencil-product columns,
+    ~1.5 ms at 50^3) the next time a WIDE solve (>= 16 columns: variances, probes, fantasies) asks for it.  The reference's per-batch
+    loop on the PCG path (evaluate -> Adam step -> condition) then pays one rebuild per step and saves two thirds of the iterations of
+    every 64-column solve in it."""
+
+    _state = True
+
+
 class two_level_min_iters(_value_context):
     """The two-level block is built only for streams whose first warm steps need at least this many CG iterations under the
     separable density model alone (uniform-like streams converge in 2-3 and never pay for it)."""

@@ -35,18 +35,20 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     import ctypes
     import subprocess
 
-    from online_gp_amd import _hip
+    from online_gp_amd import _hip, grid_ops
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "wiski.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(wiski_grid), sizeof(wiski_hyper_param), sizeof(wiski_hyper_plan), '
-                   'offsetof(wiski_hyper_param, upper), sizeof(wiski_copy_plan), offsetof(wiski_copy_plan, scalar), offsetof(wiski_copy_plan, scalar_dst)); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(wiski_grid), sizeof(wiski_hyper_param), sizeof(wiski_hyper_plan), '
+                   'offsetof(wiski_hyper_param, upper), sizeof(wiski_copy_plan), offsetof(wiski_copy_plan, scalar), offsetof(wiski_copy_plan, scalar_dst), '
+                   'sizeof(wiski_twolevel), offsetof(wiski_twolevel, d_mc), offsetof(wiski_twolevel, mc_cols)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_hip.wiski_grid), ctypes.sizeof(_hip.wiski_hyper_param), ctypes.sizeof(_hip.wiski_hyper_plan), _hip.wiski_hyper_param.upper.offset,
-            ctypes.sizeof(_hip.wiski_copy_plan), _hip.wiski_copy_plan.scalar.offset, _hip.wiski_copy_plan.scalar_dst.offset]
+            ctypes.sizeof(_hip.wiski_copy_plan), _hip.wiski_copy_plan.scalar.offset, _hip.wiski_copy_plan.scalar_dst.offset,
+            ctypes.sizeof(grid_ops.TwoLevelStruct), grid_ops.TwoLevelStruct.d_mc.offset, grid_ops.TwoLevelStruct.mc_cols.offset]
     assert got == want, (got, want)
 
 

@@ -71,6 +71,62 @@ def test_slab_kernel_block_against_numpy(g, rank, profiled):
     assert np.abs(y0.cpu().numpy() - y_sep).max() < 2e-4 * np.abs(y_sep).max()
 
 
+@pytest.mark.parametrize("g,rank,profiled,k", [((12, 8, 16), 40, True, 2), ((20, 20, 20), 96, False, 7), ((50, 50, 50), 192, True, 64)])
+def test_block_in_the_multi_column_kernels_against_numpy(g, rank, profiled, k):
+    """wiski_precond_apply_cols with a wiski_twolevel (k > 1 columns: k_tl_block_mc in front of k_spec_slab_mfma_mc<.., TL>, no exchange
+    words): every column's y, t and rho against the same numpy form as the one-column test, and against the one-column kernel."""
+    from online_gp_amd import grid_ops
+    from online_gp_amd.lazy import two_level as tlm
+
+    rng = np.random.default_rng(11)
+    gb = [[-1.1, 1.1]] * 3
+    grid = grid_ops.GridSpec(gb, list(g))
+    tcol = torch.as_tensor(np.concatenate(_toeplitz_cols(g, grid.h, 0.5)), device=DEV, dtype=torch.float32)
+    profiles = [np.clip(0.2 + rng.uniform(0, 1, gq), 1e-2, None) for gq in g] if profiled else None
+    host = {}
+    eig = grid_ops.kron_eigen(grid, tcol, profiles=profiles, host_out=host)
+    kscale, shift = 1.3, 2.5
+    blk = tlm.TwoLevelBlock(grid, torch.device(DEV), host, kscale, rank, None)
+    r_ = blk.r
+    A = rng.standard_normal((r_, r_))
+    N = (A @ A.T / r_ + np.diag(rng.uniform(0.5, 2.0, r_))) * 0.3
+    blk.N[0].copy_(torch.as_tensor(N, dtype=torch.float32))
+    X = [h.astype(np.float32).astype(np.float64) for h in host["X"]]
+    Dq = [d.astype(np.float32).astype(np.float64) for d in host["D"]]
+    Z = X if profiles is None else [np.asarray(p)[:, None] * x for p, x in zip(profiles, host["X"])]
+    Z = [z.astype(np.float32).astype(np.float64) for z in Z]
+    m = int(np.prod(g))
+    R = rng.standard_normal((k, m)) * rng.uniform(0.1, 10.0, (k, 1))
+    Rd = torch.as_tensor(R, device=DEV, dtype=torch.float32)
+    Y, T, rho = grid_ops.precond_apply_cols(grid, eig, kscale, shift, Rd, two_level=blk.struct)
+    Y0, T0, rho0 = grid_ops.precond_apply_cols(grid, eig, kscale, shift, Rd)             # separable model only
+    torch.cuda.synchronize()
+    lam = kscale * np.einsum("i,j,k->ijk", *Dq)
+    f1 = 1.0 / (1.0 + shift * lam)
+    i0, i1, i2 = blk.idx_host
+    for c_ in ([0, 1] if k == 2 else [0, k // 2, k - 1]):
+        c = np.einsum("ai,bj,ck,abc->ijk", X[0], X[1], X[2], R[c_].reshape(g), optimize=True)
+        cy, ct = c * lam * f1, c * f1
+        y_sep = np.einsum("ai,bj,ck,ijk->abc", X[0], X[1], X[2], cy, optimize=True).reshape(-1)
+        assert np.abs(Y0[c_].cpu().numpy() - y_sep).max() < 2e-4 * np.abs(y_sep).max()
+        ns = N @ c[i0, i1, i2]
+        cy[i0, i1, i2] = ns
+        ct[i0, i1, i2] = ns / lam[i0, i1, i2]
+        y_ref = np.einsum("ai,bj,ck,ijk->abc", X[0], X[1], X[2], cy, optimize=True).reshape(-1)
+        t_ref = np.einsum("ai,bj,ck,ijk->abc", Z[0], Z[1], Z[2], ct, optimize=True).reshape(-1)
+        assert np.abs(Y[c_].cpu().numpy() - y_ref).max() < 2e-4 * np.abs(y_ref).max(), c_
+        assert np.abs(T[c_].cpu().numpy() - t_ref).max() < 2e-4 * np.abs(t_ref).max(), c_
+        assert abs(float(rho[c_]) - float((c * cy).sum())) < 1e-4 * abs(float((c * cy).sum()))
+        y1, t1, rho1 = grid_ops.precond_apply(grid, eig, kscale, shift, Rd[c_].contiguous(), two_level=blk.struct)
+        assert (Y[c_] - y1).abs().max() < 1e-5 * y1.abs().max() and (T[c_] - t1).abs().max() < 1e-5 * t1.abs().max()
+        assert abs(float(rho[c_]) - float(rho1)) < 1e-5 * abs(float(rho1))
+    # more columns than the block's scratch holds: refused, not silently solved without the block
+    if k == 2:
+        blk.struct.mc_cols = 1
+        with pytest.raises(RuntimeError):
+            grid_ops.precond_apply_cols(grid, eig, kscale, shift, Rd, two_level=blk.struct)
+
+
 def _clustered(n, seed):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -127,6 +183,110 @@ def test_block_follows_the_stream_and_cuts_the_iterations():
     Gdev = blk.G.cpu().numpy()
     for k_, j in enumerate(js):
         assert np.abs(Gdev[j] - Gcol[k_]).max() < 2e-4 * np.abs(Gdev).max(), j
+
+
+def test_variance_columns_on_a_rough_kernel_take_the_block_and_match_the_fp64_port():
+    """A Matern-1/2 prior on the 50^3 grid has no spectral gap: variances are 64-column PCG solves (no spectral Woodbury factor).  On
+    the road-like stream those solves take the two-level block in its multi-column form; the variances against the fp64 CPU port
+    (oracle/baseline.py) and the iteration count against the separable preconditioner alone."""
+    from oracle import baseline
+    from online_gp_amd import settings
+    from online_gp_amd.kernels import MaternKernel, ScaleKernel
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    n0, q, steps = 20000, 4096, 12
+    X, y = _clustered(n0 + steps * q, 0)
+    Xq, _ = _clustered(64, 99)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    out = {}
+    for on in (True, False):
+        with settings.two_level_preconditioner(on), settings.cg_tolerance(1e-5), settings.skip_posterior_variances(True), settings.deferred_refresh(True), \
+                settings.deferred_bounds_check(True), torch.no_grad():
+            m = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], None, covar_module=ScaleKernel(MaternKernel(nu=0.5, ard_num_dims=3)), grid_bounds=gb, grid_size=50,
+                                      learn_additional_noise=True).eval()
+            m.prediction_cache
+            for s in range(steps):
+                sl = slice(n0 + s * q, n0 + (s + 1) * q)
+                m.stream_step(X[sl], y[sl])
+            m._finish_pending()
+            with settings.skip_posterior_variances(False):
+                var = m(Xq).variance.double().cpu().numpy()
+            post = m.prediction_cache["pred_cov"]
+            out[on] = (var, post.last_iters, post.last_two_level is not None, m)
+    (v_on, it_on, has_on, m), (v_off, it_off, has_off, _) = out[True], out[False]
+    assert has_on and not has_off
+    assert m._spectral_state(0) is None                       # no factor for this kernel: the PCG path served the request
+    assert it_on <= it_off, (it_on, it_off)        # (no spectral gap: 192 modes are a small part of what the data inform -- 29 against 31)
+    ell = m.covar_module.base_kernel.base_kernel.lengthscale.detach().reshape(-1).double().cpu().numpy()
+    osc = float(m.covar_module.base_kernel.outputscale.detach())
+    B = baseline.StreamingBaseline([[-1.1, 1.1]] * 3, 50, kind="matern12", lengthscale=ell, outputscale=osc, sigma2=float(m._sigma2(0)), dtype=np.float64)
+    B.absorb(X.double().cpu().numpy(), y[:, 0].double().cpu().numpy())
+    want = B.variance(Xq.double().cpu().numpy()[:16])
+    for name, v in (("two-level", v_on), ("separable", v_off)):
+        dv = np.max(np.abs(v[:16] - want) / want)
+        print(f"Matern-1/2 50^3 road-like, 16 variances, {name}: {dv:.2e} (iterations {it_on if name == 'two-level' else it_off})")
+        assert dv <= 1e-2
+
+
+def test_block_is_rebuilt_from_the_statistics_after_a_hyper_step():
+    """A hyper-parameter step moves the eigenbasis and the tracker loses its block (G lives in the old basis).  The next WIDE solve
+    rebuilds it from the stencil (settings.two_level_rebuild): G = X_S^T A X_S by that route equals the Gram matrix of ALL absorbed
+    points projected on the new basis (the streaming route), the 64-column variance solve takes far fewer iterations than under the
+    separable model, the variances agree with a tight separable solve, and the stream continues on the rebuilt block."""
+    from online_gp_amd import grid_ops, settings
+    from online_gp_amd.lazy import two_level as tlm
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    g, q, steps = 24, 452, 24
+    n0 = 2400
+    X, y = _clustered(n0 + (steps + 6) * q, 0)
+    Xq, _ = _clustered(64, 99)
+    gb = torch.tensor([[-1.1, 1.1]] * 3)
+    with settings.two_level_rank(128), settings.skip_posterior_variances(True), settings.cg_tolerance(1e-5), settings.deferred_refresh(True), \
+            settings.deferred_bounds_check(True), settings.spectral_factor(False), torch.no_grad():
+        m = FixedNoiseOnlineSKIGP(X[:n0], y[:n0], None, grid_bounds=gb, grid_size=g, learn_additional_noise=True).eval()
+        m.prediction_cache
+        for s in range(steps):
+            sl = slice(n0 + s * q, n0 + (s + 1) * q)
+            m.stream_step(X[sl], y[sl])
+        m._finish_pending()
+        tr = m.__dict__["_two_level"]
+        assert tr.block is not None and tr.wanted
+        m.covar_module.base_kernel.base_kernel.lengthscale = m.covar_module.base_kernel.base_kernel.lengthscale.detach() * 0.9       # the hyper step
+        m._memo.pop("prediction_cache", None)
+        m.prediction_cache                                   # warm generic refresh: the tracker sees the new basis and gives up
+        assert tr.block is None and not tr.covered
+        with settings.skip_posterior_variances(False):
+            var = m(Xq).variance.double().cpu().numpy()
+        post = m.prediction_cache["pred_cov"]
+        it_block = post.last_iters
+        assert tr.rebuilds == 1 and tr.block is not None and tr.covered and post.last_two_level is not None
+        blk = tr.block
+        # the same G from the points: every absorbed point projected on the block's basis
+        n_seen = n0 + steps * q
+        ref = tlm.TwoLevelBlock(m._grid, torch.device(DEV), m._memo["precond"][0]["eig_host"], post.kscale, 128, None)
+        ref.launch_refresh([(X[:n_seen].contiguous(), None)], 0, float(n_seen))
+        ref.finish()
+        torch.cuda.synchronize()
+        Gs, Gp = blk.G.cpu().numpy(), ref.G.cpu().numpy()
+        assert np.abs(Gs - Gp).max() < 5e-4 * np.abs(Gp).max(), np.abs(Gs - Gp).max() / np.abs(Gp).max()
+        # against the separable model alone
+        with settings.two_level_rebuild(False), settings.two_level_preconditioner(False), settings.skip_posterior_variances(False):
+            m._memo.pop("prediction_cache", None)
+            var0 = m(Xq).variance.double().cpu().numpy()
+            it_sep = m.prediction_cache["pred_cov"].last_iters
+        assert np.abs(var - var0).max() < 2e-3 * var0.max()
+        assert it_block <= it_sep - 3, (it_block, it_sep)
+        # the stream goes on with the rebuilt block
+        m._memo.pop("prediction_cache", None)
+        m.prediction_cache
+        its = []
+        for s in range(steps, steps + 6):
+            sl = slice(n0 + s * q, n0 + (s + 1) * q)
+            m.stream_step(X[sl], y[sl])
+            its.append(m._last_iters[0])
+        m._finish_pending()
+        assert tr.block is blk and tr.covered and np.mean(its[2:]) <= 4.0, its
 
 
 def test_generic_refresh_takes_the_block_too():
