@@ -91,6 +91,7 @@ class TwoLevelBlock:
         self.Vtab = torch.as_tensor(np.concatenate([t.reshape(-1) for t in tabs])).to(device)
         S = np.stack([len(D[q]) - 1 - idx[q] for q in range(3)]).astype(np.int32)
         self.S = torch.as_tensor(S).to(device).contiguous()
+        self._S_long = self.S.long()
         self.lam_unit = torch.as_tensor(lam / kscale).to(device)         # eigenvalues of kron D (kscale applied by wiski_woodbury_c)
         self.kscale = float(kscale)
         self.G = torch.zeros((r, r), dtype=torch.float64, device=device)
@@ -167,29 +168,49 @@ class TwoLevelBlock:
         self.weight_at_launch = weight
         self.refreshes += 1
 
+    def rebase(self, eig_host, kscale):
+        """The same index set S on a NEW eigenbasis (a hyper-parameter step moved the tables a little: the r modes of largest
+        eigenvalue are nearly the same ones, and any S gives a symmetric positive definite preconditioner): new eigenvector tables
+        and eigenvalues, G and N to be rebuilt by the caller -- two host-to-device copies instead of a new block."""
+        X, D = eig_host["X"], eig_host["D"]
+        idx = self.idx_host
+        lam = np.ones(self.r)
+        for q in range(3):
+            lam = lam * D[q][idx[q]]
+        tabs = [np.ascontiguousarray(X[q][:, ::-1][:, :self.kw]) for q in range(3)]
+        self.Vtab.copy_(torch.as_tensor(np.concatenate([t.reshape(-1) for t in tabs])))
+        self.lam_unit.copy_(torch.as_tensor(lam))
+        self.kscale = float(kscale)
+        self.active, self.in_flight, self.failed = -1, None, False
+        self.rebases = getattr(self, "rebases", 0) + 1
+
     def rebuild_from_stencil(self, stencil, weight):
         """G = X_S^T A X_S from the statistics themselves (r stencil-product columns in chunks of 64 + d mode products each), N from it,
         on the CURRENT stream, switched in at once: what a block costs where no history of points in this eigenbasis exists -- after a
         hyper-parameter step, a handed-over kernel cache, an all-reduced statistics delta (~1.5 ms at 50^3, r = 192; the streaming
         refresh pipeline then continues from it)."""
         g, dev, r = self.grid.g, self.device, self.r
+        torch.cuda.current_stream(dev).wait_stream(self.side)     # (a refresh of an earlier block may still be using the shared workspace)
         Vq, o = [], 0
         for q in range(3):
-            Vq.append(self.Vtab[o:o + g[q] * self.kw].reshape(g[q], self.kw))
+            Vq.append(self.Vtab[o:o + g[q] * self.kw].reshape(g[q], self.kw).float())
             o += g[q] * self.kw
-        S = self.S.long()
-        G = torch.empty((r, r), dtype=torch.float64, device=dev)
-        for lo in range(0, r, 64):
-            hi = min(lo + 64, r)
+        S = self._S_long
+        # (fp32 throughout: G only preconditions; all r columns in one pass where they fit in 256 MB, else in chunks of 64)
+        step = r if r * self.grid.m * 4 <= (1 << 28) else 64
+        G = torch.empty((r, r), dtype=torch.float32, device=dev)
+        for lo in range(0, r, step):
+            hi = min(lo + step, r)
             c = hi - lo
             Bc = Vq[0][:, S[0, lo:hi]].t()
             for q in (1, 2):
                 Bc = Bc.reshape(c, -1, 1) * Vq[q][:, S[q, lo:hi]].t().reshape(c, 1, -1)
-            AB = grid_ops.stencil_spmv(self.grid, stencil, Bc.reshape(c, self.grid.m).to(torch.float32).contiguous())
-            P = AB.double().reshape((c,) + tuple(g))
+            AB = grid_ops.stencil_spmv(self.grid, stencil, Bc.reshape(c, self.grid.m).contiguous())
+            P = AB.reshape((c,) + tuple(g))
             for q in range(3):
                 P = torch.tensordot(P, Vq[q], dims=([1], [0]))
             G[lo:hi] = P[(slice(None), S[0], S[1], S[2])]
+        G = G.double()
         self.G = (0.5 * (G + G.t())).contiguous()
         if getattr(self, "_bad_host", None) is None:
             self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -264,6 +285,8 @@ class TwoLevelTracker:
             self.lose()
 
     def lose(self):
+        if self.block is not None and not self.block.failed:
+            self._spare = self.block                   # rebuild() may put it on the next eigenbasis (TwoLevelBlock.rebase)
         self.pending, self.pending_n, self.covered, self.block, self.block_key = [], 0, False, None, None
 
     def rebuild(self, grid, device, pst, kscale, stencil, weight, err):
@@ -272,7 +295,13 @@ class TwoLevelTracker:
         tracker.  Every absorbed point is in the stencil, so the tracker is whole again afterwards.  Returns the struct, or None."""
         if not self.wanted or pst is None or "eig_host" not in pst or settings.two_level_rebuild.off():
             return None
-        blk = TwoLevelBlock(grid, device, pst["eig_host"], kscale, settings.two_level_rank.value(), err)
+        blk = getattr(self, "_spare", None)
+        self._spare = None
+        if (blk is not None and blk.grid is grid and blk.r == min(settings.two_level_rank.value(), MAXR) and getattr(blk, "rebases", 0) % 32 != 31
+                and (blk.in_flight is None or blk.in_flight[0].query())):
+            blk.rebase(pst["eig_host"], kscale)        # (every 32nd time the modes are selected afresh)
+        else:
+            blk = TwoLevelBlock(grid, device, pst["eig_host"], kscale, settings.two_level_rank.value(), err)
         blk.rebuild_from_stencil(stencil, weight)
         self.block, self.block_key, self._eig_ref = blk, (id(pst["eig"][0]), float(kscale), settings.two_level_rank.value()), pst["eig"]
         self.pending, self.pending_n, self.covered = [], 0, True

@@ -62,3 +62,12 @@ with settings.cg_tolerance(TOL), settings.skip_posterior_variances(True), settin
             U2, Z2 = post.solve_columns(Wt, two_level=tl)
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         print(f"tol {tol:g} 64 columns, two-level: iterations {post.last_iters}  median {np.median(ts) * 1e3:.3f} ms   max |dU| / max |U| = {float((U2 - U).abs().max() / U.abs().max()):.2e}")
+    # what a rebuild from the statistics costs (settings.two_level_rebuild: after a hyper-parameter step)
+    pst = m._memo["precond"][0]
+    for rep in range(3):
+        tr.lose()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tl2 = tr.rebuild(m._grid, dev, pst, post.kscale, post.wtw.stencil, float(m._wsum[0]), m._err)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(f"rebuild from the stencil: host {1e3 * (t1 - t0):.3f} ms, until the device is done {1e3 * (t2 - t0):.3f} ms")
