@@ -50,6 +50,9 @@
 // not move (delay 0..18: 17.7..18.1; 5 / 6 parts 19.1 / 19.9; ring depth 3: 26.5); issuing the v windows before the first A_h tile instead of after
 // it changes nothing, back to back or inside the solver (17.5..17.9 either way on one box, trace means 17.9..18.25).  Taken while A_h is Infinity-Cache resident (<= 192 MB; solve.hip: sym_xcd_map -- a stencil that streams from HBM prefers ONE interleaved address stream); WISKI_SYM_XCD=0 / 1 forces the plain / contiguous mapping, also for the LDS-window kernel k_stencil_spmv4_sym.
 //
+// Round 5: the four parts of a row block as the four waves of ONE workgroup (489 workgroups to dispatch and retire instead of 1 956; waves still
+// independent, own LDS slices): 17.65 / 17.87 us against 17.63 / 18.33 back to back, 20.10 against 20.19 us per dispatch in bench.py -- nothing; not kept.
+//
 // Requires d == 3, m % 4 == 0.  part holds (nparts + 1) * m reals: part[y] = direct term of part y (plain stores),
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
 #pragma once
