@@ -210,7 +210,7 @@ int wiski_pcg_f64(const wiski_grid* grid, const double* d_A_st, const double* d_
  * is called -- in place, SUM, d_dots fp64, must be ordered after the work already queued on `stream` and before what is
  * queued next (tests route it through another transport).  One right-hand side, half stencil, m % 4 == 0; any d, fp32 and fp64
  * (d = 3 fp32: the LDS-DMA kernel on a part table; otherwise the LDS-window kernel on the replica's group range); the RCCL route
- * (comm != NULL) sums fp32 vectors only. */
+ * (comm != NULL) sums the vector in its own precision (ncclFloat32 / ncclFloat64). */
 typedef int (*wiski_allreduce_fn)(void* ctx, void* d_vec, int64_t n_vec, int32_t elem_bytes, double* d_dots, int64_t n_dots, void* stream);
 typedef struct wiski_shard {
   int32_t rank, nranks;

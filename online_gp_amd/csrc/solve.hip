@@ -1960,7 +1960,6 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
   if (sharded) {
     if (!sym || !wide || k != 1 || shard->rank < 0 || shard->rank >= shard->nranks) return WISKI_E_BADARG;
     if (!shard->comm && !shard->allreduce) return WISKI_E_BADARG;
-    if (shard->comm && sizeof(real) != 4) return WISKI_E_BADARG;      // (the in-C RCCL route sums fp32 vectors; fp64 shards use the callback)
     shard_group_range(sym_groups(G.d), shard->rank, shard->nranks, &sh_lo, &sh_hi);   // may be empty (more ranks than groups): zeros
     sh_dma = sym_use_dma<real>(G, k);
     if (sh_dma) shard_parts_d3(sh_lo, sh_hi, &stab);
@@ -1988,7 +1987,7 @@ static int pcg_impl(const wiski_grid* grid, const real* d_A, const real* d_tcol,
     const int64_t nd = dots ? (int64_t)k * PCG_DOT_COL : 0;
     if (shard->comm) {
       if constexpr (sizeof(real) == 4) return wiski_allreduce_stats_f32(shard->comm, nullptr, 0, (float*)hp, m, nullptr, 0, dots, nd, s);
-      else return WISKI_E_BADARG;
+      else return wiski_allreduce_stats_f64(shard->comm, nullptr, 0, (double*)hp, m, nullptr, 0, dots, nd, s);
     }
     return shard->allreduce(shard->ctx, hp, (int64_t)m, (int32_t)sizeof(real), dots, nd, s);
   };

@@ -265,11 +265,11 @@ class ShardedStatsUpdater:
         import os
 
         want = os.environ.get("WISKI_SHARD_TRANSPORT", "torch")
-        if want == "rccl" and dist.get_backend(group) == "nccl" and not gloo_cuda and m._dtype == torch.float32:      # (the C route sums fp32 vectors)
+        if want == "rccl" and dist.get_backend(group) == "nccl" and not gloo_cuda:
             if getattr(self, "_shard_comm", None) is None:
                 sc = RcclCommunicator(group)
                 # (sums of small integers: exact in fp32 / fp64 whatever the reduction order)
-                probe = torch.arange(1, 1025, dtype=torch.float32, device=m._device) * (1 + dist.get_rank(group))
+                probe = torch.arange(1, 1025, dtype=m._dtype, device=m._device) * (1 + dist.get_rank(group))
                 pb, ps = probe[:16].clone(), probe[:4].double()
                 refs = [t.clone() for t in (probe, pb, ps)]
                 for t in refs:

@@ -542,13 +542,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         SUM over the ranks of the two tensors (dots may be None); `allreduce_full(t)`: the same for one large tensor, used
         when a consumer needs the whole stencil again (leave_stencil_shard).  `comm`: an ncclComm_t (wiski_comm_*) -- the per-product
         all-reduce is then issued from C on the solve's stream (one grouped RCCL launch, no re-entry into Python); a single rank
-        with a communicator owns every group and still takes that path (fp32 only; fp64 replicas use the callback).  Returns False
+        with a communicator owns every group and still takes that path (both precisions).  Returns False
         where the sharded step does not apply (then nothing changes): one output, native half stencil, m % 4 == 0, a grid beyond the
         dense regime.  Any d and both precisions: the d = 3 fp32 products run on the LDS-DMA kernel's part table, all others on
         the LDS-window kernel restricted to the replica's group range."""
         op = _wtw_ops(self._kernel_cache["WtW"])[0]
-        if ((world <= 1 and not comm) or self.num_outputs != 1 or self._use_dense() or not op.is_half or self._grid.m % 4 or op.root is not None
-                or (comm and self._dtype != torch.float32)):
+        if (world <= 1 and not comm) or self.num_outputs != 1 or self._use_dense() or not op.is_half or self._grid.m % 4 or op.root is not None:
             return False
         if self.__dict__.get("_stencil_shard") is not None:
             return True
