@@ -25,6 +25,7 @@ timeout 200 python tools/bench_small_potrf.py 2>&1 | grep -v amdgpu > $O/small_p
 timeout 200 python tools/refstep_probe.py > $O/refstep_probe.txt 2>&1; tail -2 $O/refstep_probe.txt
 timeout 600 python tools/c4_probe.py 200 2>&1 | tail -2 > $O/c4.txt; cat $O/c4.txt
 bash tools/jobs/r5denseref.sh > /dev/null 2>&1; cp $R/gpurun_out/r5denseref/out.txt $O/dense_refstep.txt; head -10 $O/dense_refstep.txt
+timeout 300 python tools/tl_cold_probe.py 2>&1 | grep -v amdgpu > $O/tl_cold_probe.txt; grep "64 columns\|rebuild" $O/tl_cold_probe.txt
 bash tools/jobs/r5n2.sh > $O/n2.txt 2>&1; cp $R/gpurun_out/r5n2/out.txt $O/n2_out.txt; tail -3 $O/n2.txt
 python -c "
 import json; r=json.load(open('$O/bench.json')); e=r['extra']
