@@ -197,6 +197,8 @@ class InducingPosterior(_Operator):
         k = RHS.shape[0] if RHS.dim() > 1 else 1
         if two_level is None and self.two_level_provider is not None:
             two_level = self.two_level_provider(self, k)          # the stream's block for THIS eigenbasis as it stands now, or None
+        if two_level is not None and k > 1 and not (two_level.d_mc and k <= two_level.mc_cols):
+            two_level = None                                      # (a caller's block without room for k columns: the separable model alone)
         self.last_two_level = two_level
         ce = self.check_every
         if k >= 16 and k * self.grid.m >= (1 << 21):

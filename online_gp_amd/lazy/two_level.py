@@ -118,6 +118,12 @@ class TwoLevelBlock:
         self.weight_at_launch = 0.0
         self.refreshes = 0
 
+    def ensure_cols(self, k):
+        """Room in the multi-column scratch for a solve of k columns (grown on demand: settings.variance_chunk above 64)."""
+        if k > self.struct.mc_cols:
+            self.mc = torch.empty((2, int(k), self.r), dtype=torch.float32, device=self.device)
+            self.struct.d_mc, self.struct.mc_cols = self.mc.data_ptr(), int(k)
+
     # ------------------------------------------------------------------------------------------------- refresh --
     def launch_refresh(self, points, step, weight, gscale=1.0, subsample=None):
         """Queue, on the side stream: G += sum F^T diag(wa) F over `points` [(X, wa or None), ...], then N -> the spare buffer."""
@@ -308,7 +314,7 @@ class TwoLevelTracker:
         self.rebuilds += 1
         return blk.struct
 
-    def current(self, pst, kscale):
+    def current(self, pst, kscale, cols=1):
         """The block as it stands, for a solve that is not a streaming step (variance / probe / fantasy columns; any number of
         columns up to the block's scratch): its struct if one is active for exactly this eigenbasis, else None.  No side effects --
         the refresh pipeline moves with for_step() only; points still pending cost such a solve iterations, nothing else."""
@@ -316,6 +322,7 @@ class TwoLevelTracker:
         if (blk is None or not self.covered or blk.failed or blk.active < 0 or pst is None or "eig" not in pst or
                 self.block_key != (id(pst["eig"][0]), float(kscale), settings.two_level_rank.value())):
             return None
+        blk.ensure_cols(cols)
         return blk.struct
 
     def for_step(self, grid, device, pst, kscale, weight, err, lockstep=False, last_iters=0, subsample=None):

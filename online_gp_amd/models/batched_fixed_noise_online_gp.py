@@ -526,10 +526,11 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         pst = self._memo.get("precond", {}).get(0)
         if pst is None or pst.get("eig") is not post.eigen:
             return None
-        tl = tr.current(pst, post.kscale)
+        tl = tr.current(pst, post.kscale, cols=k)
         if tl is None and k >= 16 and tr.wanted:        # (8 or 1 columns: the q = 1 reference step on the PCG path 5.0 -> 5.2 / 6.4 ms: the rebuild costs more than narrow solves save)
             tl = tr.rebuild(self._grid, self._device, pst, post.kscale, post.wtw.stencil, float(self._wsum[0]), self._err)
             if tl is not None:
+                tr.block.ensure_cols(k)
                 self._poll_hint_sticky = 2                   # a new block: the next warm steps poll after 2 iterations (as _two_level_step)
         return tl
 

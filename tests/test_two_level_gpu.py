@@ -277,6 +277,13 @@ def test_block_is_rebuilt_from_the_statistics_after_a_hyper_step():
             it_sep = m.prediction_cache["pred_cov"].last_iters
         assert np.abs(var - var0).max() < 2e-3 * var0.max()
         assert it_block <= it_sep - 3, (it_block, it_sep)
+        # a wider chunk than the block's scratch was made for: the scratch grows, the solve still takes the block
+        with settings.skip_posterior_variances(False), settings.variance_chunk(128):
+            m._memo.pop("prediction_cache", None)
+            Xw, _ = _clustered(128, 98)
+            vw = m(Xw).variance
+            pw = m.prediction_cache["pred_cov"]
+        assert pw.last_two_level is not None and pw.last_two_level.mc_cols >= 128 and pw.last_iters <= it_block + 2 and bool(torch.isfinite(vw).all())
         # the stream goes on with the rebuilt block
         m._memo.pop("prediction_cache", None)
         m.prediction_cache
