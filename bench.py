@@ -379,8 +379,29 @@ def main():
     with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), settings.deferred_refresh(True), \
             torch.no_grad():
         # headline: the configured stream; N > 1: the exchange the cost model picks ("auto")
+        headline_ex, calib = "auto", None
+        if world > 1 and os.environ.get("WISKI_BENCH_EXCHANGE") in ("stencil", "points", "stats"):
+            headline_ex = os.environ["WISKI_BENCH_EXCHANGE"]
+        elif world > 1 and os.environ.get("WISKI_BENCH_NO_STENCIL_SHARD") != "1":
+            # N > 1: two exchanges can carry the step -- the stencil-sharded one (divides the absorb and every A p by N, pays one m-vector
+            # all-reduce per CG iteration) and the point exchange (no collective inside the solve; every rank absorbs all N q points
+            # with the owner-computes kernel).  Which is faster depends on the node's collective latency: three un-timed blocks of each
+            # (block times are MAX over ranks, so every rank sees the same numbers) decide which one the timed headline runs; both
+            # are timed again, the same way, in extra.updates_per_s_exchange_*
+            calib = {}
+            for ex in ("stencil", "points"):
+                try:
+                    _, _, bs, _, _, _ = run_stream(args.stream, ex, 3, 7, profile=False)
+                    calib[ex] = float(np.median(bs)) / K * 1e3
+                except Exception as exc:  # noqa: BLE001
+                    calib[ex] = None
+                    calib[ex + "_error"] = repr(exc)[:200]
+            ok = {k_: v_ for k_, v_ in calib.items() if isinstance(v_, float)}
+            headline_ex = min(ok, key=ok.get) if ok else "auto"
+            if calib.get("stencil") is None:
+                os.environ["WISKI_BENCH_NO_STENCIL_SHARD"] = "1"       # (the fallback below and the extras must not try it again)
         try:
-            model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=os.environ.get("WISKI_BENCH_NOSAMPLE") != "1")
+            model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, headline_ex, args.blocks, 0, profile=os.environ.get("WISKI_BENCH_NOSAMPLE") != "1")
             headline_note = None
         except Exception as exc:  # noqa: BLE001
             if world == 1:
@@ -410,6 +431,9 @@ def main():
                                              else "not built (the separable density model converges in < %g iterations on this stream)" % settings.two_level_min_iters.value())
         if headline_note:
             extra["headline_note"] = headline_note
+        if calib is not None:
+            extra["exchange_calibration_ms_per_step"] = calib
+            extra["exchange_chosen"] = headline_ex
 
         if world > 1 and not args.no_extras:
             try:                                   # same on every rank (deterministic legs): a failure is recorded, the headline line survives
