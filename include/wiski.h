@@ -434,6 +434,10 @@ int wiski_root_update_f64(int32_t m, int32_t r, int32_t q, double* d_L, int32_t 
  *                         sum_jj' Wt[j][j'] b_j^T (kron_q SymToeplitz(tcol_q)) b_j' w.r.t. tcol_q -- the MLL backward (BWM:19-51). */
 int wiski_basis_project_f32(const wiski_grid* grid, const float* d_x, int64_t n, const double* d_V, int32_t kmax, const int32_t* d_S, int32_t r, const float* d_scale, const double* d_colscale, const double* d_tcol, double* d_F, int64_t ldf, double* d_prior, int32_t* d_err, void* stream);
 int wiski_basis_project_f64(const wiski_grid* grid, const double* d_x, int64_t n, const double* d_V, int32_t kmax, const int32_t* d_S, int32_t r, const double* d_scale, const double* d_colscale, const double* d_tcol, double* d_F, int64_t ldf, double* d_prior, int32_t* d_err, void* stream);
+/* h[j] += sum_p F[p][j] t_p with t_p = d_wby[p] (/ d_scale[p] when the rows of F carry that scale; NULL: none): W^T D^-1 y of a batch in the
+ * basis of F (wiski_basis_project), the right-hand-side half of a streamed update of the spectral factor's statistics (BFN:160). */
+int wiski_basis_absorb_h_f32(int64_t n, int32_t r, const double* d_F, int64_t ldf, const float* d_wby, const float* d_scale, double* d_h, void* stream);
+int wiski_basis_absorb_h_f64(int64_t n, int32_t r, const double* d_F, int64_t ldf, const double* d_wby, const double* d_scale, double* d_h, void* stream);
 int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_Wt, const int32_t* d_S, const double* d_ev, double* d_D, void* stream);
 /* Dominant eigenvectors of the d symmetric-Toeplitz factors after a small change of their first columns, refined ON THE DEVICE from
  * the previous ones (no host eigh, no device-to-host copy): d_tcol [sum g] the new columns, d_Vin / d_Vout per-dim tables [g_q][kw]

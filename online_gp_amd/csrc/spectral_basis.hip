@@ -779,6 +779,37 @@ __global__ __launch_bounds__(1024) void k_tail_c(int r, const double* __restrict
   }
 }
 
+// h[j] += sum_p F[p][j] t_p, t_p = wby[p] (/ scale[p] when the rows of F carry a scale): the right-hand side of the statistics in the factor's
+// reference basis, after the batch's Gram update (was a framework element-wise op + a library gemv).  Columns over threads, points in chunks.
+template <typename real>
+__global__ __launch_bounds__(256) void k_absorb_h(int n, int r, const double* __restrict__ F, int64_t ldf, const real* __restrict__ wby,
+                                                  const real* __restrict__ scale, double* __restrict__ h) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int p0 = blockIdx.y * 64, p1 = p0 + 64 < n ? p0 + 64 : n;
+  if (j >= r) return;
+  double acc = 0;
+  for (int p = p0; p < p1; ++p) {
+    const double t = scale ? (double)wby[p] / (double)scale[p] : (double)wby[p];
+    acc += F[(int64_t)p * ldf + j] * t;
+  }
+  if (gridDim.y == 1) h[j] += acc;
+  else unsafeAtomicAdd(h + j, acc);
+}
+extern "C" int wiski_basis_absorb_h_f32(int64_t n, int32_t r, const double* d_F, int64_t ldf, const float* d_wby, const float* d_scale, double* d_h, void* stream) {
+  if (n < 0 || r < 1 || !d_F || !d_wby || !d_h || ldf < r || n > (int64_t)1 << 30) return WISKI_E_BADARG;
+  if (n == 0) return WISKI_OK;
+  hipLaunchKernelGGL((k_absorb_h<float>), dim3((unsigned)((r + 255) / 256), (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_F, ldf,
+                     d_wby, d_scale, d_h);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+extern "C" int wiski_basis_absorb_h_f64(int64_t n, int32_t r, const double* d_F, int64_t ldf, const double* d_wby, const double* d_scale, double* d_h, void* stream) {
+  if (n < 0 || r < 1 || !d_F || !d_wby || !d_h || ldf < r || n > (int64_t)1 << 30) return WISKI_E_BADARG;
+  if (n == 0) return WISKI_OK;
+  hipLaunchKernelGGL((k_absorb_h<double>), dim3((unsigned)((r + 255) / 256), (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (int)n, (int)r, d_F, ldf,
+                     d_wby, d_scale, d_h);
+  return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
 extern "C" int wiski_factor_tail(int32_t r_ref, int32_t r, const double* d_TS, const double* d_href, const double* d_sq, const double* d_Linv,
                                  const double* d_chol, double* d_out, void* stream) {
   if (r_ref < 1 || r < 1 || !d_TS || !d_href || !d_sq || !d_Linv || !d_chol || !d_out) return WISKI_E_BADARG;

@@ -35,10 +35,12 @@ is read back before the state is handed out; a failed verdict -- or every 64th s
 Then wiski_woodbury_c, wiski_potrf_inverse (one-workgroup Cholesky + explicit inverse for r <= 480) and wiski_factor_tail
 (DESIGN 3.9).
 """
+import ctypes
+
 import numpy as np
 import torch
 
-from .. import grid_ops, settings
+from .. import _hip, grid_ops, settings
 
 KMAX = 32
 GUARD = 6          # extra eigenvectors per dim carried for the device-side subspace iteration
@@ -349,8 +351,11 @@ class SpectralWoodburyFactor:
         sc = None if wa is None else wa.sqrt().contiguous()
         F = grid_ops.basis_project(self.grid, X, self.ref.Vtab, self.ref.kmax, self.ref.S, scale=sc, err=self.err)
         grid_ops.gemm(F, F, ta=True, alpha=1.0, beta=1.0, C=self.G_ref)
-        t = wby.double() if wa is None else wby.double() / sc.double()       # rows of F already carry sqrt(wa)
-        self.h_ref.addmv_(F.t(), t)
+        # h_ref += F^T t, t = wby (/ sqrt(wa): the rows of F already carry it) -- one small launch (wiski_basis_absorb_h)
+        wby = wby.contiguous()
+        rc = _hip.fn("wiski_basis_absorb_h", wby.dtype)(ctypes.c_int64(F.shape[0]), ctypes.c_int32(F.shape[1]), _hip.dptr(F), ctypes.c_int64(F.shape[1]),
+                                                        _hip.dptr(wby), _hip.dptr(sc), _hip.dptr(self.h_ref), _hip.stream_ptr(self.device))
+        _hip.check(rc, "wiski_basis_absorb_h")
         self.data_version += 1
         self.idle_absorbs += 1
 
