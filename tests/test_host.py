@@ -240,3 +240,22 @@ def test_dpp_broadcast_spmm_has_no_valu_to_dpp_hazard():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_dpp_hazards.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 hazards") == 4, r.stdout          # fp32 / fp64, with and without the p . Ap epilogue
+
+
+def test_two_level_mode_selection_is_the_top_of_the_tensor_product_spectrum():
+    """lazy/two_level.select_modes (host arithmetic): the r tensor-product modes of largest eigenvalue among the KMAX largest per dim,
+    returned in block order (sorted by i0, then i1, then i2) with their eigenvalues -- against a brute-force sort."""
+    from online_gp_amd.lazy import two_level as tlm
+
+    rng = np.random.default_rng(4)
+    D = [np.sort(rng.uniform(1e-6, 1.0, g) ** 3) for g in (12, 9, 40)]          # table order: ascending
+    for rank in (1, 17, 200):
+        idx, lam = tlm.select_modes(D, 2.5, rank)
+        r = idx.shape[1]
+        assert r == min(rank, 12 * 9 * min(40, tlm.KMAX), tlm.MAXR)
+        full = 2.5 * np.einsum("i,j,k->ijk", D[0], D[1], D[2])
+        assert np.allclose(lam, full[idx[0], idx[1], idx[2]], rtol=1e-14)
+        top = np.sort(full.reshape(-1))[::-1][:r]
+        assert np.allclose(np.sort(lam)[::-1], top, rtol=1e-14)
+        keys = idx[0] * 10 ** 6 + idx[1] * 10 ** 3 + idx[2]
+        assert np.all(np.diff(keys) > 0)                                          # block order, no mode twice
