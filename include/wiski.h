@@ -438,6 +438,15 @@ int wiski_basis_project_f64(const wiski_grid* grid, const double* d_x, int64_t n
  * basis of F (wiski_basis_project), the right-hand-side half of a streamed update of the spectral factor's statistics (BFN:160). */
 int wiski_basis_absorb_h_f32(int64_t n, int32_t r, const double* d_F, int64_t ldf, const float* d_wby, const float* d_scale, double* d_h, void* stream);
 int wiski_basis_absorb_h_f64(int64_t n, int32_t r, const double* d_F, int64_t ldf, const double* d_wby, const double* d_scale, double* d_h, void* stream);
+/* The spectral factor's refresh after a hyper-parameter step in ONE host call: wiski_basis_eig_update_adaptive (niter = 2, resid_ok = 1e300:
+ * wiski_basis_eig_update) -> wiski_basis_change -> G = T^T G_ref T -> wiski_woodbury_c -> wiski_potrf_inverse -> wiski_factor_tail, queued
+ * back to back on `stream` (OSR:113-146 refreshes its caches after every optimiser step; here that is seven kernels' worth of launches and no
+ * host work in between).  All products in one packed fp64 buffer d_out of off[14] doubles; off[0..13] (wiski_factor_refresh_layout) are the
+ * offsets of Vout, ev, resid, Tq, TS, lam_kuu, GT, G, chol (C factorised in place), sqG, lam, sq, Linv, tail (as wiski_factor_tail's d_out).
+ * nV = sum_q g_q kw; d_work / d_verdict as wiski_basis_change; d_info as wiski_potrf_inverse; verdict_event: NULL or a hipEvent_t recorded on
+ * `stream` right behind the change of basis (the verdict can then be read without waiting for the factorisation). */
+int wiski_factor_refresh_layout(int32_t d, int64_t nV, int32_t kw, int32_t r_ref, int32_t r, int64_t* off);
+int wiski_factor_refresh(int32_t d, const int32_t* d_g, int64_t nV, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse, const double* d_Vref, int32_t kref, int32_t niter, double resid_ok, const int32_t* d_Sref, const int32_t* d_S, int32_t r_ref, int32_t r, double* d_work, double* d_verdict, const double* d_Gref, const double* d_href, double kscale, int32_t* d_info, double* d_out, void* verdict_event, void* stream);
 int wiski_basis_pair_reduce(int32_t d, int32_t r, int32_t kmax, const double* d_Wt, const int32_t* d_S, const double* d_ev, double* d_D, void* stream);
 /* Dominant eigenvectors of the d symmetric-Toeplitz factors after a small change of their first columns, refined ON THE DEVICE from
  * the previous ones (no host eigh, no device-to-host copy): d_tcol [sum g] the new columns, d_Vin / d_Vout per-dim tables [g_q][kw]

@@ -1078,3 +1078,43 @@ extern "C" int wiski_spectral_evaluate_y_f64(int32_t n, int32_t r, const double*
                                              double* d_var, void* stream) {
   return spectral_evaluate_y_impl<double>(n, r, d_Y, d_F, d_prior, d_t, kscale, d_s2, d_y, d_err, d_ws, d_out, d_mean, d_var, stream);
 }
+
+// ------------------------------------------------ the factor's refresh after a hyper-parameter step, ONE host call ---
+// wiski_basis_eig_update_adaptive -> wiski_basis_change -> G = T^T G_ref T (two GEMMs) -> wiski_woodbury_c -> wiski_potrf_inverse ->
+// wiski_factor_tail, queued back to back (the same launches as the seven calls; the host-language wrapper made each of them cost
+// ~6-8 us of interpreter time in a step that is bound by exactly that).  Every product lives in ONE packed fp64 buffer whose layout both
+// sides compute with wiski_factor_refresh_layout: offsets (in doubles, multiples of 32) of
+//   0 Vout [nV]  1 ev [d kw]  2 resid [d]  3 Tq [d 32 32]  4 TS [r_ref r]  5 lam_kuu [r]  6 GT [r_ref r]  7 G [r r]  8 C -> chol [r r]
+//   9 sqG [r r]  10 lam [r]  11 sq [r]  12 Linv [r r]  13 tail [6 r + 2]  and the total in off[14].
+extern "C" int wiski_factor_refresh_layout(int32_t d, int64_t nV, int32_t kw, int32_t r_ref, int32_t r, int64_t* off) {
+  if (d < 1 || d > WISKI_MAX_DIM || nV < 1 || kw < 1 || r_ref < 1 || r < 1 || !off) return WISKI_E_BADARG;
+  const int64_t sz[14] = {nV, (int64_t)d * kw, d, (int64_t)d * 32 * 32, (int64_t)r_ref * r, r, (int64_t)r_ref * r, (int64_t)r * r, (int64_t)r * r,
+                          (int64_t)r * r, r, r, (int64_t)r * r, 6 * (int64_t)r + 2};
+  int64_t o = 0;
+  for (int i = 0; i < 14; ++i) {
+    off[i] = o;
+    o += (sz[i] + 31) / 32 * 32;
+  }
+  off[14] = o;
+  return WISKI_OK;
+}
+extern "C" int wiski_factor_refresh(int32_t d, const int32_t* d_g, int64_t nV, const double* d_tcol, const double* d_Vin, int32_t kw, int32_t kuse,
+                                    const double* d_Vref, int32_t kref, int32_t niter, double resid_ok, const int32_t* d_Sref, const int32_t* d_S,
+                                    int32_t r_ref, int32_t r, double* d_work, double* d_verdict, const double* d_Gref, const double* d_href,
+                                    double kscale, int32_t* d_info, double* d_out, void* verdict_event, void* stream) {
+  int64_t o[15];
+  if (int rc = wiski_factor_refresh_layout(d, nV, kw, r_ref, r, o)) return rc;
+  if (!d_g || !d_tcol || !d_Vin || !d_Vref || !d_Sref || !d_S || !d_work || !d_verdict || !d_Gref || !d_href || !d_info || !d_out) return WISKI_E_BADARG;
+  double *Vout = d_out + o[0], *ev = d_out + o[1], *resid = d_out + o[2], *Tq = d_out + o[3], *TS = d_out + o[4], *lamk = d_out + o[5], *GT = d_out + o[6],
+         *G = d_out + o[7], *C = d_out + o[8], *sqG = d_out + o[9], *lam = d_out + o[10], *sq = d_out + o[11], *Linv = d_out + o[12], *tail = d_out + o[13];
+  if (int rc = eig_update_launch(d, d_g, d_tcol, d_Vin, kw, kuse, Vout, ev, resid, d_Vref, kref, Tq, niter, resid_ok, stream)) return rc;
+  if (int rc = wiski_basis_change(d, d_g, kref, kw, r_ref, r, Tq, d_Sref, d_S, ev, d_tcol, resid, TS, lamk, d_work, d_verdict, stream)) return rc;
+  // (the verdict sits in the caller's pinned memory from here on: an event of the caller's marks the spot, so that reading it does not
+  //  wait for the factorisation behind it)
+  if (verdict_event && hipEventRecord((hipEvent_t)verdict_event, (hipStream_t)stream) != hipSuccess) return WISKI_E_LAUNCH;
+  if (int rc = wiski_gemm_f64(1, 0, r_ref, r, r_ref, 1.0, d_Gref, r_ref, TS, r, 0.0, GT, r, stream)) return rc;      // G_ref TS (G_ref symmetric)
+  if (int rc = wiski_gemm_f64(1, 0, r, r, r_ref, 1.0, TS, r, GT, r, 0.0, G, r, stream)) return rc;                    // T^T G_ref T
+  if (int rc = wiski_woodbury_c(r, G, lamk, kscale, C, lam, sq, sqG, stream)) return rc;
+  if (int rc = wiski_potrf_inverse_f64(r, C, r, Linv, r, d_info, stream)) return rc;
+  return wiski_factor_tail(r_ref, r, TS, d_href, sq, Linv, C, tail, stream);
+}

@@ -861,6 +861,41 @@ def basis_change(g_dev, Tq, kref, ref_S, kw, S, ev, tcol64, resid, work, verdict
     return TS, lam, verdict
 
 
+_REFRESH_LAYOUT = {}
+
+
+def factor_refresh(g_dev, tcol64, Vin, kw, kuse, ref_Vtab, kref, ref_S, S, work, verdict_pinned, G_ref, h_ref, kscale, info, resid_ok=None, verdict_event=None):
+    """``wiski_factor_refresh``: the spectral factor's whole refresh after a hyper-parameter step -- eigenvector update, change of basis
+    (+ verdict into pinned memory), G = T^T G_ref T, C, Cholesky + inverse, the tail products -- queued by ONE call into ONE packed buffer.
+    verdict_event: a torch.cuda.Event that has been recorded at least once (its handle exists); the call records it behind the change of basis.
+    Returns a dict of views: Vtab, ev [d, kw], TS, lam_kuu, G, chol, sqG, lam, sq, Linv and factor_tail's seven outputs."""
+    d, r_ref = ref_S.shape
+    r = S.shape[1]
+    nV = Vin.numel()
+    key = (d, nV, kw, r_ref, r)
+    off = _REFRESH_LAYOUT.get(key)
+    if off is None:
+        buf = (ctypes.c_int64 * 15)()
+        _hip.check(_hip.lib().wiski_factor_refresh_layout(ctypes.c_int32(d), ctypes.c_int64(nV), ctypes.c_int32(kw), ctypes.c_int32(r_ref), ctypes.c_int32(r), buf),
+                   "wiski_factor_refresh_layout")
+        off = _REFRESH_LAYOUT[key] = [int(v) for v in buf]
+    out = torch.empty(off[14], dtype=torch.float64, device=Vin.device)
+    niter, rok = (0, float(resid_ok)) if resid_ok is not None else (2, 1e300)
+    rc = _hip.lib().wiski_factor_refresh(ctypes.c_int32(d), _hip.dptr(g_dev), ctypes.c_int64(nV), _hip.dptr(tcol64), _hip.dptr(Vin), ctypes.c_int32(kw),
+                                         ctypes.c_int32(kuse), _hip.dptr(ref_Vtab), ctypes.c_int32(kref), ctypes.c_int32(niter), ctypes.c_double(rok),
+                                         _hip.dptr(ref_S), _hip.dptr(S), ctypes.c_int32(r_ref), ctypes.c_int32(r), _hip.dptr(work),
+                                         ctypes.c_void_p(verdict_pinned.data_ptr()), _hip.dptr(G_ref), _hip.dptr(h_ref), ctypes.c_double(float(kscale)),
+                                         _hip.dptr(info), _hip.dptr(out), None if verdict_event is None else ctypes.c_void_p(verdict_event.cuda_event),
+                                         _hip.stream_ptr(Vin.device))
+    _hip.check(rc, "wiski_factor_refresh")
+    t = out[off[13]:off[13] + 6 * r + 2]
+    return {"Vtab": out[off[0]:off[0] + nV], "ev": out[off[1]:off[1] + d * kw].view(d, kw), "TS": out[off[4]:off[4] + r_ref * r].view(r_ref, r),
+            "lam_kuu": out[off[5]:off[5] + r], "G": out[off[7]:off[7] + r * r].view(r, r), "chol": out[off[8]:off[8] + r * r].view(r, r),
+            "sqG": out[off[9]:off[9] + r * r].view(r, r), "lam": out[off[10]:off[10] + r], "sq": out[off[11]:off[11] + r],
+            "Linv": out[off[12]:off[12] + r * r].view(r, r),
+            "tail": (t[:r], t[r:2 * r], t[2 * r:3 * r], t[3 * r:4 * r], t[4 * r:5 * r], t[5 * r], t[5 * r + 1])}
+
+
 def factor_tail(TS, h_ref, sq, Linv, chol):
     """``wiski_factor_tail``: (hr, c_half, t, coef, zeta, bMb, logdet) -- views of one packed fp64 tensor -- in three launches."""
     r_ref, r = TS.shape

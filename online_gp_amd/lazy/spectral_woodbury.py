@@ -372,6 +372,14 @@ class SpectralWoodburyFactor:
             basis, TS, defect_ok = cur["basis"], cur["TS"], True
         elif not _host_path and cur is not None and self.ref is not None and torch.is_tensor(tcol64) and tcol64.is_cuda \
                 and self._device_refresh_ok(cur, key):
+            if settings.fused_factor_refresh.on():
+                # the whole refresh -- eigenvectors, change of basis, G, C, Cholesky + inverse, tail -- behind ONE C call (wiski_factor_refresh)
+                new = self._device_refresh_fused(cur, key, tcol64, tail, kscale)
+                if self._chk is not None and not self._verdict():
+                    self.cur = None
+                    return self.state(key, tcol64, kscale, eig=eig, _host_path=True)
+                self.cur = new
+                return new
             basis, TS = self._device_refresh(cur, tcol64, tail)
             defect_ok = True
         else:
@@ -467,6 +475,37 @@ class SpectralWoodburyFactor:
         self._dev_refreshes += 1
         self.device_refreshes += 1
         return basis, TS
+
+    def _device_refresh_fused(self, cur, key, tcol64, tail, kscale):
+        """_device_refresh + everything state() builds on it, queued by one call (grid_ops.factor_refresh); returns the new state."""
+        old, ref = cur["basis"], self.ref
+        gd = self._grid_dev()
+        work = self.__dict__.get("_bc_work")
+        if work is None or work.shape[0] < old.r + 1:
+            work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
+        hosts = self.__dict__.get("_chk_hosts")
+        if hosts is None:
+            hosts = self._chk_hosts = [torch.zeros(3, dtype=torch.float64).pin_memory(), torch.zeros(3, dtype=torch.float64).pin_memory()]
+            self._chk_events = [torch.cuda.Event(), torch.cuda.Event()]
+        slot = self._dev_refreshes_total = (self.__dict__.get("_dev_refreshes_total", 0) + 1) & 1
+        host, ev = hosts[slot], self._chk_events[slot]
+        info = self.__dict__.get("_info")
+        if info is None:
+            info = self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if not self.__dict__.get("_chk_events_live"):
+            for e_ in self._chk_events:              # (torch creates the handle at the first record: the C call records it from then on)
+                e_.record()
+            self._chk_events_live = True
+        o = grid_ops.factor_refresh(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax, ref.S, old.S, work, host, self.G_ref, self.h_ref,
+                                    kscale, info, resid_ok=(tail * 1e-3 / 8.0) if settings.adaptive_eig_update.on() else None, verdict_event=ev)
+        basis = SpectralBasis.on_device(old, o["Vtab"], o["ev"], None, lam=o["lam_kuu"])
+        self._chk = (host, ev, (tail * 1e-3, 1.5 * max(tail, old.short0), tail))
+        self._dev_refreshes += 1
+        self.device_refreshes += 1
+        hr, ch, t, coef, zeta, bMb, logdet = o["tail"]
+        return {"key": key, "kscale": kscale, "data_version": self.data_version, "basis": basis, "TS": o["TS"], "lam": o["lam"], "sq": o["sq"], "G": o["G"],
+                "chol": o["chol"], "Linv": o["Linv"], "info": info, "tail": tail, "sqG": o["sqG"], "hr": hr, "c_half": ch, "t": t, "coef": coef,
+                "zeta": zeta, "bMb": bMb, "logdet": logdet}
 
     def _change_of_basis(self, basis):
         """T [r_ref, r] and the eigenvalue-weighted defect max_j lam_j (1 - |T[:, j]|^2) / trace (what the reference

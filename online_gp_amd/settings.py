@@ -229,6 +229,14 @@ class two_level_rank(_value_context):
     _global_value = 192
 
 
+class fused_factor_refresh(_feature_flag):
+    """The spectral factor's refresh after a hyper-parameter step (eigenvector update -> change of basis -> G -> C -> Cholesky + inverse -> tail
+    products) queued by ONE C call (``wiski_factor_refresh``) instead of seven wrapped ones: the same launches, ~40 us less interpreter time
+    in a step that is bound by it.  Off: the call-by-call form (identical results)."""
+
+    _state = True
+
+
 class two_level_rebuild(_feature_flag):
     """Where the stream's two-level block was lost -- a hyper-parameter step or a density-profile re-solve moved the eigenbasis, points
     reached the statistics behind the tracker's back -- rebuild it from the statistics themselves (X_S^T A X_S: r stencil-product columns,

@@ -723,3 +723,43 @@ def test_factor_glue_kernels_against_their_torch_forms():
         for a, b in zip(verdict.tolist(), ref_v):
             assert abs(a - b) < 1e-10 * max(1.0, abs(b)), (rep, verdict.tolist(), ref_v)
         assert float(work.abs().max()) == 0.0
+
+
+def test_fused_factor_refresh_equals_the_call_by_call_form():
+    """wiski_factor_refresh (eigenvector update -> change of basis -> G -> C -> Cholesky + inverse -> tail, one host call, one packed
+    buffer) against the same launches issued one wrapper at a time (settings.fused_factor_refresh off): every product of the state,
+    over a short drift of the hyper-parameters, and the verdict read through the event the C call records."""
+    from online_gp_amd import settings
+
+    rng = np.random.default_rng(33)
+    d, g, n = 3, 16, 600
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(2 * X[:, 0]) * X[:, 1] + 0.1 * rng.standard_normal(n)
+    Xs = torch.as_tensor(rng.uniform(-1, 1, (20, d)), device=DEV)
+    states = {}
+    for fused in (True, False):
+        with settings.fused_factor_refresh(fused):
+            m = _model(X, y, g, torch.float64)
+            m.eval()
+            m(Xs).variance
+            fac = m._spectral[0]
+            k = m.covar_module.base_kernel
+            out = []
+            for step in range(4):
+                f = 1.0 + 0.01 * (-1) ** step * (1 + step % 3)
+                with torch.no_grad():
+                    k.base_kernel.lengthscale = k.base_kernel.lengthscale * torch.tensor([f, 1.0 / f, f ** 0.5], device=DEV).reshape(1, -1)
+                    m.likelihood.second_noise = float(m.likelihood.second_noise) * f
+                m._dump_caches()
+                v = m(Xs).variance
+                st = fac.cur
+                out.append({k_: st[k_].clone() for k_ in ("TS", "G", "chol", "Linv", "lam", "sq", "sqG", "hr", "c_half", "t", "coef", "zeta", "bMb", "logdet")}
+                           | {"var": v.clone(), "verdict": fac.last_verdict, "Vtab": st["basis"].Vtab.clone(), "lam_kuu": st["basis"].lam_kuu.clone()})
+            assert fac.device_refreshes == 4
+            states[fused] = out
+    for a, b in zip(states[True], states[False]):
+        # (the change of basis sums with atomics: equal up to the order of the additions)
+        assert np.allclose(a["verdict"], b["verdict"], rtol=1e-6, atol=1e-18)
+        for k_ in a:
+            if k_ == "verdict":
+                continue
+            assert torch.allclose(a[k_], b[k_], rtol=1e-9, atol=1e-12 * float(b[k_].abs().max())), k_
