@@ -533,6 +533,24 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) mrow[a][r] = tl_ns > 0 ? tl.mask[i0 * 64 + wr * 16 * RT + a * 16 + (lane >> 4) * 4 + r] : 0ull;
   }
+  // two-level: this wave's rows of N (row e = w, w + NW, ...; three 64-column chunks each: r <= 192, <= 8 rows per wave) requested
+  // NOW -- they do not depend on the exchange, and fetched after it (L2, ~0.7 us per row, one row after the other) they were most of
+  // what the block cost the kernel
+  constexpr int TL_PF_ROWS = 8, TL_PF_CH = 3;
+  float npf[TL ? TL_PF_ROWS : 1][TL ? TL_PF_CH : 1];
+  bool tl_pf = false;
+  if constexpr (TL) {
+    tl_pf = tl_ns > 0 && tl.r <= 64 * TL_PF_CH && tl_ns <= NW * TL_PF_ROWS;      // block-uniform
+    if (tl_pf) {
+#pragma unroll
+      for (int i = 0; i < TL_PF_ROWS; ++i) {
+        const int e = w + NW * i;
+        const float* __restrict__ nrow = tl.N + (int64_t)(tl_o0 + (e < tl_ns ? e : 0)) * tl.r;
+#pragma unroll
+        for (int j = 0; j < TL_PF_CH; ++j) npf[i][j] = (e < tl_ns && lane + 64 * j < tl.r) ? nrow[lane + 64 * j] : 0.f;
+      }
+    }
+  }
   SPEC_STAMP(6);
   tX.commit(bufA, SPEC_LDT);           // every image is written in full (padding = zeros); bufB is first written by P2
   tV1.commit(sV1, SPEC_LDT);
@@ -610,14 +628,34 @@ __global__ __launch_bounds__(64 * NW) void k_spec_slab_mfma(GridDev<float> G, co
       __syncthreads();
       // (3) the rows of N c_S of this slab: one wave per row, lanes stride the columns
       float rsel = 0.f;
-      for (int e = w; e < tl_ns; e += NW) {
-        const float* __restrict__ nrow = tl.N + (int64_t)(tl_o0 + e) * tl.r;
-        float d = 0.f;
-        for (int q = lane; q < tl.r; q += 64) d += nrow[q] * sC[q];
-        d = wave_reduce_sum<float>(d);
-        if (lane == 0) {
-          sCp[e] = d;
-          rsel += sC[tl_o0 + e] * d;
+      if (tl_pf) {
+        float cq[TL_PF_CH];
+#pragma unroll
+        for (int j = 0; j < TL_PF_CH; ++j) cq[j] = lane + 64 * j < tl.r ? sC[lane + 64 * j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TL_PF_ROWS; ++i) {
+          const int e = w + NW * i;
+          if (e < tl_ns) {                                     // wave-uniform
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < TL_PF_CH; ++j) d += npf[i][j] * cq[j];
+            d = wave_reduce_sum<float>(d);
+            if (lane == 0) {
+              sCp[e] = d;
+              rsel += sC[tl_o0 + e] * d;
+            }
+          }
+        }
+      } else {
+        for (int e = w; e < tl_ns; e += NW) {
+          const float* __restrict__ nrow = tl.N + (int64_t)(tl_o0 + e) * tl.r;
+          float d = 0.f;
+          for (int q = lane; q < tl.r; q += 64) d += nrow[q] * sC[q];
+          d = wave_reduce_sum<float>(d);
+          if (lane == 0) {
+            sCp[e] = d;
+            rsel += sC[tl_o0 + e] * d;
+          }
         }
       }
       if (rho != nullptr && h == 1) {
