@@ -60,6 +60,10 @@ __device__ __forceinline__ void spmmb_fma(double& acc, double coef, double w) {
 // Requesting the operands of both terms before the first FMA (one memory latency per group) beats term-by-term order by 5 us;
 // a barrier per group (to keep the block's four waves, whose windows overlap by 6 rows, in step for L1 hits) costs 2..5 us; term-by-term
 // order ENFORCED with scheduling barriers (79 instead of 94 VGPRs, fp64 124 instead of 173) is 6 us slower in fp32 and no faster in fp64.
+// Round 5: the block's four waves on tiles 48 rows apart (two short of a grid line at 50^3: the window of wave w + 1 for group g is 20 / 22 of the
+// one wave w loads for group g + 1 a step later) instead of consecutive ones: 136-138 us against 135 -- sharing windows through L1 changes nothing:
+// the ~1 200 row loads per tile are bound by the L1's 64 B / clk (4 clk per 256-byte row: 71 us; + 29 us of coefficient loads = the 117 us of the
+// loads-only ablation), not by L2 fetches.  An LDS-staged window (128 B / clk) would halve the 71 us at the price of one block per CU.
 template <typename real, bool DOT, int RT, int VAR>
 __global__ __launch_bounds__(256) void k_spmm_sym_bcast(GridDev<real> G, const real* __restrict__ A_h, int64_t a_len, const real* __restrict__ Vt,
                                                         int k, int ng, real* __restrict__ Ot, double* __restrict__ dots) {
