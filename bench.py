@@ -20,15 +20,23 @@ in HBM before the timed region.
 
 Timing: W warm-up steps, then R *blocks* of exactly K steps, every block
 bracketed by a barrier + torch.cuda.synchronize() on both sides and reduced with
-MAX over ranks; `ms_per_step` / `value` = all timed steps / the summed time of the
-timed blocks, blocks slower than 1.5x the median block left out as host hiccups and
-counted in `extra.blocks_dropped` (R is chosen so that the timed region lasts
->= ~0.3 s: a single 20-step block is 5 ms).  The blocks of a pass are NOT alike -- at
-50^3 the first ~45 steps after the init data need 3 CG iterations, the later ones 2
--- so the block times are bimodal and their median sits on the edge between the two
-populations; it is reported beside the mean in `extra`.  The stream of a pass never
-exceeds UCI 3droad's 434 874 points: when it is used up the model is rebuilt from
-the init data (un-timed) and the next pass streams fresh points.
+MAX over ranks; `ms_per_step` / `value` = ALL timed steps / the summed time of ALL
+timed blocks -- no block is left out (what a mean without the blocks slower than
+1.5x the median would read is in `extra`, with those blocks listed).  R is chosen
+so that the timed region lasts >= ~0.3 s (a single 20-step block is 5 ms).  The
+blocks of a pass are NOT alike -- at 50^3 the first ~45 steps after the init data
+need 3 CG iterations, the later ones 2 -- so the block times are bimodal; their
+median is reported beside the mean in `extra`.  The stream of a pass never exceeds
+UCI 3droad's 434 874 points: when it is used up the model is rebuilt from the init
+data (un-timed) and the next pass streams fresh points.
+
+N > 1: `python bench.py --gpus N` spawns its own N ranks (re-executes itself under
+torch.distributed.run on 127.0.0.1) when no launcher set WORLD_SIZE; under
+`python -m torch.distributed.run ... bench.py --gpus N` it is a rank.  One device
+per rank over nccl (= RCCL); a box with fewer devices than ranks is refused unless
+WISKI_BENCH_BACKEND=gloo asks for the self-test arrangement (every rank on cuda:0,
+gloo; exercises the N > 1 code path, never a reported number).  The line names the
+exchange that ran (`config.parallelism`) and what carried it (`collective`).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the half-stencil
 SpMV of the CG, HBM-bound; per-dispatch HIP events on its launch stream),
@@ -219,6 +227,25 @@ def dense_regime_reference_steps(dev):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run with N ranks on this
+    node (rendezvous on 127.0.0.1, a free port) -- exactly the driver's own launch line -- and return its exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher (WORLD_SIZE unset), spawning %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,24 +276,35 @@ def main():
         gc.collect()
         gc.freeze()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the launcher of its own N ranks (one per GPU) and relays their exit code; rank 0's
+        # JSON line goes to the inherited stdout
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    # self-test hook for 1-GPU boxes: WISKI_BENCH_BACKEND=gloo puts every rank on cuda:0 and uses gloo, so that the
-    # N > 1 code path can be exercised without a second device (never used for reported numbers)
-    selftest = os.environ.get("WISKI_BENCH_BACKEND") == "gloo"
-    if selftest:
-        local_rank = 0
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (they must agree: the line's n_gpus is the world size)")
+    from online_gp_amd.distributed import pick_backend, rccl_info
+
+    # WISKI_BENCH_BACKEND=gloo: self-test arrangement for 1-GPU boxes (every rank on cuda:0, gloo), so that the N > 1 code path
+    # can be exercised without a second device -- never used for reported numbers; without it a rank per device over RCCL
+    force = os.environ.get("WISKI_BENCH_BACKEND") or ("nccl" if world > 1 else None)
+    backend, dev_of = pick_backend(world, torch.cuda.device_count(), force)
+    selftest = world > 1 and backend == "gloo"
+    local_rank = dev_of(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    collective = None
     if world > 1:
         if selftest:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        collective = rccl_info(device=dev)           # backend, ranks an all-reduce really summed over, RCCL versions
+        collective["one_device_per_rank"] = not selftest
+        if collective["ranks_seen"] != world:
+            raise SystemExit(f"bench.py: the communicator summed over {collective['ranks_seen']} ranks, expected {world}")
 
     from online_gp_amd import _hip, grid_ops, settings
     from online_gp_amd.distributed import ShardedStatsUpdater
@@ -842,6 +880,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            "collective": collective,
             "config": {"workload": ("road-like CLUSTERED (points along 64 poly-lines, sigma 0.02: SURVEY 8d's stand-in for UCI 3droad; the uniform variant: extra.uniform_stream_*) " if args.stream == "clustered" else "UNIFORM (the road-like clustered variant of SURVEY 8d: extra.clustered_stream_*) ") + f"3droad-sized synthetic stream d={d}, {args.grid}^{d} inducing grid (m={grid.m}), RBF-ARD fixed hypers, "
                                    f"CG solve path, q={q} points/step/GPU, init {args.n_init} points, cg_tol={tol:g}; {R} timed blocks of {K} steps (all steps / summed block time)",
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": par},

@@ -545,6 +545,10 @@ int wiski_comm_unique_id_bytes(void);
 int wiski_comm_unique_id(void* id_out);
 int wiski_comm_init_rank(const void* id_bytes, int32_t nranks, int32_t rank, void** comm_out);
 int wiski_comm_destroy(void* comm);
+/* What the loaded librccl reports: its version code (ncclGetVersion; e.g. 22203) and, for a communicator, the number of ranks
+ * it joins and this rank's index (comm may be NULL: version only; any out pointer may be NULL).  bench.py prints these in
+ * its JSON line so that a multi-GPU number says which RCCL carried it and how many ranks the communicator really saw. */
+int wiski_comm_info(void* comm, int32_t* version_out, int32_t* nranks_out, int32_t* rank_out);
 int wiski_allreduce_stats_f32(void* comm, float* d_half, int64_t n_half, float* d_b, int64_t n_b, float* d_cnt, int64_t n_cnt, double* d_scal, int64_t n_scal, void* stream);
 int wiski_allreduce_stats_f64(void* comm, double* d_half, int64_t n_half, double* d_b, int64_t n_b, double* d_cnt, int64_t n_cnt, double* d_scal, int64_t n_scal, void* stream);
 

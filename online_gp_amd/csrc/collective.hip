@@ -24,6 +24,9 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;              // optional (reporting only)
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   bool ok = false;
 };
 Rccl g_rccl;
@@ -45,6 +48,9 @@ const Rccl& rccl() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))sym("ncclGetVersion");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.GroupStart && g_rccl.GroupEnd;
   });
   return g_rccl;
@@ -100,6 +106,21 @@ int wiski_comm_destroy(void* comm) {
   if (!R.ok) return WISKI_E_LAUNCH;
   if (!comm) return WISKI_E_BADARG;
   return R.CommDestroy((ncclComm_t)comm) == ncclSuccess ? WISKI_OK : WISKI_E_LAUNCH;
+}
+
+int wiski_comm_info(void* comm, int32_t* version_out, int32_t* nranks_out, int32_t* rank_out) {
+  const Rccl& R = rccl();
+  if (!R.ok) return WISKI_E_LAUNCH;
+  int v = 0, n = 0, r = -1;
+  if (version_out && R.GetVersion && R.GetVersion(&v) != ncclSuccess) return WISKI_E_LAUNCH;
+  if (comm) {
+    if (R.CommCount && R.CommCount((ncclComm_t)comm, &n) != ncclSuccess) return WISKI_E_LAUNCH;
+    if (R.CommUserRank && R.CommUserRank((ncclComm_t)comm, &r) != ncclSuccess) return WISKI_E_LAUNCH;
+  }
+  if (version_out) *version_out = v;
+  if (nranks_out) *nranks_out = n;
+  if (rank_out) *rank_out = r;
+  return WISKI_OK;
 }
 
 int wiski_allreduce_stats_f32(void* comm, float* d_half, int64_t n_half, float* d_b, int64_t n_b, float* d_cnt, int64_t n_cnt, double* d_scal, int64_t n_scal, void* stream) {

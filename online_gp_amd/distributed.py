@@ -18,6 +18,47 @@ import torch
 import torch.distributed as dist
 
 
+def pick_backend(world, n_devices, force=None):
+    """(backend, device index of rank r) for a `world`-rank job on a box that shows `n_devices` GPUs: ``"nccl"`` (= RCCL over
+    xGMI) with one device per rank whenever the box has a device for every rank -- RCCL refuses two ranks on one device --,
+    otherwise ``"gloo"`` with every rank on device 0: the self-test arrangement of the 1-GPU boxes, never used for reported
+    numbers.  ``force`` ("nccl" / "gloo") overrides; forcing nccl without enough devices raises."""
+    if force not in (None, "", "nccl", "gloo"):
+        raise ValueError("force must be 'nccl' or 'gloo'")
+    if force == "nccl" and n_devices < world:
+        raise RuntimeError(f"nccl (RCCL) needs one device per rank: {world} ranks, {n_devices} devices visible")
+    if force == "gloo" or (not force and n_devices < world):
+        return "gloo", (lambda rank: 0)
+    return "nccl", (lambda rank: rank)
+
+
+def rccl_info(group=None, device=None):
+    """What carried the collectives of a run, for the record (bench.py's JSON line): torch.distributed's backend and world size,
+    the number of ranks an all-reduce of ones really summed over (`ranks_seen`), the RCCL version of torch's communicator, and the
+    version code of the librccl that libwiski's own transport resolves (wiski_comm_info; no second communicator is made).
+    Collective: every rank must call it."""
+    info = {"backend": None, "world_size": 1, "ranks_seen": 1}
+    if not (dist.is_available() and dist.is_initialized()):
+        return info
+    info["backend"], info["world_size"] = dist.get_backend(group), dist.get_world_size(group)
+    one = torch.ones(1, dtype=torch.float32, device=device if info["backend"] == "nccl" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    info["ranks_seen"] = int(round(float(one.item())))
+    if info["backend"] == "nccl":
+        try:
+            info["torch_rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # noqa: BLE001
+            info["torch_rccl_version"] = "unavailable: " + repr(exc)[:80]
+        import ctypes
+
+        from . import _hip
+
+        ver = ctypes.c_int32(0)
+        rc = _hip.lib().wiski_comm_info(None, ctypes.byref(ver), None, None)
+        info["wiski_rccl_version_code"] = ver.value if rc == 0 else f"unavailable (rc {rc})"
+    return info
+
+
 def allreduce_sum_(tensors, group=None):
     """In-place SUM all-reduce of a list of tensors (no-op without a process group).
     Tensors of one dtype are coalesced by the backend where it pays; the dominant
@@ -83,15 +124,20 @@ class RcclCommunicator:
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank(group) if world > 1 else 0
         buf = (ctypes.c_ubyte * nb)()
-        if rank == 0:
-            _hip.check(lib.wiski_comm_unique_id(buf), "wiski_comm_unique_id")
+        rc0 = lib.wiski_comm_unique_id(buf) if rank == 0 else 0
         if world > 1:
-            t = torch.tensor(list(buf), dtype=torch.uint8)
+            # (rank 0's status travels with the id: a rank 0 that raised BEFORE the broadcast would leave the others waiting in it)
+            t = torch.tensor(list(buf) + [1 if rc0 else 0], dtype=torch.uint8)
             backend = dist.get_backend(group)
             if backend == "nccl":
                 t = t.cuda()
             dist.broadcast(t, src=0, group=group)
-            buf = (ctypes.c_ubyte * nb)(*t.cpu().tolist())
+            got = t.cpu().tolist()
+            buf = (ctypes.c_ubyte * nb)(*got[:nb])
+            if got[nb]:
+                raise _hip.WiskiError("wiski_comm_unique_id failed on rank 0 (librccl not resolvable?)")
+        else:
+            _hip.check(rc0, "wiski_comm_unique_id")
         comm = ctypes.c_void_p()
         _hip.check(lib.wiski_comm_init_rank(buf, ctypes.c_int32(world), ctypes.c_int32(rank), ctypes.byref(comm)), "wiski_comm_init_rank")
         self.handle, self.world, self.rank, self._lib = comm, world, rank, lib
@@ -142,6 +188,7 @@ class ShardedStatsUpdater:
         self.comm = comm            # RcclCommunicator: the statistics exchange goes through the C ABI's wiski_allreduce_stats
         self._delta = None
         self._res_delta = None
+        self._lens = None
         self.last_exchange = None
 
     def _use_points(self, q, world, dev):
@@ -150,12 +197,9 @@ class ShardedStatsUpdater:
         if self.exchange == "stats":
             return False
         m = self.model
-        if not self.equal_shards:
-            t = torch.tensor([float(q), -float(q)], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            hi, neg_lo = t.tolist()
-            if hi != -neg_lo:
-                return False
+        hi, lo = self._shard_lengths(q, dev)
+        if hi != lo:
+            return False
         if self.exchange == "points":
             return True
         grid = m._grid
@@ -163,6 +207,19 @@ class ShardedStatsUpdater:
         atomics = world * q * (T * (T + 1) // 2) * m.num_outputs
         stencil_bytes = 2 * ((grid.R + 1) // 2) * grid.m * m.num_outputs * (4 if m._dtype == torch.float32 else 8)
         return atomics < stencil_bytes
+
+    def _shard_lengths(self, q, dev):
+        """(longest, shortest) shard length of this call over the ranks: the same pair on every rank, so decisions that gate a
+        collective can be taken from it.  ``equal_shards=True`` promises (q, q); otherwise one tiny MAX all-reduce + host read,
+        made once per call (``_lens`` is dropped at the top of update() / stream_step())."""
+        if self.equal_shards:
+            return q, q
+        if self._lens is None:
+            t = torch.tensor([float(q), -float(q)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            hi, neg_lo = t.tolist()
+            self._lens = (int(hi), int(-neg_lo))
+        return self._lens
 
     def _gather_rows(self, packed, world):
         """All-gather the rows of ``packed`` [q_r, c] over the ranks -> (all rows in rank order, offset of this rank's rows).
@@ -212,6 +269,7 @@ class ShardedStatsUpdater:
             Y = Y[:, None]
         d = m._grid.d
         q = X.reshape(-1, d).shape[0]
+        self._lens = None
         # the gathered routes ("points" / "stencil") take shards of any length: unless equal shards were promised the lengths are
         # exchanged first and the gather is padded (a hard-wired torch.empty_like(packed) receive buffer hangs or corrupts the
         # collective when the ranks disagree); the cost-model route keeps its own decision
@@ -321,6 +379,7 @@ class ShardedStatsUpdater:
         if noise is not None:
             noise = m._canon_noise(noise, Y)
         q = X.reshape(-1, m._grid.d).shape[0]
+        self._lens = None
         if self.comm is None and self._use_points(q, world, m._kernel_cache["_stats"].device):
             self.last_exchange = "points"
             self._update_points(X, Y, noise, world)
@@ -328,14 +387,17 @@ class ShardedStatsUpdater:
         self.last_exchange = "stats"
         # the two-level preconditioner's block follows the stream point by point (lazy/two_level.py); an all-reduced increment carries no
         # points, so the shards' coordinates (+ weights) are all-gathered beside it -- q (d + 1) reals per rank, against the 86 MB of the
-        # statistics -- and noted by the tracker in _absorb.  Without a process group able to gather (comm-only callers): this rank's
-        # shard weighted by the number of ranks, an unbiased estimate of the same sum.
-        m.__dict__["_stats_world"] = world
+        # statistics -- and noted by the tracker in _absorb.  Without a process group able to gather (comm-only callers) the block is
+        # given up (every replica must keep the SAME preconditioner: the path's collective decisions assume replicated state).
         m.__dict__.pop("_stats_points", None)
         applies = getattr(m, "_two_level_applies", None)
         want_tl = applies is not None and applies() and m.__dict__.get("_two_level") is not None
         in_use = getattr(m, "_spectral_in_use", None)
-        want_fac = in_use is not None and in_use() and X.reshape(-1, m._grid.d).shape[0] <= 2048
+        # want_fac gates a collective (the gather below): it is decided from replicated state and from shard lengths every rank agrees on,
+        # never from this rank's own q -- and the limit (the factor re-projects past 2048 absorbed rows) applies to the gathered total
+        want_fac = in_use is not None and in_use() and self.comm is None and m.num_outputs == 1
+        if want_fac:
+            want_fac = world * self._shard_lengths(q, m._kernel_cache["_stats"].device)[0] <= 2048
         gathered_pts = None
         if self.comm is None and m.num_outputs == 1 and (want_tl or want_fac):
             X2 = X.reshape(-1, m._grid.d).to(m._device, m._dtype)

@@ -460,12 +460,7 @@ class SpectralWoodburyFactor:
             work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
         # (the verdict goes straight into pinned host memory from the kernel -- no copy launch; two alternating buffers: the previous
         #  verdict may not have been read yet when the next refresh is queued)
-        hosts = self.__dict__.get("_chk_hosts")
-        if hosts is None:
-            hosts = self._chk_hosts = [torch.zeros(3, dtype=torch.float64).pin_memory(), torch.zeros(3, dtype=torch.float64).pin_memory()]
-            self._chk_events = [torch.cuda.Event(), torch.cuda.Event()]
-        slot = self._dev_refreshes_total = (self.__dict__.get("_dev_refreshes_total", 0) + 1) & 1
-        host, ev = hosts[slot], self._chk_events[slot]
+        host, ev = self._verdict_slot()
         TS, lam, _ = grid_ops.basis_change(gd[0], Tq, ref.kmax, ref.S, old.kmax, old.S, ev_tab, tcol64, resid, work[:old.r + 1], verdict_pinned=host)
         basis = SpectralBasis.on_device(old, Vtab, ev_tab, None, lam=lam)
         ev.record()
@@ -476,6 +471,20 @@ class SpectralWoodburyFactor:
         self.device_refreshes += 1
         return basis, TS
 
+    def _verdict_slot(self):
+        """(pinned verdict buffer, event) of the next refresh: two alternating pairs, the previous verdict may not have been read yet
+        when the next refresh is queued.  The events are recorded once where they are made -- torch creates the handle at the first
+        record, and the C call (verdict_event) records a handle, not the Python object -- so a factor that makes its own pair (a
+        clone() drops the original's) never hands C a null handle."""
+        hosts = self.__dict__.get("_chk_hosts")
+        if hosts is None:
+            hosts = self._chk_hosts = [torch.zeros(3, dtype=torch.float64).pin_memory(), torch.zeros(3, dtype=torch.float64).pin_memory()]
+            self._chk_events = [torch.cuda.Event(), torch.cuda.Event()]
+            for e_ in self._chk_events:
+                e_.record()
+        slot = self._dev_refreshes_total = (self.__dict__.get("_dev_refreshes_total", 0) + 1) & 1
+        return hosts[slot], self._chk_events[slot]
+
     def _device_refresh_fused(self, cur, key, tcol64, tail, kscale):
         """_device_refresh + everything state() builds on it, queued by one call (grid_ops.factor_refresh); returns the new state."""
         old, ref = cur["basis"], self.ref
@@ -483,19 +492,10 @@ class SpectralWoodburyFactor:
         work = self.__dict__.get("_bc_work")
         if work is None or work.shape[0] < old.r + 1:
             work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
-        hosts = self.__dict__.get("_chk_hosts")
-        if hosts is None:
-            hosts = self._chk_hosts = [torch.zeros(3, dtype=torch.float64).pin_memory(), torch.zeros(3, dtype=torch.float64).pin_memory()]
-            self._chk_events = [torch.cuda.Event(), torch.cuda.Event()]
-        slot = self._dev_refreshes_total = (self.__dict__.get("_dev_refreshes_total", 0) + 1) & 1
-        host, ev = hosts[slot], self._chk_events[slot]
+        host, ev = self._verdict_slot()
         info = self.__dict__.get("_info")
         if info is None:
             info = self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
-        if not self.__dict__.get("_chk_events_live"):
-            for e_ in self._chk_events:              # (torch creates the handle at the first record: the C call records it from then on)
-                e_.record()
-            self._chk_events_live = True
         o = grid_ops.factor_refresh(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax, ref.S, old.S, work, host, self.G_ref, self.h_ref,
                                     kscale, info, resid_ok=(tail * 1e-3 / 8.0) if settings.adaptive_eig_update.on() else None, verdict_event=ev)
         basis = SpectralBasis.on_device(old, o["Vtab"], o["ev"], None, lam=o["lam_kuu"])

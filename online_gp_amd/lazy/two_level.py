@@ -224,14 +224,27 @@ class TwoLevelBlock:
         rc = _hip.lib().wiski_twolevel_refresh_f32(self.grid.ref, None, ctypes.c_int64(0), None, _hip.dptr(self.Vtab), ctypes.c_int32(self.kw),
                                                     _hip.dptr(self.S), ctypes.c_int32(r), _hip.dptr(self.lam_unit), ctypes.c_double(self.kscale),
                                                     ctypes.c_double(1.0), _hip.dptr(self.G), _hip.dptr(self.work), ctypes.c_int64(self.work.numel()),
-                                                    _hip.dptr(self.N[0]), None, None, _hip.stream_ptr(dev))
+                                                    _hip.dptr(self.N[0]), ctypes.c_void_p(self.d_cs.data_ptr() + 8 * self.r),
+                                                    ctypes.c_void_p(self._bad_host.data_ptr()), _hip.stream_ptr(dev))
         _hip.check(rc, "wiski_twolevel_refresh")
+        # the verdict (pinned word) must be read before N preconditions anything: G was accumulated in fp32 here, and a slightly
+        # indefinite G (long or heavy streams) or a non-finite stencil fails the one-workgroup Cholesky, which poisons N with NaN by
+        # design.  The solve this block was rebuilt for polls the host every iteration anyway: waiting for the ~1.5 ms refresh
+        # shifts nothing
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        done.synchronize()
+        if int(self._bad_host[0]):
+            self.failed = True
+            self.active = -1
+            return False
         self.active = 0
         self.struct.d_N = self.N[0].data_ptr()
         self.in_flight = None
         self.weight_at_launch = weight
         self.refreshes += 1
         self.rebuilt = True
+        return True
 
     def tick(self, step, lag, lockstep=False):
         """Switch a finished refresh in.  lockstep (replicas that must take identical iterations): exactly `lag` steps after it was
@@ -308,7 +321,9 @@ class TwoLevelTracker:
             blk.rebase(pst["eig_host"], kscale)        # (every 32nd time the modes are selected afresh)
         else:
             blk = TwoLevelBlock(grid, device, pst["eig_host"], kscale, settings.two_level_rank.value(), err)
-        blk.rebuild_from_stencil(stencil, weight)
+        if not blk.rebuild_from_stencil(stencil, weight):
+            self.rebuild_failures = getattr(self, "rebuild_failures", 0) + 1
+            return None                                # the solve runs without the block (two_level = None)
         self.block, self.block_key, self._eig_ref = blk, (id(pst["eig"][0]), float(kscale), settings.two_level_rank.value()), pst["eig"]
         self.pending, self.pending_n, self.covered = [], 0, True
         self.rebuilds += 1

@@ -273,15 +273,12 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if (mine or half_delta is not None) and self.num_outputs == 1:
             if half_delta is not None:
                 # the increment arrives by all-reduce: other ranks' points never pass here.  The updater hands the gathered coordinates over
-                # (_stats_points); failing that the block -- a PRECONDITIONER whose G is a sum of one rank-one term per point -- takes this
-                # rank's shard weighted by the number of ranks, an unbiased estimate of the whole increment
-                sw = self.__dict__.get("_stats_world")
+                # (_stats_points).  Failing that (callers with only an ncclComm_t, nothing to gather through) the block is given up: noting
+                # this rank's own shard instead would leave every replica with a DIFFERENT preconditioner, hence different CG iterates and
+                # iteration counts -- and the collective decisions of the path (carried residual, poll hints) assume replicated state
                 pts = self.__dict__.pop("_stats_points", None)
                 if pts is not None and not init:
                     self._two_level_note(pts[0], pts[1])            # every rank's points, gathered beside the all-reduce (distributed.py)
-                elif sw and not init:
-                    w1 = torch.full((X.shape[0],), float(sw), dtype=self._dtype, device=self._device) if unit else float(sw) / noise[:, 0].clamp_min(1e-7)
-                    self._two_level_note(X, w1)
                 else:
                     self._two_level_lose()
             else:
@@ -527,7 +524,8 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
         if pst is None or pst.get("eig") is not post.eigen:
             return None
         tl = tr.current(pst, post.kscale, cols=k)
-        if tl is None and k >= 16 and tr.wanted:        # (8 or 1 columns: the q = 1 reference step on the PCG path 5.0 -> 5.2 / 6.4 ms: the rebuild costs more than narrow solves save)
+        warming = tr.block is not None and tr.covered and not tr.block.failed and tr.block.active < 0 and tr.block.in_flight is not None
+        if tl is None and k >= 16 and tr.wanted and not warming:   # (a block whose first refresh is in flight is not thrown away for a ~1.5 ms rebuild; 8 or 1 columns: the q = 1 reference step on the PCG path 5.0 -> 5.2 / 6.4 ms: the rebuild costs more than narrow solves save)
             tl = tr.rebuild(self._grid, self._device, pst, post.kscale, post.wtw.stencil, float(self._wsum[0]), self._err)
             if tl is not None:
                 tr.block.ensure_cols(k)

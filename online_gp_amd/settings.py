@@ -170,7 +170,9 @@ class spectral_preconditioner(_feature_flag):
 
 class cg_check_every(_value_context):
     """Iterations between host-side convergence checks of wiski_pcg (warm-started refreshes poll
-    first at the iteration count of the previous refresh)."""
+    first at the iteration count of the previous refresh).  Wide solves (>= 16 columns and >= 2^21
+    entries: the variance / probe solves on large grids) poll after EVERY iteration whatever this
+    says -- an iteration there costs ~50 polls (lazy/operators.py: solve_columns)."""
 
     _global_value = 3
 

@@ -184,6 +184,34 @@ def _worker(rank, world, port, tmpdir):
         sl2 = slice(rank * 20, (rank + 1) * 20)
         mean = upd.stream_step(X[1, sl2], Y[1, sl2])
         ok = ok and torch.equal(model.last_batch, X[1]) and torch.equal(mean, X[1, sl2, 0])
+    # the gather beside the statistics all-reduce (spectral factor follows the gathered points) is a COLLECTIVE: whether it runs must
+    # not depend on this rank's own shard length.  Shards straddling the factor's 2048-row limit (1500 / 2500) used to send one rank
+    # into the all-gather and not the other; now the decision comes from lengths both ranks agree on, applied to the gathered total
+    class _Fac:
+        ref, stale = object(), False
+
+        def __init__(self):
+            self.rows = []
+
+        def absorb(self, Xa, wa, wby):
+            self.rows.append(Xa.shape[0])
+
+    rng2 = np.random.default_rng(5)
+    for (n_a, n_b), expect_rows in (((1500, 2500), None), ((400, 600), 1000)):
+        Xb = torch.from_numpy(rng2.uniform(-1, 1, (n_a + n_b, 2)))
+        Yb = torch.from_numpy(rng2.standard_normal((n_a + n_b, 1)))
+        model = StubModel(gb, g)
+        model._spectral_in_use = lambda: True
+        fac = _Fac()
+        model._spectral = {0: fac}
+        upd = ShardedStatsUpdater(model, exchange="stats")
+        slb = slice(0, n_a) if rank == 0 else slice(n_a, n_a + n_b)
+        upd.update(Xb[slb], Yb[slb], torch.ones_like(Yb[slb]))
+        one = StubModel(gb, g)
+        one.condition_on_observations(Xb, Yb, torch.ones_like(Yb))
+        ok = ok and upd.last_exchange == "stats" and model.num_data == n_a + n_b
+        ok = ok and torch.allclose(model._kernel_cache["WtW"].stencil, one._kernel_cache["WtW"].stencil, atol=1e-10)
+        ok = ok and (fac.rows == [expect_rows] if expect_rows else (fac.rows == [] and fac.stale))
     open(os.path.join(tmpdir, f"ok_{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()

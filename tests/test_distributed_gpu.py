@@ -14,15 +14,40 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmpdir):
+def _join(rank, world, port):
+    """Join the test's process group and return this rank's device.  On a box with a device for every rank: nccl (= RCCL over
+    xGMI), one device per rank -- the arrangement the product runs in; on the 1-GPU boxes: gloo with every rank on cuda:0
+    (online_gp_amd.distributed.pick_backend; WISKI_TEST_BACKEND forces one)."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from online_gp_amd.distributed import pick_backend
+
+    backend, dev_of = pick_backend(world, torch.cuda.device_count(), os.environ.get("WISKI_TEST_BACKEND"))
+    dev = torch.device("cuda", dev_of(rank))
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dev
+
+
+def _transport(monkeypatch, transport):
+    """torch: the per-product all-reduce through torch.distributed's communicator (RCCL on a multi-GPU box, gloo through the host on
+    a 1-GPU box).  rccl: the in-C transport (wiski_allreduce_stats on libwiski's own ncclComm_t, grouped launch on the solve's
+    stream) -- it needs one device per rank, so it runs the first time a test box shows two devices."""
+    if transport == "rccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the in-C RCCL transport needs one device per rank (RCCL refuses two ranks on one device)")
+    monkeypatch.setenv("WISKI_SHARD_TRANSPORT", transport)        # (inherited by the spawned ranks)
+
+
+def _worker(rank, world, port, tmpdir):
+    dev = _join(rank, world, port)
     from online_gp_amd.distributed import ShardedStatsUpdater
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
 
-    dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
     X = torch.as_tensor(rng.uniform(-1, 1, (40 + 3 * 2048, 3)), device=dev, dtype=torch.float32)
     y = torch.sin(2 * X[:, :1]) + 0.1 * torch.as_tensor(rng.standard_normal((X.shape[0], 1)), device=dev, dtype=torch.float32)
@@ -67,15 +92,11 @@ def _worker_stream_step(rank, world, port, tmpdir):
     """ShardedStatsUpdater.stream_step (point exchange -> the model's one-call step on the gathered batch, deferred poll) on a
     grid past the dense regime: every rank's replica equals plain conditioning on the concatenated shards, and the returned
     means are the rank's slice of the pre-update predictive means."""
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _join(rank, world, port)
     from online_gp_amd import settings
     from online_gp_amd.distributed import ShardedStatsUpdater
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
 
-    dev = torch.device("cuda:0")
     rng = np.random.default_rng(3)
     q, steps = 4608, 4            # 9216 gathered points per step: the owner-computes absorb (batches >= 8192) inside the one-call step
     X = torch.as_tensor(rng.uniform(-1, 1, (500 + steps * world * q, 3)), device=dev, dtype=torch.float32)
@@ -109,15 +130,11 @@ def _worker_stencil_shard(rank, world, port, tmpdir):
     multiplies only ITS groups of the half stencil, one m-vector all-reduce per CG iteration completes A p (here through gloo:
     both ranks share the one GPU).  Checked on every rank: identical CG iteration counts to a single-process model fed the
     concatenated batches, the same means, and -- after leave_stencil_shard() sums the disjoint shards -- the same statistics."""
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _join(rank, world, port)
     from online_gp_amd import grid_ops, settings
     from online_gp_amd.distributed import ShardedStatsUpdater
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
 
-    dev = torch.device("cuda:0")
     rng = np.random.default_rng(7)
     q, steps, n0 = 1024, 6, 3000
     X = torch.as_tensor(rng.uniform(-1, 1, (n0 + steps * world * q, 3)), device=dev, dtype=torch.float32)
@@ -195,6 +212,7 @@ def _worker_stencil_shard(rank, world, port, tmpdir):
         ok = ok and trm.block is not None and trm.block.active >= 0 and trm.block.refreshes == trr.block.refreshes
         ok = ok and hist_ref == hist_got and model.__dict__.get("_stencil_shard") is not None
         msgs.append(f"two-level iters ref {hist_ref} got {hist_got} refreshes {trm.block.refreshes if trm.block else None}")
+    msgs.append(f"transport {upd.shard_transport} backend {dist.get_backend()} device {dev}")
     open(os.path.join(tmpdir, f"st_{rank}"), "w").write(("1" if ok else "0") + " " + "; ".join(msgs))
     dist.barrier()
     dist.destroy_process_group()
@@ -204,15 +222,11 @@ def _worker_stencil_shard_any_d(rank, world, port, tmpdir):
     """The stencil-sharded step outside d = 3 / fp32 (round 4): the LDS-window SpMV restricted to the replica's group range.
     BASELINE config 2's geometry scaled down (d = 4, fp64, 12^4) and a 2-D fp32 grid beyond the dense regime (64^2): same means,
     iteration counts and (re-summed) statistics as a single-process model fed the concatenated batches."""
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _join(rank, world, port)
     from online_gp_amd import grid_ops, settings
     from online_gp_amd.distributed import ShardedStatsUpdater
     from online_gp_amd.models import FixedNoiseOnlineSKIGP
 
-    dev = torch.device("cuda:0")
     ok, msgs = True, []
 
     def chk(ok_, tag, val):
@@ -259,7 +273,9 @@ def _worker_stencil_shard_any_d(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-def test_stencil_sharded_stream_step_any_dimension_world2(tmp_path):
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+def test_stencil_sharded_stream_step_any_dimension_world2(tmp_path, monkeypatch, transport):
+    _transport(monkeypatch, transport)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker_stencil_shard_any_d, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
@@ -267,12 +283,16 @@ def test_stencil_sharded_stream_step_any_dimension_world2(tmp_path):
         assert res.startswith("1"), res
 
 
-def test_stencil_sharded_stream_step_world2(tmp_path):
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+def test_stencil_sharded_stream_step_world2(tmp_path, monkeypatch, transport):
+    _transport(monkeypatch, transport)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker_stencil_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         res = open(tmp_path / f"st_{r}").read()
         assert res.startswith("1"), res
+        if transport == "rccl":
+            assert "transport rccl" in res, res
 
 
 def test_sharded_stream_step_world2(tmp_path):
@@ -375,16 +395,12 @@ def _worker_c5(rank, world, port, tmpdir):
     """BASELINE config 5's data-parallel leg on its geometry: d = 2, 30^2 grid, Matern-1/2, heteroscedastic noise, batch 6 per
     step, points dealt round-robin to the ranks, exchange = all-reduce of the statistics (the north-star form); every rank's
     replica must equal the data-space oracle on the whole stream."""
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _join(rank, world, port)
     from oracle import dataspace
     from online_gp_amd.distributed import ShardedStatsUpdater
     from online_gp_amd.kernels import GridInterpolationKernel, MaternKernel, ScaleKernel
     from online_gp_amd.models import OnlineSKIBotorchModel
 
-    dev = torch.device("cuda:0")
     rng = np.random.default_rng(5)
     n0, q, steps = 10, 6, 20
     X = rng.uniform(0, 1, (n0 + q * steps, 2)); y = np.sin(5 * X[:, 0]) * np.cos(4 * X[:, 1]) + 0.1 * rng.standard_normal(X.shape[0])

@@ -259,3 +259,56 @@ def test_two_level_mode_selection_is_the_top_of_the_tensor_product_spectrum():
         assert np.allclose(np.sort(lam)[::-1], top, rtol=1e-14)
         keys = idx[0] * 10 ** 6 + idx[1] * 10 ** 3 + idx[2]
         assert np.all(np.diff(keys) > 0)                                          # block order, no mode twice
+
+
+def test_backend_selection_of_multi_rank_runs():
+    """One device per rank over nccl (= RCCL) whenever the box has a device for every rank; the 1-GPU boxes' self-test
+    arrangement (gloo, every rank on device 0) otherwise; a forced nccl without the devices is refused.  bench.py and
+    tests/test_distributed_gpu.py both take their backend from this function."""
+    from online_gp_amd.distributed import pick_backend
+
+    b, dev_of = pick_backend(2, 8)
+    assert b == "nccl" and [dev_of(r) for r in range(2)] == [0, 1]
+    b, dev_of = pick_backend(8, 8)
+    assert b == "nccl" and [dev_of(r) for r in range(8)] == list(range(8))
+    b, dev_of = pick_backend(2, 1)
+    assert b == "gloo" and [dev_of(r) for r in range(2)] == [0, 0]
+    b, dev_of = pick_backend(2, 8, "gloo")
+    assert b == "gloo" and dev_of(1) == 0
+    with pytest.raises(RuntimeError):
+        pick_backend(2, 1, "nccl")
+    with pytest.raises(ValueError):
+        pick_backend(2, 2, "mpi")
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run with N ranks on
+    127.0.0.1 (the driver's own launch line) instead of benchmarking one GPU and printing n_gpus = 1."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "10", "--warmup", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7                                   # the launcher's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "10", "--warmup", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a launcher whose world size disagrees with --gpus is refused (the line's n_gpus must be the world size)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit):
+        bench.main()
