@@ -341,6 +341,7 @@ def main():
         X0, y0 = synth_stream(args.n_init, d, seed0, dev, dtype, kind)        # identical init on every rank
         block_s, iters = [], []
         ms_sum, n_launch = 0.0, 0
+        st_sum, st_n = 0.0, 0
         R, p = blocks, 0
         model = upd = None
         while R <= 0 or len(block_s) < R:
@@ -405,6 +406,9 @@ def main():
                     # the loop is pipelined (a step returns with its refresh in flight): the events are read here, outside the
                     # timed region, once the block has drained -- reading them after each step would wait for the GPU
                     tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+                    if lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl)) == 0:      # the same dispatches by their in-kernel stamps
+                        st_sum += tms.value
+                        st_n += int(nl.value)
                     if lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl)) == 0:
                         ms_sum += tms.value
                         n_launch += int(nl.value)
@@ -412,6 +416,7 @@ def main():
         bt = torch.tensor(block_s, dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        run_stream.stamps = (st_sum, st_n)
         return model, upd, bt.tolist(), iters, ms_sum, n_launch
 
     with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), settings.deferred_refresh(True), \
@@ -440,6 +445,7 @@ def main():
                 os.environ["WISKI_BENCH_NO_STENCIL_SHARD"] = "1"       # (the fallback below and the extras must not try it again)
         try:
             model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, headline_ex, args.blocks, 0, profile=os.environ.get("WISKI_BENCH_NOSAMPLE") != "1")
+            stamp_ms, stamp_n = run_stream.stamps
             headline_note = None
         except Exception as exc:  # noqa: BLE001
             if world == 1:
@@ -449,6 +455,7 @@ def main():
             headline_note = ("stencil-sharded step failed, fell back: " + repr(exc))[:300]
             os.environ["WISKI_BENCH_NO_STENCIL_SHARD"] = "1"
             model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=False)
+            stamp_ms, stamp_n = 0.0, 0
         R = len(block_s)
         med = float(np.median(block_s))
         # the headline counts EVERY timed block (round 5; rounds 1-4 left blocks > 1.5x the median out as host hiccups and said so): what a
@@ -642,6 +649,27 @@ def main():
                      "fused_form_rows_per_s": nq / (fused_us * 1e-6), "note": "the product path uses the fused form (weights recomputed from x, 16 B/row)",
                      "timing": "median of 5 torch.cuda.Event brackets of 6 launches"},
                 ]
+                # the SAME product where HBM really serves the operand: BASELINE config 2's geometry (d = 4, 30^4, fp64) -- the symmetric half
+                # stencil is 1 201 x 810 000 doubles = 7.8 GB, 30x the Infinity Cache, streamed once per launch (the 50^3 fp32 operand
+                # of the headline kernel is 86 MB and stays cache-resident)
+                try:
+                    g4 = grid_ops.GridSpec(torch.tensor([[-1.1, 1.1]] * 4), 30)
+                    H4 = (g4.R + 1) // 2
+                    A4 = torch.empty((H4, g4.m), device=dev, dtype=torch.float64).uniform_(-1.0, 1.0)
+                    V4 = torch.randn((1, g4.m), device=dev, dtype=torch.float64)
+                    grid_ops.stencil_spmv(g4, A4, V4)
+                    us4 = event_us(lambda i: grid_ops.stencil_spmv(g4, A4, V4), 3)
+                    b4 = (H4 * g4.m + 3 * g4.m) * 8
+                    roofline_secondary.append(
+                        {"kernel": "k_stencil_spmv4_sym<double> (the symmetric half-stencil A_h . p at BASELINE config 2's geometry: d = 4, 30^4, fp64; A_h = %.2f GB, HBM-served)" % (H4 * g4.m * 8 / 1e9),
+                         "bound": "hbm", "achieved": b4 / (us4 * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b4 / (us4 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "avg_launch_us": us4, "algorithmic_bytes_per_launch": b4, "infinity_cache_resident": False,
+                         "frac_of_measured_copy_ceiling_6.29_TBs": b4 / (us4 * 1e-6) / 1e9 / 6290.0,
+                         "timing": "median of 5 torch.cuda.Event brackets of 3 products (wiski_stencil_spmv_sym: product + partial-vector reduction), ~1.5 ms each"})
+                    del A4, V4
+                    torch.cuda.empty_cache()
+                except Exception as exc:  # noqa: BLE001
+                    extra.setdefault("errors", []).append(("extras (30^4 fp64 SpMV leg): " + repr(exc))[:300])
                 if own_us is not None:
                     roofline_secondary.append(
                         {"kernel": "k_bin_points + k_owner_lines (owner-computes absorb of 8 q points: the batch a rank absorbs after a point exchange at N = 8)",
@@ -822,8 +850,16 @@ def main():
 
             g_lo, g_hi = shard_groups(d, 0, world)
             spmv_bytes = sum(b - a for a, b in half_stencil_group_slices(grid, g_lo, g_hi)) * es + 3 * grid.m * es
-        avg_ms = spmv_ms / max(spmv_n, 1)
-        achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        # two clocks on the same sampled dispatches: (a) stamps taken inside the kernel -- earliest wave start to latest wave end of
+        # every dispatch (100 MHz wall clock, wiski_prof_stamps): the kernel alone, what rocprofv3's begin / end timestamps measure too;
+        # (b) the start / stop HIP events attached to the dispatch packet, which bracket [predecessor complete -> this kernel
+        # complete] and so contain the ~2.4 us of dispatch latency in front of the first wave.  `achieved` / `frac` use (a) where the
+        # kernel is stamped (k_spmv_sym_dma), (b) is reported beside it (event_*).
+        ev_ms = spmv_ms / max(spmv_n, 1)
+        ev_achieved = spmv_bytes / (ev_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        stamped = stamp_n > 0 and stamp_n >= 0.9 * spmv_n
+        avg_ms = stamp_ms / stamp_n if stamped else ev_ms
+        achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if (spmv_n or stamped) else 0.0
         dma = dtype == torch.float32 and d == 3 and grid.m % 4 == 0 and os.environ.get("WISKI_SYM_DMA", "1") != "0"
         kname = "k_spmv_sym_dma<2, true>" if dma else "k_stencil_spmv4_sym<%s, 1, true>" % ("float" if args.dtype == "f32" else "double")
         # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (tools/pmc_traffic.py),
@@ -864,7 +900,7 @@ def main():
         empty_us = ctypes.c_double(0)
         if lib.wiski_prof_empty(ctypes.c_int32(64), ctypes.byref(empty_us), _hip.stream_ptr(dev)) != 0:
             empty_us.value = float("nan")
-        net_us = avg_ms * 1e3 - empty_us.value
+        net_us = ev_ms * 1e3 - empty_us.value
         res = {
             "metric": "streaming updates/sec (WISKI, 50^3 inducing grid)",
             "timed_region_s": float(np.sum(block_s)),
@@ -886,7 +922,10 @@ def main():
                        "batch_per_gpu": q, "global_batch": q * world, "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "launches": spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
+                         "launches": stamp_n if stamped else spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
+                         "clock": ("in-kernel stamps: earliest wave start -> latest wave end of each sampled dispatch (s_memrealtime, 100 MHz), wiski_prof_stamps"
+                                   if stamped else "HIP events attached to each dispatch (this kernel carries no in-kernel stamps)"),
+                         "event_launches": spmv_n, "event_avg_launch_us": ev_ms * 1e3, "event_achieved": ev_achieved, "event_frac": ev_achieved / HBM_PEAK_GBS,
                          # everything in `committed_take` (and `traffic` above) was read back from files under profiles/: a separate run of
                          # this command under rocprofv3, committed with the round -- evidence beside this run's own events, not part of them
                          "committed_take": {"rocprofv3_avg_launch_us": rp_us, "rocprofv3_frac": (spmv_bytes / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
@@ -897,7 +936,7 @@ def main():
                          "infinity_cache_resident": bool(spmv_bytes < 200e6),
                          "empty_dispatch_us": empty_us.value,
                          "net_of_empty_dispatch_frac": (spmv_bytes / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if net_us > 0 else None,
-                         "timing": "start/stop HIP events attached to each SpMV dispatch (hipExtLaunchKernel) on its launch stream, every 4th timed step; read once per block after it has drained.  The event pair brackets [predecessor complete -> this kernel complete], i.e. it contains the dispatch latency in front of the first wave (an empty kernel reads 4 us by it; under rocprofv3 the same dispatches read 24.2 us by events and 18.4 us by the trace's begin / end timestamps), which is why rocprofv3_avg_launch_us is lower",
+                         "timing": "every SpMV dispatch of every 4th timed step, on its launch stream, read once per block after it has drained: avg_launch_us / achieved / frac by the kernel's own begin / end stamps (first wave started -> last wave finished); event_* by the start/stop HIP events attached to the same dispatches (hipExtLaunchKernel), whose pair brackets [predecessor complete -> this kernel complete] and so contains the dispatch latency in front of the first wave (an empty kernel reads ~4 us by it)",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
                          "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es},

@@ -564,6 +564,12 @@ int wiski_read_flag(const int32_t* d_flag, int32_t* h_value, void* stream);
  * synchronise the stream before calling it. */
 int wiski_prof_start(int32_t max_launches);
 int wiski_prof_stop(double* total_ms, int64_t* launches);
+/* The same recorded dispatches by stamps taken INSIDE the kernel (k_spmv_sym_dma: 100 MHz wall clock, earliest wave start /
+ * latest wave end of each dispatch): summed [first wave started -> last wave finished] time and the number of stamped
+ * dispatches.  The event pair of wiski_prof_stop brackets [predecessor complete -> kernel complete] and so contains the
+ * dispatch latency in front of the first wave (~2.4 us); this figure is the kernel alone.  Call before wiski_prof_stop,
+ * stream synchronised. */
+int wiski_prof_stamps(double* total_ms, int64_t* launches);
 /* between start and stop: switch the event attachment off / on again without touching what has been recorded (sample some
  * steps of a pipelined loop, read all events once the loop has drained) */
 int wiski_prof_enable(int32_t on);

@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void k_gather_ell(const int32_t* __restrict__ 
   }
 }
 
+#include "gather_ell_dma.h"
+
 // ------------------------------------------------------------- W^T columns --
 // out[p][idx] += val for the T taps of query p (one dense m-column per query).
 template <typename real, int D>
@@ -386,10 +388,55 @@ static int gather_zero_impl(const wiski_grid* grid, const real* d_x, int64_t n, 
   return WISKI_OK;
 }
 
+static int ell_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return n;
+}
+// tuning hooks of tools/gather_ell_probe.py (passes per tile, waves per CU; 0 = default)
+static int g_ell_p = 0, g_ell_wpc = 0, g_ell_off = 0;
+extern "C" void wiski_gather_ell_tune(int32_t p, int32_t wpc, int32_t off) { g_ell_p = p; g_ell_wpc = wpc; g_ell_off = off; }
+
+template <typename real, int LPR, int P>
+static int gather_ell_dma_launch(const int32_t* d_idx, const real* d_val, int64_t n, const real* d_v, real* d_out, hipStream_t s) {
+  using Gm = EllDmaGeom<real, LPR, P>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)k_gather_ell_dma<real, LPR, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS_B) != hipSuccess) return WISKI_E_LAUNCH;
+    attr_done = true;
+  }
+  const int64_t ntiles = (n + Gm::RPT - 1) / Gm::RPT;
+  int wpc = (int)((160 * 1024) / Gm::LDS_B);
+  const int cap = g_ell_wpc > 0 ? g_ell_wpc : 8;
+  if (wpc > cap) wpc = cap;
+  int64_t waves = (int64_t)ell_cu_count() * wpc;
+  if (waves > ntiles) waves = ntiles;
+  hipLaunchKernelGGL((k_gather_ell_dma<real, LPR, P>), dim3((unsigned)waves), dim3(64), Gm::LDS_B, s, d_idx, d_val, n, d_v, d_out, ntiles);
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
 template <typename real>
 static int gather_ell_impl(const int32_t* d_idx, const real* d_val, int64_t n, int32_t T, const real* d_v, real* d_out, void* stream) {
   if (n == 0) return WISKI_OK;
   if (!d_idx || !d_val || !d_v || !d_out) return WISKI_E_BADARG;
+  // large row counts with 16-byte aligned arrays: the LDS-DMA staged kernel (gather_ell_dma.h); small ones are launch-bound either way
+  if (!g_ell_off && n * (int64_t)T >= ((int64_t)1 << 20) && (((uintptr_t)d_idx | (uintptr_t)d_val) & 15) == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    const bool p8 = g_ell_p == 8;
+#define ELL_DMA(LPR_) return p8 ? gather_ell_dma_launch<real, LPR_, 8>(d_idx, d_val, n, d_v, d_out, s) : gather_ell_dma_launch<real, LPR_, 4>(d_idx, d_val, n, d_v, d_out, s)
+    switch (T) {
+      case 4: ELL_DMA(1);
+      case 16: ELL_DMA(4);
+      case 64: ELL_DMA(16);
+      case 256: ELL_DMA(64);
+      default: return WISKI_E_BADARG;
+    }
+#undef ELL_DMA
+  }
   int lpr = T / 4;
   int64_t rpb = 256 / (lpr > 0 ? lpr : 1);
   int64_t blocks = (n + rpb - 1) / rpb;

@@ -19,7 +19,14 @@ static struct WiskiProf {
   bool on = false;
   std::vector<hipEvent_t> ev;
   size_t used = 0;
+  // in-kernel stamps (k_spmv_sym_dma): per recorded dispatch 64 "first wave started" words (atomic min) and 64 "last wave
+  // finished" words (atomic max) of the 100 MHz wall clock -- [2][cap][64]; the events above bracket [predecessor complete ->
+  // this kernel complete] and so contain the dispatch latency in front of the first wave, these do not
+  unsigned long long* d_stamp = nullptr;
+  size_t stamp_cap = 0;
+  std::vector<unsigned char> stamped;
 } g_prof;
+constexpr int PROF_STAMP_SLOTS = 64;
 
 extern "C" int wiski_prof_start(int max_launches) {
   if (max_launches < 1) return WISKI_E_BADARG;
@@ -28,9 +35,31 @@ extern "C" int wiski_prof_start(int max_launches) {
     if (hipEventCreate(&e) != hipSuccess) return WISKI_E_LAUNCH;
     g_prof.ev.push_back(e);
   }
+  if (g_prof.stamp_cap < (size_t)max_launches) {
+    if (g_prof.d_stamp) (void)hipFree(g_prof.d_stamp);
+    g_prof.d_stamp = nullptr;
+    g_prof.stamp_cap = 0;
+    if (hipMalloc(&g_prof.d_stamp, (size_t)max_launches * 2 * PROF_STAMP_SLOTS * sizeof(unsigned long long)) == hipSuccess) g_prof.stamp_cap = (size_t)max_launches;
+    else (void)hipGetLastError();
+  }
+  if (g_prof.d_stamp) {   // begin words: large; end words: 0 (synchronous: this call sits outside every timed region)
+    const size_t half = g_prof.stamp_cap * PROF_STAMP_SLOTS * sizeof(unsigned long long);
+    if (hipMemset(g_prof.d_stamp, 0x7f, half) != hipSuccess || hipMemset((char*)g_prof.d_stamp + half, 0, half) != hipSuccess) return WISKI_E_LAUNCH;
+  }
+  g_prof.stamped.assign(g_prof.stamp_cap, 0);
   g_prof.used = 0;
   g_prof.on = true;
   return WISKI_OK;
+}
+
+// the stamp words of the dispatch launch_timed is about to record (or NULL: not recording / no room)
+static inline unsigned long long* prof_stamp_begin() {
+  if (!(g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) || !g_prof.d_stamp || g_prof.used / 2 >= g_prof.stamp_cap) return nullptr;
+  g_prof.stamped[g_prof.used / 2] = 1;
+  return g_prof.d_stamp + (g_prof.used / 2) * PROF_STAMP_SLOTS;
+}
+static inline unsigned long long* prof_stamp_end(unsigned long long* begin) {
+  return begin ? begin + g_prof.stamp_cap * PROF_STAMP_SLOTS : nullptr;
 }
 
 extern "C" int wiski_prof_enable(int32_t on) {
@@ -50,6 +79,32 @@ extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
   if (total_ms) *total_ms = tot;
   if (launches) *launches = (int64_t)(g_prof.used / 2);
   g_prof.used = 0;
+  return WISKI_OK;
+}
+
+// The same dispatches by their in-kernel stamps: sum over the stamped dispatches of (latest "wave finished" - earliest "wave
+// started"), 100 MHz wall clock.  Call BEFORE wiski_prof_stop (which forgets the dispatches); the stream must be synchronised.
+extern "C" int wiski_prof_stamps(double* total_ms, int64_t* launches) {
+  const size_t nd = g_prof.used / 2 < g_prof.stamp_cap ? g_prof.used / 2 : g_prof.stamp_cap;
+  double tot = 0;
+  int64_t cnt = 0;
+  if (nd && g_prof.d_stamp) {
+    std::vector<unsigned long long> b(nd * PROF_STAMP_SLOTS), e(nd * PROF_STAMP_SLOTS);
+    if (hipMemcpy(b.data(), g_prof.d_stamp, b.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(e.data(), g_prof.d_stamp + g_prof.stamp_cap * PROF_STAMP_SLOTS, e.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+      return WISKI_E_LAUNCH;
+    for (size_t i = 0; i < nd; ++i) {
+      if (!g_prof.stamped[i]) continue;
+      unsigned long long lo = ~0ull, hi = 0;
+      for (int j = 0; j < PROF_STAMP_SLOTS; ++j) {
+        if (b[i * PROF_STAMP_SLOTS + j] < lo) lo = b[i * PROF_STAMP_SLOTS + j];
+        if (e[i * PROF_STAMP_SLOTS + j] > hi) hi = e[i * PROF_STAMP_SLOTS + j];
+      }
+      if (hi > lo) { tot += (double)(hi - lo) * 1e-5; ++cnt; }   // 10 ns ticks -> ms
+    }
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
   return WISKI_OK;
 }
 
@@ -1047,7 +1102,8 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         return WISKI_E_LAUNCH;                                                                                                    \
       lds_set = sh;                                                                                                               \
     }                                                                                                                             \
-    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab, xcd_rb); \
+    unsigned long long* st_b = prof_stamp_begin();                                                                                \
+    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab, xcd_rb, st_b, prof_stamp_end(st_b)); \
   } while (0)
       if (g_sym_dma_nst == 3) {
         if (dots) SYMDMA(3, true); else SYMDMA(3, false);

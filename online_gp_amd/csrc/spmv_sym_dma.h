@@ -57,33 +57,8 @@
 // part[nparts] += transposed terms (must be zero on entry; re-zeroed by the consumer).
 #pragma once
 
-__device__ __forceinline__ void glds_b128(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-// the A_h stream: read once per launch, so "sc0 nt" (stream through the XCD's L2 without keeping the line; the bare ring of
-// tools/ubench/stream_ubench.hip moves 86 MB in 10.8 us with it against 12.1 us plain; nt / sc1 / sc0 sc1 alone: no change)
-__device__ __forceinline__ void glds_b128_stream(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-#ifdef WISKI_DMA_PLAIN_STREAM
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-#else
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 nt\n\ts_mov_b32 m0, %0"
-#endif
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-__device__ __forceinline__ void glds_b32(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
+#include "lds_dma.h"   // glds_b128 / glds_b128_stream / glds_b32, wave_lgkm_fence, lds_addr
+
 // counted wait on the vector-memory queue; n is wave-uniform and a multiple of 7 (instructions per tile)
 __device__ __forceinline__ void wait_vm_tiles(int tiles_ahead) {
   if (tiles_ahead >= 3) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
@@ -91,10 +66,6 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles_ahead) {
   else if (tiles_ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void wave_lgkm_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }
-
 constexpr int SYMDMA_TILE = 7 * 256;   // reals of one group tile
 
 #ifndef WISKI_DMA_ABLATE
@@ -131,9 +102,15 @@ struct SymDmaParts {
 template <int NST, bool DOT>
 __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const float* __restrict__ A_h, const float* __restrict__ V, int W4, int WP,
                                                      int nparts, float* __restrict__ part, const float* __restrict__ add, float beta,
-                                                     double* __restrict__ dots, int delay, SymDmaParts tab, int xcd_rb) {
+                                                     double* __restrict__ dots, int delay, SymDmaParts tab, int xcd_rb,
+                                                     unsigned long long* __restrict__ stamp_begin, unsigned long long* __restrict__ stamp_end) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
+  // measurement hook (wiski_prof_*; NULL otherwise): when the first wave of the dispatch started / the last one finished, by the
+  // 100 MHz wall clock.  The start time is read here and kept in a register; both words go out at the very end as fire-and-forget
+  // 64-bit atomics (min / max) spread over 64 words, ~30 waves per word (an atomic up here, under `lane == 0`, also costs the
+  // compiler its proof that the LDS-DMA destinations below are wave-uniform)
+  const unsigned long long t_begin = stamp_begin ? (unsigned long long)wall_clock64() : 0ull;
   const int m = G.m, S0 = G.stride[0], S1 = G.stride[1];
   // work units ("parts"), heaviest first in dispatch order.  nparts = 4: whole chunks d0 = 1, 2, 3, 0.
   // nparts = 7: the 7-group chunks split into digits 0..3 / 4..6 of the middle stencil digit (4 + 3 tiles).
@@ -353,6 +330,10 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
     if (lane == 0) pcg_dot_add(dots, 0, pd);
   }
   DMA_STAMP(12);
+  if (stamp_end && lane == 0) {
+    __hip_atomic_fetch_min(stamp_begin + ((blockIdx.x + 7 * blockIdx.y) & 63), t_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(stamp_end + ((blockIdx.x + 7 * blockIdx.y) & 63), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef WISKI_DMA_TIMING
   if (lane == 0)
     for (int i = 0; i < 16; ++i) g_dma_dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = dma_ts[i];

@@ -18,7 +18,6 @@ import torch
 
 from .. import settings
 from ..mlls import BatchedWoodburyMarginalLogLikelihood, mll_feature_surrogate, sm_partial_mll
-from .stems import Identity
 
 _LR_FLOOR = 1e-4          # eta_min of the cosine schedules
 _REPLAY = 1024            # replay sample size of the BatchNorm refresh
@@ -28,6 +27,18 @@ EVAL_CHUNK = 1024         # evaluate() batch size
 def _cosine_lr(base, floor, step, total):
     """Closed form of torch's CosineAnnealingLR(T_max=total, eta_min=floor) after `step` steps."""
     return floor + 0.5 * (base - floor) * (1.0 + math.cos(math.pi * step / total))
+
+
+class _NoOptimizer:
+    """What a parameter-free stem gets instead of Adam: the optimiser surface the loops below use, doing nothing."""
+
+    param_groups = ()
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+    def step(self):
+        pass
 
 
 class _ReplayBuffer:
@@ -89,7 +100,8 @@ class StreamingSKIWrapper(torch.nn.Module):
         capturable = True
         self.gp_optimizer = adam(self.gp.parameters(), gp_lr)
         capturable = False
-        self.stem_optimizer = adam(self.stem.parameters(), stem_lr)
+        stem_params = [p for p in self.stem.parameters() if p.requires_grad]
+        self.stem_optimizer = adam(stem_params, stem_lr) if stem_params else _NoOptimizer()     # (Identity: nothing to learn)
         self.__dict__["_graphed"] = None              # a captured hyper step belongs to its optimiser
 
     def set_lr(self, gp_lr, stem_lr=None, bn_mom=None):
@@ -100,7 +112,8 @@ class StreamingSKIWrapper(torch.nn.Module):
                     layer.momentum = bn_mom
 
     def _stem_has_modules(self):
-        return next(iter(self.stem.modules()), None) is not None
+        """True if the stem carries running statistics (batch normalisation) that must keep seeing inputs."""
+        return any(isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) for mod in self.stem.modules())
 
     def _as_rows(self, inputs):
         return inputs.reshape(-1, self.stem.input_dim)
@@ -167,7 +180,7 @@ class StreamingSKIWrapper(torch.nn.Module):
         return float(loss.detach())
 
     def _stem_step(self, inputs, gp_targets, noise):
-        if type(self.stem) is Identity:              # parameter-free by construction: nothing to differentiate
+        if isinstance(self.stem_optimizer, _NoOptimizer):    # parameter-free stem: nothing to differentiate
             return 0
         self.stem.eval()                             # deterministic features while differentiating
         feats = self.stem(inputs)

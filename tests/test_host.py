@@ -312,3 +312,21 @@ def test_bench_spawns_its_own_ranks_without_a_launcher(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_stems_shapes_and_parameter_free_identity():
+    """Identity owns nothing to learn (the streaming wrapper gives it a no-op optimiser); LinearStem / MLP map into (-1, 1)
+    (reference online_gp/models/stems.py: BatchNorm without affine, tanh(z / 2)); hidden widths may come as the reference's
+    comma-separated configuration string."""
+    from online_gp_amd.models import MLP, Identity, LinearStem
+
+    ident = Identity(3)
+    x = torch.randn(17, 3)
+    assert ident(x) is x and list(ident.parameters()) == [] and (ident.input_dim, ident.output_dim) == (3, 3)
+    for stem in (LinearStem(3, 2), MLP(3, 2, 2, "16,8"), MLP(3, 2, 1, [5])):
+        z = stem(x)
+        assert z.shape == (17, 2) and float(z.abs().max()) < 1.0 and (stem.input_dim, stem.output_dim) == (3, 2)
+        assert any(isinstance(m, torch.nn.BatchNorm1d) and not m.affine for m in stem.modules())
+    assert [m.out_features for m in MLP(3, 2, 2, "16,8") if isinstance(m, torch.nn.Linear)] == [16, 8, 2]
+    with pytest.raises(ValueError):
+        MLP(3, 2, 3, "16,8")

@@ -174,3 +174,14 @@ def test_openmp_port_variance_matches_the_data_space_oracle():
     O = dataspace.DataSpaceGP([[-1.1, 1.1]] * d, g, sigma2=0.7).fit(X, y, nz)
     _, vo = O.predict(Xs)
     assert np.abs(B.variance(Xs) - vo).max() < 1e-10 * vo.max()
+
+
+def test_golden_files_say_where_their_numbers_come_from():
+    """Every fixture stores `source`: "oracle" (this repo's data-space exact GP; the reference cannot be imported in this image:
+    parity unpinned) or "reference" (regenerated by make_golden.py --from-reference where gpytorch exists)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+    assert len(files) >= 9
+    for f in files:
+        assert str(np.load(f)["source"]) in ("oracle", "reference"), f
