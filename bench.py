@@ -341,7 +341,7 @@ def main():
         X0, y0 = synth_stream(args.n_init, d, seed0, dev, dtype, kind)        # identical init on every rank
         block_s, iters = [], []
         ms_sum, n_launch = 0.0, 0
-        st_sum, st_n = 0.0, 0
+        st_sum, st_n, st_each = 0.0, 0, []
         R, p = blocks, 0
         model = upd = None
         while R <= 0 or len(block_s) < R:
@@ -406,9 +406,11 @@ def main():
                     # the loop is pipelined (a step returns with its refresh in flight): the events are read here, outside the
                     # timed region, once the block has drained -- reading them after each step would wait for the GPU
                     tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
-                    if lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl)) == 0:      # the same dispatches by their in-kernel stamps
+                    each = (ctypes.c_double * 256)()
+                    if lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl), each, ctypes.c_int64(256)) == 0:      # the same dispatches by their in-kernel stamps
                         st_sum += tms.value
                         st_n += int(nl.value)
+                        st_each.extend(each[:min(int(nl.value), 256)])
                     if lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl)) == 0:
                         ms_sum += tms.value
                         n_launch += int(nl.value)
@@ -416,7 +418,7 @@ def main():
         bt = torch.tensor(block_s, dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-        run_stream.stamps = (st_sum, st_n)
+        run_stream.stamps = (st_sum, st_n, st_each)
         return model, upd, bt.tolist(), iters, ms_sum, n_launch
 
     with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), settings.deferred_refresh(True), \
@@ -445,7 +447,7 @@ def main():
                 os.environ["WISKI_BENCH_NO_STENCIL_SHARD"] = "1"       # (the fallback below and the extras must not try it again)
         try:
             model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, headline_ex, args.blocks, 0, profile=os.environ.get("WISKI_BENCH_NOSAMPLE") != "1")
-            stamp_ms, stamp_n = run_stream.stamps
+            stamp_ms, stamp_n, stamp_each = run_stream.stamps
             headline_note = None
         except Exception as exc:  # noqa: BLE001
             if world == 1:
@@ -455,7 +457,7 @@ def main():
             headline_note = ("stencil-sharded step failed, fell back: " + repr(exc))[:300]
             os.environ["WISKI_BENCH_NO_STENCIL_SHARD"] = "1"
             model, upd, block_s, iters, spmv_ms, spmv_n = run_stream(args.stream, "auto", args.blocks, 0, profile=False)
-            stamp_ms, stamp_n = 0.0, 0
+            stamp_ms, stamp_n, stamp_each = 0.0, 0, []
         R = len(block_s)
         med = float(np.median(block_s))
         # the headline counts EVERY timed block (round 5; rounds 1-4 left blocks > 1.5x the median out as host hiccups and said so): what a
@@ -581,6 +583,8 @@ def main():
                 mu = model.prediction_cache["pred_mean"][0, :, 0].contiguous()
                 grid_ops.gather_ell(idx, val, mu)
                 ell_us = event_us(lambda i: grid_ops.gather_ell(idx, val, mu), 6)
+                grid_ops.gather_ell(idx, val, mu, grid=grid)
+                ellg_us = event_us(lambda i: grid_ops.gather_ell(idx, val, mu, grid=grid), 6)
                 ell_bytes = nq * (T * (4 + es) + es)
                 fused_us = event_us(lambda i: grid_ops.gather(grid, Xq, mu, errf), 6)
                 # the owner-computes absorb (scatter_owner.h): what a rank pays for the N q points of a point exchange -- 8 q points here
@@ -643,11 +647,15 @@ def main():
                      "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_us": sc_us, "algorithmic_bytes_per_point": sc_bytes, "points_per_s": q / (sc_us * 1e-6),
                      "lane_atomics_per_s": q * (T * (T + 1) // 2 + 2 * T) / (sc_us * 1e-6), "timing": "median of 5 torch.cuda.Event brackets of 8 launches"},
-                    {"kernel": "k_gather_ell (predictive interpolated MVM from stored idx/val, 2^20 query rows)", "bound": "hbm",
-                     "achieved": ell_bytes / (ell_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ell_bytes / (ell_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "avg_launch_us": ell_us, "algorithmic_bytes_per_row": T * (4 + es) + es,
-                     "fused_form_rows_per_s": nq / (fused_us * 1e-6), "note": "the product path uses the fused form (weights recomputed from x, 16 B/row)",
-                     "timing": "median of 5 torch.cuda.Event brackets of 6 launches"},
+                    {"kernel": "k_gather_ell_dma<float, 16, 8, true> (+ k_ell_pack_v8): predictive interpolated MVM from stored idx/val rows, 2^20 query rows, "
+                               "rows staged through LDS by LDS-DMA, v gathered from its blocked copy (wiski_gather_ell_grid)", "bound": "hbm",
+                     "achieved": ell_bytes / (ellg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ell_bytes / (ellg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "avg_launch_us": ellg_us, "algorithmic_bytes_per_row": T * (4 + es) + es, "infinity_cache_resident": False,
+                     "plain_form_us": ell_us, "plain_form_frac": ell_bytes / (ell_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "plain_form": "k_gather_ell_dma<float, 16, 8, false> (wiski_gather_ell: any idx, v row-major)",
+                     "fused_form_rows_per_s": nq / (fused_us * 1e-6), "note": "the product path uses the fused form (weights recomputed from x, 16 B/row); "
+                     "what bounds the ELL form is the gather of v behind the stream, not the stream (profiles/r06_gather_ell_probe.txt: 6.4 TB/s with the gathers served by L1)",
+                     "timing": "median of 5 torch.cuda.Event brackets of 6 calls (pack + gather)"},
                 ]
                 # the SAME product where HBM really serves the operand: BASELINE config 2's geometry (d = 4, 30^4, fp64) -- the symmetric half
                 # stencil is 1 201 x 810 000 doubles = 7.8 GB, 30x the Infinity Cache, streamed once per launch (the 50^3 fp32 operand
@@ -925,6 +933,9 @@ def main():
                          "launches": stamp_n if stamped else spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
                          "clock": ("in-kernel stamps: earliest wave start -> latest wave end of each sampled dispatch (s_memrealtime, 100 MHz), wiski_prof_stamps"
                                    if stamped else "HIP events attached to each dispatch (this kernel carries no in-kernel stamps)"),
+                         "median_launch_us": float(np.median(stamp_each)) if (stamped and stamp_each) else None,
+                         "frac_at_median_launch": (spmv_bytes / (float(np.median(stamp_each)) * 1e-6) / 1e9 / HBM_PEAK_GBS) if (stamped and stamp_each) else None,
+                         "launches_over_1.25x_median": int(np.sum(np.asarray(stamp_each) > 1.25 * np.median(stamp_each))) if (stamped and stamp_each) else None,
                          "event_launches": spmv_n, "event_avg_launch_us": ev_ms * 1e3, "event_achieved": ev_achieved, "event_frac": ev_achieved / HBM_PEAK_GBS,
                          # everything in `committed_take` (and `traffic` above) was read back from files under profiles/: a separate run of
                          # this command under rocprofv3, committed with the round -- evidence beside this run's own events, not part of them

@@ -87,6 +87,14 @@ int wiski_gather_rows_f64(const wiski_grid* grid, const double* d_x, int64_t n, 
  * (the layout InterpolatedLazyTensor keeps; BFN:206-210). k == 1 only. */
 int wiski_gather_ell_f32(const int32_t* d_idx, const float* d_val, int64_t n, int32_t T, const float* d_v, float* d_out, void* stream);
 int wiski_gather_ell_f64(const int32_t* d_idx, const double* d_val, int64_t n, int32_t T, const double* d_v, double* d_out, void* stream);
+/* The same product for rows written by wiski_interp on `grid` (idx[tap] = base + sum_q c_q stride_q; T = 4^d): in fp32 d_v is first
+ * copied into a blocked layout (second-to-last dim in blocks of 4 stored 8 wide, csrc/gather_ell_dma.h) in which a row's taps fall
+ * into 7 cache lines instead of ~17.5 -- the gathers of v, not the idx / val stream, bound the plain form.  d_vpack: scratch of
+ * wiski_gather_ell_pack_elems(grid) reals, 16-byte aligned (0 elements: d = 1 or a grid too large -- pass NULL).  fp64, small row
+ * counts, d = 1, a NULL or misaligned scratch take wiski_gather_ell. */
+int wiski_gather_ell_grid_f32(const wiski_grid* grid, const int32_t* d_idx, const float* d_val, int64_t n, const float* d_v, float* d_vpack, float* d_out, void* stream);
+int wiski_gather_ell_grid_f64(const wiski_grid* grid, const int32_t* d_idx, const double* d_val, int64_t n, const double* d_v, double* d_vpack, double* d_out, void* stream);
+int64_t wiski_gather_ell_pack_elems(const wiski_grid* grid);
 
 /* a2+a3+a4+URLT:58 -- replaces _initialize_caches / _update_cache_dicts /
  * UpdatedRootLazyTensor.update's `tensor + V V^T` (BFN:31-60,155-171):
@@ -569,7 +577,7 @@ int wiski_prof_stop(double* total_ms, int64_t* launches);
  * dispatches.  The event pair of wiski_prof_stop brackets [predecessor complete -> kernel complete] and so contains the
  * dispatch latency in front of the first wave (~2.4 us); this figure is the kernel alone.  Call before wiski_prof_stop,
  * stream synchronised. */
-int wiski_prof_stamps(double* total_ms, int64_t* launches);
+int wiski_prof_stamps(double* total_ms, int64_t* launches, double* each_us, int64_t each_cap);   /* each_us (may be NULL): the first each_cap dispatches one by one, microseconds */
 /* between start and stop: switch the event attachment off / on again without touching what has been recorded (sample some
  * steps of a pipelined loop, read all events once the loop has drained) */
 int wiski_prof_enable(int32_t on);

@@ -103,9 +103,57 @@ struct EllDmaGeom {
   static constexpr unsigned LDS_B = NST * STAGE_B + RPT * (unsigned)sizeof(real);
 };
 
-template <typename real, int LPR, int P>
+// ---- grid-aware form (wiski_gather_ell_grid, fp32): v re-laid so that a row's taps fall into 7 cache lines instead of ~17.5 -------
+// What bounds the kernel above is not the idx / val stream but the gathers of v: in the row-major v a row's T taps sit in T / 4
+// different cache lines (one per tap prefix: 16 at d = 3, ~17.5 with the 16-byte groups that straddle a line), every one an L2
+// request that queues in the CU's in-order vector-memory path behind the stream's HBM requests (measured, tools/gather_ell_probe.py:
+// all gathers served by L1 -> 6.4 TB/s; a quarter of the lines -> 6.1 TB/s; as they are -> 4.3-4.7 TB/s).  wiski_interp's rows are
+// structured -- idx[tap] = base + sum_q c_q stride_q -- so for them v can be read from a BLOCKED copy in which the second-to-last
+// dim K is cut into blocks of 4 stored 8 wide (each block carries its successor as a halo: twice the memory of v, 1 MB at 50^3):
+//     v8[outer][jK >> 2][jL][0..7] = v[outer][4 (jK >> 2) + 0..7][jL]      (outer = the leading dims, jL the last one; zeros past gK)
+// Lane (prefix, cL) of a row loads the 32 contiguous bytes of block jK >> 2 at jL + cL (two 16-byte loads, the second in the same
+// line three times out of four) and takes its four cK values at offset jK & 3; the four lanes of a prefix read 128 contiguous
+// bytes, so a row touches 4^(d-2) x 1.75 = 7 lines at d = 3.  (A 4-wide blocking that fetches block b + 1 separately was built
+// first: as many lines as it saves in L it adds in K -- 112-118 us against 116 for the plain form; without the second block's
+// lines 97 us, which is what the halo buys.)  fp64 rows gain nothing from it (8 doubles are 64 bytes: as many lines as before)
+// and take the plain form.
+struct EllV4Geo {
+  unsigned gL, gK, nbk;      // sizes of the last and second-to-last dim, K blocks of 4
+  unsigned mulL, shL;        // n / gL = mulL ? __umulhi(n, mulL) >> shL : n   (exact for 0 <= n < 2^31, Granlund-Montgomery)
+  unsigned mulK, shK;
+};
+static inline void ell_magic(unsigned d, unsigned* mul, unsigned* sh) {
+  if (d <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;
+  *mul = (unsigned)(((1ull << (31 + L)) + d - 1) / d);
+  *sh = L - 1;
+}
+__device__ __forceinline__ unsigned ell_div(unsigned n, unsigned mul, unsigned sh) { return mul ? __umulhi(n, mul) >> sh : n; }
+
+// v [m] (row-major grid vector) -> v8 [outer][nbk][gL][8]; one thread per 32-byte group
+template <typename real>
+__global__ __launch_bounds__(256) void k_ell_pack_v8(const real* __restrict__ v, real* __restrict__ v8, EllV4Geo geo, int64_t groups) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= groups) return;
+  const unsigned jL = (unsigned)(e % geo.gL);
+  const int64_t r = e / geo.gL;
+  const unsigned b = (unsigned)(r % geo.nbk);
+  const int64_t outer = r / geo.nbk;
+  real q[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const unsigned jK = 4 * b + t;
+    q[t] = jK < geo.gK ? v[(outer * geo.gK + jK) * geo.gL + jL] : (real)0;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v8[8 * e + t] = q[t];
+}
+
+template <typename real, int LPR, int P, bool V4 = false>
 __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict__ idx, const real* __restrict__ val, int64_t n,
-                                                       const real* __restrict__ v, real* __restrict__ out, int64_t ntiles) {
+                                                       const real* __restrict__ v, real* __restrict__ out, int64_t ntiles, int contig,
+                                                       EllV4Geo geo) {
   using Gm = EllDmaGeom<real, LPR, P>;
   constexpr int RPP = Gm::RPP, RPT = Gm::RPT, VI = Gm::VI, IPT = Gm::IPT, NST = Gm::NST;
   constexpr int T = 4 * LPR;
@@ -115,10 +163,22 @@ __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict
   real* __restrict__ obuf = reinterpret_cast<real*>(smem + NST * Gm::STAGE_B);
   const int64_t nwaves = gridDim.x;
   const int64_t w = blockIdx.x;
-  const int64_t nt = w < ntiles ? (ntiles - w + nwaves - 1) / nwaves : 0;      // tiles of this wave: w, w + nwaves, ...
+  // tiles of this wave: w, w + nwaves, ... (one interleaved address stream per array), or with contig the contiguous range
+  // [w per, (w + 1) per)
+#ifdef WISKI_ELL_ABLATE   // timing ablations (wrong results; tools/gather_ell_probe.py --ablate with a -DWISKI_ELL_ABLATE build): gathers served by L1,
+  // no refill of the stages, the 4 lanes of a quad gather the same 16 bytes (a quarter of the accesses per row)
+  const bool abl_gather = (contig & 2) != 0, abl_stream = (contig & 4) != 0, abl_quad = (contig & 8) != 0;
+#else
+  constexpr bool abl_gather = false, abl_stream = false, abl_quad = false;
+#endif
+  contig &= 1;
+  const int64_t per = (ntiles + nwaves - 1) / nwaves;
+  const int64_t nt = contig ? (w * per < ntiles ? (ntiles - w * per < per ? ntiles - w * per : per) : 0)
+                            : (w < ntiles ? (ntiles - w + nwaves - 1) / nwaves : 0);
+  const int64_t t0 = contig ? w * per : w, tstep = contig ? 1 : nwaves;
 
   auto issue_tile = [&](int64_t k) {       // always IPT wave instructions (the counted waits rely on it)
-    const int64_t row0 = (w + k * nwaves) * RPT;
+    const int64_t row0 = (t0 + k * tstep) * RPT;
     const unsigned dst = stage_a + (unsigned)(k % NST) * Gm::STAGE_B;
     constexpr int EPG = 16 / (int)sizeof(real);                // reals per 16-byte group
     if (row0 + RPT <= n) {                                     // (wave-uniform) a whole tile: lane l copies 16-byte group l of every KiB
@@ -150,6 +210,64 @@ __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict
     // already seen to that: this is then a no-op)
     if (k + 1 < nt) wait_vmcnt_imm<IPT>(); else wait_vmcnt_imm<0>();
     const char* st = smem + (k % NST) * Gm::STAGE_B;
+    if constexpr (V4) {
+      // lane (row in pass, prefix, cL): idx of its tap (prefix, cK = 0, cL) and the four weights val[(prefix, cK, cL)], cK = 0..3
+      static_assert(LPR >= 4, "the blocked form needs d >= 2");
+      const int sub = lane % LPR;
+      const int e0 = (lane / LPR) * T + (sub >> 2) * 16 + (sub & 3);
+      int i0[P];
+      real a[P][4];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        i0[p] = reinterpret_cast<const int*>(st + 1024 * p)[e0];
+        const real* av = reinterpret_cast<const real*>(st + Gm::IDX_B + 1024 * VI * p) + e0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[p][c] = av[4 * c];
+      }
+      wave_lgkm_fence();                       // the stage has been copied out
+      EllQuad<real> g0[P], g1[P];
+      unsigned sh[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const unsigned q = ell_div((unsigned)i0[p], geo.mulL, geo.shL), jL = (unsigned)i0[p] - q * geo.gL;
+        const unsigned o = ell_div(q, geo.mulK, geo.shK), jK = q - o * geo.gK;
+        sh[p] = jK & 3;
+        const real* __restrict__ src = v + 8 * (((size_t)o * geo.nbk + (jK >> 2)) * geo.gL + jL);
+        g0[p].load4(src);
+        g1[p].load4(src + 4);
+      }
+      if (k + NST < nt) {
+        issue_tile(k + NST);
+        wait_vmcnt_imm<IPT>();
+      } else {
+        wait_vmcnt_imm<0>();
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) { g0[p].tie(); g1[p].tie(); }
+      const int64_t row0 = (t0 + k * tstep) * RPT;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        real e[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { e[c] = g0[p].get(c); e[4 + c] = g1[p].get(c); }
+        if (sh[p] & 1) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) e[c] = e[c + 1];
+        }
+        if (sh[p] & 2) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) e[c] = e[c + 2];
+        }
+        real s = a[p][0] * e[0] + a[p][1] * e[1] + a[p][2] * e[2] + a[p][3] * e[3];
+        s = ell_group_sum<real, LPR>(s);
+        if (lane % LPR == LPR - 1) obuf[p * RPP + lane / LPR] = s;
+      }
+      wave_lgkm_fence();
+      for (int r = lane; r < RPT; r += 64)
+        if (row0 + r < n) out[row0 + r] = obuf[r];
+      wave_lgkm_fence();
+      continue;
+    }
     int4 id[P];
     real a[P][4];
 #pragma unroll
@@ -172,8 +290,12 @@ __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict
     const bool refill = k + NST < nt;
     if (__builtin_amdgcn_ballot_w64(broken != 0) == 0) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) g[p].load4(v + id[p].x);
-      if (refill) { issue_tile(k + NST); wait_gathers<IPT>(g); } else wait_gathers<0>(g);
+      for (int p = 0; p < P; ++p) {
+        int ix = id[p].x;
+        if (abl_quad) ix = __builtin_amdgcn_mov_dpp(ix, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
+        g[p].load4(v + (abl_gather ? 4 * (lane & 15) : ix));
+      }
+      if (refill && !abl_stream) { issue_tile(k + NST); wait_gathers<IPT>(g); } else wait_gathers<0>(g);
     } else {
       // arbitrary indices (never produced by wiski_interp): single loads, each waited for on the spot (this drains the queue;
       // the counted waits that follow can then only wait longer than needed)
@@ -184,7 +306,7 @@ __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict
       }
       if (refill) issue_tile(k + NST);
     }
-    const int64_t row0 = (w + k * nwaves) * RPT;
+    const int64_t row0 = (t0 + k * tstep) * RPT;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       real s = a[p][0] * g[p].get(0) + a[p][1] * g[p].get(1) + a[p][2] * g[p].get(2) + a[p][3] * g[p].get(3);

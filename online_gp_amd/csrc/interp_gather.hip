@@ -396,9 +396,9 @@ static int ell_cu_count() {
   }
   return n;
 }
-// tuning hooks of tools/gather_ell_probe.py (passes per tile, waves per CU; 0 = default)
-static int g_ell_p = 0, g_ell_wpc = 0, g_ell_off = 0;
-extern "C" void wiski_gather_ell_tune(int32_t p, int32_t wpc, int32_t off) { g_ell_p = p; g_ell_wpc = wpc; g_ell_off = off; }
+// tuning hooks of tools/gather_ell_probe.py (passes per tile, total waves, register-staged kernel instead, contiguous tile ranges; 0 = default)
+static int g_ell_p = 0, g_ell_waves = 0, g_ell_off = 0, g_ell_contig = 0;
+extern "C" void wiski_gather_ell_tune(int32_t p, int32_t waves, int32_t off, int32_t contig) { g_ell_p = p; g_ell_waves = waves; g_ell_off = off; g_ell_contig = contig; }
 
 template <typename real, int LPR, int P>
 static int gather_ell_dma_launch(const int32_t* d_idx, const real* d_val, int64_t n, const real* d_v, real* d_out, hipStream_t s) {
@@ -409,14 +409,77 @@ static int gather_ell_dma_launch(const int32_t* d_idx, const real* d_val, int64_
     attr_done = true;
   }
   const int64_t ntiles = (n + Gm::RPT - 1) / Gm::RPT;
-  int wpc = (int)((160 * 1024) / Gm::LDS_B);
-  const int cap = g_ell_wpc > 0 ? g_ell_wpc : 8;
-  if (wpc > cap) wpc = cap;
-  int64_t waves = (int64_t)ell_cu_count() * wpc;
+  int64_t waves = g_ell_waves > 0 ? g_ell_waves : (int64_t)ell_cu_count() * 2;
   if (waves > ntiles) waves = ntiles;
-  hipLaunchKernelGGL((k_gather_ell_dma<real, LPR, P>), dim3((unsigned)waves), dim3(64), Gm::LDS_B, s, d_idx, d_val, n, d_v, d_out, ntiles);
+  hipLaunchKernelGGL((k_gather_ell_dma<real, LPR, P>), dim3((unsigned)waves), dim3(64), Gm::LDS_B, s, d_idx, d_val, n, d_v, d_out, ntiles, g_ell_contig, EllV4Geo{});
   WISKI_LAUNCH_CHECK();
   return WISKI_OK;
+}
+
+template <typename real>
+static int gather_ell_impl(const int32_t* d_idx, const real* d_val, int64_t n, int32_t T, const real* d_v, real* d_out, void* stream);
+
+static inline bool ell_v4_geo(const wiski_grid* grid, EllV4Geo* geo, int64_t* groups) {
+  if (!grid || grid->d < 2 || grid->d > WISKI_MAX_DIM) return false;
+  int64_t m = 1;
+  for (int q = 0; q < grid->d; ++q) m *= grid->g[q];
+  if (m >= ((int64_t)1 << 29)) return false;                  // (flat and packed indices stay below 2^31)
+  geo->gL = (unsigned)grid->g[grid->d - 1];
+  geo->gK = (unsigned)grid->g[grid->d - 2];
+  geo->nbk = (geo->gK + 3) / 4;
+  ell_magic(geo->gL, &geo->mulL, &geo->shL);
+  ell_magic(geo->gK, &geo->mulK, &geo->shK);
+  *groups = m / ((int64_t)geo->gK * geo->gL) * geo->nbk * geo->gL;
+  return true;
+}
+
+template <typename real, int LPR, int P>
+static int gather_ell_v4_launch(const EllV4Geo& geo, const int32_t* d_idx, const real* d_val, int64_t n, const real* d_v4, real* d_out, hipStream_t s) {
+  using Gm = EllDmaGeom<real, LPR, P>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)k_gather_ell_dma<real, LPR, P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gm::LDS_B) != hipSuccess) return WISKI_E_LAUNCH;
+    attr_done = true;
+  }
+  const int64_t ntiles = (n + Gm::RPT - 1) / Gm::RPT;
+  int64_t waves = g_ell_waves > 0 ? g_ell_waves : (int64_t)ell_cu_count() * 3;     // (measured: 3 per CU here, 2 for the plain form)
+  if (waves > ntiles) waves = ntiles;
+  hipLaunchKernelGGL((k_gather_ell_dma<real, LPR, P, true>), dim3((unsigned)waves), dim3(64), Gm::LDS_B, s, d_idx, d_val, n, d_v4, d_out, ntiles, g_ell_contig, geo);
+  WISKI_LAUNCH_CHECK();
+  return WISKI_OK;
+}
+
+template <typename real>
+static int gather_ell_grid_impl(const wiski_grid* grid, const int32_t* d_idx, const real* d_val, int64_t n, const real* d_v, real* d_vpack, real* d_out, void* stream) {
+  if (!grid || grid->d < 1 || grid->d > WISKI_MAX_DIM) return WISKI_E_BADARG;
+  int T = 1;
+  for (int q = 0; q < grid->d; ++q) T *= 4;
+  if (n == 0) return WISKI_OK;
+  if (!d_idx || !d_val || !d_v || !d_out) return WISKI_E_BADARG;
+  if constexpr (sizeof(real) == 8) {
+    return gather_ell_impl<real>(d_idx, d_val, n, T, d_v, d_out, stream);       // (no gain in fp64: see gather_ell_dma.h)
+  } else {
+  EllV4Geo geo;
+  int64_t groups = 0;
+  // the blocked copy pays from ~2^14 rows on (one extra pass over v); d = 1 rows touch one or two lines as they are
+  if (!d_vpack || g_ell_off || !ell_v4_geo(grid, &geo, &groups) || n * (int64_t)T < ((int64_t)1 << 20) || (((uintptr_t)d_idx | (uintptr_t)d_val | (uintptr_t)d_vpack) & 15) != 0)
+    return gather_ell_impl<real>(d_idx, d_val, n, T, d_v, d_out, stream);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((k_ell_pack_v8<real>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, d_v, d_vpack, geo, groups);
+  const int pp = g_ell_p ? g_ell_p : 8;
+#define ELL_V4(LPR_)                                                                                     \
+  do {                                                                                                   \
+    if (pp == 4) return gather_ell_v4_launch<real, LPR_, 4>(geo, d_idx, d_val, n, d_vpack, d_out, s);    \
+    return gather_ell_v4_launch<real, LPR_, 8>(geo, d_idx, d_val, n, d_vpack, d_out, s);                 \
+  } while (0)
+  switch (T) {
+    case 16: ELL_V4(4);
+    case 64: ELL_V4(16);
+    case 256: ELL_V4(64);
+    default: return WISKI_E_BADARG;
+  }
+#undef ELL_V4
+  }
 }
 
 template <typename real>
@@ -426,8 +489,13 @@ static int gather_ell_impl(const int32_t* d_idx, const real* d_val, int64_t n, i
   // large row counts with 16-byte aligned arrays: the LDS-DMA staged kernel (gather_ell_dma.h); small ones are launch-bound either way
   if (!g_ell_off && n * (int64_t)T >= ((int64_t)1 << 20) && (((uintptr_t)d_idx | (uintptr_t)d_val) & 15) == 0) {
     hipStream_t s = (hipStream_t)stream;
-    const bool p8 = g_ell_p == 8;
-#define ELL_DMA(LPR_) return p8 ? gather_ell_dma_launch<real, LPR_, 8>(d_idx, d_val, n, d_v, d_out, s) : gather_ell_dma_launch<real, LPR_, 4>(d_idx, d_val, n, d_v, d_out, s)
+    const int pp = g_ell_p ? g_ell_p : 8;
+#define ELL_DMA(LPR_)                                                                                  \
+  do {                                                                                                 \
+    if (pp == 4) return gather_ell_dma_launch<real, LPR_, 4>(d_idx, d_val, n, d_v, d_out, s);          \
+    if constexpr (sizeof(real) == 4) if (pp == 16) return gather_ell_dma_launch<real, LPR_, 16>(d_idx, d_val, n, d_v, d_out, s); \
+    return gather_ell_dma_launch<real, LPR_, 8>(d_idx, d_val, n, d_v, d_out, s);                       \
+  } while (0)
     switch (T) {
       case 4: ELL_DMA(1);
       case 16: ELL_DMA(4);
@@ -496,6 +564,13 @@ int wiski_gather_rows_f32(const wiski_grid* g, const float* x, int64_t n, const 
 int wiski_gather_rows_f64(const wiski_grid* g, const double* x, int64_t n, const double* Vr, int32_t ncols, double* out, int32_t* err, void* s) { return gather_rows_impl<double>(g, x, n, Vr, ncols, out, err, s); }
 int wiski_gather_ell_f32(const int32_t* idx, const float* val, int64_t n, int32_t T, const float* v, float* out, void* s) { return gather_ell_impl<float>(idx, val, n, T, v, out, s); }
 int wiski_gather_ell_f64(const int32_t* idx, const double* val, int64_t n, int32_t T, const double* v, double* out, void* s) { return gather_ell_impl<double>(idx, val, n, T, v, out, s); }
+int wiski_gather_ell_grid_f32(const wiski_grid* g, const int32_t* idx, const float* val, int64_t n, const float* v, float* vpack, float* out, void* s) { return gather_ell_grid_impl<float>(g, idx, val, n, v, vpack, out, s); }
+int wiski_gather_ell_grid_f64(const wiski_grid* g, const int32_t* idx, const double* val, int64_t n, const double* v, double* vpack, double* out, void* s) { return gather_ell_grid_impl<double>(g, idx, val, n, v, vpack, out, s); }
+int64_t wiski_gather_ell_pack_elems(const wiski_grid* g) {
+  EllV4Geo geo;
+  int64_t groups = 0;
+  return ell_v4_geo(g, &geo, &groups) ? 8 * groups : 0;
+}
 int wiski_wt_columns_f32(const wiski_grid* g, const float* x, int64_t n, float* out, int32_t* err, void* s) { return wt_columns_impl<float>(g, x, n, out, err, s); }
 int wiski_wt_columns_f64(const wiski_grid* g, const double* x, int64_t n, double* out, int32_t* err, void* s) { return wt_columns_impl<double>(g, x, n, out, err, s); }
 }

@@ -19,14 +19,16 @@ static struct WiskiProf {
   bool on = false;
   std::vector<hipEvent_t> ev;
   size_t used = 0;
-  // in-kernel stamps (k_spmv_sym_dma): per recorded dispatch 64 "first wave started" words (atomic min) and 64 "last wave
-  // finished" words (atomic max) of the 100 MHz wall clock -- [2][cap][64]; the events above bracket [predecessor complete ->
-  // this kernel complete] and so contain the dispatch latency in front of the first wave, these do not
-  unsigned long long* d_stamp = nullptr;
-  size_t stamp_cap = 0;
-  std::vector<unsigned char> stamped;
+  // in-kernel stamps (k_spmv_sym_dma): every wave of a recorded dispatch stores its own (start, end) pair of the 100 MHz wall
+  // clock with ONE plain 16-byte store at its very end -- no atomics (a first version funnelled min / max atomics into 64 words
+  // per dispatch: +1.5 us per dispatch by the events).  The events above bracket [predecessor complete -> this kernel complete]
+  // and so contain the dispatch latency in front of the first wave; max(end) - min(start) over the waves does not.
+  unsigned long long* d_stamp = nullptr;     // arena of pairs
+  size_t stamp_pairs = 0, stamp_used = 0;
+  struct Span { size_t off, n; };
+  std::vector<Span> spans;                   // per recorded dispatch (n == 0: not stamped)
 } g_prof;
-constexpr int PROF_STAMP_SLOTS = 64;
+constexpr size_t PROF_STAMP_ARENA_PAIRS = (size_t)1 << 20;   // 16 MB: 256 dispatches of 4096 waves
 
 extern "C" int wiski_prof_start(int max_launches) {
   if (max_launches < 1) return WISKI_E_BADARG;
@@ -35,36 +37,36 @@ extern "C" int wiski_prof_start(int max_launches) {
     if (hipEventCreate(&e) != hipSuccess) return WISKI_E_LAUNCH;
     g_prof.ev.push_back(e);
   }
-  if (g_prof.stamp_cap < (size_t)max_launches) {
-    if (g_prof.d_stamp) (void)hipFree(g_prof.d_stamp);
-    g_prof.d_stamp = nullptr;
-    g_prof.stamp_cap = 0;
-    if (hipMalloc(&g_prof.d_stamp, (size_t)max_launches * 2 * PROF_STAMP_SLOTS * sizeof(unsigned long long)) == hipSuccess) g_prof.stamp_cap = (size_t)max_launches;
-    else (void)hipGetLastError();
+  if (!g_prof.d_stamp) {
+    if (hipMalloc(&g_prof.d_stamp, PROF_STAMP_ARENA_PAIRS * 2 * sizeof(unsigned long long)) == hipSuccess) g_prof.stamp_pairs = PROF_STAMP_ARENA_PAIRS;
+    else { (void)hipGetLastError(); g_prof.d_stamp = nullptr; }
   }
-  if (g_prof.d_stamp) {   // begin words: large; end words: 0 (synchronous: this call sits outside every timed region)
-    const size_t half = g_prof.stamp_cap * PROF_STAMP_SLOTS * sizeof(unsigned long long);
-    if (hipMemset(g_prof.d_stamp, 0x7f, half) != hipSuccess || hipMemset((char*)g_prof.d_stamp + half, 0, half) != hipSuccess) return WISKI_E_LAUNCH;
-  }
-  g_prof.stamped.assign(g_prof.stamp_cap, 0);
+  // (synchronous: this call sits outside every timed region) a pair whose end word is still 0 was never written
+  if (g_prof.d_stamp && g_prof.stamp_used &&
+      hipMemset(g_prof.d_stamp, 0, g_prof.stamp_used * 2 * sizeof(unsigned long long)) != hipSuccess) return WISKI_E_LAUNCH;
+  if (g_prof.d_stamp && !g_prof.stamp_used && hipMemset(g_prof.d_stamp, 0, g_prof.stamp_pairs * 2 * sizeof(unsigned long long)) != hipSuccess) return WISKI_E_LAUNCH;
+  g_prof.stamp_used = 0;
+  g_prof.spans.assign((size_t)max_launches, WiskiProf::Span{0, 0});
   g_prof.used = 0;
   g_prof.on = true;
   return WISKI_OK;
 }
 
-// the stamp words of the dispatch launch_timed is about to record (or NULL: not recording / no room)
-static inline unsigned long long* prof_stamp_begin() {
-  if (!(g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) || !g_prof.d_stamp || g_prof.used / 2 >= g_prof.stamp_cap) return nullptr;
-  g_prof.stamped[g_prof.used / 2] = 1;
-  return g_prof.d_stamp + (g_prof.used / 2) * PROF_STAMP_SLOTS;
-}
-static inline unsigned long long* prof_stamp_end(unsigned long long* begin) {
-  return begin ? begin + g_prof.stamp_cap * PROF_STAMP_SLOTS : nullptr;
-}
-
 extern "C" int wiski_prof_enable(int32_t on) {
   g_prof.on = on != 0;
   return WISKI_OK;
+}
+
+// the stamp pairs (one per wave) of the dispatch launch_timed is about to record, or NULL: not recording / no room
+static inline unsigned long long* prof_stamp_pairs(size_t nwaves) {
+  static const bool off = getenv("WISKI_PROF_NOSTAMP") != nullptr;   // A/B of what the stamps themselves cost
+  const size_t i = g_prof.used / 2;
+  if (off || !(g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) || !g_prof.d_stamp || i >= g_prof.spans.size() ||
+      g_prof.stamp_used + nwaves > g_prof.stamp_pairs)
+    return nullptr;
+  g_prof.spans[i] = WiskiProf::Span{g_prof.stamp_used, nwaves};
+  g_prof.stamp_used += nwaves;
+  return g_prof.d_stamp + 2 * g_prof.spans[i].off;
 }
 
 // Stops recording; the caller must have synchronised the stream(s).
@@ -84,23 +86,27 @@ extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
 
 // The same dispatches by their in-kernel stamps: sum over the stamped dispatches of (latest "wave finished" - earliest "wave
 // started"), 100 MHz wall clock.  Call BEFORE wiski_prof_stop (which forgets the dispatches); the stream must be synchronised.
-extern "C" int wiski_prof_stamps(double* total_ms, int64_t* launches) {
-  const size_t nd = g_prof.used / 2 < g_prof.stamp_cap ? g_prof.used / 2 : g_prof.stamp_cap;
+extern "C" int wiski_prof_stamps(double* total_ms, int64_t* launches, double* each_us, int64_t each_cap) {
+  const size_t nd = g_prof.used / 2 < g_prof.spans.size() ? g_prof.used / 2 : g_prof.spans.size();
   double tot = 0;
   int64_t cnt = 0;
-  if (nd && g_prof.d_stamp) {
-    std::vector<unsigned long long> b(nd * PROF_STAMP_SLOTS), e(nd * PROF_STAMP_SLOTS);
-    if (hipMemcpy(b.data(), g_prof.d_stamp, b.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(e.data(), g_prof.d_stamp + g_prof.stamp_cap * PROF_STAMP_SLOTS, e.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
-      return WISKI_E_LAUNCH;
+  if (nd && g_prof.d_stamp && g_prof.stamp_used) {
+    std::vector<unsigned long long> h(2 * g_prof.stamp_used);
+    if (hipMemcpy(h.data(), g_prof.d_stamp, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return WISKI_E_LAUNCH;
     for (size_t i = 0; i < nd; ++i) {
-      if (!g_prof.stamped[i]) continue;
+      const WiskiProf::Span sp = g_prof.spans[i];
       unsigned long long lo = ~0ull, hi = 0;
-      for (int j = 0; j < PROF_STAMP_SLOTS; ++j) {
-        if (b[i * PROF_STAMP_SLOTS + j] < lo) lo = b[i * PROF_STAMP_SLOTS + j];
-        if (e[i * PROF_STAMP_SLOTS + j] > hi) hi = e[i * PROF_STAMP_SLOTS + j];
+      for (size_t w = 0; w < sp.n; ++w) {
+        const unsigned long long b = h[2 * (sp.off + w)], e = h[2 * (sp.off + w) + 1];
+        if (!e) continue;                      // (a padded workgroup that returned at once)
+        if (b < lo) lo = b;
+        if (e > hi) hi = e;
       }
-      if (hi > lo) { tot += (double)(hi - lo) * 1e-5; ++cnt; }   // 10 ns ticks -> ms
+      if (hi > lo) {
+        if (each_us && cnt < each_cap) each_us[cnt] = (double)(hi - lo) * 1e-2;   // 10 ns ticks -> us
+        tot += (double)(hi - lo) * 1e-5;                                         // -> ms
+        ++cnt;
+      }
     }
   }
   if (total_ms) *total_ms = tot;
@@ -1102,8 +1108,8 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
         return WISKI_E_LAUNCH;                                                                                                    \
       lds_set = sh;                                                                                                               \
     }                                                                                                                             \
-    unsigned long long* st_b = prof_stamp_begin();                                                                                \
-    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab, xcd_rb, st_b, prof_stamp_end(st_b)); \
+    unsigned long long* st_p = prof_stamp_pairs((size_t)grd.x * grd.y);                                                           \
+    launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab, xcd_rb, st_p); \
   } while (0)
       if (g_sym_dma_nst == 3) {
         if (dots) SYMDMA(3, true); else SYMDMA(3, false);

@@ -103,14 +103,14 @@ template <int NST, bool DOT>
 __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const float* __restrict__ A_h, const float* __restrict__ V, int W4, int WP,
                                                      int nparts, float* __restrict__ part, const float* __restrict__ add, float beta,
                                                      double* __restrict__ dots, int delay, SymDmaParts tab, int xcd_rb,
-                                                     unsigned long long* __restrict__ stamp_begin, unsigned long long* __restrict__ stamp_end) {
+                                                     unsigned long long* __restrict__ stamp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
-  // measurement hook (wiski_prof_*; NULL otherwise): when the first wave of the dispatch started / the last one finished, by the
-  // 100 MHz wall clock.  The start time is read here and kept in a register; both words go out at the very end as fire-and-forget
-  // 64-bit atomics (min / max) spread over 64 words, ~30 waves per word (an atomic up here, under `lane == 0`, also costs the
-  // compiler its proof that the LDS-DMA destinations below are wave-uniform)
-  const unsigned long long t_begin = stamp_begin ? (unsigned long long)wall_clock64() : 0ull;
+  // measurement hook (wiski_prof_*; NULL otherwise): this wave's start and end by the 100 MHz wall clock.  The start is read here
+  // and kept in a register; the pair leaves as ONE plain 16-byte store at the very end (no atomics: they cost 1.5 us per dispatch;
+  // an atomic up here under `lane == 0` also costs the compiler its proof that the LDS-DMA destinations below are wave-uniform).
+  // The host takes max(end) - min(start) over the waves of the dispatch (wiski_prof_stamps).
+  const unsigned long long t_begin = stamp ? (unsigned long long)wall_clock64() : 0ull;
   const int m = G.m, S0 = G.stride[0], S1 = G.stride[1];
   // work units ("parts"), heaviest first in dispatch order.  nparts = 4: whole chunks d0 = 1, 2, 3, 0.
   // nparts = 7: the 7-group chunks split into digits 0..3 / 4..6 of the middle stencil digit (4 + 3 tiles).
@@ -330,9 +330,12 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
     if (lane == 0) pcg_dot_add(dots, 0, pd);
   }
   DMA_STAMP(12);
-  if (stamp_end && lane == 0) {
-    __hip_atomic_fetch_min(stamp_begin + ((blockIdx.x + 7 * blockIdx.y) & 63), t_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_max(stamp_end + ((blockIdx.x + 7 * blockIdx.y) & 63), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (stamp && lane == 0) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 pr;
+    pr[0] = t_begin;
+    pr[1] = (unsigned long long)wall_clock64();
+    *reinterpret_cast<u64x2*>(stamp + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)) = pr;
   }
 #ifdef WISKI_DMA_TIMING
   if (lane == 0)

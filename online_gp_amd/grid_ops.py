@@ -160,10 +160,29 @@ def gather_rows(grid, x, Vr, err):
     return out
 
 
-def gather_ell(idx, val, v):
+_ELL_PACK = {}
+
+
+def gather_ell(idx, val, v, grid=None):
+    """out[r] = sum_t val[r, t] * v[idx[r, t]] from stored interpolation rows (a14, ELL form; BFN:206-210).  With ``grid`` -- the
+    rows were written by :func:`interp` on that grid -- large row counts go through ``wiski_gather_ell_grid``: v is first copied
+    into a blocked layout in which a row's taps touch about half as many cache lines (csrc/gather_ell_dma.h)."""
     n, T = idx.shape
     out = torch.empty((n,), dtype=val.dtype, device=val.device)
-    rc = _hip.fn("wiski_gather_ell", val.dtype)(_hip.dptr(idx), _hip.dptr(val), ctypes.c_int64(n), ctypes.c_int32(T), _hip.dptr(v.contiguous()),
+    v = v.contiguous()
+    if grid is not None and grid.d >= 2 and T == grid.T:
+        f = _hip.lib().wiski_gather_ell_pack_elems
+        f.restype = ctypes.c_int64
+        ne = int(f(grid.ref))
+        key = (val.device, val.dtype)
+        pack = _ELL_PACK.get(key)
+        if ne and (pack is None or pack.numel() < ne):
+            pack = _ELL_PACK[key] = torch.empty((ne,), dtype=val.dtype, device=val.device)
+        rc = _hip.fn("wiski_gather_ell_grid", val.dtype)(grid.ref, _hip.dptr(idx), _hip.dptr(val), ctypes.c_int64(n), _hip.dptr(v),
+                                                         _hip.dptr(pack) if ne else None, _hip.dptr(out), _hip.stream_ptr(val.device))
+        _hip.check(rc, "wiski_gather_ell_grid")
+        return out
+    rc = _hip.fn("wiski_gather_ell", val.dtype)(_hip.dptr(idx), _hip.dptr(val), ctypes.c_int64(n), ctypes.c_int32(T), _hip.dptr(v),
                                                 _hip.dptr(out), _hip.stream_ptr(val.device))
     _hip.check(rc, "wiski_gather_ell")
     return out

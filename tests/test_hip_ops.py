@@ -81,6 +81,44 @@ def test_gather_and_ell(d, g, tdt, ndt, tol):
     assert int(err.item()) == 0
 
 
+@pytest.mark.parametrize("d,g", [(1, 300), (2, 23), (3, 14), (3, 50), (4, 9)])
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float32, np.float32, 2e-5), (torch.float64, np.float64, 1e-12)])
+def test_ell_gather_streaming_kernels_against_the_oracle(d, g, tdt, ndt, tol):
+    """The large-row-count forms of the predictive interpolated MVM (BFN:206-210,235; north_star's sparse interpolation SpMM with
+    LDS-staged row tiles): k_gather_ell_dma (idx / val rows by LDS-DMA, any idx) and its grid-aware form on the blocked copy of v
+    (wiski_gather_ell_grid), against the C oracle's gather on the same points -- a ragged last tile, points in the one-hot boundary
+    cells of the grid, non-cubic grids, arbitrary (unstructured) indices through the plain entry."""
+    from online_gp_amd import grid_ops
+    from oracle import cport
+
+    rng = np.random.default_rng(100 * d + g)
+    gs = [g + (q % 2) * 3 for q in range(d)]                      # (non-cubic: the last two dims differ)
+    gb = [[-1.1, 1.1]] * d
+    grid = grid_ops.GridSpec(gb, gs)
+    T = 4 ** d
+    n = (1 << 20) // T * 2 + 37                                     # past the streaming kernels' threshold, ragged last tile
+    X = rng.uniform(-1.1, 1.1, (n, d))                             # the whole extent: first / last cells take the one-hot branch
+    X[:7] = -1.1; X[7:13] = 1.1
+    B2 = cport.MatrixFreeWISKI(gb, gs)
+    v = rng.standard_normal(grid.m)
+    ref = B2.gather(X.astype(ndt).astype(np.float64), v.astype(ndt).astype(np.float64)[None])[:, 0]
+    err = grid_ops.new_err_flag("cuda")
+    Xt, vt = _t(X.astype(ndt), tdt), _t(v.astype(ndt), tdt)
+    idx, val = grid_ops.interp(grid, Xt, err)
+    assert int(err.item()) == 0
+    scale = np.abs(ref).max()
+    same = (val.double() * vt.double()[idx.long()]).sum(1)         # the stored rows' own product in fp64: what both kernels must reproduce
+    for name, out in (("plain", grid_ops.gather_ell(idx, val, vt)), ("grid", grid_ops.gather_ell(idx, val, vt, grid=grid))):
+        assert np.abs(out.double().cpu().numpy() - ref).max() < 5 * tol * scale, name
+        assert float((out.double() - same).abs().max()) < 0.1 * tol * scale, name
+    # unstructured rows (every third row's second tap re-pointed): the plain entry's slow path gives the exact sparse product
+    idx2 = idx.clone()
+    idx2[::3, 1] = idx2[::3, 0]
+    want = (val.double() * vt.double()[idx2.long()]).sum(1)
+    got = grid_ops.gather_ell(idx2, val, vt)
+    assert float((got.double() - want).abs().max()) < tol * scale
+
+
 @pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 37, 5000])
 def test_gather_zero_and_pcg_zero_regions(tdt, n):

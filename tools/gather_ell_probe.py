@@ -29,12 +29,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1 << 20)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--policy", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda")
     lib = _hip.lib()
     tune = lib.wiski_gather_ell_tune
     for d, g, dt in ((3, 50, torch.float32), (3, 50, torch.float64), (2, 200, torch.float32), (4, 20, torch.float32), (1, 4000, torch.float32), (4, 20, torch.float64)):
-        if a.quick and not (d == 3 and dt == torch.float32):
+        if a.quick and not (d == 3 or (d == 4 and dt == torch.float32)):
             continue
         grid = grid_ops.GridSpec([[-1.1, 1.1]] * d, g)
         T = 4 ** d
@@ -48,15 +50,36 @@ def main():
         want = (val.double() * v.double()[idx.long()]).sum(1)
         byts = n * (T * (4 + es) + es)
         print(f"d={d} g={g} {str(dt)[6:]} rows={n} T={T}  ({byts / 1e6:.0f} MB)", flush=True)
-        for name, p, wpc, off in [("k_gather_ell (registers)", 0, 0, 1)] + [(f"dma P={p} wpc={w}", p, w, 0) for p in (4, 8) for w in (2, 3, 4, 5, 6, 8, 10, 12)]:
-            tune(ctypes.c_int32(p), ctypes.c_int32(wpc), ctypes.c_int32(off))
+        if d >= 2:          # the grid-aware form on the blocked copy of v
+            tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
+            og = grid_ops.gather_ell(idx, val, v, grid=grid)
+            print(f"   grid-aware form: max rel dev {float((og.double() - want).abs().max() / want.abs().max()):.1e}", flush=True)
+            for p_ in (4, 8):
+                for wv in (512, 768, 1024, 2048):
+                    for ab in (0,):
+                        tune(ctypes.c_int32(p_), ctypes.c_int32(wv), ctypes.c_int32(0), ctypes.c_int32(ab))
+                        us = event_us(lambda: grid_ops.gather_ell(idx, val, v, grid=grid), 6)
+                        print(f"   {'grid-aware (pack + blocked gather) P=%d waves=%d%s' % (p_, wv, ' ABLATED second block' if ab else ''):72s} {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s  frac {byts / us / 1e6 / 8.0:5.3f}", flush=True)
+        cfgs = [("k_gather_ell (registers)", 0, 0, 1, 0)]
+        for p in (4, 8, 16):
+            if p == 16 and dt == torch.float64:
+                continue
+            for wv in (128, 192, 256, 320, 384, 512, 768, 1024, 2048):
+                for cg in (0, 1):
+                    cfgs.append((f"dma P={p} waves={wv}{' contiguous' if cg else ''}", p, wv, 0, cg))
+        if a.ablate:
+            cfgs = [(f"dma P=8 waves={wv} {nm}", 8, wv, 0, cg) for wv in (512, 1024) for nm, cg in (("", 0), ("ABLATED gather (L1 hits)", 2), ("ABLATED stream (no refill)", 4), ("ABLATED both", 6))]
+        if a.policy:
+            cfgs = [(f"dma P=8 waves={wv} {nm}", 8, wv, 0, cg) for wv in (512, 768, 1024, 2048) for nm, cg in (("", 0), ("ABLATED: a quad gathers ONE 16-byte group (1/4 of the lines)", 8))]
+        for name, p, wv, off, cg in cfgs:
+            tune(ctypes.c_int32(p), ctypes.c_int32(wv), ctypes.c_int32(off), ctypes.c_int32(cg))
             out = grid_ops.gather_ell(idx, val, v)
             torch.cuda.synchronize()
             dev_ = float((out.double() - want).abs().max() / want.abs().max())
             us = event_us(lambda: grid_ops.gather_ell(idx, val, v), 6)
-            print(f"   {name:28s} {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s  frac {byts / us / 1e6 / 8.0:5.3f}   max rel dev {dev_:.1e}", flush=True)
+            print(f"   {name:52s} {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s  frac {byts / us / 1e6 / 8.0:5.3f}   max rel dev {dev_:.1e}", flush=True)
         # arbitrary (non-consecutive) indices take the slow path: same answer
-        tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
+        tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
         idx2 = idx.clone()
         idx2[::3, 1] = idx2[::3, 0]                    # break the run of 4 in every third row
         want2 = (val.double() * v.double()[idx2.long()]).sum(1)
@@ -65,7 +88,7 @@ def main():
         # a sliced (16-byte aligned at row granularity, still contiguous) view and a small batch
         out3 = grid_ops.gather_ell(idx[5:5 + 4096], val[5:5 + 4096], v)
         print(f"   4096-row slice: max rel dev {float((out3.double() - want[5:5 + 4096]).abs().max() / want.abs().max()):.1e}", flush=True)
-    tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
+    tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
 
 
 if __name__ == "__main__":
