@@ -15,6 +15,11 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda"
 
 RTOL = {torch.float64: 1e-4, torch.float32: 1e-2}   # north-star tolerances (BASELINE.json)
+# fp32 assertions INSIDE the north-star bar: about 3x the deviation measured on MI355X (printed by the tests as "MEASURED ...";
+# profiles/r06_parity_measured.txt), so that a regression that stays below 1e-2 is still caught
+TIGHT_MEAN_6K, TIGHT_VAR_6K = 5e-5, 3e-5                        # measured 1.3e-5 / 7.5e-6
+TIGHT_VAR_C3 = {"default path": 6e-3, "pcg path": 3e-3}         # measured 5.4e-4 / 5.2e-4 (uniform), 2.1e-3 / 1.1e-3 (road-like: 434 874 points of fp32 statistics)
+TIGHT_CLF_MEAN = 1e-5                                           # measured 2.7e-6
 
 
 def _mk_kernel(kind, d, gb, g, ell, osc):
@@ -297,8 +302,10 @@ def test_c3_scale_properties_50cubed_fp32():
     s2 = float(model.likelihood.second_noise.detach())
     O = dataspace.DataSpaceGP([[-1.1, 1.1]] * 3, 50, sigma2=s2).fit(X.double().cpu().numpy(), y[:, 0].double().cpu().numpy(), np.ones(n))
     mo, vo = O.predict(Xs.double().cpu().numpy())
-    assert np.abs(mean - mo).max() <= 1e-2 * np.abs(mo).max()
-    assert np.abs(var - vo).max() <= 1e-2 * np.abs(vo).max()
+    dm, dv = np.abs(mean - mo).max() / np.abs(mo).max(), np.abs(var - vo).max() / np.abs(vo).max()
+    print(f"MEASURED 50^3 fp32, 6k points vs the data-space GP: mean {dm:.2e} variance {dv:.2e}")
+    assert dm <= 1e-2 and dv <= 1e-2          # the north-star's fp32 bar
+    assert dm <= TIGHT_MEAN_6K and dv <= TIGHT_VAR_6K   # ~3x what is measured (fp32 statistics, 1e-6 solves): a regression inside the bar is still caught
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
@@ -356,8 +363,9 @@ def test_c3_full_stream_checkpoints_vs_cpu_port(kind):
             v_pcg = model(Xtg[:64]).variance.double().cpu().numpy()
     for name, v in (("default path", v_def), ("pcg path", v_pcg)):
         dv = np.max(np.abs(v - want_v) / want_v)
-        print(f"{kind} end of stream, 64 variances, {name}: max rel dev vs the fp64 port = {dv:.2e}")
+        print(f"MEASURED {kind} end of stream, 64 variances, {name}: max rel dev vs the fp64 port = {dv:.2e}")
         assert dv <= 1e-2
+        assert dv <= TIGHT_VAR_C3[name]      # ~3x what is measured
     if kind == "clustered":
         # the road-like stream keeps a two-level block, and the 64-column variance solve above went through it (multi-column form:
         # k_tl_coef_mc / k_tl_apply_mc / k_spec_slab_mfma_mc<.., TL>): 4-5 iterations where the separable model alone takes 15
@@ -427,7 +435,9 @@ def test_dirichlet_classifier_wrapper_banana_like():
         osc = float(k.outputscale.detach().double().reshape(-1)[o if k.outputscale.numel() > 1 else 0])
         O = dataspace.DataSpaceGP([[-1.0, 1.0]] * 2, 16, "rbf", ell, osc, 1.0).fit(X[:400], ty[:, o].double().cpu().numpy(), s2i[:, o].double().cpu().numpy())
         mo, _ = O.predict(X[400:420])
-        assert np.abs(means[o] - mo).max() <= 1e-2 * np.abs(mo).max()
+        dmo = np.abs(means[o] - mo).max() / np.abs(mo).max()
+        print(f"MEASURED classifier output {o}: mean dev {dmo:.2e}")
+        assert dmo <= 1e-2 and dmo <= TIGHT_CLF_MEAN
 
 
 def test_c2_full_stream_30pow4_fp64_parity():

@@ -10,6 +10,7 @@ import torch
 from oracle import dataspace, spec
 
 pytestmark = pytest.mark.gpu
+TIGHT_VAR_DRIFT = 5e-6       # measured 4.7e-7 (variance after 30 hyper steps at 50^3 vs the fp64 port; the mean has its own 1e-3 assertion, measured 4.1e-5)
 DEV = "cuda"
 TH = float(np.log(2.0))
 
@@ -622,8 +623,9 @@ def test_reference_step_loop_at_50pow3_matches_the_cpu_port_after_hyper_drift():
     dm = np.abs(mean - want).max() / np.abs(want).max()
     want_v = B.variance(Xt.numpy()[:24]) + s2
     dv = np.max(np.abs(var[:24] - want_v) / want_v)
-    print(f"after {steps} hyper steps (ell {ell0} -> {ell}, sigma2 {s20:.4f} -> {s2:.4f}): mean dev {dm:.2e}, variance dev {dv:.2e}")
+    print(f"MEASURED after {steps} hyper steps (ell {ell0} -> {ell}, sigma2 {s20:.4f} -> {s2:.4f}): mean dev {dm:.2e}, variance dev {dv:.2e}")
     assert dm <= 1e-2 and dv <= 1e-2
+    assert dv <= TIGHT_VAR_DRIFT       # ~3x what is measured on MI355X (profiles/r06_parity_measured.txt)
     assert dm <= 1e-3            # what the truncated fp64 factor on fp32 statistics actually gives (a few 1e-5)
 
 

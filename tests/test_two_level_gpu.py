@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 pytestmark = pytest.mark.gpu
+TIGHT_VAR_ROUGH = 1e-5       # measured 1.9e-6 (Matern-1/2 50^3, 16 variances vs the fp64 port)
 DEV = "cuda"
 
 
@@ -224,8 +225,9 @@ def test_variance_columns_on_a_rough_kernel_take_the_block_and_match_the_fp64_po
     want = B.variance(Xq.double().cpu().numpy()[:16])
     for name, v in (("two-level", v_on), ("separable", v_off)):
         dv = np.max(np.abs(v[:16] - want) / want)
-        print(f"Matern-1/2 50^3 road-like, 16 variances, {name}: {dv:.2e} (iterations {it_on if name == 'two-level' else it_off})")
-        assert dv <= 1e-2
+        print(f"MEASURED Matern-1/2 50^3 road-like, 16 variances, {name}: {dv:.2e} (iterations {it_on if name == 'two-level' else it_off})")
+        assert dv <= 1e-2                  # the north-star's fp32 bar
+        assert dv <= TIGHT_VAR_ROUGH       # ~3x what is measured on MI355X (profiles/r06_parity_measured.txt)
 
 
 def test_block_is_rebuilt_from_the_statistics_after_a_hyper_step():
