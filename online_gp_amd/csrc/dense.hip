@@ -261,14 +261,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm128(int M, int N, int K, real a
       }
 }
 
-static int gemm128_min_blocks() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WISKI_GEMM128_MIN_BLOCKS");    // 0 disables the large-tile kernel (A/B hook for tools/bench_dense.py)
-    v = e ? atoi(e) : 32;
-  }
-  return v;
-}
+static int gemm128_min_blocks() { return 32; }
 
 // 32 x 32 tiles, BK = 32, register prefetch: for products whose 64 x 64 tiling leaves most of the chip idle (the spectral factor's
 // T^T G_ref T: 540 x 327 outputs are 54 big tiles on 256 CUs -- and 187 small ones).  4 waves, one 16 x 16 MFMA tile each.
@@ -338,11 +331,8 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
       // where it wins (tools/gemm_mid_probe.py, profiles/r05_gemm_mid.txt; n = side of a square product):
       //   fp32  n = 800 .. 1600: 35 / 50 / 98 / 116 / 132 us -> 29 / 37 / 65 / 75 / 109 us (n = 1000: 40 -> 54 TF, TN 62 TF)   => 110 .. 800 tiles
       //   fp64  n = 1000 / 1400 / 1600: 61 / 178 / 249 us -> 57 / 124 / 189 us (A^T B 53 / 116 / 175, A B^T 71 -> 60 at 1000)   => 240 .. 900 tiles
-      static const int p_min_env = [] { const char* e = getenv("WISKI_GEMM64P_MIN"); return e ? atoi(e) : -1; }();
-      static const int p_max_env = [] { const char* e = getenv("WISKI_GEMM64P_MAX"); return e ? atoi(e) : -1; }();
-      static const int p_nw = [] { const char* e = getenv("WISKI_GEMM64P_NW"); return e && atoi(e) == 4 ? 4 : 8; }();
-      const int p_min = p_min_env >= 0 ? p_min_env : (sizeof(real) == 4 ? 110 : 240);
-      const int p_max = p_max_env >= 0 ? p_max_env : (sizeof(real) == 4 ? 800 : 900);
+      const int p_min = sizeof(real) == 4 ? 110 : 240;
+      const int p_max = sizeof(real) == 4 ? 800 : 900;
       if (nb64 >= p_min && nb64 <= p_max && K >= 128) {
         dim3 g6((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
 #define G64P(NWV)                                                                                                                                      \
@@ -352,13 +342,12 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
     else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true, NWV, 64>), g6, dim3(64 * NWV), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);   \
     else hipLaunchKernelGGL((k_gemm128<real, true, true, NWV, 64>), g6, dim3(64 * NWV), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);                   \
   } while (0)
-        if (p_nw == 4) G64P(4);
-        else G64P(8);
+        G64P(8);
 #undef G64P
         return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
       }
     }
-    static const bool small_on = [] { const char* e = getenv("WISKI_GEMM32"); return !(e && e[0] == '0'); }();
+    constexpr bool small_on = true;
     static const int small_max_env = [] { const char* e = getenv("WISKI_GEMM32_MAX_TILES"); return e ? atoi(e) : 0; }();
     const int small_max = small_max_env > 0 ? small_max_env : (sizeof(real) == 8 ? 500 : 300);
     if (small_on && nb64 < small_max && K >= 64 && (int64_t)M * N >= 32 * 32 * 8) {
@@ -380,20 +369,14 @@ static int launch_gemm(int ta, int tb, int M, int N, int K, real alpha, const re
     if (minb > 0 && nb >= (sizeof(real) == 8 ? 4 * minb : minb) && K >= 256) {
       dim3 g2((unsigned)((N + G2N - 1) / G2N), (unsigned)((M + G2M - 1) / G2M));
       // 8 waves per 128 x 128 tile (64 x 32 per wave) beat 4 at every size measured: twice the waves per CU hide the LDS and
-      // barrier latency of the K loop (fp32 n = 2048: 89 -> 100 TF, fp64 n = 4096: 45 -> 61 TF); the 4-wave form stays as an A/B hook
-      static const int nw8_max = [] { const char* e = getenv("WISKI_GEMM128_NW8_MAX_BLOCKS"); return e ? atoi(e) : (1 << 30); }();
-      if (nb <= nw8_max) {
+      // barrier latency of the K loop (fp32 n = 2048: 89 -> 100 TF, fp64 n = 4096: 45 -> 61 TF)
+      {
         if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
         else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
         else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
         else hipLaunchKernelGGL((k_gemm128<real, true, true, 8>), g2, dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
         return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
       }
-      if (!ta && !tb) hipLaunchKernelGGL((k_gemm128<real, false, false, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      else if (ta && !tb) hipLaunchKernelGGL((k_gemm128<real, true, false, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      else if (!ta && tb) hipLaunchKernelGGL((k_gemm128<real, false, true, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      else hipLaunchKernelGGL((k_gemm128<real, true, true, 4>), g2, dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-      return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
     }
   }
   dim3 grd((unsigned)((N + GBN - 1) / GBN), (unsigned)((M + GBM - 1) / GBM));
@@ -656,13 +639,7 @@ __global__ __launch_bounds__(256) void k_logdiag(int n, const real* __restrict__
   if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
 }
 
-static bool small_path_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("WISKI_POTRF_SMALL");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+static bool small_path_enabled() { return true; }
 
 // n <= 480: the one-workgroup factorisation of dense_small.h (and, with d_X, the explicit inverse of the factor)
 template <typename real>

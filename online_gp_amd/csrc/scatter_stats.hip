@@ -408,15 +408,7 @@ static int64_t owner_min_points() {
   return v;
 }
 
-// timing ablations of the owner-computes kernels (wrong results; tools/owner_probe.py): 1 no point visits, 2 no write-back
-static int owner_ablate() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WISKI_OWNER_ABLATE");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+static int owner_ablate() { return 0; }
 
 template <typename real>
 static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y, const real* d_wa, const real* d_wb, const real* d_noise,
@@ -480,23 +472,11 @@ static int scatter_impl(const wiski_grid* grid, const real* d_x, const real* d_y
     hipLaunchKernelGGL((k_bin_points<real>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, G, d_x, d_y, d_wa, d_wb, d_noise, n, d_stats, d_err,
                        d_u, d_res != nullptr ? 1 : 0, d_mean_out, head, next, rec, epoch, (uint32_t*)z1, n1_bytes / 4, (uint32_t*)z2, n2_bytes / 4,
                        (const long long*)d_guard, (long long)guard_expect);
-    static int owner_nt = 0;                         // threads per owner block (WISKI_OWNER_THREADS = 256 | 512)
-    if (owner_nt == 0) {
-      const char* e = getenv("WISKI_OWNER_THREADS");
-      owner_nt = e ? atoi(e) : 256;                  // measured at 50^3, 4096 points: 69 us with 256, 88 us with 512
-      if (owner_nt != 128 && owner_nt != 512) owner_nt = 256;
-    }
+    constexpr int owner_nt = 256;                    // threads per owner block (measured at 50^3, 4096 points: 69 us with 256, 88 us with 512)
     const size_t lds = owner_lds;
     const int abl = owner_ablate();
-    if (owner_nt == 512)
-      hipLaunchKernelGGL((k_owner_lines<real, 512>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(512), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
-                         (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
-    else if (owner_nt == 128)
-      hipLaunchKernelGGL((k_owner_lines<real, 128>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(128), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
-                         (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
-    else
-      hipLaunchKernelGGL((k_owner_lines<real, 256>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(256), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
-                         (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
+    hipLaunchKernelGGL((k_owner_lines<real, owner_nt>), dim3((unsigned)(G.g[0] * G.g[1])), dim3(owner_nt), lds, (hipStream_t)stream, G, d_A_st, d_b, d_cnt, d_res,
+                       (const unsigned long long*)head, (const int32_t*)next, (const real*)rec, epoch, (const long long*)d_guard, (long long)guard_expect, abl);
     return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
   }
   const int grp = half ? 64 : (G.T < 64 ? G.T : 64);

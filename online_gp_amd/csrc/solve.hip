@@ -656,26 +656,10 @@ static inline bool sym_xcd_map(int64_t a_bytes) {
   if (g_sym_xcd >= 0) return g_sym_xcd != 0;
   return a_bytes <= (int64_t)192 << 20;
 }
-static int g_sym_nch = 0;   // tuning override (WISKI_SYM_NCH)
-static int g_sym_bs = 0;    // tuning override (WISKI_SYM_BLOCK): threads per block of the wide symmetric SpMV
-static inline int sym_block() {
-  if (g_sym_bs == 0) {
-    const char* e = getenv("WISKI_SYM_BLOCK");
-    g_sym_bs = e ? atoi(e) : 128;
-    if (g_sym_bs != 64 && g_sym_bs != 128 && g_sym_bs != 256) g_sym_bs = 128;
-  }
-  return g_sym_bs;
-}
-static inline int sym_nch_lds(int d) {
-  if (g_sym_nch == 0) {
-    const char* e = getenv("WISKI_SYM_NCH");
-    g_sym_nch = e ? atoi(e) : -1;
-  }
+static inline int sym_block() { return 128; }    // threads per block of the wide symmetric SpMV (64 / 256 measured: no better)
+static inline int sym_nch_lds(int d) {           // chunks of the LDS-window kernel: 7 (or every group of a small stencil)
   const int ng = sym_groups(d);
-  int nch = g_sym_nch > 0 ? g_sym_nch : 7;
-  if (nch > 7) nch = 7;
-  if (nch > ng) nch = ng;
-  return nch;
+  return ng < 7 ? ng : 7;
 }
 
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -915,42 +899,24 @@ __global__ __launch_bounds__(256) void k_stencil_spmv4_sym(GridDev<real> G, cons
 
 // Which wide half-stencil kernel serves (G, k): the LDS-DMA pipelined one (d = 3, fp32, one right-hand side; 4 chunks)
 // or the LDS-window one (anything else with m % 4 == 0; up to 7 chunks).  WISKI_SYM_DMA=0 forces the latter,
-// WISKI_SYM_DMA_NST sets the ring depth (2 or 3) and WISKI_SYM_DMA_PARTS the work split (4..7): A/B hooks for
-// tools/spmv_probe.py.
-static int g_sym_dma = -1, g_sym_dma_nst = 0, g_sym_dma_parts = 4, g_sym_dma_delay = 0;
+// Ring depth 2, the 4-part work split and the late start of the light chunk (12 x 0.43 us at 50^3, scaled with m) are what the
+// sweeps of rounds 2-4 settled on (spmv_sym_dma.h: 3-deep ring 22.8 us, 5 / 6 / 7 parts 19.1 / 19.9 / 20.5, delay 0..28: 18.0 at 12).
+static int g_sym_dma = -1;
+constexpr int g_sym_dma_nst = 2, g_sym_dma_parts = 4, g_sym_dma_delay = 12;
 template <typename real>
 static inline bool sym_use_dma(const GridDev<real>& G, int k) {
   if constexpr (sizeof(real) != 4) return false;
   if (g_sym_dma < 0) {
     const char* e = getenv("WISKI_SYM_DMA");
     g_sym_dma = e ? atoi(e) : 1;
-    const char* n = getenv("WISKI_SYM_DMA_NST");
-    g_sym_dma_nst = n ? atoi(n) : 2;
-    if (g_sym_dma_nst != 2 && g_sym_dma_nst != 3) g_sym_dma_nst = 2;
-    const char* pp = getenv("WISKI_SYM_DMA_PARTS");
-    g_sym_dma_parts = pp ? atoi(pp) : 4;
-    if (g_sym_dma_parts < 4 || g_sym_dma_parts > 7) g_sym_dma_parts = 4;
-    const char* dl = getenv("WISKI_SYM_DMA_DELAY");     // late start of the light chunk, units of 0.43 us at 50^3 (scaled with m)
-    g_sym_dma_delay = dl ? atoi(dl) : 12;               // swept 0..28 at 50^3: 18.40..18.56 us at 0, 18.03..18.20 at 12, 20.4 at 24
-    if (g_sym_dma_delay < 0 || g_sym_dma_delay > 64) g_sym_dma_delay = 12;
   }
   return g_sym_dma != 0 && G.d == 3 && k == 1 && (G.m % 4) == 0 && symdma_lds_bytes(G.g[2], g_sym_dma_nst) <= 64 * 1024;
 }
 // Many right-hand sides (k >= 32): the lanes-are-columns SpMM (spmm_sym_cols.h) reads A_h once per 64 columns and leaves
-// ONE finished vector per column in part[0] (no atomically accumulated partial).  WISKI_SPMM_COLS=0 disables it.
-static int g_spmm_cols = -1, g_spmm_cols_min = -1;
+// ONE finished vector per column in part[0] (no atomically accumulated partial).
 static inline bool sym_use_bcast();
 static inline bool sym_use_cols(int k, size_t es) {
-  if (g_spmm_cols < 0) {
-    const char* e = getenv("WISKI_SPMM_COLS");
-    g_spmm_cols = e ? atoi(e) : 1;
-    const char* mn = getenv("WISKI_SPMM_COLS_MIN");
-    g_spmm_cols_min = mn ? atoi(mn) : 0;
-    // the row-major images (64 columns per slice) must fit behind part[0]: 64 m <= 7 k m
-    if (g_spmm_cols_min && g_spmm_cols_min < 16) g_spmm_cols_min = 16;
-  }
-  if (g_spmm_cols == 0) return false;
-  if (g_spmm_cols_min) return k >= g_spmm_cols_min;
+  // (the row-major images, 64 columns per slice, must fit behind part[0]: 64 m <= 7 k m, i.e. k >= 16)
   // Scalar-path kernel, measured at 50^3: 288 us at k = 16 (the 4-column kernel: 180), 240 us at k = 64 (670) -> from 32 columns.
   // The broadcast kernel costs the same for any k <= 64 (fp32 131..140 us, fp64 322..369 us) against 158 us (fp32, 4-column LDS-DMA
   // kernel) / 290 us (fp64, LDS-window kernel) at k = 16 and 229 / 429 us at k = 24: from 16 (fp32) / 24 (fp64) columns.
@@ -967,16 +933,12 @@ static inline bool sym_use_bcast() {
 }
 static inline int spmmc_kp(int k) { return (k + 15) / 16 * 16; }
 // A few right-hand sides (2 <= k < 32; d = 3, fp32): the multi-column LDS-DMA kernel (spmv_sym_dma_mc.h), 4 (2) columns per pass
-// over A_h with the built-in 4-part split.  WISKI_SYM_DMA_MC=0 falls back to the LDS-window kernel.
-static int g_sym_dma_mc = -1;
+// over A_h with the built-in 4-part split (WISKI_SYM_DMA=0 also sends these to the LDS-window kernel).
 template <typename real>
 static inline bool sym_use_dma_mc(const GridDev<real>& G, int k) {
   if constexpr (sizeof(real) != 4) return false;
-  if (g_sym_dma_mc < 0) {
-    const char* e = getenv("WISKI_SYM_DMA_MC");
-    g_sym_dma_mc = e ? atoi(e) : 1;
-  }
-  return g_sym_dma_mc != 0 && G.d == 3 && k >= 2 && !sym_use_cols(k, sizeof(real)) && (G.m % 4) == 0 && G.g[2] >= 4 &&
+  if (g_sym_dma < 0) (void)sym_use_dma<real>(G, 1);
+  return g_sym_dma != 0 && G.d == 3 && k >= 2 && !sym_use_cols(k, sizeof(real)) && (G.m % 4) == 0 && G.g[2] >= 4 &&
          symdma_mc_lds_bytes(G.g[2], k >= 4 ? 4 : 2) <= 64 * 1024;
 }
 // number of direct partial vectors the wide half-stencil SpMV writes for (G, k); one more is accumulated atomically
@@ -1111,11 +1073,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     unsigned long long* st_p = prof_stamp_pairs((size_t)grd.x * grd.y);                                                           \
     launch_timed(k_spmv_sym_dma<NST, DOT>, grd, dim3(64), sh, s, G, A_h, V, W4, WP, g_sym_dma_parts, part, add, beta, dots, delay, tab, xcd_rb, st_p); \
   } while (0)
-      if (g_sym_dma_nst == 3) {
-        if (dots) SYMDMA(3, true); else SYMDMA(3, false);
-      } else {
-        if (dots) SYMDMA(2, true); else SYMDMA(2, false);
-      }
+      if (dots) SYMDMA(2, true); else SYMDMA(2, false);
 #undef SYMDMA
       return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
     }
@@ -1527,12 +1485,7 @@ static int kron_grad_impl(const wiski_grid* grid, const real* d_tcol, const real
       }
       off2 += G.g[r];
     }
-    static int lag_gram = -1;
-    if (lag_gram < 0) {
-      const char* e = getenv("WISKI_LAG_GRAM");
-      lag_gram = e ? atoi(e) : 1;
-    }
-    if (lag_gram && G.g[q] <= 64 && k <= 4096 && m % G.g[q] == 0) {
+    if (G.g[q] <= 64 && k <= 4096 && m % G.g[q] == 0) {
       const int post = G.stride[q];
       const int ntile = post > 1 ? (m / (G.g[q] * post)) * ((post + 63) / 64) : (m / G.g[q] + 63) / 64;
       int bx = ntile < 1 ? 1 : ntile;

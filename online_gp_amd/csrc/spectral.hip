@@ -1338,13 +1338,9 @@ static int launch_slab(const GridDev<real>& G, const real* V1, const real* V2, c
     if (even) SLAB_MFMA2(KS, 2);   \
     else SLAB_MFMA2(KS, 1);        \
   } while (0)
-    static int slab_waves = 0;                         // waves per block of the slab kernels (WISKI_SLAB_WAVES = 4 | 8)
-    if (slab_waves == 0) {
-      const char* e = getenv("WISKI_SLAB_WAVES");
-      slab_waves = (e && atoi(e) == 4) ? 4 : 8;
-    }
+    constexpr int slab_waves = 8;                      // waves per block of the slab kernels (4 measured slower: DESIGN 3.3)
     // three or more columns: blocks that own a slab for a strided set of columns (about one block per CU)
-    if (two_level ? k >= 2 : (k >= 3 && getenv("WISKI_SLAB_MC_OFF") == nullptr)) {
+    if (two_level ? k >= 2 : k >= 3) {
       const bool alt = Z1 != V1 || Z2 != V2;
       float* tl_c = two_level ? two_level->d_mc : nullptr;                                       // c_S [k][r]
       const float* tl_d = two_level ? two_level->d_mc + (int64_t)two_level->mc_cols * two_level->r : nullptr;   // N c_S [k][r]

@@ -77,7 +77,7 @@ static int stream_step_impl(const wiski_grid* grid, const typename StreamArgs<re
     // is exactly when RESUME below queues nothing more), and only then wait for the poll.  The absorb then executes while
     // the host reads the poll and queues the next solve.
     bool spec = false;
-    if (q > 0 && d_mean_out && getenv("WISKI_NO_SPECULATION") == nullptr) {
+    if (q > 0 && d_mean_out) {
       const void* guard = nullptr;
       int64_t expect = 0;
       if (wiski_pcg_async_guard(as, &guard, &expect) == WISKI_OK) {

@@ -454,7 +454,7 @@ class SpectralWoodburyFactor:
         ref = self.ref
         # (adaptive: Rayleigh-Ritz in the previous span; subspace iteration only if the residual gets within a factor 8 of the verdict's limit)
         Vtab, ev_tab, resid, Tq = grid_ops.basis_eig_update(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax,
-                                                            resid_ok=(tail * 1e-3 / 8.0) if settings.adaptive_eig_update.on() else None)
+                                                            resid_ok=tail * 1e-3 / 8.0)
         work = self.__dict__.get("_bc_work")
         if work is None or work.shape[0] < old.r + 1:
             work = self._bc_work = torch.zeros(max(old.r + 1, 2049), dtype=torch.float64, device=self.device)
@@ -497,7 +497,7 @@ class SpectralWoodburyFactor:
         if info is None:
             info = self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
         o = grid_ops.factor_refresh(gd[0], tcol64, old.Vtab, old.kmax, old.kuse, ref.Vtab, ref.kmax, ref.S, old.S, work, host, self.G_ref, self.h_ref,
-                                    kscale, info, resid_ok=(tail * 1e-3 / 8.0) if settings.adaptive_eig_update.on() else None, verdict_event=ev)
+                                    kscale, info, resid_ok=tail * 1e-3 / 8.0, verdict_event=ev)
         basis = SpectralBasis.on_device(old, o["Vtab"], o["ev"], None, lam=o["lam_kuu"])
         self._chk = (host, ev, (tail * 1e-3, 1.5 * max(tail, old.short0), tail))
         self._dev_refreshes += 1

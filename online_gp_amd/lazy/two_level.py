@@ -102,15 +102,12 @@ class TwoLevelBlock:
         self.work = _WORK[wkey]
         if str(device) not in _SIDE:
             # lowest device priority (torch's own range stops at "normal"): the refresh kernels then yield wave slots to the SpMV of the
-            # main stream where they meet (WISKI_TL_SIDE_PRIORITY=normal: a plain torch stream, as before round 5)
-            import os
-
+            # main stream where they meet (measured against a plain torch stream: profiles/r05_side_priority.txt)
             side = None
-            if os.environ.get("WISKI_TL_SIDE_PRIORITY", "low") == "low":
-                h = ctypes.c_void_p()
-                with torch.cuda.device(device):
-                    if _hip.lib().wiski_side_stream_create(ctypes.c_int32(1), ctypes.byref(h)) == 0 and h.value:
-                        side = torch.cuda.ExternalStream(h.value, device=device)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                if _hip.lib().wiski_side_stream_create(ctypes.c_int32(1), ctypes.byref(h)) == 0 and h.value:
+                    side = torch.cuda.ExternalStream(h.value, device=device)
             _SIDE[str(device)] = side if side is not None else torch.cuda.Stream(device=device)
         self.side = _SIDE[str(device)]
         self.in_flight = None                  # (event, step it was launched at, buffer index)
@@ -380,7 +377,7 @@ class TwoLevelTracker:
             dq = float(self.pending[-1][0].shape[0])
             lag = float(max(settings.two_level_lag.value(), 1))
             lo, hi = weight + lag * dq, max(growth * weight, weight + dq) + lag * dq
-            gscale = 0.5 * (lo + hi) / max(weight, 1.0) if settings.two_level_predictive.on() else 1.0
+            gscale = 0.5 * (lo + hi) / max(weight, 1.0)
             pts, self.pending, self.pending_n = self.pending, [], 0
             blk.launch_refresh(pts, self.step, weight, gscale, subsample)
         return blk.struct if blk.active >= 0 else None

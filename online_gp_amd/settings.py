@@ -256,12 +256,6 @@ class two_level_min_iters(_value_context):
     _global_value = 4.0
 
 
-class two_level_predictive(_feature_flag):
-    """Compute each block for the absorbed weight expected in the middle of its service life (G scaled accordingly) rather than
-    for the weight at the time of the refresh: a block is always somewhat old when it is used."""
-
-    _state = True
-
 
 class two_level_subsample(_value_context):
     """The two-level block's Gram matrix is accumulated from every `n`-th absorbed point (weighted by n): an unbiased estimate
@@ -352,14 +346,6 @@ class fused_hyper_step(_feature_flag):
 
     _state = True
 
-
-class adaptive_eig_update(_feature_flag):
-    """Device-side eigenvector refresh after a hyper-parameter step (``spectral_device_refresh``): Rayleigh-Ritz in the span of the previous
-    eigenvectors + guard vectors first, the two steps of subspace iteration only when the residual of that gets within a factor 8 of the
-    verdict's limit (``wiski_basis_eig_update_adaptive``; one Adam step leaves the new vectors inside the old span to ~1e-14).  Off: always
-    two steps of subspace iteration, then Rayleigh-Ritz."""
-
-    _state = True
 
 
 class fused_evaluate(_feature_flag):

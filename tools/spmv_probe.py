@@ -1,5 +1,5 @@
 """Time the stencil SpMV (full vs symmetric half layout) at a given grid with HIP-event brackets
-(wiski_prof_*), on a stencil filled by the real scatter kernel.  WISKI_SYM_NCH tunes the chunk count."""
+(wiski_prof_*), on a stencil filled by the real scatter kernel."""
 import argparse
 import ctypes
 import os
@@ -54,7 +54,7 @@ def main():
         res[name] = out
         print(f"{name}: {us:8.2f} us/launch ({nl.value} launches)  {byts / 1e6:8.1f} MB  {byts / us / 1e6:6.2f} TB/s", flush=True)
     diff = (res["full"] - res["half"]).abs().max().item() / res["full"].abs().max().item()
-    print(f"max rel diff half vs full: {diff:.2e}  (WISKI_SYM_NCH={os.environ.get('WISKI_SYM_NCH', 'default')})")
+    print(f"max rel diff half vs full: {diff:.2e}")
 
 
 if __name__ == "__main__":
