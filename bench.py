@@ -188,7 +188,7 @@ def dense_reference_timings(dev):
 def dense_regime_reference_steps(dev):
     """The reference's per-batch loop (evaluate -> Adam step on the MLL -> condition; experiments/regression.py:48-54, OSR:113-146) on the
     SMALL inducing grids every shipped reference configuration uses (BASELINE configs 1 / 4 / 5: 64 nodes, 10^3 Matern-5/2, 30^2 Matern-1/2),
-    fp64, q = 1 and 8: ms per step through the device pipeline (settings.spectral_dense_regime, DESIGN 3.11), and the same loop with the
+    fp64, q = 1 and 8: ms per step through the device pipeline (settings.spectral_dense_regime, DESIGN 3.9), and the same loop with the
     pipeline off (the nodal dense factor, one framework op at a time: round 4's path) for the 64-node case."""
     from online_gp_amd import settings
     from online_gp_amd.kernels import MaternKernel, ScaleKernel

@@ -228,7 +228,7 @@ typedef struct wiski_shard {
 } wiski_shard;
 int wiski_shard_groups(int32_t d, int32_t rank, int32_t nranks, int32_t* g_lo, int32_t* g_hi);
 
-/* Two-level preconditioner of the fused fp32 solve (d = 3; DESIGN.md 3.3b).  The separable model
+/* Two-level preconditioner of the fused fp32 solve (d = 3; DESIGN.md 3.3).  The separable model
  * P = (Kt^-1 + a kron_q diag(t_q))^-1 is exact only for a separable data density; on road-like (line-clustered) streams
  * W^T D^-1 W is far from that and a warm CG step needs 6 iterations instead of 2.5.  In the generalized eigenbasis X of the
  * separable model (the tables wiski_pcg already transforms with: X^T (kron diag t) X = I, Kt = X^-T D X^-1) the system

@@ -18,7 +18,7 @@ The first steps run eagerly (they also serve as the warm-up the allocator wants 
 not apply -- dense regime, rough kernel, a foreign optimiser -- the caller's eager path runs instead.  Several outputs (the Dirichlet
 classifier's two) are one graph: one factor, one set of staging buffers per output.
 
-Two refinements (round 4, DESIGN 3.10).  (i) For the reference's own parameterisation -- (Scale of)* RBF | Matern, homoskedastic second
+Two refinements (round 4, DESIGN 3.9).  (i) For the reference's own parameterisation -- (Scale of)* RBF | Matern, homoskedastic second
 noise, plain Adam, no registered priors -- the step is recorded WITHOUT autograd (``_capture_fused``, csrc/hyper_step.hip): 11 graph
 nodes instead of 40, and the graph leaves the Toeplitz columns and sigma2 of the UPDATED hyper-parameters behind (``read_loss`` hands
 them to the model's memo together with the loss: one host read).  (ii) ``prepare()``: evaluate() of a batch checks and stages the

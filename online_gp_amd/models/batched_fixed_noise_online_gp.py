@@ -514,7 +514,7 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
 
     def _two_level_for_solve(self, post, k):
         """The stream's two-level block for a solve of k columns through `post` (variances, probes, fantasies: 15 -> 4-5 iterations
-        per 64-column solve on the road-like stream, DESIGN.md 3.3b): the tracker's block if it belongs to the operator's
+        per 64-column solve on the road-like stream, DESIGN.md 3.3): the tracker's block if it belongs to the operator's
         eigenbasis; where it was lost (hyper-parameter step, profile re-solve, points behind the tracker's back) and the solve is
         wide, a block rebuilt from the statistics (settings.two_level_rebuild)."""
         tr = self.__dict__.get("_two_level") if self._two_level_applies() else None

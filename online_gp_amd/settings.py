@@ -299,7 +299,7 @@ class spectral_factor(_feature_flag):
 class spectral_dense_regime(_feature_flag):
     """Small inducing grids (m <= max_cholesky_size: the reference's own configurations) take the reference's per-batch loop
     -- evaluate -> Adam step on the MLL -> condition (experiments/regression.py:48-54) -- through the spectral factor's device
-    pipeline as well (at FULL rank for rough kernels: no truncation at all; DESIGN 3.11), where the owner of the model asks for it
+    pipeline as well (at FULL rank for rough kernels: no truncation at all; DESIGN 3.9), where the owner of the model asks for it
     (the streaming wrappers do: ``model._stream_owner``).  Off: every dense-regime request builds the nodal dense factor
     (lazy/dense_woodbury.py), one framework op at a time."""
 

@@ -1,7 +1,7 @@
 """The reference's per-batch loop (experiments/regression.py:48-54: evaluate -> Adam step on the MLL -> condition;
 online_gp/models/online_ski_regression.py:113-146, BWM:19-51) on the SMALL inducing grids the reference actually ships
 (bayesopt.py:81-84 10^3, qnIPV_experiment.py:98 30^2, config/model/wiski_gp_regression.yaml 16^2, the notebook's 1-D grid),
-through the device pipeline (settings.spectral_dense_regime; DESIGN 3.11).  Every check here is against the data-space oracle
+through the device pipeline (settings.spectral_dense_regime; DESIGN 3.9).  Every check here is against the data-space oracle
 (oracle/dataspace.py: exact GP on the SKI kernel, n x n Cholesky in numpy fp64) at the hyper-parameters the loop has DRIFTED to --
 not against another path of this build."""
 import numpy as np
