@@ -270,7 +270,8 @@ def main():
     # worse: the per-step temporaries that sit in reference cycles then pile up and the caching allocator has to hipMalloc in
     # the middle of a block (also ~80 ms).  So: collect + freeze the long-lived heap at every leg boundary (gc_settle), which
     # leaves the collector only the young objects of the leg to look at.
-    torch.set_num_threads(usable_cpus())            # host-side tensor work (stream generation) must not over-subscribe the CPU quota
+    # host-side tensor work (stream generation) must not over-subscribe the CPU quota -- which all ranks of a node share
+    torch.set_num_threads(max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))))
     def gc_settle():
         gc.unfreeze()
         gc.collect()
@@ -647,7 +648,7 @@ def main():
                      "achieved": q * sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q * sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_us": sc_us, "algorithmic_bytes_per_point": sc_bytes, "points_per_s": q / (sc_us * 1e-6),
                      "lane_atomics_per_s": q * (T * (T + 1) // 2 + 2 * T) / (sc_us * 1e-6), "timing": "median of 5 torch.cuda.Event brackets of 8 launches"},
-                    {"kernel": "k_gather_ell_dma<float, 16, 8, true> (+ k_ell_pack_v8): predictive interpolated MVM from stored idx/val rows, 2^20 query rows, "
+                    {"kernel": "k_gather_ell_dma<float, 16, 8, true> (+ k_ell_pack_v4s): predictive interpolated MVM from stored idx/val rows, 2^20 query rows, "
                                "rows staged through LDS by LDS-DMA, v gathered from its blocked copy (wiski_gather_ell_grid)", "bound": "hbm",
                      "achieved": ell_bytes / (ellg_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ell_bytes / (ellg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_us": ellg_us, "algorithmic_bytes_per_row": T * (4 + es) + es, "infinity_cache_resident": False,

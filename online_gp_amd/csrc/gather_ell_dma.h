@@ -103,24 +103,25 @@ struct EllDmaGeom {
   static constexpr unsigned LDS_B = NST * STAGE_B + RPT * (unsigned)sizeof(real);
 };
 
-// ---- grid-aware form (wiski_gather_ell_grid, fp32): v re-laid so that a row's taps fall into 7 cache lines instead of ~17.5 -------
+// ---- grid-aware form (wiski_gather_ell_grid, fp32): v re-laid so that every lane's four taps are ONE aligned 16-byte group ------------
 // What bounds the kernel above is not the idx / val stream but the gathers of v: in the row-major v a row's T taps sit in T / 4
 // different cache lines (one per tap prefix: 16 at d = 3, ~17.5 with the 16-byte groups that straddle a line), every one an L2
 // request that queues in the CU's in-order vector-memory path behind the stream's HBM requests (measured, tools/gather_ell_probe.py:
-// all gathers served by L1 -> 6.4 TB/s; a quarter of the lines -> 6.1 TB/s; as they are -> 4.3-4.7 TB/s).  wiski_interp's rows are
+// all gathers served by L1 -> 6.4 TB/s; a quarter of the accesses -> 6.1 TB/s; as they are -> 4.3-4.7 TB/s).  wiski_interp's rows are
 // structured -- idx[tap] = base + sum_q c_q stride_q -- so for them v can be read from a BLOCKED copy in which the second-to-last
-// dim K is cut into blocks of 4 stored 8 wide (each block carries its successor as a halo: twice the memory of v, 1 MB at 50^3):
-//     v8[outer][jK >> 2][jL][0..7] = v[outer][4 (jK >> 2) + 0..7][jL]      (outer = the leading dims, jL the last one; zeros past gK)
-// Lane (prefix, cL) of a row loads the 32 contiguous bytes of block jK >> 2 at jL + cL (two 16-byte loads, the second in the same
-// line three times out of four) and takes its four cK values at offset jK & 3; the four lanes of a prefix read 128 contiguous
-// bytes, so a row touches 4^(d-2) x 1.75 = 7 lines at d = 3.  (A 4-wide blocking that fetches block b + 1 separately was built
-// first: as many lines as it saves in L it adds in K -- 112-118 us against 116 for the plain form; without the second block's
-// lines 97 us, which is what the halo buys.)  fp64 rows gain nothing from it (8 doubles are 64 bytes: as many lines as before)
-// and take the plain form.
+// dim K is cut into groups of 4, stored once for every alignment s = 0..3 of the stencil's first K index (4 x the memory of v: 2 MB
+// at 50^3, L2-resident):
+//     v4s[s][outer][b][jL][0..3] = v[outer][4 b + s + 0..3][jL]            (outer = the leading dims, jL the last one; zeros past gK)
+// Lane (prefix, cL) of a row loads the ONE aligned 16-byte group (s = jK & 3, b = jK >> 2) at jL + cL: 16 accesses per row as in the
+// plain form, but the four lanes of a prefix read 64 contiguous bytes, so a row touches 4^(d-2) x 1.4 = ~5.5 lines at d = 3 instead of
+// ~17.5.  (Built first: K-blocks of 4 with block b + 1 fetched separately -- as many lines as it saves in L it adds in K, 112-118 us
+// against 116 for the plain form; then blocks stored 8 wide, two loads per lane, 108-110 us: the cost is per 16-byte access as much as per
+// line.)  fp64 rows take the plain form (a lane's four doubles are 32 bytes: two accesses either way).
 struct EllV4Geo {
   unsigned gL, gK, nbk;      // sizes of the last and second-to-last dim, K blocks of 4
   unsigned mulL, shL;        // n / gL = mulL ? __umulhi(n, mulL) >> shL : n   (exact for 0 <= n < 2^31, Granlund-Montgomery)
   unsigned mulK, shK;
+  unsigned groups;           // 16-byte groups per alignment copy: outer * nbk * gL
 };
 static inline void ell_magic(unsigned d, unsigned* mul, unsigned* sh) {
   if (d <= 1) { *mul = 0; *sh = 0; return; }
@@ -131,23 +132,25 @@ static inline void ell_magic(unsigned d, unsigned* mul, unsigned* sh) {
 }
 __device__ __forceinline__ unsigned ell_div(unsigned n, unsigned mul, unsigned sh) { return mul ? __umulhi(n, mul) >> sh : n; }
 
-// v [m] (row-major grid vector) -> v8 [outer][nbk][gL][8]; one thread per 32-byte group
+// v [m] (row-major grid vector) -> v4s [4][outer][nbk][gL][4]; one thread per 16-byte group
 template <typename real>
-__global__ __launch_bounds__(256) void k_ell_pack_v8(const real* __restrict__ v, real* __restrict__ v8, EllV4Geo geo, int64_t groups) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= groups) return;
-  const unsigned jL = (unsigned)(e % geo.gL);
-  const int64_t r = e / geo.gL;
+__global__ __launch_bounds__(256) void k_ell_pack_v4s(const real* __restrict__ v, real* __restrict__ v4s, EllV4Geo geo, int64_t groups) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (shift, group)
+  if (e >= 4 * groups) return;
+  const unsigned sft = (unsigned)(e / groups);
+  const int64_t g = e - (int64_t)sft * groups;
+  const unsigned jL = (unsigned)(g % geo.gL);
+  const int64_t r = g / geo.gL;
   const unsigned b = (unsigned)(r % geo.nbk);
   const int64_t outer = r / geo.nbk;
-  real q[8];
+  real q[4];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const unsigned jK = 4 * b + t;
+  for (int t = 0; t < 4; ++t) {
+    const unsigned jK = 4 * b + sft + t;
     q[t] = jK < geo.gK ? v[(outer * geo.gK + jK) * geo.gL + jL] : (real)0;
   }
 #pragma unroll
-  for (int t = 0; t < 8; ++t) v8[8 * e + t] = q[t];
+  for (int t = 0; t < 4; ++t) v4s[4 * e + t] = q[t];
 }
 
 template <typename real, int LPR, int P, bool V4 = false>
@@ -225,16 +228,12 @@ __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict
         for (int c = 0; c < 4; ++c) a[p][c] = av[4 * c];
       }
       wave_lgkm_fence();                       // the stage has been copied out
-      EllQuad<real> g0[P], g1[P];
-      unsigned sh[P];
+      EllQuad<real> g0[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const unsigned q = ell_div((unsigned)i0[p], geo.mulL, geo.shL), jL = (unsigned)i0[p] - q * geo.gL;
         const unsigned o = ell_div(q, geo.mulK, geo.shK), jK = q - o * geo.gK;
-        sh[p] = jK & 3;
-        const real* __restrict__ src = v + 8 * (((size_t)o * geo.nbk + (jK >> 2)) * geo.gL + jL);
-        g0[p].load4(src);
-        g1[p].load4(src + 4);
+        g0[p].load4(v + 4 * ((size_t)(jK & 3) * geo.groups + ((size_t)o * geo.nbk + (jK >> 2)) * geo.gL + jL));
       }
       if (k + NST < nt) {
         issue_tile(k + NST);
@@ -243,22 +242,11 @@ __global__ __launch_bounds__(64) void k_gather_ell_dma(const int32_t* __restrict
         wait_vmcnt_imm<0>();
       }
 #pragma unroll
-      for (int p = 0; p < P; ++p) { g0[p].tie(); g1[p].tie(); }
+      for (int p = 0; p < P; ++p) g0[p].tie();
       const int64_t row0 = (t0 + k * tstep) * RPT;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        real e[8];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { e[c] = g0[p].get(c); e[4 + c] = g1[p].get(c); }
-        if (sh[p] & 1) {
-#pragma unroll
-          for (int c = 0; c < 7; ++c) e[c] = e[c + 1];
-        }
-        if (sh[p] & 2) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) e[c] = e[c + 2];
-        }
-        real s = a[p][0] * e[0] + a[p][1] * e[1] + a[p][2] * e[2] + a[p][3] * e[3];
+        real s = a[p][0] * g0[p].get(0) + a[p][1] * g0[p].get(1) + a[p][2] * g0[p].get(2) + a[p][3] * g0[p].get(3);
         s = ell_group_sum<real, LPR>(s);
         if (lane % LPR == LPR - 1) obuf[p * RPP + lane / LPR] = s;
       }

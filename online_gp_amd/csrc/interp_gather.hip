@@ -430,6 +430,8 @@ static inline bool ell_v4_geo(const wiski_grid* grid, EllV4Geo* geo, int64_t* gr
   ell_magic(geo->gL, &geo->mulL, &geo->shL);
   ell_magic(geo->gK, &geo->mulK, &geo->shK);
   *groups = m / ((int64_t)geo->gK * geo->gL) * geo->nbk * geo->gL;
+  if (16 * *groups >= ((int64_t)1 << 31)) return false;
+  geo->groups = (unsigned)*groups;
   return true;
 }
 
@@ -465,7 +467,7 @@ static int gather_ell_grid_impl(const wiski_grid* grid, const int32_t* d_idx, co
   if (!d_vpack || g_ell_off || !ell_v4_geo(grid, &geo, &groups) || n * (int64_t)T < ((int64_t)1 << 20) || (((uintptr_t)d_idx | (uintptr_t)d_val | (uintptr_t)d_vpack) & 15) != 0)
     return gather_ell_impl<real>(d_idx, d_val, n, T, d_v, d_out, stream);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((k_ell_pack_v8<real>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, d_v, d_vpack, geo, groups);
+  hipLaunchKernelGGL((k_ell_pack_v4s<real>), dim3((unsigned)((4 * groups + 255) / 256)), dim3(256), 0, s, d_v, d_vpack, geo, groups);
   const int pp = g_ell_p ? g_ell_p : 8;
 #define ELL_V4(LPR_)                                                                                     \
   do {                                                                                                   \
@@ -569,7 +571,7 @@ int wiski_gather_ell_grid_f64(const wiski_grid* g, const int32_t* idx, const dou
 int64_t wiski_gather_ell_pack_elems(const wiski_grid* g) {
   EllV4Geo geo;
   int64_t groups = 0;
-  return ell_v4_geo(g, &geo, &groups) ? 8 * groups : 0;
+  return ell_v4_geo(g, &geo, &groups) ? 16 * groups : 0;
 }
 int wiski_wt_columns_f32(const wiski_grid* g, const float* x, int64_t n, float* out, int32_t* err, void* s) { return wt_columns_impl<float>(g, x, n, out, err, s); }
 int wiski_wt_columns_f64(const wiski_grid* g, const double* x, int64_t n, double* out, int32_t* err, void* s) { return wt_columns_impl<double>(g, x, n, out, err, s); }
