@@ -874,7 +874,7 @@ def main():
         # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (tools/pmc_traffic.py),
         # NOT in this run -- read back from the committed profile and labelled with its source
         traffic, traffic_source = None, None
-        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if args.grid == 50 and d == 3 and kname in pmc["kernels"]:
@@ -888,7 +888,7 @@ def main():
         try:
             import csv
 
-            for fn in ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
+            for fn in ("r06_bench_kernel_stats.csv", "r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
                 if not os.path.exists(os.path.join(ROOT, "profiles", fn)):
                     continue
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:

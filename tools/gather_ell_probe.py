@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--policy", action="store_true")
+    ap.add_argument("--final", action="store_true", help="the library's defaults only (for a rocprofv3 run): d = 3 fp32, 20 launches each")
     a = ap.parse_args()
     dev = torch.device("cuda")
     lib = _hip.lib()
@@ -50,6 +51,18 @@ def main():
         want = (val.double() * v.double()[idx.long()]).sum(1)
         byts = n * (T * (4 + es) + es)
         print(f"d={d} g={g} {str(dt)[6:]} rows={n} T={T}  ({byts / 1e6:.0f} MB)", flush=True)
+        if a.final:
+            if not (d == 3 and dt == torch.float32):
+                continue
+            for name, fn, arg in (("k_gather_ell (registers)", lambda: grid_ops.gather_ell(idx, val, v), (0, 0, 1, 0)),
+                                  ("k_gather_ell_dma, plain (library default)", lambda: grid_ops.gather_ell(idx, val, v), (0, 0, 0, 0)),
+                                  ("k_gather_ell_dma, grid-aware (library default)", lambda: grid_ops.gather_ell(idx, val, v, grid=grid), (0, 0, 0, 0))):
+                tune(*(ctypes.c_int32(x) for x in arg))
+                fn(); torch.cuda.synchronize()
+                us = event_us(fn, 10, reps=2)
+                print(f"   {name:52s} {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s  frac {byts / us / 1e6 / 8.0:5.3f}", flush=True)
+            tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
+            continue
         if d >= 2:          # the grid-aware form on the blocked copy of v
             tune(ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0))
             og = grid_ops.gather_ell(idx, val, v, grid=grid)
