@@ -54,6 +54,35 @@ class DenseLazyTensor(LazyCovariance):
         return DenseLazyTensor(self.tensor[item])
 
 
+class RootLazyTensor(LazyCovariance):
+    """R R^T (+ diag(extra)) from a root R [n, r] -- what gpytorch's RootLazyTensor is to the reference's ``fast_pred_samples``
+    branch (BFN:229-243): a covariance that is sampled in O(n r) without ever factorising an n x n matrix.  ``extra`` (optional,
+    [n] >= 0) is a diagonal term the root does not carry (the prior variance a truncated basis leaves out)."""
+
+    def __init__(self, root, extra=None):
+        self.root = root
+        self.extra = extra
+        n = root.shape[-2]
+        self.shape = torch.Size(tuple(root.shape[:-2]) + (n, n))
+        self.dtype, self.device = root.dtype, root.device
+
+    def diag(self):
+        d = (self.root * self.root).sum(-1)
+        return d if self.extra is None else d + self.extra
+
+    def evaluate(self):
+        full = self.root @ self.root.transpose(-1, -2)
+        if self.extra is not None:
+            full = full + torch.diag_embed(self.extra)
+        return full
+
+    def root_decomposition(self):
+        return self
+
+    def __getitem__(self, item):
+        return DenseLazyTensor(self.evaluate()[item])
+
+
 class MultivariateNormal:
     def __init__(self, mean, covariance):
         self.loc = mean
@@ -94,6 +123,16 @@ class MultivariateNormal:
         return self.mean - s, self.mean + s
 
     def rsample(self, sample_shape=torch.Size()):
+        # a covariance that knows a root of itself (RootLazyTensor; PredictiveCovariance from the spectral or the dense factor) is
+        # sampled through it: loc + R z (+ sqrt(extra) z'), exact for R R^T + diag(extra), no n x n factorisation and no jitter
+        rd = getattr(self._covar, "root_decomposition", None)
+        rt = rd() if rd is not None else None
+        if rt is not None and rt.root.dim() == 2 and self.loc.dim() == 1:
+            z = torch.randn(*sample_shape, rt.root.shape[-1], dtype=rt.root.dtype, device=rt.root.device)
+            out = self.loc + z @ rt.root.t()
+            if rt.extra is not None:
+                out = out + rt.extra.clamp_min(0).sqrt() * torch.randn(*sample_shape, *self.loc.shape, dtype=rt.root.dtype, device=rt.root.device)
+            return out
         cov = self.covariance_matrix
         n = cov.shape[-1]
         jitter = 1e-6 if cov.dtype == torch.float32 else 1e-8

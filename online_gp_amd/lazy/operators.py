@@ -345,6 +345,33 @@ class PredictiveCovariance(LazyCovariance):
                     idx = torch.arange(nb, device=self.device)
                     full[s // q:e // q] = G[idx, :, idx, :]
 
+    def root_decomposition(self):
+        """A root of this covariance where a factor provides one without a solve (the counterpart of the reference's
+        ``fast_pred_samples`` branch, BFN:229-243 -- there a Lanczos root of rank <= n*, truncated without an error estimate):
+        spectral factor: R = sigma (chol^-1 F*^T)^T [n*, r] plus the left-out prior variance as a diagonal term -- exactly the
+        covariance ``evaluate()`` returns; dense factor: R = sigma W* L_M with M = L_M L_M^T (factorised once per posterior) -- exact.
+        None on the PCG path (rough kernels on large grids) and for blocked covariances: callers then factorise ``evaluate()``."""
+        from ..distributions import RootLazyTensor
+
+        if self.block is not None:
+            return None
+        if getattr(self, "_root", None) is not None:
+            return self._root
+        s = self.sigma2 ** 0.5
+        if hasattr(self.post, "dense"):
+            LM = getattr(self.post, "_chol_M", None)
+            if LM is None:
+                LM = self.post._chol_M = grid_ops.psd_safe_cholesky(self.post.dense.contiguous())
+            R = grid_ops.gather(self.post.grid, self.x, LM.t().contiguous(), self.err) * s        # W* L_M  [n*, m]
+            self._root = RootLazyTensor(R)
+            return self._root
+        sp = self.spectral() if self.spectral is not None else None
+        if sp is None:
+            return None
+        Y = sp._solve()                                                                           # chol^-1 F*^T  [r, n*]
+        self._root = RootLazyTensor((Y.t() * s).to(self.dtype).contiguous(), (sp._tail * self.sigma2).to(self.dtype))
+        return self._root
+
     def diag(self):
         if self._diag is None:
             self._solve_chunks(False)

@@ -920,6 +920,9 @@ class FixedNoiseOnlineSKIGP(torch.nn.Module):
             covs = [PredictiveCovariance(_wtw_post, Xf, self._hyper()[o][1] if self.has_learnable_noise else 1.0, self._err, chunk=chunk,
                                          block=block if X.dim() > 2 else None, spectral=None if sq is None else (lambda o=o: sq[o]))
                     for o, _wtw_post in enumerate(posts)]
+        if covs is not None and settings.fast_pred_samples.on():
+            # BFN:229-243: hand out a root form of the covariance where a factor provides one (else the exact covariance, as always)
+            covs = [(c.root_decomposition() or c) for c in covs]
         # output shapes follow :248-252
         if out == 1:
             mean_o = mean[:, 0].reshape(lead)

@@ -80,6 +80,13 @@ class fast_pred_var(_feature_flag):
 
 
 class fast_pred_samples(_feature_flag):
+    """gpytorch.settings.fast_pred_samples: upstream then returns the predictive covariance as a RootLazyTensor built from a
+    Lanczos root of the inducing posterior (BFN:229-243).  Here: where a factor provides a root without a solve -- the spectral
+    Woodbury factor on large grids, the dense factor on small ones -- ``model(X)`` returns ``distributions.RootLazyTensor`` (root
+    [n*, r] + the left-out prior variance as a diagonal term: the SAME covariance the default path returns, no Lanczos
+    truncation); on the PCG path (rough kernels on large grids) the exact covariance is returned as before.  Independently of this
+    flag ``MultivariateNormal.rsample`` samples through such a root whenever the covariance has one."""
+
     _state = False
 
 

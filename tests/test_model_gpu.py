@@ -1066,3 +1066,60 @@ def test_preconditioner_eigenbasis_is_resolved_for_every_hyperparameter_change()
             m2.covar_module.base_kernel.base_kernel.lengthscale = k.lengthscale.detach().clone()
         mean_cold = m2(Xq).mean
         assert (mean_warm - mean_cold).abs().max().item() < 1e-9 * mean_cold.abs().max().item()
+
+
+@pytest.mark.parametrize("case", ["spectral", "dense", "pcg"])
+def test_root_form_of_the_predictive_covariance_and_fast_pred_samples(case):
+    """BFN:229-243 (`fast_pred_samples`): the reference hands out a RootLazyTensor from a Lanczos root of the inducing posterior.  Here
+    a factor provides the root without a solve: the spectral Woodbury factor (large grid, smooth kernel: root + left-out prior
+    variance as a diagonal term) and the dense factor (small grid: W* L_M) -- and the root's covariance IS the covariance the
+    default path returns, which is checked against the data-space oracle; sampling goes through the root (no n x n factorisation).
+    On the PCG path (Matern-1/2 on a large grid) no root exists: the flag changes nothing and sampling factorises the exact matrix."""
+    from online_gp_amd import settings
+    from online_gp_amd.distributions import RootLazyTensor
+    from online_gp_amd.kernels import MaternKernel, ScaleKernel
+    from online_gp_amd.models import FixedNoiseOnlineSKIGP
+
+    rng = np.random.default_rng(5)
+    d, g = (3, 14) if case != "dense" else (3, 8)
+    n, ns = 600, 24
+    X = rng.uniform(-1, 1, (n, d)); y = np.sin(2 * X.sum(1)) + 0.1 * rng.standard_normal(n)
+    Xs = rng.uniform(-1, 1, (ns, d))
+    gb = [[-1.1, 1.1]] * d
+    cov_mod = ScaleKernel(MaternKernel(nu=0.5, ard_num_dims=d)).to(DEV) if case == "pcg" else None
+    Xt, yt = torch.as_tensor(X, device=DEV), torch.as_tensor(y, device=DEV)[:, None]
+    with settings.cg_tolerance(1e-10):
+        m = FixedNoiseOnlineSKIGP(Xt, yt, torch.ones_like(yt), grid_bounds=torch.tensor(gb), grid_size=g, learn_additional_noise=True, covar_module=cov_mod).eval()
+        Xst = torch.as_tensor(Xs, device=DEV)
+        exact = m(Xst)
+        C = exact.covariance_matrix.double()
+        with settings.fast_pred_samples(True):
+            fast = m(Xst)
+        lc = fast.lazy_covariance_matrix
+        if case == "pcg":
+            assert not isinstance(lc, RootLazyTensor) and exact.lazy_covariance_matrix.root_decomposition() is None
+        else:
+            assert isinstance(lc, RootLazyTensor) and lc.root.shape[0] == ns
+            assert (lc.extra is not None) == (case == "spectral")
+            scale = float(C.diagonal().max())
+            assert float((lc.evaluate().double() - C).abs().max()) < 1e-7 * scale
+            assert torch.allclose(fast.variance.double(), exact.variance.double(), rtol=1e-7, atol=1e-12 * scale)
+            # ... and that covariance is the oracle's (kernel hyper-parameters at their defaults)
+            k = m.covar_module.base_kernel
+            O = dataspace.DataSpaceGP(gb, g, "rbf", k.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1), float(k.outputscale),
+                                      float(m.likelihood.second_noise)).fit(X, y, np.ones(n))
+            _, Co = O.predict(Xs, full_cov=True)
+            assert np.abs(C.cpu().numpy() - Co).max() < 1e-4 * np.abs(Co).max()
+        # sampling: through the root where there is one (also with the flag off), Cholesky of the exact matrix otherwise
+        torch.manual_seed(0)
+        S = (fast if case != "pcg" else exact).rsample(torch.Size([40000])).double()
+        assert S.shape == (40000, ns)
+        emp = torch.cov(S.t())
+        assert float((emp - C).abs().max()) < 0.05 * float(C.diagonal().max())
+        assert float((S.mean(0) - exact.mean.double()).abs().max()) < 0.05 * float(C.diagonal().max().sqrt())
+        if case != "pcg":
+            torch.manual_seed(0)
+            S2 = exact.rsample(torch.Size([8])).double()          # flag off: the same root route
+            torch.manual_seed(0)
+            S3 = fast.rsample(torch.Size([8])).double()
+            assert torch.allclose(S2, S3, rtol=1e-9, atol=1e-9)
