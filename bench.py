@@ -937,6 +937,7 @@ def main():
                          "median_launch_us": float(np.median(stamp_each)) if (stamped and stamp_each) else None,
                          "frac_at_median_launch": (spmv_bytes / (float(np.median(stamp_each)) * 1e-6) / 1e9 / HBM_PEAK_GBS) if (stamped and stamp_each) else None,
                          "launches_over_1.25x_median": int(np.sum(np.asarray(stamp_each) > 1.25 * np.median(stamp_each))) if (stamped and stamp_each) else None,
+                         "launch_us_percentiles_10_25_50_75_90_95_99": [float(v) for v in np.percentile(stamp_each, [10, 25, 50, 75, 90, 95, 99])] if (stamped and stamp_each) else None,
                          "event_launches": spmv_n, "event_avg_launch_us": ev_ms * 1e3, "event_achieved": ev_achieved, "event_frac": ev_achieved / HBM_PEAK_GBS,
                          # everything in `committed_take` (and `traffic` above) was read back from files under profiles/: a separate run of
                          # this command under rocprofv3, committed with the round -- evidence beside this run's own events, not part of them
