@@ -208,14 +208,15 @@ def test_sm_partial_mll_value_matches_dense_restatement_and_is_differentiable():
     assert np.abs(xt.grad.cpu().numpy()[0] - fd).max() < 1e-4 * max(np.abs(fd).max(), 1e-3)
 
 
-def test_learned_stem_streaming_update_runs():
-    from online_gp_amd.models import LinearStem, OnlineSKIRegression
+@pytest.mark.parametrize("kind", ["linear", "mlp"])
+def test_learned_stem_streaming_update_runs(kind):
+    from online_gp_amd.models import MLP, LinearStem, OnlineSKIRegression
 
     torch.manual_seed(0)
     rng = np.random.default_rng(0)
     X = rng.uniform(-1, 1, (400, 5)); y = np.sin(X[:, :1] + X[:, 1:2]) + 0.1 * rng.standard_normal((400, 1))
     Xt, yt = torch.as_tensor(X, device=DEV, dtype=torch.float32), torch.as_tensor(y, device=DEV, dtype=torch.float32)
-    stem = LinearStem(5, 2).to(DEV)
+    stem = (LinearStem(5, 2) if kind == "linear" else MLP(5, 2, 2, "16,8")).to(DEV)     # (the reference's config strings: "hidden_dims: 16,8")
     r = OnlineSKIRegression(stem, Xt[:200], yt[:200], 1e-2, 16, 1.0)
     w0 = stem[0].weight.detach().clone()
     for s in range(200, 260, 20):
