@@ -330,3 +330,21 @@ def test_stems_shapes_and_parameter_free_identity():
     assert [m.out_features for m in MLP(3, 2, 2, "16,8") if isinstance(m, torch.nn.Linear)] == [16, 8, 2]
     with pytest.raises(ValueError):
         MLP(3, 2, 3, "16,8")
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """The library's environment switches (getenv("WISKI_...") in csrc/, os.environ in the package) are the ones INTEGRATION.md 3 lists -- and no more
+    than twelve: a knob of a measured-and-rejected variant becomes a constant, not a switch (round 6)."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for f in glob.glob(os.path.join(root, "online_gp_amd", "csrc", "*")):
+        if f.endswith((".hip", ".h")):
+            found |= set(re.findall(r'getenv\("(WISKI_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(root, "online_gp_amd", "**", "*.py"), recursive=True):
+        found |= set(re.findall(r'environ(?:\.get)?\(?\[?"(WISKI_[A-Z0-9_]+)"', open(f).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert len(found) <= 12, sorted(found)
+    for name in sorted(found):
+        assert "`" + name + "`" in doc, f"{name} is read by the library but not documented in INTEGRATION.md"
