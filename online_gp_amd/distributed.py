@@ -41,6 +41,8 @@ def rccl_info(group=None, device=None):
     if not (dist.is_available() and dist.is_initialized()):
         return info
     info["backend"], info["world_size"] = dist.get_backend(group), dist.get_world_size(group)
+    if info["backend"] == "nccl" and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     one = torch.ones(1, dtype=torch.float32, device=device if info["backend"] == "nccl" else "cpu")
     dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
     info["ranks_seen"] = int(round(float(one.item())))
