@@ -87,11 +87,11 @@ int wiski_gather_rows_f64(const wiski_grid* grid, const double* d_x, int64_t n, 
  * (the layout InterpolatedLazyTensor keeps; BFN:206-210). k == 1 only. */
 int wiski_gather_ell_f32(const int32_t* d_idx, const float* d_val, int64_t n, int32_t T, const float* d_v, float* d_out, void* stream);
 int wiski_gather_ell_f64(const int32_t* d_idx, const double* d_val, int64_t n, int32_t T, const double* d_v, double* d_out, void* stream);
-/* The same product for rows written by wiski_interp on `grid` (idx[tap] = base + sum_q c_q stride_q; T = 4^d): in fp32 d_v is first
+/* The same product for rows written by wiski_interp on `grid` (idx[tap] = base + sum_q c_q stride_q; T = 4^d): d_v is first
  * copied into a blocked layout (second-to-last dim in groups of 4, once per alignment of the stencil: csrc/gather_ell_dma.h) in which
- * every lane's four taps are one aligned 16-byte group and a row touches ~5.5 cache lines instead of ~17.5 -- the gathers of v, not the
+ * every lane's four taps are one aligned group of four reals and a row touches ~5.5 cache lines instead of ~17.5 -- the gathers of v, not the
  * idx / val stream, bound the plain form.  d_vpack: scratch of
- * wiski_gather_ell_pack_elems(grid) reals, 16-byte aligned (0 elements: d = 1 or a grid too large -- pass NULL).  fp64, small row
+ * wiski_gather_ell_pack_elems(grid) reals, 16-byte aligned (0 elements: d = 1 or a grid too large -- pass NULL).  Small row
  * counts, d = 1, a NULL or misaligned scratch take wiski_gather_ell. */
 int wiski_gather_ell_grid_f32(const wiski_grid* grid, const int32_t* d_idx, const float* d_val, int64_t n, const float* d_v, float* d_vpack, float* d_out, void* stream);
 int wiski_gather_ell_grid_f64(const wiski_grid* grid, const int32_t* d_idx, const double* d_val, int64_t n, const double* d_v, double* d_vpack, double* d_out, void* stream);

@@ -103,7 +103,7 @@ struct EllDmaGeom {
   static constexpr unsigned LDS_B = NST * STAGE_B + RPT * (unsigned)sizeof(real);
 };
 
-// ---- grid-aware form (wiski_gather_ell_grid, fp32): v re-laid so that every lane's four taps are ONE aligned 16-byte group ------------
+// ---- grid-aware form (wiski_gather_ell_grid): v re-laid so that every lane's four taps are ONE aligned 16-byte group ------------
 // What bounds the kernel above is not the idx / val stream but the gathers of v: in the row-major v a row's T taps sit in T / 4
 // different cache lines (one per tap prefix: 16 at d = 3, ~17.5 with the 16-byte groups that straddle a line), every one an L2
 // request that queues in the CU's in-order vector-memory path behind the stream's HBM requests (measured, tools/gather_ell_probe.py:
@@ -116,7 +116,7 @@ struct EllDmaGeom {
 // plain form, but the four lanes of a prefix read 64 contiguous bytes, so a row touches 4^(d-2) x 1.4 = ~5.5 lines at d = 3 instead of
 // ~17.5.  (Built first: K-blocks of 4 with block b + 1 fetched separately -- as many lines as it saves in L it adds in K, 112-118 us
 // against 116 for the plain form; then blocks stored 8 wide, two loads per lane, 108-110 us: the cost is per 16-byte access as much as per
-// line.)  fp64 rows take the plain form (a lane's four doubles are 32 bytes: two accesses either way).
+// line.)  fp64 alike (a group is 32 bytes, two loads per lane: 183 -> 149 us at 50^3).
 struct EllV4Geo {
   unsigned gL, gK, nbk;      // sizes of the last and second-to-last dim, K blocks of 4
   unsigned mulL, shL;        // n / gL = mulL ? __umulhi(n, mulL) >> shL : n   (exact for 0 <= n < 2^31, Granlund-Montgomery)

@@ -444,7 +444,7 @@ static int gather_ell_v4_launch(const EllV4Geo& geo, const int32_t* d_idx, const
     attr_done = true;
   }
   const int64_t ntiles = (n + Gm::RPT - 1) / Gm::RPT;
-  int64_t waves = g_ell_waves > 0 ? g_ell_waves : (int64_t)ell_cu_count() * 3;     // (measured: 3 per CU here, 2 for the plain form)
+  int64_t waves = g_ell_waves > 0 ? g_ell_waves : (int64_t)ell_cu_count() * (sizeof(real) == 4 ? 3 : 2);     // (measured: fp32 2-3 per CU alike, fp64 2: 149 / 156 / 202 us at 2 / 3 / 4)
   if (waves > ntiles) waves = ntiles;
   hipLaunchKernelGGL((k_gather_ell_dma<real, LPR, P, true>), dim3((unsigned)waves), dim3(64), Gm::LDS_B, s, d_idx, d_val, n, d_v4, d_out, ntiles, g_ell_contig, geo);
   WISKI_LAUNCH_CHECK();
@@ -458,9 +458,7 @@ static int gather_ell_grid_impl(const wiski_grid* grid, const int32_t* d_idx, co
   for (int q = 0; q < grid->d; ++q) T *= 4;
   if (n == 0) return WISKI_OK;
   if (!d_idx || !d_val || !d_v || !d_out) return WISKI_E_BADARG;
-  if constexpr (sizeof(real) == 8) {
-    return gather_ell_impl<real>(d_idx, d_val, n, T, d_v, d_out, stream);       // (no gain in fp64: see gather_ell_dma.h)
-  } else {
+  {
   EllV4Geo geo;
   int64_t groups = 0;
   // the blocked copy pays from ~2^14 rows on (one extra pass over v); d = 1 rows touch one or two lines as they are
