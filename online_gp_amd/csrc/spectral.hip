@@ -1063,7 +1063,14 @@ __global__ __launch_bounds__(256) void k_spec_mode0_mfma(GridDev<float> G, const
   __shared__ double s_red[16];
   const int g0 = G.g[0], Sf = G.stride[0], m = G.m;
   const int cc = blockIdx.y;
-  const int s0 = blockIdx.x * 32;
+  // Fibre tiles, XCD-contiguous (round 6): the launch pads grid.x to 8 * per, workgroup b (on XCD b % 8 for every blockIdx.y, since the row of
+  // the grid is a multiple of 8 long) takes tile (b % 8) * per + b / 8.  A tile row is 32 floats = 128 bytes at a 4 Sf-byte row stride that is not
+  // a multiple of 128 (50^3: 10 000), so every row segment straddles two cache lines and shares each with the neighbouring tile: with tiles dealt
+  // round-robin the two halves of every line of every vector were fetched (and partially written) by two different XCDs.
+  const int ntile = (Sf + 31) >> 5, per = (ntile + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= ntile) return;
+  const int s0 = tile * 32;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   const float* __restrict__ V0;
@@ -1226,7 +1233,7 @@ static int launch_mode0(const GridDev<real>& G, const real* Va, const real* Vb, 
                         const real* rvec, int dot_c0, double* dots, hipStream_t s) {
   const int g0 = G.g[0], Sf = G.stride[0];
   if constexpr (sizeof(real) == 4) {
-    dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)ncols);
+    dim3 grd((unsigned)(8 * (((Sf + 31) / 32 + 7) / 8)), (unsigned)ncols);     // (padded: XCD-contiguous fibre tiles, see the kernel)
 #define M0(KS, VW)                                                                                                                          \
   hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 0>), grd, dim3(256), 0, s, G, Va, Vb, split, transposed, src, dst, rvec, dot_c0,            \
                      DOT ? dots : (double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, PcgScal{nullptr, 0, nullptr}, 0, 0.0,         \
@@ -1246,7 +1253,7 @@ static int launch_mode0(const GridDev<real>& G, const real* Va, const real* Vb, 
 static int launch_mode0_fwd_upd(const GridDev<float>& G, const float* V0, float* r, float* dst, int k, int it, int apply, double tol2, float* p,
                                 float* pt, float* part, int nch, int zl, float* u, float* z, PcgScal S, hipStream_t s) {
   const int g0 = G.g[0], Sf = G.stride[0];
-  dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)k);
+  dim3 grd((unsigned)(8 * (((Sf + 31) / 32 + 7) / 8)), (unsigned)k);
 #define M2(KS, VW)                                                                                                                        \
   hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 2>), grd, dim3(256), 0, s, G, V0, V0, 0, 0, (const float*)r, dst, (const float*)nullptr, 0, \
                      (double*)nullptr, k, it, p, pt, S, apply, tol2, part, nch, zl, u, z)
@@ -1260,7 +1267,7 @@ static int launch_mode0_bwd_updp(const GridDev<real>& G, const real* X0, const r
                                  PcgScal S, hipStream_t s) {
   const int g0 = G.g[0], Sf = G.stride[0];
   if constexpr (sizeof(real) == 4) {
-    dim3 grd((unsigned)((Sf + 31) / 32), (unsigned)(2 * k));
+    dim3 grd((unsigned)(8 * (((Sf + 31) / 32 + 7) / 8)), (unsigned)(2 * k));
 #define M1(KS, VW)                                                                                                                       \
   hipLaunchKernelGGL((k_spec_mode0_mfma<KS, VW, 1>), grd, dim3(256), 0, s, G, Z0, X0, 0, 1, src, (float*)nullptr, (const float*)nullptr, 0, \
                      (double*)nullptr, k, it, p, pt, S, 0, 0.0, (float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr)
