@@ -1007,7 +1007,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
     real* Ot = part;
     if (sym_use_bcast()) {   // coefficients on the vector path, DPP row broadcast (spmm_sym_bcast.h); operands in 64-column slices
       const int ns = (k + 63) / 64;
-      dim3 tg((unsigned)((m + 63) / 64), (unsigned)ns);
+      dim3 tg((unsigned)(8 * (((m + 63) / 64 + 7) / 8)), (unsigned)ns);            // (padded: XCD-contiguous row tiles, see the kernel)
       if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true, true>), tg, dim3(256), 0, s, m, k, 64 * ns, V, Vt, add, beta, dots);
       else hipLaunchKernelGGL((k_transpose_cm_rm<real, false, true>), tg, dim3(256), 0, s, m, k, 64 * ns, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
       const int ng = sym_groups(G.d);
@@ -1030,7 +1030,7 @@ static int launch_spmv4_sym(const GridDev<real>& G, const real* A_h, const real*
 #undef SPMMB_LAUNCH
       return hipGetLastError() == hipSuccess ? WISKI_OK : WISKI_E_LAUNCH;
     }
-    dim3 tg((unsigned)((m + 63) / 64), (unsigned)((kp + 63) / 64));
+    dim3 tg((unsigned)(8 * (((m + 63) / 64 + 7) / 8)), (unsigned)((kp + 63) / 64));
     if (dots && add) hipLaunchKernelGGL((k_transpose_cm_rm<real, true>), tg, dim3(256), 0, s, m, k, kp, V, Vt, add, beta, dots);
     else hipLaunchKernelGGL((k_transpose_cm_rm<real, false>), tg, dim3(256), 0, s, m, k, kp, V, Vt, (const real*)nullptr, (real)0, (double*)nullptr);
     // grid.x is padded to a multiple of 8: workgroup b runs on XCD b % 8 and takes tile (b % 8) * (grid.x / 8) + b / 8, so

@@ -91,7 +91,13 @@ template <typename real, bool DOT, bool SLICED = false>
 __global__ __launch_bounds__(256) void k_transpose_cm_rm(int m, int k, int kp, const real* __restrict__ V, real* __restrict__ Vt,
                                                          const real* __restrict__ add, real beta, double* __restrict__ dots) {
   __shared__ real tile[64][65];
-  const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  // XCD-contiguous row tiles (grid.x padded to 8 * per; workgroup b sits on XCD b % 8 whatever blockIdx.y): an XCD converts one contiguous eighth
+  // of the rows -- the eighth the product kernel's tiles on the same XCD read afterwards -- and the 256-byte column segments of neighbouring tiles,
+  // which share cache lines (a column starts at 4 c m bytes: not a multiple of 128), meet in one L2 instead of being fetched by two
+  const int nti = (m + 63) >> 6, per = (nti + 7) >> 3;
+  const int ti = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (ti >= nti) return;
+  const int i0 = ti * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   double part[16];
 #pragma unroll
