@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="number of timed K-step blocks (0 = enough for ~0.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extras (profiling runs)")
+    ap.add_argument("--sample-every", type=int, default=4, help="SpMV dispatches of every n-th timed step carry events + in-kernel stamps")
+    ap.add_argument("--stamp-dump", default=None, help="write the raw per-wave stamps of every sampled SpMV dispatch here (.npz; tools/stamp_report.py)")
     ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
 
@@ -392,7 +394,7 @@ def main():
                 t0 = time.perf_counter()
                 for k in range(K):
                     t = Wm + r * K + k
-                    sampled = profile and t % 4 == 0        # per-dispatch events on every SpMV launch queued by every 4th step's call
+                    sampled = profile and t % args.sample_every == 0        # per-dispatch events on every SpMV launch queued by every 4th step's call
                     if sampled:
                         lib.wiski_prof_enable(ctypes.c_int32(1))
                     _, it = step(Xs[t * q:(t + 1) * q], ys[t * q:(t + 1) * q])
@@ -407,11 +409,20 @@ def main():
                     # the loop is pipelined (a step returns with its refresh in flight): the events are read here, outside the
                     # timed region, once the block has drained -- reading them after each step would wait for the GPU
                     tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
-                    each = (ctypes.c_double * 256)()
-                    if lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl), each, ctypes.c_int64(256)) == 0:      # the same dispatches by their in-kernel stamps
+                    each = (ctypes.c_double * 1024)()
+                    if lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl), each, ctypes.c_int64(1024)) == 0:      # every SpMV dispatch of the block by its in-kernel stamps
                         st_sum += tms.value
                         st_n += int(nl.value)
-                        st_each.extend(each[:min(int(nl.value), 256)])
+                        st_each.extend(each[:min(int(nl.value), 1024)])
+                        if args.stamp_dump:                 # (diagnostic: which waves, on which CUs, made a slow dispatch slow)
+                            for i in range(1024):
+                                nw = ctypes.c_int64(0)
+                                lib.wiski_prof_stamps_raw(ctypes.c_int64(i), None, ctypes.c_int64(0), ctypes.byref(nw))
+                                if nw.value <= 0:
+                                    continue
+                                raw = np.zeros(2 * nw.value, dtype=np.uint64)
+                                lib.wiski_prof_stamps_raw(ctypes.c_int64(i), raw.ctypes.data_as(ctypes.c_void_p), nw, ctypes.byref(nw))
+                                run_stream.raw.append(raw)
                     if lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl)) == 0:
                         ms_sum += tms.value
                         n_launch += int(nl.value)
@@ -420,8 +431,11 @@ def main():
         if world > 1:
             dist.all_reduce(bt, op=dist.ReduceOp.MAX)
         run_stream.stamps = (st_sum, st_n, st_each)
+        if args.stamp_dump and profile and rank == 0 and run_stream.raw:
+            np.savez_compressed(args.stamp_dump, **{f"d{i:04d}": r for i, r in enumerate(run_stream.raw)})
         return model, upd, bt.tolist(), iters, ms_sum, n_launch
 
+    run_stream.raw = []
     with settings.skip_posterior_variances(True), settings.cg_tolerance(tol), settings.deferred_bounds_check(True), settings.deferred_refresh(True), \
             torch.no_grad():
         # headline: the configured stream; N > 1: the exchange the cost model picks ("auto")
@@ -859,14 +873,16 @@ def main():
 
             g_lo, g_hi = shard_groups(d, 0, world)
             spmv_bytes = sum(b - a for a, b in half_stencil_group_slices(grid, g_lo, g_hi)) * es + 3 * grid.m * es
-        # two clocks on the same sampled dispatches: (a) stamps taken inside the kernel -- earliest wave start to latest wave end of
-        # every dispatch (100 MHz wall clock, wiski_prof_stamps): the kernel alone, what rocprofv3's begin / end timestamps measure too;
-        # (b) the start / stop HIP events attached to the dispatch packet, which bracket [predecessor complete -> this kernel
-        # complete] and so contain the ~2.4 us of dispatch latency in front of the first wave.  `achieved` / `frac` use (a) where the
-        # kernel is stamped (k_spmv_sym_dma), (b) is reported beside it (event_*).
+        # two clocks: (a) stamps taken inside the kernel -- earliest wave start to latest wave end of a dispatch (100 MHz wall clock,
+        # wiski_prof_stamps): the kernel alone, what rocprofv3's begin / end timestamps measure too.  They cost nothing measurable, so
+        # EVERY SpMV dispatch of the timed blocks carries them (a stride-4 sample of the steps, the round-6 first cut, read 0.55-0.60
+        # from one run to the next with ~115 dispatches: profiles/r06_stamp_sampling.txt);
+        # (b) the start / stop HIP events attached to the dispatch packet (they do cost: the dispatches of every 4th step), which
+        # bracket [predecessor complete -> this kernel complete] and so contain the ~2.4 us of dispatch latency in front of the first
+        # wave.  `achieved` / `frac` use (a) where the kernel is stamped (k_spmv_sym_dma), (b) is reported beside it (event_*).
         ev_ms = spmv_ms / max(spmv_n, 1)
         ev_achieved = spmv_bytes / (ev_ms * 1e-3) / 1e9 if spmv_n else 0.0
-        stamped = stamp_n > 0 and stamp_n >= 0.9 * spmv_n
+        stamped = stamp_n > 0 and stamp_n >= spmv_n
         avg_ms = stamp_ms / stamp_n if stamped else ev_ms
         achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if (spmv_n or stamped) else 0.0
         dma = dtype == torch.float32 and d == 3 and grid.m % 4 == 0 and os.environ.get("WISKI_SYM_DMA", "1") != "0"
@@ -932,7 +948,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname + " (symmetric half-stencil A_h . p inside wiski_pcg)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches": stamp_n if stamped else spmv_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": spmv_bytes,
-                         "clock": ("in-kernel stamps: earliest wave start -> latest wave end of each sampled dispatch (s_memrealtime, 100 MHz), wiski_prof_stamps"
+                         "clock": ("in-kernel stamps: earliest wave start -> latest wave end of EVERY dispatch of the timed blocks (s_memrealtime, 100 MHz), wiski_prof_stamps"
                                    if stamped else "HIP events attached to each dispatch (this kernel carries no in-kernel stamps)"),
                          "median_launch_us": float(np.median(stamp_each)) if (stamped and stamp_each) else None,
                          "frac_at_median_launch": (spmv_bytes / (float(np.median(stamp_each)) * 1e-6) / 1e9 / HBM_PEAK_GBS) if (stamped and stamp_each) else None,
@@ -949,7 +965,7 @@ def main():
                          "infinity_cache_resident": bool(spmv_bytes < 200e6),
                          "empty_dispatch_us": empty_us.value,
                          "net_of_empty_dispatch_frac": (spmv_bytes / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if net_us > 0 else None,
-                         "timing": "every SpMV dispatch of every 4th timed step, on its launch stream, read once per block after it has drained: avg_launch_us / achieved / frac by the kernel's own begin / end stamps (first wave started -> last wave finished); event_* by the start/stop HIP events attached to the same dispatches (hipExtLaunchKernel), whose pair brackets [predecessor complete -> this kernel complete] and so contains the dispatch latency in front of the first wave (an empty kernel reads ~4 us by it)",
+                         "timing": "avg_launch_us / achieved / frac: the kernel's own begin / end stamps (first wave started -> last wave finished) of every SpMV dispatch of the timed blocks, read once per block after it has drained; event_*: the start/stop HIP events attached to the dispatches of every 4th timed step (hipExtLaunchKernel), whose pair brackets [predecessor complete -> this kernel complete] and so contains the dispatch latency in front of the first wave (an empty kernel reads ~4 us by it)",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
                          "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es},

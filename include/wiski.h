@@ -573,12 +573,17 @@ int wiski_read_flag(const int32_t* d_flag, int32_t* h_value, void* stream);
  * synchronise the stream before calling it. */
 int wiski_prof_start(int32_t max_launches);
 int wiski_prof_stop(double* total_ms, int64_t* launches);
-/* The same recorded dispatches by stamps taken INSIDE the kernel (k_spmv_sym_dma: 100 MHz wall clock, earliest wave start /
- * latest wave end of each dispatch): summed [first wave started -> last wave finished] time and the number of stamped
- * dispatches.  The event pair of wiski_prof_stop brackets [predecessor complete -> kernel complete] and so contains the
- * dispatch latency in front of the first wave (~2.4 us); this figure is the kernel alone.  Call before wiski_prof_stop,
- * stream synchronised. */
+/* Stamps taken INSIDE the kernel (k_spmv_sym_dma: 100 MHz wall clock, earliest wave start / latest wave end of each dispatch):
+ * summed [first wave started -> last wave finished] time and the number of stamped dispatches.  EVERY such dispatch between
+ * wiski_prof_start and wiski_prof_stop is stamped (no measurable cost), with or without the events of wiski_prof_enable.  The
+ * event pair of wiski_prof_stop brackets [predecessor complete -> kernel complete] and so contains the dispatch latency in
+ * front of the first wave (~2.4 us); this figure is the kernel alone.  Readable until the next wiski_prof_start, stream
+ * synchronised. */
 int wiski_prof_stamps(double* total_ms, int64_t* launches, double* each_us, int64_t each_cap);   /* each_us (may be NULL): the first each_cap dispatches one by one, microseconds */
+/* the raw per-wave pairs of recorded dispatch i (tools/stamp_report.py): pairs[2w] = start | placement << 48 (simd(2) pipe(2)
+ * cu(4) sh(1) se(3) xcc(4), low to high), pairs[2w+1] = end (0: padding workgroup), w = blockIdx.y * gridDim.x + blockIdx.x;
+ * *nwaves = the dispatch's wave count (0: not stamped); at most cap pairs are copied (pairs may be NULL) */
+int wiski_prof_stamps_raw(int64_t i, uint64_t* pairs, int64_t cap, int64_t* nwaves);
 /* between start and stop: switch the event attachment off / on again without touching what has been recorded (sample some
  * steps of a pipelined loop, read all events once the loop has drained) */
 int wiski_prof_enable(int32_t on);

@@ -16,7 +16,8 @@
 // Optional HIP-event bracket around every stencil-SpMV launch, recorded on the
 // stream the kernel runs on (bench.py's roofline leg).  Off by default.
 static struct WiskiProf {
-  bool on = false;
+  bool on = false;       // events are attached to the dispatches (wiski_prof_enable)
+  bool armed = false;    // between wiski_prof_start and wiski_prof_stop: every k_spmv_sym_dma dispatch is stamped, events or not
   std::vector<hipEvent_t> ev;
   size_t used = 0;
   // in-kernel stamps (k_spmv_sym_dma): every wave of a recorded dispatch stores its own (start, end) pair of the 100 MHz wall
@@ -26,8 +27,9 @@ static struct WiskiProf {
   unsigned long long* d_stamp = nullptr;     // arena of pairs
   size_t stamp_pairs = 0, stamp_used = 0;
   struct Span { size_t off, n; };
-  std::vector<Span> spans;                   // per recorded dispatch (n == 0: not stamped)
+  std::vector<Span> spans;                   // per stamped dispatch, in launch order
 } g_prof;
+constexpr unsigned long long PROF_CLOCK_MASK = 0xffffffffffffull;   // the stamps keep 48 bits of the 100 MHz clock
 constexpr size_t PROF_STAMP_ARENA_PAIRS = (size_t)1 << 20;   // 16 MB: 256 dispatches of 4096 waves
 
 extern "C" int wiski_prof_start(int max_launches) {
@@ -46,9 +48,10 @@ extern "C" int wiski_prof_start(int max_launches) {
       hipMemset(g_prof.d_stamp, 0, g_prof.stamp_used * 2 * sizeof(unsigned long long)) != hipSuccess) return WISKI_E_LAUNCH;
   if (g_prof.d_stamp && !g_prof.stamp_used && hipMemset(g_prof.d_stamp, 0, g_prof.stamp_pairs * 2 * sizeof(unsigned long long)) != hipSuccess) return WISKI_E_LAUNCH;
   g_prof.stamp_used = 0;
-  g_prof.spans.assign((size_t)max_launches, WiskiProf::Span{0, 0});
+  g_prof.spans.clear();
   g_prof.used = 0;
   g_prof.on = true;
+  g_prof.armed = true;
   return WISKI_OK;
 }
 
@@ -60,18 +63,16 @@ extern "C" int wiski_prof_enable(int32_t on) {
 // the stamp pairs (one per wave) of the dispatch launch_timed is about to record, or NULL: not recording / no room
 static inline unsigned long long* prof_stamp_pairs(size_t nwaves) {
   static const bool off = getenv("WISKI_PROF_NOSTAMP") != nullptr;   // A/B of what the stamps themselves cost
-  const size_t i = g_prof.used / 2;
-  if (off || !(g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) || !g_prof.d_stamp || i >= g_prof.spans.size() ||
-      g_prof.stamp_used + nwaves > g_prof.stamp_pairs)
-    return nullptr;
-  g_prof.spans[i] = WiskiProf::Span{g_prof.stamp_used, nwaves};
+  if (off || !g_prof.armed || !g_prof.d_stamp || g_prof.stamp_used + nwaves > g_prof.stamp_pairs) return nullptr;
+  g_prof.spans.push_back(WiskiProf::Span{g_prof.stamp_used, nwaves});
   g_prof.stamp_used += nwaves;
-  return g_prof.d_stamp + 2 * g_prof.spans[i].off;
+  return g_prof.d_stamp + 2 * g_prof.spans.back().off;
 }
 
 // Stops recording; the caller must have synchronised the stream(s).
 extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
   g_prof.on = false;
+  g_prof.armed = false;
   double tot = 0;
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
     float ms = 0;
@@ -84,10 +85,12 @@ extern "C" int wiski_prof_stop(double* total_ms, int64_t* launches) {
   return WISKI_OK;
 }
 
-// The same dispatches by their in-kernel stamps: sum over the stamped dispatches of (latest "wave finished" - earliest "wave
-// started"), 100 MHz wall clock.  Call BEFORE wiski_prof_stop (which forgets the dispatches); the stream must be synchronised.
+// By in-kernel stamps: sum over the stamped dispatches of (latest "wave finished" - earliest "wave started"), 100 MHz wall clock.
+// EVERY k_spmv_sym_dma dispatch between wiski_prof_start and wiski_prof_stop is stamped (the stamps cost nothing measurable), whether
+// wiski_prof_enable has the events attached or not -- an unbiased sample where the events, which do cost, cover a subset.  The stamps
+// stay readable until the next wiski_prof_start; the stream must be synchronised.
 extern "C" int wiski_prof_stamps(double* total_ms, int64_t* launches, double* each_us, int64_t each_cap) {
-  const size_t nd = g_prof.used / 2 < g_prof.spans.size() ? g_prof.used / 2 : g_prof.spans.size();
+  const size_t nd = g_prof.spans.size();
   double tot = 0;
   int64_t cnt = 0;
   if (nd && g_prof.d_stamp && g_prof.stamp_used) {
@@ -97,8 +100,9 @@ extern "C" int wiski_prof_stamps(double* total_ms, int64_t* launches, double* ea
       const WiskiProf::Span sp = g_prof.spans[i];
       unsigned long long lo = ~0ull, hi = 0;
       for (size_t w = 0; w < sp.n; ++w) {
-        const unsigned long long b = h[2 * (sp.off + w)], e = h[2 * (sp.off + w) + 1];
+        unsigned long long b = h[2 * (sp.off + w)] & PROF_CLOCK_MASK, e = h[2 * (sp.off + w) + 1];   // (bits 48.. of the start word: placement)
         if (!e) continue;                      // (a padded workgroup that returned at once)
+        if (e < b) e += PROF_CLOCK_MASK + 1;   // the 48-bit clock wrapped between the two reads (once in 32 days)
         if (b < lo) lo = b;
         if (e > hi) hi = e;
       }
@@ -111,6 +115,21 @@ extern "C" int wiski_prof_stamps(double* total_ms, int64_t* launches, double* ea
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = cnt;
+  return WISKI_OK;
+}
+
+// The raw pairs of recorded dispatch i (same lifetime as wiski_prof_stamps): pairs[2w] = start | placement << 48 (simd(2) pipe(2)
+// cu(4) sh(1) se(3) xcc(4), low to high), pairs[2w+1] = end (0: the workgroup was padding), w = blockIdx.y * gridDim.x +
+// blockIdx.x.  *nwaves: the dispatch's wave count (0: not stamped).  For tools/stamp_report.py; nothing in the product reads it.
+extern "C" int wiski_prof_stamps_raw(int64_t i, uint64_t* pairs, int64_t cap, int64_t* nwaves) {
+  if (!nwaves || i < 0) return WISKI_E_BADARG;
+  *nwaves = 0;
+  if ((size_t)i >= g_prof.spans.size() || !g_prof.d_stamp) return WISKI_OK;
+  const WiskiProf::Span sp = g_prof.spans[(size_t)i];
+  *nwaves = (int64_t)sp.n;
+  if (!pairs || !sp.n) return WISKI_OK;
+  const size_t n = (size_t)cap < sp.n ? (size_t)cap : sp.n;
+  if (hipMemcpy(pairs, g_prof.d_stamp + 2 * sp.off, n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return WISKI_E_LAUNCH;
   return WISKI_OK;
 }
 

@@ -333,8 +333,11 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   if (stamp && lane == 0) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     u64x2 pr;
-    pr[0] = t_begin;
-    pr[1] = (unsigned long long)wall_clock64();
+    // where the wave ran, in the 16 bits above the 48-bit clock of the START word (wiski_prof_stamps masks them; read back by
+    // wiski_prof_stamps_raw): HW_ID[15:4] = simd(2) pipe(2) cu(4) sh(1) se(3), XCC_ID[3:0] above them
+    const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (31 << 11)) >> 4) & 0xfffu, xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xfu;
+    pr[0] = (t_begin & 0xffffffffffffull) | ((unsigned long long)(hw | (xcc << 12)) << 48);
+    pr[1] = (unsigned long long)wall_clock64() & 0xffffffffffffull;
     *reinterpret_cast<u64x2*>(stamp + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)) = pr;
   }
 #ifdef WISKI_DMA_TIMING

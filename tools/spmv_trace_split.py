@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
-side = ("k_potrf_coop", "k_gram_acc", "k_basis_project", "k_gemm32", "k_woodbury_c", "k_tl_scale_cast")
+side = ("k_potrf_coop", "k_potrf_small", "k_tri_inv_small", "k_gram_acc", "k_basis_project", "k_gemm32", "k_woodbury_c", "k_tl_scale_cast")
 side_iv = [(s, e) for s, e, n in ev if any(x in n for x in side)]
 main = [(s, e, n) for s, e, n in ev if not any(x in n for x in side)]
 groups = {}
