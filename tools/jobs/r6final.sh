@@ -17,6 +17,7 @@ cd $R
 python tools/trace_medians.py $O/bench_kernel_trace.csv > $O/kernel_medians.txt; head -14 $O/kernel_medians.txt
 python tools/gap_report.py $O/bench_kernel_trace.csv > $O/gap_report.txt
 python tools/spmv_trace_split.py $O/bench_kernel_trace.csv > $O/spmv_split.txt 2>&1; tail -3 $O/spmv_split.txt
+python tools/spmv_overlap.py $O/bench_kernel_trace.csv > $O/spmv_overlap.txt 2>&1; head -8 $O/spmv_overlap.txt
 python tools/pmc_traffic.py /tmp/pmc_f/f_counter_collection.csv /tmp/pmc_w/w_counter_collection.csv $O/pmc_traffic.json | grep -i "spmv\|scatter\|slab"
 python tools/pmc_traffic.py /tmp/pmc_ef/f_counter_collection.csv /tmp/pmc_ef/f_counter_collection.csv $O/pmc_traffic_ell.json | grep -i "ell\|pack"
 rm -f $O/bench_kernel_trace.csv
