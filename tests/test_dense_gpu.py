@@ -385,7 +385,7 @@ def test_root_space_objects_match_the_dense_reference_b1():
         Q, KL, proj = (t.cpu().numpy() for t in (m.current_qmatrix, m.current_inducing_compression_matrix, m.root_space_projection))
         ev, ev1 = np.linalg.eigvalsh(0.5 * (Q + Q.T)), np.linalg.eigvalsh(0.5 * (Q1 + Q1.T))
         assert np.abs(ev - ev1).max() < 1e-8 * ev1.max()
-        qf, qf1 = float(proj.T @ np.linalg.solve(Q, proj)), float(proj1.T @ np.linalg.solve(Q1, proj1))
+        qf, qf1 = (proj.T @ np.linalg.solve(Q, proj)).item(), (proj1.T @ np.linalg.solve(Q1, proj1)).item()
         assert abs(qf - qf1) < 1e-9 * abs(qf1)
         Kb = m.Kuu_response[0].cpu().numpy().reshape(-1, 1)
         mean_ref_alg = Kb - KL @ np.linalg.solve(Q, proj)                       # BFN:375-376 from the model's own pieces
