@@ -14,7 +14,7 @@ DEV = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu
 
 def _hypers(gp):
     k = gp.covar_module.base_kernel
-    return (k.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1).astype(np.float64), float(k.outputscale.detach()), float(gp.likelihood.second_noise.detach()))
+    return (k.base_kernel.lengthscale.detach().cpu().numpy().reshape(-1).astype(np.float64), float(torch.as_tensor(k.outputscale).detach()), float(torch.as_tensor(gp.likelihood.second_noise).detach()))
 
 
 def _stream(d, n, seed):
