@@ -521,6 +521,65 @@ def test_half_stencil_spmv_dma_kernel_on_3d_grids(gs):
         assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
 
 
+def test_in_kernel_stamps_of_the_dma_spmv_cover_every_dispatch():
+    """Measurement hook (wiski_prof_start / enable / stamps / stamps_raw / stop, include/wiski.h): between start and stop EVERY
+    dispatch of k_spmv_sym_dma is stamped by its own waves -- with the events attached (enable 1) or not (enable 0) -- each live wave
+    leaves start < end and the compute unit it ran on, padding workgroups leave nothing, and the product is what it is without the hook."""
+    import ctypes
+
+    from online_gp_amd import _hip, grid_ops
+
+    lib = _hip.lib()
+    rng = np.random.default_rng(5)
+    gb = [[-1.1, 1.1]] * 3
+    gs = [20, 24, 50]
+    grid = grid_ops.GridSpec(gb, gs)
+    n = 400
+    B2 = cport.MatrixFreeWISKI(gb, gs, sigma2=0.5, dtype=np.float64)
+    B2.absorb(rng.uniform(-1.1, 1.1, (n, 3)), rng.standard_normal(n), rng.uniform(0.5, 2.0, n), init=True)
+    A = grid_ops.half_stencil_from_offset_major(grid, _t(B2.A, torch.float32)[(grid.R - 1) // 2:].contiguous())
+    V = _t(rng.standard_normal((1, grid.m)), torch.float32)
+    plain = grid_ops.stencil_spmv(grid, A, V)
+    torch.cuda.synchronize()
+    assert lib.wiski_prof_start(ctypes.c_int32(8)) == 0
+    outs = []
+    for on in (1, 0, 1):
+        lib.wiski_prof_enable(ctypes.c_int32(on))
+        outs.append(grid_ops.stencil_spmv(grid, A, V))
+    torch.cuda.synchronize()
+    tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+    each = (ctypes.c_double * 8)()
+    assert lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl), each, ctypes.c_int64(8)) == 0
+    assert nl.value == 3 and all(0.5 < each[i] < 1e4 for i in range(3)), (nl.value, list(each)[:3])     # microseconds
+    assert abs(sum(each[:3]) * 1e-3 - tms.value) < 1e-9
+    nrb = (grid.m + 255) // 256
+    for i in range(3):
+        nw = ctypes.c_int64(0)
+        assert lib.wiski_prof_stamps_raw(ctypes.c_int64(i), None, ctypes.c_int64(0), ctypes.byref(nw)) == 0
+        assert nw.value >= 4 * nrb and nw.value % 4 == 0, nw.value                    # 4 parts x (row blocks, padded to the XCD map)
+        raw = np.zeros(2 * nw.value, dtype=np.uint64)
+        assert lib.wiski_prof_stamps_raw(ctypes.c_int64(i), raw.ctypes.data_as(ctypes.c_void_p), nw, ctypes.byref(nw)) == 0
+        start, end = raw[0::2] & np.uint64((1 << 48) - 1), raw[1::2]
+        live = end != 0
+        assert live.sum() == 4 * nrb, (int(live.sum()), nrb)                           # padding workgroups return before the stamp
+        assert (end[live] > start[live]).all()
+        span = (int(end[live].max()) - int(start[live].min())) * 1e-2
+        assert abs(span - each[i]) < 1e-6, (span, each[i])
+        xcc = (raw[0::2][live] >> np.uint64(60)) & np.uint64(15)
+        assert xcc.max() <= 7 and len(np.unique(xcc)) >= 2                             # an MI355X has 8 XCDs; workgroups are dealt round-robin
+    nw = ctypes.c_int64(-1)
+    assert lib.wiski_prof_stamps_raw(ctypes.c_int64(3), None, ctypes.c_int64(0), ctypes.byref(nw)) == 0 and nw.value == 0
+    ems, enl = ctypes.c_double(0), ctypes.c_int64(0)
+    assert lib.wiski_prof_stop(ctypes.byref(ems), ctypes.byref(enl)) == 0
+    assert enl.value == 2 and ems.value > 0                                            # events only where they were switched on
+    for o in outs:
+        assert torch.equal(o, plain) or (o - plain).abs().max() < 1e-6 * plain.abs().max()   # (the transposed term is accumulated with atomics)
+    after = grid_ops.stencil_spmv(grid, A, V)                                          # after stop: no stamps, nothing recorded
+    torch.cuda.synchronize()
+    assert lib.wiski_prof_stamps(ctypes.byref(tms), ctypes.byref(nl), None, ctypes.c_int64(0)) == 0 and nl.value == 3
+    assert (after - plain).abs().max() < 1e-6 * plain.abs().max()
+
+
 @pytest.mark.parametrize("tdt,tol", [(torch.float32, 2e-5), (torch.float64, 1e-13)])
 @pytest.mark.parametrize("k", [16, 49, 64, 100])
 @pytest.mark.parametrize("gs", [(6, 10, 14), (8, 5, 9), (4, 4, 4), (20, 24, 50), (5, 7, 64), (4, 5, 7), (30, 10)])
