@@ -262,7 +262,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="number of timed K-step blocks (0 = enough for ~0.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extras (profiling runs)")
-    ap.add_argument("--sample-every", type=int, default=4, help="SpMV dispatches of every n-th timed step carry events + in-kernel stamps")
+    ap.add_argument("--sample-every", type=int, default=0, help="n > 0: the SpMV dispatches of every n-th TIMED step carry start/stop events too "
+                    "(they cost ~0.8 us per dispatch and skew the waves' start by XCD: default 0 = events only in one extra un-timed block)")
     ap.add_argument("--stamp-dump", default=None, help="write the raw per-wave stamps of every sampled SpMV dispatch here (.npz; tools/stamp_report.py)")
     ap.add_argument("--check-every", type=int, default=None, help="CG iterations between host convergence checks")
     args = ap.parse_args()
@@ -371,6 +372,7 @@ def main():
             model.prediction_cache                         # cold solve on the init data (not timed)
             gc_settle()
             nb = per_pass if R <= 0 else min(per_pass, R - len(block_s))
+            ev_block = profile and p == 0 and args.sample_every <= 0     # one extra, UN-TIMED block whose SpMV dispatches carry events
             Xs, ys = synth_stream((Wm + per_pass * K) * q, d, seed0 + 1000 + 97 * p + rank, dev, dtype, kind)
             lib.wiski_prof_start(ctypes.c_int32(256))      # creates the event pool outside the timed region
             lib.wiski_prof_stop(None, None)
@@ -394,7 +396,7 @@ def main():
                 t0 = time.perf_counter()
                 for k in range(K):
                     t = Wm + r * K + k
-                    sampled = profile and t % args.sample_every == 0        # per-dispatch events on every SpMV launch queued by every 4th step's call
+                    sampled = profile and args.sample_every > 0 and t % args.sample_every == 0   # (option) events inside the timed region
                     if sampled:
                         lib.wiski_prof_enable(ctypes.c_int32(1))
                     _, it = step(Xs[t * q:(t + 1) * q], ys[t * q:(t + 1) * q])
@@ -426,6 +428,21 @@ def main():
                     if lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl)) == 0:
                         ms_sum += tms.value
                         n_launch += int(nl.value)
+            if ev_block:
+                # the second clock, outside the timed region: the next K steps of the same stream with start/stop events on every SpMV
+                # dispatch (in-kernel stamps show what the events do to the dispatch they ride on: +0.8 us, the waves of six XCDs start
+                # 1.2 us after the other two -- profiles/r06_spmv_tail.txt section 5)
+                Xe, ye = synth_stream(K * q, d, seed0 + 5000 + rank, dev, dtype, kind)
+                barrier()
+                lib.wiski_prof_start(ctypes.c_int32(256))
+                for k in range(K):
+                    step(Xe[k * q:(k + 1) * q], ye[k * q:(k + 1) * q])
+                model._finish_pending()
+                barrier()
+                tms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+                if lib.wiski_prof_stop(ctypes.byref(tms), ctypes.byref(nl)) == 0:
+                    ms_sum += tms.value
+                    n_launch += int(nl.value)
             p += 1
         bt = torch.tensor(block_s, dtype=torch.float64, device=dev)
         if world > 1:
@@ -885,13 +902,16 @@ def main():
         # two clocks: (a) stamps taken inside the kernel -- earliest wave start to latest wave end of a dispatch (100 MHz wall clock,
         # wiski_prof_stamps): the kernel alone, what rocprofv3's begin / end timestamps measure too.  They cost nothing measurable, so
         # EVERY SpMV dispatch of the timed blocks carries them (a stride-4 sample of the steps, the round-6 first cut, read 0.55-0.60
-        # from one run to the next with ~115 dispatches: profiles/r06_stamp_sampling.txt);
-        # (b) the start / stop HIP events attached to the dispatch packet (they do cost: the dispatches of every 4th step), which
-        # bracket [predecessor complete -> this kernel complete] and so contain the ~2.4 us of dispatch latency in front of the first
-        # wave.  `achieved` / `frac` use (a) where the kernel is stamped (k_spmv_sym_dma), (b) is reported beside it (event_*).
+        # from one run to the next with ~115 dispatches: profiles/r06_spmv_tail.txt section 4);
+        # (b) the start / stop HIP events attached to the dispatch packet, which bracket [predecessor complete -> this kernel complete]
+        # and so contain the ~2.4 us of dispatch latency in front of the first wave.  The events are not free -- the stamps of the
+        # dispatches they ride on read 0.8 us more, the waves of six XCDs start 1.2 us after those of the other two, the step is 5 %
+        # slower with all of them on (profiles/r06_spmv_tail.txt section 5) -- so they are taken in ONE extra block of K steps of the
+        # same stream, outside the timed region.  `achieved` / `frac` use (a) where the kernel is stamped (k_spmv_sym_dma); (b) is
+        # reported beside it (event_*).
         ev_ms = spmv_ms / max(spmv_n, 1)
         ev_achieved = spmv_bytes / (ev_ms * 1e-3) / 1e9 if spmv_n else 0.0
-        stamped = stamp_n > 0 and stamp_n >= spmv_n
+        stamped = stamp_n > 0
         avg_ms = stamp_ms / stamp_n if stamped else ev_ms
         achieved = spmv_bytes / (avg_ms * 1e-3) / 1e9 if (spmv_n or stamped) else 0.0
         dma = dtype == torch.float32 and d == 3 and grid.m % 4 == 0 and os.environ.get("WISKI_SYM_DMA", "1") != "0"
@@ -974,7 +994,7 @@ def main():
                          "infinity_cache_resident": bool(spmv_bytes < 200e6),
                          "empty_dispatch_us": empty_us.value,
                          "net_of_empty_dispatch_frac": (spmv_bytes / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if net_us > 0 else None,
-                         "timing": "avg_launch_us / achieved / frac: the kernel's own begin / end stamps (first wave started -> last wave finished) of every SpMV dispatch of the timed blocks, read once per block after it has drained; event_*: the start/stop HIP events attached to the dispatches of every 4th timed step (hipExtLaunchKernel), whose pair brackets [predecessor complete -> this kernel complete] and so contains the dispatch latency in front of the first wave (an empty kernel reads ~4 us by it)",
+                         "timing": "avg_launch_us / achieved / frac: the kernel's own begin / end stamps (first wave started -> last wave finished) of every SpMV dispatch of the timed blocks, read once per block after it has drained; event_*: the start/stop HIP events attached to every SpMV dispatch of one extra, un-timed block of the same stream (hipExtLaunchKernel; inside the timed region they would perturb what they measure: +0.8 us per dispatch by the stamps), whose pair brackets [predecessor complete -> this kernel complete] and so contains the dispatch latency in front of the first wave (an empty kernel reads ~4 us by it)",
                          # context only: SURVEY.md 8(d) prices this product at the FULL stencil (R m s + 2 m s); the kernel
                          # computes the same A.p from the symmetric half, so `frac` above uses the bytes it really needs
                          "survey_8d_full_stencil_bytes": grid.R * grid.m * es + 2 * grid.m * es},
