@@ -55,7 +55,7 @@ def test_fantasize_matches_per_fantasy_oracle(kind, d, g, dense):
         assert tuple(fm.batch_shape) == (F, b) and fm.num_data == 42
         Yf = fm.train_targets                                   # [F, b, q]
         s2 = float(m._sigma2(0))
-        fnoise = float(m.likelihood.noise.mean())
+        fnoise = float(m.likelihood.noise.detach().mean())
         ell = m.covar_module.base_kernel.base_kernel.lengthscale.detach().double().cpu().numpy().reshape(-1)
         osc = float(m.covar_module.base_kernel.outputscale.detach().double())
         Xq = torch.as_tensor(rng.uniform(0.05, 0.95, (5, d)), device=DEV)
