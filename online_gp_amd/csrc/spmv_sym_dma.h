@@ -144,10 +144,17 @@ __global__ __launch_bounds__(64) void k_spmv_sym_dma(GridDev<float> G, const flo
   // are about three tiles in (50^3: delay = 12, 18.5 -> 18.1 us back to back; 6..8 and 14..20 are no better than 0, 24+ worse).
   if (!tab.n && nparts == 4 && blockIdx.y == 3)
     for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(16);
-  // xcd_rb != 0: grid.x is padded to 8 * xcd_rb and workgroup b (on XCD b % 8) takes row block (b % 8) * xcd_rb + b / 8, so every
-  // XCD sweeps ONE contiguous eighth of the rows (for all parts) and fetches only that eighth of v (+ the 3-plane halo) into its L2
-  const int rb = xcd_rb ? (int)(blockIdx.x & 7) * xcd_rb + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  if (xcd_rb && rb * 256 >= G.m) return;
+  // xcd_rb != 0: grid.x is padded to 8 * xcd_rb (xcd_rb = ceil(row blocks / 8)) and workgroup b (on XCD b % 8) takes the (b / 8)-th row
+  // block of ITS contiguous range, so every XCD sweeps one contiguous eighth of the rows (for all parts) and fetches only that eighth of v
+  // (+ the 3-plane halo) into its L2.  The ranges are BALANCED -- nrb / 8 blocks each, the first nrb % 8 XCDs one more -- not xcd_rb
+  // each with the remainder on the last XCD: at 50^3 that was 62 x 7 + 55 and the launch ended with the seven full XCDs.
+  int rb = (int)blockIdx.x;
+  if (xcd_rb) {
+    const int nrb = (G.m + 255) >> 8, base = nrb >> 3, rem = nrb & 7;
+    const int x = (int)(blockIdx.x & 7), sl = (int)(blockIdx.x >> 3);
+    if (sl >= base + (x < rem ? 1 : 0)) return;
+    rb = x * base + (x < rem ? x : rem) + sl;
+  }
   const int iw0 = rb * 256;
   const int i4 = iw0 + 4 * lane;
   const bool live = i4 < m;
