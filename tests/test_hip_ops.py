@@ -668,7 +668,7 @@ def test_fused_hyper_columns_match_the_op_graph_and_the_oracle(dtype, kind, ard,
     # oracle: closed-form columns at the same hyper-parameters
     ell = base.lengthscale.detach().double().cpu().numpy().reshape(-1)
     ell = np.broadcast_to(ell, (d,)) if ell.size == 1 else ell
-    s = float(cov.outputscale) if scaled else 1.0
+    s = float(cov.outputscale.detach()) if scaled else 1.0
     g0, h, gs = spec.make_grid([[-1.0, 1.0 + 0.3 * q] for q in range(d)], g)
     okind = {"rbf": "rbf", "matern0.5": "matern12", "matern1.5": "matern32", "matern2.5": "matern52"}[kind]
     ref = np.concatenate(spec.toeplitz_columns(okind, h, gs, ell, s))
